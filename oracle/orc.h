@@ -1,0 +1,145 @@
+/* CPU oracle for the MI355X batch-SNARK-verification hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY: only tests/, __graft_entry__.smoke() and bench.py's
+ * cpu_baseline leg may load this library.  The product (snarkos_amd/, libmi355x_snark.so)
+ * never links, imports or calls anything in oracle/.
+ *
+ * PARITY UNPINNED.  The reference (zosorock/snarkOS) reaches this arithmetic only through
+ * Ledger::check_next_block / check_transaction_basic
+ * (reference node/bft/ledger-service/src/ledger.rs:319-347); the arithmetic itself is in
+ * snarkvm-{algorithms,curves,fields} 1.0.0 @ git rev dea322b3d374ac0fa7dae26cf006bf67acd52e9e
+ * (reference Cargo.toml:47-52, Cargo.lock:3578-3580), which is not vendored, and the
+ * reference's own tests hold no golden vector for this path.  This
+ * file restates the published algorithms (Montgomery CIOS, Jacobian G1, ate pairing over the
+ * BLS12 seed, Pippenger bucket MSM, radix-2 NTT, KZG10 check / batch_check) and is pinned by
+ * oracle/pyref.py (independent Python big-int implementation) and by algebraic identities
+ * (tests/test_oracle_*.py), not by reference outputs.
+ */
+#ifndef ORC_H
+#define ORC_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- ABI-layout types (identical to include/mi355x_snark.h) ---- */
+typedef struct { uint64_t l[4]; } orc_fr;        /* Montgomery unless stated */
+typedef struct { uint64_t l[4]; } orc_bigint256; /* canonical integer */
+typedef struct { uint64_t l[6]; } orc_fq;        /* Montgomery */
+typedef struct { orc_fq x, y; } orc_g1_affine;   /* 96 B; infinity <=> x == y == 0 */
+typedef struct { orc_fq x, y, z; } orc_g1_jac;   /* 144 B Jacobian; infinity <=> z == 0 */
+typedef struct { orc_fq c0, c1; } orc_fq2;
+typedef struct { orc_fq2 x, y; } orc_g2_affine;  /* 192 B; infinity <=> all zero */
+typedef struct { orc_fq2 c0, c1, c2; } orc_fq6;
+typedef struct { orc_fq6 c0, c1; } orc_fq12;     /* 576 B */
+typedef struct { orc_g1_affine g; orc_g2_affine h, tau_h; } orc_kzg_vk;
+
+/* ---- fields ---- */
+void orc_fr_mul(orc_fr *r, const orc_fr *a, const orc_fr *b);
+void orc_fr_add(orc_fr *r, const orc_fr *a, const orc_fr *b);
+void orc_fr_sub(orc_fr *r, const orc_fr *a, const orc_fr *b);
+void orc_fr_inv(orc_fr *r, const orc_fr *a);
+void orc_fr_from_canonical(orc_fr *r, const orc_bigint256 *a);
+void orc_fr_to_canonical(orc_bigint256 *r, const orc_fr *a);
+void orc_fq_mul(orc_fq *r, const orc_fq *a, const orc_fq *b);
+void orc_fq_add(orc_fq *r, const orc_fq *a, const orc_fq *b);
+void orc_fq_sub(orc_fq *r, const orc_fq *a, const orc_fq *b);
+void orc_fq_inv(orc_fq *r, const orc_fq *a);
+void orc_fq_from_canonical(orc_fq *r, const uint64_t *limbs6);
+void orc_fq_to_canonical(uint64_t *limbs6, const orc_fq *a);
+void orc_fq12_mul(orc_fq12 *r, const orc_fq12 *a, const orc_fq12 *b);
+void orc_fq12_inv(orc_fq12 *r, const orc_fq12 *a);
+void orc_fq12_frobenius(orc_fq12 *r, const orc_fq12 *a, int power);
+void orc_fq12_one(orc_fq12 *r);
+int orc_fq12_is_one(const orc_fq12 *a);
+
+/* ---- G1 / G2 ---- */
+void orc_g1_generator(orc_g1_affine *g);
+void orc_g2_generator(orc_g2_affine *g);
+int orc_g1_is_on_curve(const orc_g1_affine *p);
+void orc_g1_add(orc_g1_jac *r, const orc_g1_jac *a, const orc_g1_jac *b);
+void orc_g1_add_mixed(orc_g1_jac *r, const orc_g1_jac *a, const orc_g1_affine *b);
+void orc_g1_double(orc_g1_jac *r, const orc_g1_jac *a);
+void orc_g1_neg_affine(orc_g1_affine *r, const orc_g1_affine *a);
+void orc_g1_from_affine(orc_g1_jac *r, const orc_g1_affine *a);
+void orc_g1_to_affine(orc_g1_affine *r, const orc_g1_jac *a);
+void orc_g1_batch_to_affine(orc_g1_affine *r, const orc_g1_jac *a, size_t n);
+void orc_g1_mul(orc_g1_jac *r, const orc_g1_affine *p, const orc_bigint256 *k);
+void orc_g2_mul(orc_g2_affine *r, const orc_g2_affine *p, const orc_bigint256 *k);
+int orc_g2_is_on_curve(const orc_g2_affine *p);
+/* k*G for many k with a fixed-base table (generator only; used by the synthetic prover) */
+void orc_g1_fixed_base_batch(orc_g1_affine *out, const orc_fr *k_mont, size_t n);
+
+/* ---- MSM (snarkvm_algorithms::msm::VariableBase::msm; scalars canonical) ---- */
+void orc_msm_naive(orc_g1_jac *out, const orc_g1_affine *bases, const orc_bigint256 *scalars, size_t n);
+void orc_msm_pippenger(orc_g1_jac *out, const orc_g1_affine *bases, const orc_bigint256 *scalars, size_t n,
+                       int threads);
+
+/* ---- NTT (snarkvm_algorithms::fft::EvaluationDomain::{fft,ifft,coset_fft,coset_ifft}_in_place) ---- */
+void orc_fr_omega(orc_fr *w, uint32_t log_n);
+int orc_ntt(orc_fr *data, uint32_t log_n, int inverse, int coset, int threads);
+void orc_dft_naive(orc_fr *out, const orc_fr *in, uint32_t log_n);
+
+/* ---- pairing ---- */
+#define ORC_MILLER_STEPS 70 /* 63 doublings + 6 additions (+1 spare) for x = 0x8508c00000000001 */
+typedef struct { orc_fq2 c1, c3; } orc_line;  /* l(P) = yP + (c1 * xP) w + c3 w^3 */
+typedef struct { int n; int infinity; orc_line lines[ORC_MILLER_STEPS]; } orc_g2_prepared;
+void orc_g2_prepare(orc_g2_prepared *out, const orc_g2_affine *q);
+void orc_miller_loop(orc_fq12 *f, const orc_g1_affine *p, const orc_g2_prepared *q);
+void orc_final_exponentiation(orc_fq12 *r, const orc_fq12 *f); /* f^(3 (q^12-1)/r) */
+void orc_pairing(orc_fq12 *r, const orc_g1_affine *p, const orc_g2_affine *q);
+int orc_pairing_product_is_one(const orc_g1_affine *ps, const orc_g2_prepared *const *qs, size_t n);
+
+/* ---- KZG10 (snarkvm_algorithms::polycommit::kzg10::KZG10::{check,batch_check}) ---- */
+int orc_kzg_check(const orc_kzg_vk *vk, const orc_g1_affine *comm, const orc_fr *point, const orc_fr *value,
+                  const orc_g1_affine *witness);
+int orc_kzg_batch_check(const orc_kzg_vk *vk, const orc_g1_affine *comms, const orc_fr *points,
+                        const orc_fr *values, const orc_g1_affine *witnesses, size_t n,
+                        const uint8_t *randomizers128);
+
+/* ---- SHA-256 (stand-in Fiat-Shamir transcript) ---- */
+void orc_sha256(uint8_t out[32], const uint8_t *data, size_t len);
+
+/* ---- VarunaShaped-v1 synthetic batch (DESIGN.md section "VarunaShaped-v1") ---- */
+#define ORC_VS_VK_COMMS 12
+#define ORC_VS_PROOF_COMMS 9
+#define ORC_VS_EVALS 21
+#define ORC_VS_INPUTS 16
+#define ORC_VS_BETA_PROOF_COMMS 5 /* C_0..C_4 and V_0..V_5 open at beta; the rest at gamma */
+#define ORC_VS_BETA_VK_COMMS 6
+typedef struct { orc_g1_affine comms[ORC_VS_VK_COMMS]; uint8_t digest[32]; } orc_vs_circuit_vk; /* 1184 B */
+typedef struct {
+    uint32_t circuit;
+    uint32_t _pad[3];
+    orc_fr inputs[ORC_VS_INPUTS];
+    orc_g1_affine comms[ORC_VS_PROOF_COMMS];
+    orc_fr evals[ORC_VS_EVALS];
+    orc_g1_affine w[2];
+} orc_vs_proof; /* 2256 B */
+
+/* Deterministic synthetic prover with a toy SRS (tau derived from the seed).  corrupt_per_1024 of every
+ * 1024 proofs (chosen by the PRNG) are corrupted; expected[i] receives the ground-truth verdict. */
+void orc_vs_generate(uint64_t seed, size_t n_proofs, size_t n_circuits, uint32_t corrupt_per_1024,
+                     orc_kzg_vk *vk, orc_vs_circuit_vk *circuits, orc_vs_proof *proofs,
+                     uint8_t *randomizers128 /* n_proofs*2*16 */, uint8_t *expected);
+/* transcript only: z_beta, z_gamma, xi (Montgomery Fr) */
+void orc_vs_challenges(const orc_vs_circuit_vk *cvk, const orc_vs_proof *p, orc_fr *z_beta, orc_fr *z_gamma,
+                       orc_fr *xi);
+/* one proof at a time, per-proof pairing product (the reference's shape: rayon over transactions) */
+int orc_vs_verify_one(const orc_kzg_vk *vk, const orc_g2_prepared *h, const orc_g2_prepared *tau_h,
+                      const orc_vs_circuit_vk *circuits, const orc_vs_proof *p, const uint8_t *rand2x16);
+void orc_vs_verify_batch_cpu(const orc_kzg_vk *vk, const orc_vs_circuit_vk *circuits, const orc_vs_proof *proofs,
+                             size_t n, const uint8_t *randomizers128, uint8_t *verdicts, int threads);
+/* aggregated form (one random-linear-combination MSM + one pairing product): returns all_ok */
+int orc_vs_verify_aggregated(const orc_kzg_vk *vk, const orc_vs_circuit_vk *circuits, size_t n_circuits,
+                             const orc_vs_proof *proofs, size_t n, const uint8_t *randomizers128,
+                             uint8_t *alg_ok, orc_g1_affine *total_c, orc_g1_affine *total_w, int threads);
+
+int orc_self_test(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,645 @@
+/* CPU oracle: MSM, NTT, KZG10, SHA-256, VarunaShaped-v1.  TEST INFRASTRUCTURE ONLY (see orc.h).
+ *
+ * Restates (published algorithms; snarkVM 1.0.0 @ dea322b sources are not available):
+ *   msm::VariableBase::msm            -> orc_msm_naive / orc_msm_pippenger   
+ *   fft::EvaluationDomain::*_in_place -> orc_ntt                             
+ *   kzg10::KZG10::{check,batch_check} -> orc_kzg_check / orc_kzg_batch_check
+ *   the per-transaction verify loop of VM::check_transactions (rayon over transactions, one
+ *   pairing product per proof)        -> orc_vs_verify_batch_cpu             
+ */
+#include "orc_internal.h"
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+static void g1_set_inf(orc_g1_jac *r) {
+    memset(r, 0, sizeof *r);
+    fq_one(F(&r->x));
+    fq_one(F(&r->y));
+}
+
+/* ------------------------------------------------------------------ MSM */
+void orc_msm_naive(orc_g1_jac *out, const orc_g1_affine *bases, const orc_bigint256 *scalars, size_t n) {
+    orc_g1_jac acc, t;
+    g1_set_inf(&acc);
+    for (size_t i = 0; i < n; i++) {
+        orc_g1_mul(&t, &bases[i], &scalars[i]);
+        orc_g1_add(&acc, &acc, &t);
+    }
+    *out = acc;
+}
+
+static inline unsigned get_window(const orc_bigint256 *s, int bit, int c) {
+    int limb = bit >> 6, off = bit & 63;
+    uint64_t v = s->l[limb] >> off;
+    if (off + c > 64 && limb < 3) v |= s->l[limb + 1] << (64 - off);
+    return (unsigned)(v & ((1ull << c) - 1));
+}
+
+void orc_msm_pippenger(orc_g1_jac *out, const orc_g1_affine *bases, const orc_bigint256 *scalars, size_t n,
+                       int threads) {
+    if (n < 15) { orc_msm_naive(out, bases, scalars, n); return; }
+    int c = (int)floor(log((double)n)) + 2; /* snarkVM's window heuristic */
+    if (c > 20) c = 20;
+    int nwin = (253 + c - 1) / c;
+    orc_g1_jac *wsum = (orc_g1_jac *)malloc(sizeof(orc_g1_jac) * nwin);
+    if (threads < 1) threads = 1;
+#pragma omp parallel for schedule(dynamic, 1) num_threads(threads)
+    for (int w = 0; w < nwin; w++) {
+        size_t nb = ((size_t)1 << c) - 1;
+        orc_g1_jac *buckets = (orc_g1_jac *)malloc(sizeof(orc_g1_jac) * nb);
+        for (size_t b = 0; b < nb; b++) g1_set_inf(&buckets[b]);
+        for (size_t i = 0; i < n; i++) {
+            unsigned d = get_window(&scalars[i], w * c, c);
+            if (d) orc_g1_add_mixed(&buckets[d - 1], &buckets[d - 1], &bases[i]);
+        }
+        orc_g1_jac run, sum;
+        g1_set_inf(&run);
+        g1_set_inf(&sum);
+        for (size_t b = nb; b-- > 0;) {
+            orc_g1_add(&run, &run, &buckets[b]);
+            orc_g1_add(&sum, &sum, &run);
+        }
+        wsum[w] = sum;
+        free(buckets);
+    }
+    orc_g1_jac acc;
+    g1_set_inf(&acc);
+    for (int w = nwin - 1; w >= 0; w--) {
+        for (int k = 0; k < c; k++) orc_g1_double(&acc, &acc);
+        orc_g1_add(&acc, &acc, &wsum[w]);
+    }
+    free(wsum);
+    *out = acc;
+}
+
+/* ------------------------------------------------------------------ NTT */
+void orc_fr_omega(orc_fr *w, uint32_t log_n) {
+    fr_t t;
+    memcpy(&t, ORC_FR_ROOT_OF_UNITY, 32);
+    for (uint32_t i = log_n; i < ORC_FR_TWO_ADICITY; i++) fr_sqr(&t, &t);
+    memcpy(w, &t, 32);
+}
+void orc_dft_naive(orc_fr *out, const orc_fr *in, uint32_t log_n) {
+    size_t n = (size_t)1 << log_n;
+    fr_t w, wi, wij, acc, t;
+    orc_fr_omega((orc_fr *)&w, log_n);
+    fr_one(&wi);
+    for (size_t i = 0; i < n; i++) {
+        fr_zero(&acc);
+        fr_one(&wij);
+        for (size_t j = 0; j < n; j++) {
+            fr_mul(&t, S(&in[j]), &wij);
+            fr_add(&acc, &acc, &t);
+            fr_mul(&wij, &wij, &wi);
+        }
+        memcpy(&out[i], &acc, 32);
+        fr_mul(&wi, &wi, &w);
+    }
+}
+static size_t bitrev(size_t x, uint32_t bits) {
+    size_t r = 0;
+    for (uint32_t i = 0; i < bits; i++) { r = (r << 1) | (x & 1); x >>= 1; }
+    return r;
+}
+int orc_ntt(orc_fr *data, uint32_t log_n, int inverse, int coset, int threads) {
+    if (log_n > ORC_FR_TWO_ADICITY) return -1;
+    size_t n = (size_t)1 << log_n;
+    fr_t *a = (fr_t *)data;
+    fr_t w, g, gi;
+    if (threads < 1) threads = 1;
+    orc_fr_omega((orc_fr *)&w, log_n);
+    if (inverse) fr_inv(&w, &w);
+    memcpy(&g, ORC_FR_GENERATOR, 32);
+    memcpy(&gi, ORC_FR_GENERATOR_INV, 32);
+    if (coset && !inverse) {
+        fr_t p;
+        fr_one(&p);
+        for (size_t i = 0; i < n; i++) { fr_mul(&a[i], &a[i], &p); fr_mul(&p, &p, &g); }
+    }
+    for (size_t i = 0; i < n; i++) {
+        size_t j = bitrev(i, log_n);
+        if (i < j) { fr_t t = a[i]; a[i] = a[j]; a[j] = t; }
+    }
+    /* twiddle table w^k, k < n/2 */
+    size_t half = n / 2 ? n / 2 : 1;
+    fr_t *tw = (fr_t *)malloc(sizeof(fr_t) * half);
+    fr_one(&tw[0]);
+    for (size_t k = 1; k < half; k++) fr_mul(&tw[k], &tw[k - 1], &w);
+    for (uint32_t s = 1; s <= log_n; s++) {
+        size_t m = (size_t)1 << s, hm = m >> 1, stride = n / m;
+#pragma omp parallel for schedule(static) num_threads(threads) if (n >= 4096)
+        for (size_t idx = 0; idx < n / 2; idx++) {
+            size_t blk = idx / hm, j = idx % hm;
+            size_t i0 = blk * m + j, i1 = i0 + hm;
+            fr_t t, u = a[i0];
+            fr_mul(&t, &a[i1], &tw[j * stride]);
+            fr_add(&a[i0], &u, &t);
+            fr_sub(&a[i1], &u, &t);
+        }
+    }
+    free(tw);
+    if (inverse) {
+        fr_t ninv, p;
+        fr_from_u64(&ninv, (uint64_t)n);
+        fr_inv(&ninv, &ninv);
+        if (coset) {
+            fr_one(&p);
+            for (size_t i = 0; i < n; i++) {
+                fr_mul(&a[i], &a[i], &ninv);
+                fr_mul(&a[i], &a[i], &p);
+                fr_mul(&p, &p, &gi);
+            }
+        } else {
+#pragma omp parallel for schedule(static) num_threads(threads) if (n >= 4096)
+            for (size_t i = 0; i < n; i++) fr_mul(&a[i], &a[i], &ninv);
+        }
+    }
+    return 0;
+}
+
+/* ------------------------------------------------------------------ KZG10 */
+static void fr_from_u128le(fr_t *r, const uint8_t *b16) {
+    uint64_t l[4] = {0, 0, 0, 0};
+    memcpy(l, b16, 16);
+    fr_from_canonical(r, l);
+}
+static void g1_mul_fr(orc_g1_jac *r, const orc_g1_affine *p, const fr_t *k_mont) {
+    orc_bigint256 k;
+    fr_to_canonical(k.l, k_mont);
+    orc_g1_mul(r, p, &k);
+}
+int orc_kzg_check(const orc_kzg_vk *vk, const orc_g1_affine *comm, const orc_fr *point, const orc_fr *value,
+                  const orc_g1_affine *witness) {
+    uint8_t one[16] = {1};
+    return orc_kzg_batch_check(vk, comm, point, value, witness, 1, one);
+}
+int orc_kzg_batch_check(const orc_kzg_vk *vk, const orc_g1_affine *comms, const orc_fr *points,
+                        const orc_fr *values, const orc_g1_affine *witnesses, size_t n,
+                        const uint8_t *randomizers128) {
+    orc_g1_jac total_c, total_w, t;
+    fr_t gs, r, rz, rv;
+    g1_set_inf(&total_c);
+    g1_set_inf(&total_w);
+    fr_zero(&gs);
+    for (size_t i = 0; i < n; i++) {
+        fr_from_u128le(&r, randomizers128 + 16 * i);
+        g1_mul_fr(&t, &comms[i], &r);
+        orc_g1_add(&total_c, &total_c, &t);
+        fr_mul(&rz, &r, S(&points[i]));
+        g1_mul_fr(&t, &witnesses[i], &rz);
+        orc_g1_add(&total_c, &total_c, &t);
+        g1_mul_fr(&t, &witnesses[i], &r);
+        orc_g1_add(&total_w, &total_w, &t);
+        fr_mul(&rv, &r, S(&values[i]));
+        fr_add(&gs, &gs, &rv);
+    }
+    fr_neg(&gs, &gs);
+    g1_mul_fr(&t, &vk->g, &gs);
+    orc_g1_add(&total_c, &total_c, &t);
+    orc_g1_affine ps[2];
+    orc_g1_to_affine(&ps[0], &total_c);
+    orc_g1_to_affine(&ps[1], &total_w);
+    orc_g1_neg_affine(&ps[1], &ps[1]);
+    orc_g2_prepared *h = (orc_g2_prepared *)malloc(sizeof *h), *th = (orc_g2_prepared *)malloc(sizeof *th);
+    orc_g2_prepare(h, &vk->h);
+    orc_g2_prepare(th, &vk->tau_h);
+    const orc_g2_prepared *qs[2] = {h, th};
+    int ok = orc_pairing_product_is_one(ps, qs, 2);
+    free(h);
+    free(th);
+    return ok;
+}
+
+/* ------------------------------------------------------------------ SHA-256 (FIPS 180-4) */
+static const uint32_t K256[64] = {
+    0x428a2f98, 0x71374491, 0xb5c0fbcf, 0xe9b5dba5, 0x3956c25b, 0x59f111f1, 0x923f82a4, 0xab1c5ed5, 0xd807aa98,
+    0x12835b01, 0x243185be, 0x550c7dc3, 0x72be5d74, 0x80deb1fe, 0x9bdc06a7, 0xc19bf174, 0xe49b69c1, 0xefbe4786,
+    0x0fc19dc6, 0x240ca1cc, 0x2de92c6f, 0x4a7484aa, 0x5cb0a9dc, 0x76f988da, 0x983e5152, 0xa831c66d, 0xb00327c8,
+    0xbf597fc7, 0xc6e00bf3, 0xd5a79147, 0x06ca6351, 0x14292967, 0x27b70a85, 0x2e1b2138, 0x4d2c6dfc, 0x53380d13,
+    0x650a7354, 0x766a0abb, 0x81c2c92e, 0x92722c85, 0xa2bfe8a1, 0xa81a664b, 0xc24b8b70, 0xc76c51a3, 0xd192e819,
+    0xd6990624, 0xf40e3585, 0x106aa070, 0x19a4c116, 0x1e376c08, 0x2748774c, 0x34b0bcb5, 0x391c0cb3, 0x4ed8aa4a,
+    0x5b9cca4f, 0x682e6ff3, 0x748f82ee, 0x78a5636f, 0x84c87814, 0x8cc70208, 0x90befffa, 0xa4506ceb, 0xbef9a3f7,
+    0xc67178f2};
+#define ROR(x, n) (((x) >> (n)) | ((x) << (32 - (n))))
+static void sha256_block(uint32_t st[8], const uint8_t *p) {
+    uint32_t w[64];
+    for (int i = 0; i < 16; i++)
+        w[i] = ((uint32_t)p[4 * i] << 24) | ((uint32_t)p[4 * i + 1] << 16) | ((uint32_t)p[4 * i + 2] << 8) | p[4 * i + 3];
+    for (int i = 16; i < 64; i++) {
+        uint32_t s0 = ROR(w[i - 15], 7) ^ ROR(w[i - 15], 18) ^ (w[i - 15] >> 3);
+        uint32_t s1 = ROR(w[i - 2], 17) ^ ROR(w[i - 2], 19) ^ (w[i - 2] >> 10);
+        w[i] = w[i - 16] + s0 + w[i - 7] + s1;
+    }
+    uint32_t a = st[0], b = st[1], c = st[2], d = st[3], e = st[4], f = st[5], g = st[6], h = st[7];
+    for (int i = 0; i < 64; i++) {
+        uint32_t t1 = h + (ROR(e, 6) ^ ROR(e, 11) ^ ROR(e, 25)) + ((e & f) ^ (~e & g)) + K256[i] + w[i];
+        uint32_t t2 = (ROR(a, 2) ^ ROR(a, 13) ^ ROR(a, 22)) + ((a & b) ^ (a & c) ^ (b & c));
+        h = g; g = f; f = e; e = d + t1; d = c; c = b; b = a; a = t1 + t2;
+    }
+    st[0] += a; st[1] += b; st[2] += c; st[3] += d; st[4] += e; st[5] += f; st[6] += g; st[7] += h;
+}
+void orc_sha256(uint8_t out[32], const uint8_t *data, size_t len) {
+    uint32_t st[8] = {0x6a09e667, 0xbb67ae85, 0x3c6ef372, 0xa54ff53a, 0x510e527f, 0x9b05688c, 0x1f83d9ab, 0x5be0cd19};
+    size_t i = 0;
+    for (; i + 64 <= len; i += 64) sha256_block(st, data + i);
+    uint8_t buf[128];
+    size_t rem = len - i;
+    memset(buf, 0, sizeof buf);
+    memcpy(buf, data + i, rem);
+    buf[rem] = 0x80;
+    size_t tot = rem + 9 <= 64 ? 64 : 128;
+    uint64_t bits = (uint64_t)len * 8;
+    for (int k = 0; k < 8; k++) buf[tot - 1 - k] = (uint8_t)(bits >> (8 * k));
+    sha256_block(st, buf);
+    if (tot == 128) sha256_block(st, buf + 64);
+    for (int k = 0; k < 8; k++) {
+        out[4 * k] = (uint8_t)(st[k] >> 24);
+        out[4 * k + 1] = (uint8_t)(st[k] >> 16);
+        out[4 * k + 2] = (uint8_t)(st[k] >> 8);
+        out[4 * k + 3] = (uint8_t)st[k];
+    }
+}
+
+/* ------------------------------------------------------------------ VarunaShaped-v1 */
+static const char VS_TAG[32] = "MI355X-VarunaShaped-v1";
+
+void orc_vs_challenges(const orc_vs_circuit_vk *cvk, const orc_vs_proof *p, orc_fr *z_beta, orc_fr *z_gamma,
+                       orc_fr *xi) {
+    uint8_t buf[32 + 21 * 32 + 64], h[32];
+    size_t o = 0;
+    memcpy(buf + o, VS_TAG, 32); o += 32;
+    memcpy(buf + o, cvk->digest, 32); o += 32;
+    memcpy(buf + o, p->inputs, sizeof p->inputs); o += sizeof p->inputs;
+    memcpy(buf + o, &p->comms[0], 2 * 96); o += 2 * 96;
+    orc_sha256(h, buf, o);
+    o = 0;
+    memcpy(buf, h, 32); o = 32;
+    memcpy(buf + o, &p->comms[2], 3 * 96); o += 3 * 96;
+    orc_sha256(h, buf, o);
+    fr_from_u128le(S(z_beta), h);
+    memcpy(buf, h, 32); o = 32;
+    memcpy(buf + o, &p->comms[5], 4 * 96); o += 4 * 96;
+    orc_sha256(h, buf, o);
+    fr_from_u128le(S(z_gamma), h);
+    memcpy(buf, h, 32); o = 32;
+    memcpy(buf + o, p->evals, sizeof p->evals); o += sizeof p->evals;
+    orc_sha256(h, buf, o);
+    fr_from_u128le(S(xi), h);
+}
+
+/* x_hat(z) = sum_k inputs[k] L_k(z) over the size-16 domain; returns 0 if z^16 == 1 (proof rejected) */
+static int vs_input_eval(fr_t *xhat, fr_t *zn_minus_1, const fr_t *inputs, const fr_t *z) {
+    fr_t w, wk[ORC_VS_INPUTS], den[ORC_VS_INPUTS], pre[ORC_VS_INPUTS], acc, one, zn, t, ninv;
+    orc_fr_omega((orc_fr *)&w, 4);
+    fr_one(&one);
+    zn = *z;
+    for (int i = 0; i < 4; i++) fr_sqr(&zn, &zn);
+    fr_sub(zn_minus_1, &zn, &one);
+    if (fr_is_zero(zn_minus_1)) return 0;
+    wk[0] = one;
+    for (int k = 1; k < ORC_VS_INPUTS; k++) fr_mul(&wk[k], &wk[k - 1], &w);
+    acc = one;
+    for (int k = 0; k < ORC_VS_INPUTS; k++) {
+        fr_sub(&den[k], z, &wk[k]);
+        pre[k] = acc;
+        fr_mul(&acc, &acc, &den[k]);
+    }
+    fr_inv(&acc, &acc);
+    fr_zero(xhat);
+    for (int k = ORC_VS_INPUTS - 1; k >= 0; k--) {
+        fr_t dinv;
+        fr_mul(&dinv, &acc, &pre[k]);
+        fr_mul(&acc, &acc, &den[k]);
+        fr_mul(&t, &inputs[k], &wk[k]);
+        fr_mul(&t, &t, &dinv);
+        fr_add(xhat, xhat, &t);
+    }
+    fr_from_u64(&ninv, ORC_VS_INPUTS);
+    fr_inv(&ninv, &ninv);
+    fr_mul(xhat, xhat, zn_minus_1);
+    fr_mul(xhat, xhat, &ninv);
+    return 1;
+}
+
+/* which query (0 = beta, 1 = gamma) polynomial p (0..20: 9 proof comms then 12 vk comms) opens at */
+static inline int vs_query_of(int p) {
+    if (p < ORC_VS_PROOF_COMMS) return p < ORC_VS_BETA_PROOF_COMMS ? 0 : 1;
+    return (p - ORC_VS_PROOF_COMMS) < ORC_VS_BETA_VK_COMMS ? 0 : 1;
+}
+
+/* Everything the verifier derives in Fr for one proof: per-polynomial MSM scalar (already times r_q),
+ * witness scalars, and the G coefficient.  Returns the algebraic-check verdict. */
+typedef struct {
+    fr_t poly_scalar[ORC_VS_EVALS]; /* r_q * xi^p */
+    fr_t w_scalar_c[2];             /* r_q * z_q     (goes with H)     */
+    fr_t w_scalar_w[2];             /* r_q           (goes with tau H) */
+    fr_t g_scalar;                  /* -(sum_q r_q val_q) */
+    int alg_ok;
+} vs_fr_work;
+
+static void vs_derive(vs_fr_work *o, const orc_vs_circuit_vk *cvk, const orc_vs_proof *p, const uint8_t *rand2x16) {
+    fr_t z[2], xi, r[2], xip, val[2], t, xhat, znm1;
+    orc_vs_challenges(cvk, p, (orc_fr *)&z[0], (orc_fr *)&z[1], (orc_fr *)&xi);
+    fr_from_u128le(&r[0], rand2x16);
+    fr_from_u128le(&r[1], rand2x16 + 16);
+    fr_one(&xip);
+    fr_zero(&val[0]);
+    fr_zero(&val[1]);
+    for (int k = 0; k < ORC_VS_EVALS; k++) {
+        int q = vs_query_of(k);
+        fr_mul(&o->poly_scalar[k], &r[q], &xip);
+        fr_mul(&t, &xip, S(&p->evals[k]));
+        fr_add(&val[q], &val[q], &t);
+        fr_mul(&xip, &xip, &xi);
+    }
+    fr_zero(&o->g_scalar);
+    for (int q = 0; q < 2; q++) {
+        fr_mul(&o->w_scalar_c[q], &r[q], &z[q]);
+        o->w_scalar_w[q] = r[q];
+        fr_mul(&t, &r[q], &val[q]);
+        fr_sub(&o->g_scalar, &o->g_scalar, &t);
+    }
+    /* public-input consistency: v_0 == x_hat(z_beta) + (z_beta^16 - 1) v_1 */
+    o->alg_ok = 0;
+    if (vs_input_eval(&xhat, &znm1, (const fr_t *)p->inputs, &z[0])) {
+        fr_mul(&t, &znm1, S(&p->evals[1]));
+        fr_add(&t, &t, &xhat);
+        o->alg_ok = fr_eq(&t, S(&p->evals[0]));
+    }
+}
+
+int orc_vs_verify_one(const orc_kzg_vk *vk, const orc_g2_prepared *h, const orc_g2_prepared *tau_h,
+                      const orc_vs_circuit_vk *circuits, const orc_vs_proof *p, const uint8_t *rand2x16) {
+    const orc_vs_circuit_vk *cvk = &circuits[p->circuit];
+    vs_fr_work fw;
+    vs_derive(&fw, cvk, p, rand2x16);
+    orc_g1_jac total_c, total_w, t;
+    g1_set_inf(&total_c);
+    g1_set_inf(&total_w);
+    for (int k = 0; k < ORC_VS_EVALS; k++) {
+        const orc_g1_affine *c = k < ORC_VS_PROOF_COMMS ? &p->comms[k] : &cvk->comms[k - ORC_VS_PROOF_COMMS];
+        g1_mul_fr(&t, c, &fw.poly_scalar[k]);
+        orc_g1_add(&total_c, &total_c, &t);
+    }
+    for (int q = 0; q < 2; q++) {
+        g1_mul_fr(&t, &p->w[q], &fw.w_scalar_c[q]);
+        orc_g1_add(&total_c, &total_c, &t);
+        g1_mul_fr(&t, &p->w[q], &fw.w_scalar_w[q]);
+        orc_g1_add(&total_w, &total_w, &t);
+    }
+    g1_mul_fr(&t, &vk->g, &fw.g_scalar);
+    orc_g1_add(&total_c, &total_c, &t);
+    orc_g1_affine ps[2];
+    orc_g1_to_affine(&ps[0], &total_c);
+    orc_g1_to_affine(&ps[1], &total_w);
+    orc_g1_neg_affine(&ps[1], &ps[1]);
+    const orc_g2_prepared *qs[2] = {h, tau_h};
+    int kzg_ok = orc_pairing_product_is_one(ps, qs, 2);
+    return fw.alg_ok && kzg_ok == 1;
+}
+
+void orc_vs_verify_batch_cpu(const orc_kzg_vk *vk, const orc_vs_circuit_vk *circuits, const orc_vs_proof *proofs,
+                             size_t n, const uint8_t *randomizers128, uint8_t *verdicts, int threads) {
+    orc_g2_prepared *h = (orc_g2_prepared *)malloc(sizeof *h), *th = (orc_g2_prepared *)malloc(sizeof *th);
+    orc_g2_prepare(h, &vk->h);
+    orc_g2_prepare(th, &vk->tau_h);
+    if (threads < 1) threads = 1;
+#pragma omp parallel for schedule(dynamic, 4) num_threads(threads)
+    for (size_t i = 0; i < n; i++)
+        verdicts[i] = (uint8_t)orc_vs_verify_one(vk, h, th, circuits, &proofs[i], randomizers128 + 32 * i);
+    free(h);
+    free(th);
+}
+
+int orc_vs_verify_aggregated(const orc_kzg_vk *vk, const orc_vs_circuit_vk *circuits, size_t n_circuits,
+                             const orc_vs_proof *proofs, size_t n, const uint8_t *randomizers128,
+                             uint8_t *alg_ok, orc_g1_affine *total_c_out, orc_g1_affine *total_w_out, int threads) {
+    /* one random-linear-combination MSM over all proofs, vk commitments merged per circuit, G merged */
+    size_t per = ORC_VS_PROOF_COMMS + 2;
+    size_t npts = n * per + n_circuits * ORC_VS_VK_COMMS + 1;
+    orc_g1_affine *pts = (orc_g1_affine *)malloc(sizeof(orc_g1_affine) * npts);
+    orc_bigint256 *sc = (orc_bigint256 *)malloc(sizeof(orc_bigint256) * npts);
+    orc_g1_affine *wpts = (orc_g1_affine *)malloc(sizeof(orc_g1_affine) * n * 2);
+    orc_bigint256 *wsc = (orc_bigint256 *)malloc(sizeof(orc_bigint256) * n * 2);
+    fr_t *vk_acc = (fr_t *)calloc(n_circuits * ORC_VS_VK_COMMS, sizeof(fr_t));
+    fr_t g_acc;
+    fr_zero(&g_acc);
+    int all_alg = 1;
+    for (size_t i = 0; i < n; i++) {
+        const orc_vs_proof *p = &proofs[i];
+        vs_fr_work fw;
+        vs_derive(&fw, &circuits[p->circuit], p, randomizers128 + 32 * i);
+        alg_ok[i] = (uint8_t)fw.alg_ok;
+        all_alg &= fw.alg_ok;
+        for (int k = 0; k < ORC_VS_PROOF_COMMS; k++) {
+            pts[i * per + k] = p->comms[k];
+            fr_to_canonical(sc[i * per + k].l, &fw.poly_scalar[k]);
+        }
+        for (int q = 0; q < 2; q++) {
+            pts[i * per + ORC_VS_PROOF_COMMS + q] = p->w[q];
+            fr_to_canonical(sc[i * per + ORC_VS_PROOF_COMMS + q].l, &fw.w_scalar_c[q]);
+            wpts[2 * i + q] = p->w[q];
+            fr_to_canonical(wsc[2 * i + q].l, &fw.w_scalar_w[q]);
+        }
+        for (int k = 0; k < ORC_VS_VK_COMMS; k++) {
+            fr_t *a = &vk_acc[p->circuit * ORC_VS_VK_COMMS + k];
+            fr_add(a, a, &fw.poly_scalar[ORC_VS_PROOF_COMMS + k]);
+        }
+        fr_add(&g_acc, &g_acc, &fw.g_scalar);
+    }
+    size_t o = n * per;
+    for (size_t c = 0; c < n_circuits; c++)
+        for (int k = 0; k < ORC_VS_VK_COMMS; k++, o++) {
+            pts[o] = circuits[c].comms[k];
+            fr_to_canonical(sc[o].l, &vk_acc[c * ORC_VS_VK_COMMS + k]);
+        }
+    pts[o] = vk->g;
+    fr_to_canonical(sc[o].l, &g_acc);
+    orc_g1_jac tc, tw;
+    orc_msm_pippenger(&tc, pts, sc, npts, threads);
+    orc_msm_pippenger(&tw, wpts, wsc, n * 2, threads);
+    orc_g1_affine ps[2];
+    orc_g1_to_affine(&ps[0], &tc);
+    orc_g1_to_affine(&ps[1], &tw);
+    if (total_c_out) *total_c_out = ps[0];
+    if (total_w_out) *total_w_out = ps[1];
+    orc_g1_neg_affine(&ps[1], &ps[1]);
+    orc_g2_prepared *h = (orc_g2_prepared *)malloc(sizeof *h), *th = (orc_g2_prepared *)malloc(sizeof *th);
+    orc_g2_prepare(h, &vk->h);
+    orc_g2_prepare(th, &vk->tau_h);
+    const orc_g2_prepared *qs[2] = {h, th};
+    int ok = orc_pairing_product_is_one(ps, qs, 2);
+    free(h); free(th); free(pts); free(sc); free(wpts); free(wsc); free(vk_acc);
+    return ok == 1 && all_alg;
+}
+
+/* ---- synthetic prover (toy SRS: tau known) ---- */
+typedef struct { uint64_t s; } smix;
+static uint64_t smix_next(smix *g) {
+    g->s += 0x9E3779B97F4A7C15ull;
+    uint64_t z = g->s;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+static void smix_fr(smix *g, fr_t *out) { /* 3 words + a 60-bit top word: always < r, then to Montgomery */
+    uint64_t l[4];
+    for (int i = 0; i < 4; i++) l[i] = smix_next(g);
+    l[3] &= 0x0fffffffffffffffull;
+    fr_from_canonical(out, l);
+}
+#define VS_DEG 4 /* coefficients per synthetic polynomial */
+static void poly_eval(fr_t *r, const fr_t *c, const fr_t *x) {
+    *r = c[VS_DEG - 1];
+    for (int i = VS_DEG - 2; i >= 0; i--) { fr_mul(r, r, x); fr_add(r, r, &c[i]); }
+}
+
+void orc_vs_generate(uint64_t seed, size_t n, size_t n_circuits, uint32_t corrupt_per_1024, orc_kzg_vk *vk,
+                     orc_vs_circuit_vk *circuits, orc_vs_proof *proofs, uint8_t *randomizers128, uint8_t *expected) {
+    smix g = {seed};
+    fr_t tau;
+    smix_fr(&g, &tau);
+    orc_g1_generator(&vk->g);
+    orc_g2_generator(&vk->h);
+    orc_bigint256 tau_c;
+    fr_to_canonical(tau_c.l, &tau);
+    orc_g2_mul(&vk->tau_h, &vk->h, &tau_c);
+
+    /* circuit polynomials and commitments */
+    fr_t *cpoly = (fr_t *)malloc(sizeof(fr_t) * n_circuits * ORC_VS_VK_COMMS * VS_DEG);
+    fr_t *ctau = (fr_t *)malloc(sizeof(fr_t) * n_circuits * ORC_VS_VK_COMMS);
+    for (size_t i = 0; i < n_circuits * ORC_VS_VK_COMMS; i++) {
+        for (int d = 0; d < VS_DEG; d++) smix_fr(&g, &cpoly[i * VS_DEG + d]);
+        poly_eval(&ctau[i], &cpoly[i * VS_DEG], &tau);
+    }
+    orc_g1_affine *ccomm = (orc_g1_affine *)malloc(sizeof(orc_g1_affine) * n_circuits * ORC_VS_VK_COMMS);
+    orc_g1_fixed_base_batch(ccomm, (const orc_fr *)ctau, n_circuits * ORC_VS_VK_COMMS);
+    for (size_t c = 0; c < n_circuits; c++) {
+        memcpy(circuits[c].comms, &ccomm[c * ORC_VS_VK_COMMS], sizeof circuits[c].comms);
+        orc_sha256(circuits[c].digest, (const uint8_t *)circuits[c].comms, sizeof circuits[c].comms);
+    }
+
+    /* proof polynomials: p_1..p_8 random; p_0 = x_hat + (X^16-1) p_1 handled through its values */
+    fr_t *ppoly = (fr_t *)malloc(sizeof(fr_t) * n * ORC_VS_PROOF_COMMS * VS_DEG);
+    fr_t *ptau = (fr_t *)malloc(sizeof(fr_t) * n * ORC_VS_PROOF_COMMS);
+    for (size_t i = 0; i < n; i++) {
+        orc_vs_proof *p = &proofs[i];
+        memset(p, 0, sizeof *p);
+        p->circuit = (uint32_t)(smix_next(&g) % n_circuits);
+        for (int k = 0; k < ORC_VS_INPUTS; k++) smix_fr(&g, S(&p->inputs[k]));
+        for (int k = 0; k < ORC_VS_PROOF_COMMS; k++)
+            for (int d = 0; d < VS_DEG; d++) smix_fr(&g, &ppoly[(i * ORC_VS_PROOF_COMMS + k) * VS_DEG + d]);
+        for (int k = 1; k < ORC_VS_PROOF_COMMS; k++)
+            poly_eval(&ptau[i * ORC_VS_PROOF_COMMS + k], &ppoly[(i * ORC_VS_PROOF_COMMS + k) * VS_DEG], &tau);
+        fr_t xh, znm1, t;
+        vs_input_eval(&xh, &znm1, (const fr_t *)p->inputs, &tau);
+        fr_mul(&t, &znm1, &ptau[i * ORC_VS_PROOF_COMMS + 1]);
+        fr_add(&ptau[i * ORC_VS_PROOF_COMMS + 0], &xh, &t);
+        for (int k = 0; k < 32; k++) randomizers128[32 * i + k] = (uint8_t)smix_next(&g);
+    }
+    orc_g1_affine *pcomm = (orc_g1_affine *)malloc(sizeof(orc_g1_affine) * n * ORC_VS_PROOF_COMMS);
+    orc_g1_fixed_base_batch(pcomm, (const orc_fr *)ptau, n * ORC_VS_PROOF_COMMS);
+    for (size_t i = 0; i < n; i++) memcpy(proofs[i].comms, &pcomm[i * ORC_VS_PROOF_COMMS], sizeof proofs[i].comms);
+
+    /* evaluations: z_beta, z_gamma depend only on inputs + commitments */
+    fr_t *wk = (fr_t *)malloc(sizeof(fr_t) * n * 2);
+    for (size_t i = 0; i < n; i++) {
+        orc_vs_proof *p = &proofs[i];
+        const orc_vs_circuit_vk *cvk = &circuits[p->circuit];
+        fr_t z[2], xi, xip, t, num[2];
+        orc_vs_challenges(cvk, p, (orc_fr *)&z[0], (orc_fr *)&z[1], (orc_fr *)&xi);
+        for (int k = 0; k < ORC_VS_EVALS; k++) {
+            int q = vs_query_of(k);
+            const fr_t *poly = k < ORC_VS_PROOF_COMMS
+                                   ? &ppoly[(i * ORC_VS_PROOF_COMMS + k) * VS_DEG]
+                                   : &cpoly[(p->circuit * ORC_VS_VK_COMMS + (k - ORC_VS_PROOF_COMMS)) * VS_DEG];
+            poly_eval(S(&p->evals[k]), poly, &z[q]);
+        }
+        { /* p_0(z_beta) = x_hat(z_beta) + (z_beta^16-1) p_1(z_beta) */
+            fr_t xh, znm1;
+            if (vs_input_eval(&xh, &znm1, (const fr_t *)p->inputs, &z[0])) {
+                fr_mul(&t, &znm1, S(&p->evals[1]));
+                fr_add(S(&p->evals[0]), &xh, &t);
+            }
+        }
+        /* xi depends on the evaluations: recompute, then the witnesses */
+        orc_vs_challenges(cvk, p, (orc_fr *)&z[0], (orc_fr *)&z[1], (orc_fr *)&xi);
+        fr_one(&xip);
+        fr_zero(&num[0]);
+        fr_zero(&num[1]);
+        for (int k = 0; k < ORC_VS_EVALS; k++) {
+            int q = vs_query_of(k);
+            const fr_t *at_tau = k < ORC_VS_PROOF_COMMS ? &ptau[i * ORC_VS_PROOF_COMMS + k]
+                                                          : &ctau[p->circuit * ORC_VS_VK_COMMS + (k - ORC_VS_PROOF_COMMS)];
+            fr_sub(&t, at_tau, S(&p->evals[k]));
+            fr_mul(&t, &t, &xip);
+            fr_add(&num[q], &num[q], &t);
+            fr_mul(&xip, &xip, &xi);
+        }
+        for (int q = 0; q < 2; q++) {
+            fr_sub(&t, &tau, &z[q]);
+            fr_inv(&t, &t);
+            fr_mul(&wk[2 * i + q], &num[q], &t);
+        }
+    }
+    orc_g1_affine *wc = (orc_g1_affine *)malloc(sizeof(orc_g1_affine) * n * 2);
+    orc_g1_fixed_base_batch(wc, (const orc_fr *)wk, n * 2);
+    for (size_t i = 0; i < n; i++) {
+        proofs[i].w[0] = wc[2 * i];
+        proofs[i].w[1] = wc[2 * i + 1];
+        expected[i] = 1;
+    }
+    /* corruption: evaluations changed AFTER the witnesses were made (xi changes too), a witness swapped,
+     * or a public input changed */
+    for (size_t i = 0; i < n; i++) {
+        if ((smix_next(&g) & 1023) >= corrupt_per_1024) continue;
+        orc_vs_proof *p = &proofs[i];
+        fr_t one;
+        fr_one(&one);
+        switch (smix_next(&g) % 4) {
+        case 0: { int k = 2 + (int)(smix_next(&g) % (ORC_VS_EVALS - 2)); fr_add(S(&p->evals[k]), S(&p->evals[k]), &one); break; }
+        case 1: p->w[smix_next(&g) & 1] = vk->g; break;
+        case 2: fr_add(S(&p->inputs[smix_next(&g) % ORC_VS_INPUTS]), S(&p->inputs[0]), &one); break;
+        default: p->comms[2 + smix_next(&g) % 7] = vk->g; break;
+        }
+        expected[i] = 0;
+    }
+    free(cpoly); free(ctau); free(ccomm); free(ppoly); free(ptau); free(pcomm); free(wk); free(wc);
+}
+
+/* ------------------------------------------------------------------ self test */
+int orc_self_test(void) {
+    orc_g1_affine g;
+    orc_g2_affine h;
+    orc_g1_generator(&g);
+    orc_g2_generator(&h);
+    if (!orc_g1_is_on_curve(&g) || !orc_g2_is_on_curve(&h)) return 1;
+    orc_bigint256 rm1;
+    memcpy(rm1.l, ORC_FR_MODULUS, 32);
+    rm1.l[0] -= 1;
+    orc_g1_jac t;
+    orc_g1_affine a, ng;
+    orc_g1_mul(&t, &g, &rm1);
+    orc_g1_to_affine(&a, &t);
+    orc_g1_neg_affine(&ng, &g);
+    if (memcmp(&a, &ng, sizeof a)) return 2;
+    /* bilinearity e(5G, 7H) == e(G, H)^35 */
+    orc_bigint256 k5 = {{5, 0, 0, 0}}, k7 = {{7, 0, 0, 0}};
+    orc_g2_affine h7;
+    orc_g1_affine g5;
+    orc_g1_mul(&t, &g, &k5);
+    orc_g1_to_affine(&g5, &t);
+    orc_g2_mul(&h7, &h, &k7);
+    orc_fq12 e1, e0, acc;
+    orc_pairing(&e1, &g5, &h7);
+    orc_pairing(&e0, &g, &h);
+    orc_fq12_one(&acc);
+    for (int i = 0; i < 35; i++) orc_fq12_mul(&acc, &acc, &e0);
+    if (memcmp(&acc, &e1, sizeof acc)) return 3;
+    if (orc_fq12_is_one(&e0)) return 4;
+    return 0;
+}

@@ -1,0 +1,265 @@
+"""ctypes binding of the CPU oracle (oracle/liboracle.so).
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and bench.py's
+cpu_baseline leg.  The product package snarkos_amd never imports this module.
+All arrays are numpy uint64 with the ABI layout of include/mi355x_snark.h.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+VS_PROOF_BYTES = 2256
+VS_CIRCUIT_VK_BYTES = 1184
+KZG_VK_BYTES = 480
+
+
+def build(force=False):
+    so = os.path.join(_HERE, "liboracle.so")
+    srcs = [os.path.join(_HERE, f) for f in ("orc_core.c", "orc_algo.c", "orc.h", "orc_internal.h", "mont_tmpl.h", "constants.h")]
+    if force or not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs if os.path.exists(s)):
+        subprocess.check_call(["make", "-C", _HERE, "-B", "liboracle.so"], stdout=subprocess.DEVNULL)
+    return so
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        _LIB = C.CDLL(build())
+        _LIB.orc_self_test.restype = C.c_int
+        _LIB.orc_ntt.restype = C.c_int
+        for f in ("orc_kzg_check", "orc_kzg_batch_check", "orc_vs_verify_one", "orc_vs_verify_aggregated",
+                  "orc_g1_is_on_curve", "orc_g2_is_on_curve", "orc_fq12_is_one", "orc_pairing_product_is_one"):
+            getattr(_LIB, f).restype = C.c_int
+    return _LIB
+
+
+def _p(a):
+    assert a.flags["C_CONTIGUOUS"]
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def u64(shape):
+    return np.zeros(shape, dtype=np.uint64)
+
+
+# ----------------------------------------------------------------------------- int <-> limb helpers
+def int_to_limbs(v, n):
+    return np.array([(v >> (64 * i)) & 0xFFFFFFFFFFFFFFFF for i in range(n)], dtype=np.uint64)
+
+
+def limbs_to_int(a):
+    return sum(int(x) << (64 * i) for i, x in enumerate(np.asarray(a).reshape(-1)))
+
+
+def fr_from_ints(vals):
+    """canonical python ints -> Montgomery (n,4) array"""
+    can = np.stack([int_to_limbs(v, 4) for v in vals]) if len(vals) else u64((0, 4))
+    out = u64(can.shape)
+    for i in range(len(vals)):
+        lib().orc_fr_from_canonical(_p(out[i]), _p(np.ascontiguousarray(can[i])))
+    return out
+
+
+def fr_to_ints(arr):
+    arr = np.ascontiguousarray(arr, dtype=np.uint64).reshape(-1, 4)
+    out = []
+    t = u64(4)
+    for i in range(arr.shape[0]):
+        lib().orc_fr_to_canonical(_p(t), _p(np.ascontiguousarray(arr[i])))
+        out.append(limbs_to_int(t))
+    return out
+
+
+def fq_from_int(v):
+    out = u64(6)
+    lib().orc_fq_from_canonical(_p(out), _p(int_to_limbs(v, 6)))
+    return out
+
+
+def fq_to_int(a):
+    t = u64(6)
+    lib().orc_fq_to_canonical(_p(t), _p(np.ascontiguousarray(a, dtype=np.uint64)))
+    return limbs_to_int(t)
+
+
+def g1_from_ints(P):
+    """affine python point (x, y) or None -> (12,) Montgomery array"""
+    out = u64(12)
+    if P is not None:
+        out[:6] = fq_from_int(P[0])
+        out[6:] = fq_from_int(P[1])
+    return out
+
+
+def g1_to_ints(a):
+    a = np.ascontiguousarray(a, dtype=np.uint64).reshape(12)
+    if not a.any():
+        return None
+    return (fq_to_int(a[:6]), fq_to_int(a[6:]))
+
+
+def g2_from_ints(Qp):
+    out = u64(24)
+    if Qp is not None:
+        out[0:6] = fq_from_int(Qp[0][0])
+        out[6:12] = fq_from_int(Qp[0][1])
+        out[12:18] = fq_from_int(Qp[1][0])
+        out[18:24] = fq_from_int(Qp[1][1])
+    return out
+
+
+def g2_to_ints(a):
+    a = np.ascontiguousarray(a, dtype=np.uint64).reshape(24)
+    if not a.any():
+        return None
+    return ((fq_to_int(a[0:6]), fq_to_int(a[6:12])), (fq_to_int(a[12:18]), fq_to_int(a[18:24])))
+
+
+def jac_to_affine(j):
+    out = u64(12)
+    lib().orc_g1_to_affine(_p(out), _p(np.ascontiguousarray(j, dtype=np.uint64)))
+    return out
+
+
+def fq12_to_power_basis(a):
+    """(72,) tower array -> 12 python ints, coefficient of w^k at index k (k = i + 2j + 6b)."""
+    a = np.ascontiguousarray(a, dtype=np.uint64).reshape(2, 3, 2, 6)
+    out = [0] * 12
+    for i in range(2):
+        for j in range(3):
+            for b in range(2):
+                out[i + 2 * j + 6 * b] = fq_to_int(a[i, j, b])
+    return out
+
+
+# ----------------------------------------------------------------------------- algorithms
+def g1_generator():
+    g = u64(12)
+    lib().orc_g1_generator(_p(g))
+    return g
+
+
+def g2_generator():
+    g = u64(24)
+    lib().orc_g2_generator(_p(g))
+    return g
+
+
+def g1_mul(p, k):
+    out = u64(18)
+    lib().orc_g1_mul(_p(out), _p(np.ascontiguousarray(p)), _p(int_to_limbs(k, 4)))
+    return jac_to_affine(out)
+
+
+def g2_mul(p, k):
+    out = u64(24)
+    lib().orc_g2_mul(_p(out), _p(np.ascontiguousarray(p)), _p(int_to_limbs(k, 4)))
+    return out
+
+
+def fixed_base_batch(k_mont):
+    k_mont = np.ascontiguousarray(k_mont, dtype=np.uint64).reshape(-1, 4)
+    out = u64((k_mont.shape[0], 12))
+    lib().orc_g1_fixed_base_batch(_p(out), _p(k_mont), C.c_size_t(k_mont.shape[0]))
+    return out
+
+
+def msm_naive(bases, scalars):
+    n = min(len(bases), len(scalars))
+    out = u64(18)
+    lib().orc_msm_naive(_p(out), _p(np.ascontiguousarray(bases)), _p(np.ascontiguousarray(scalars)), C.c_size_t(n))
+    return jac_to_affine(out)
+
+
+def msm_pippenger(bases, scalars, threads=1):
+    n = min(len(bases), len(scalars))
+    out = u64(18)
+    lib().orc_msm_pippenger(_p(out), _p(np.ascontiguousarray(bases)), _p(np.ascontiguousarray(scalars)),
+                            C.c_size_t(n), C.c_int(threads))
+    return jac_to_affine(out)
+
+
+def ntt(data, inverse=False, coset=False, threads=1):
+    a = np.array(data, dtype=np.uint64, copy=True).reshape(-1, 4)
+    log_n = a.shape[0].bit_length() - 1
+    assert 1 << log_n == a.shape[0]
+    rc = lib().orc_ntt(_p(a), C.c_uint32(log_n), C.c_int(int(inverse)), C.c_int(int(coset)), C.c_int(threads))
+    assert rc == 0
+    return a
+
+
+def dft_naive(data):
+    a = np.ascontiguousarray(data, dtype=np.uint64).reshape(-1, 4)
+    out = u64(a.shape)
+    lib().orc_dft_naive(_p(out), _p(a), C.c_uint32(a.shape[0].bit_length() - 1))
+    return out
+
+
+def pairing(p, q):
+    out = u64(72)
+    lib().orc_pairing(_p(out), _p(np.ascontiguousarray(p)), _p(np.ascontiguousarray(q)))
+    return out
+
+
+def kzg_vk(tau):
+    vk = u64(KZG_VK_BYTES // 8)
+    vk[0:12] = g1_generator()
+    vk[12:36] = g2_generator()
+    vk[36:60] = g2_mul(g2_generator(), tau)
+    return vk
+
+
+def kzg_batch_check(vk, comms, points, values, witnesses, randomizers):
+    n = len(comms)
+    rnd = np.ascontiguousarray(randomizers, dtype=np.uint8).reshape(-1)
+    assert rnd.size == 16 * n
+    return bool(lib().orc_kzg_batch_check(_p(vk), _p(np.ascontiguousarray(comms)), _p(np.ascontiguousarray(points)),
+                                          _p(np.ascontiguousarray(values)), _p(np.ascontiguousarray(witnesses)),
+                                          C.c_size_t(n), _p(rnd)))
+
+
+def sha256(b):
+    out = np.zeros(32, dtype=np.uint8)
+    buf = np.frombuffer(bytes(b), dtype=np.uint8).copy() if len(b) else np.zeros(1, dtype=np.uint8)
+    lib().orc_sha256(_p(out), _p(buf), C.c_size_t(len(b)))
+    return out.tobytes()
+
+
+class VSBatch:
+    """A synthetic VarunaShaped-v1 batch in ABI layout."""
+
+    def __init__(self, seed, n, n_circuits=8, corrupt_per_1024=0):
+        self.n, self.n_circuits, self.seed = n, n_circuits, seed
+        self.vk = np.zeros(KZG_VK_BYTES, dtype=np.uint8)
+        self.circuits = np.zeros(n_circuits * VS_CIRCUIT_VK_BYTES, dtype=np.uint8)
+        self.proofs = np.zeros(n * VS_PROOF_BYTES, dtype=np.uint8)
+        self.randomizers = np.zeros(n * 32, dtype=np.uint8)
+        self.expected = np.zeros(n, dtype=np.uint8)
+        lib().orc_vs_generate(C.c_uint64(seed), C.c_size_t(n), C.c_size_t(n_circuits), C.c_uint32(corrupt_per_1024),
+                              _p(self.vk), _p(self.circuits), _p(self.proofs), _p(self.randomizers), _p(self.expected))
+
+    def verify_cpu(self, threads=1):
+        v = np.zeros(self.n, dtype=np.uint8)
+        lib().orc_vs_verify_batch_cpu(_p(self.vk), _p(self.circuits), _p(self.proofs), C.c_size_t(self.n),
+                                      _p(self.randomizers), _p(v), C.c_int(threads))
+        return v
+
+    def verify_aggregated(self, threads=1):
+        alg = np.zeros(self.n, dtype=np.uint8)
+        tc, tw = u64(12), u64(12)
+        ok = lib().orc_vs_verify_aggregated(_p(self.vk), _p(self.circuits), C.c_size_t(self.n_circuits), _p(self.proofs),
+                                            C.c_size_t(self.n), _p(self.randomizers), _p(alg), _p(tc), _p(tw), C.c_int(threads))
+        return bool(ok), alg, tc, tw
+
+    def challenges(self, i):
+        p = self.proofs[i * VS_PROOF_BYTES:(i + 1) * VS_PROOF_BYTES]
+        circuit = int(np.frombuffer(p[:4].tobytes(), dtype=np.uint32)[0])
+        cvk = self.circuits[circuit * VS_CIRCUIT_VK_BYTES:(circuit + 1) * VS_CIRCUIT_VK_BYTES]
+        zb, zg, xi = u64(4), u64(4), u64(4)
+        lib().orc_vs_challenges(_p(np.ascontiguousarray(cvk)), _p(np.ascontiguousarray(p)), _p(zb), _p(zg), _p(xi))
+        return fr_to_ints(zb)[0], fr_to_ints(zg)[0], fr_to_ints(xi)[0]

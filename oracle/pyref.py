@@ -1,0 +1,502 @@
+"""Independent Python big-int restatement of the BLS12-377 arithmetic on the hot path.
+
+TEST INFRASTRUCTURE ONLY.  Nothing under snarkos_amd/ may import this file; it is
+used by tests/ and by oracle/gen_golden.py to pin the C oracle (oracle/*.c).
+
+PARITY UNPINNED: the reference's implementation of this path lives in the
+un-vendored crate family snarkVM 1.0.0 @ git rev dea322b (Cargo.toml:47-52,
+Cargo.lock:3578-3580 of the reference); no golden vector for MSM / NTT / KZG /
+pairing exists in the reference tree.  The oracle is
+therefore pinned by mathematics: every constant below is *derived* from the BLS12
+seed x, and every algorithm is the textbook definition (affine chord-and-tangent,
+O(n^2) DFT, generic Miller loop over E(Fq12) in the power basis Fq[w]/(w^12+5),
+final exponentiation by one big pow()).  The C oracle uses different algorithms
+(Montgomery limbs, Jacobian coordinates, tower Fq2/Fq6/Fq12, sparse lines,
+x-chains), so agreement between the two is a real cross-check.
+
+Conventions that follow the snarkVM surface named in SURVEY.md Appendix B
+(VariableBase::msm, EvaluationDomain::{fft,ifft}, KZG10::{check,batch_check}):
+  * MSM: sum_i scalars[i] * bases[i], scalars canonical integers < r.
+  * NTT: natural order in/out, omega_n = ROOT^(2^(47-log n)), ROOT = 22^((r-1)/2^47);
+    inverse scales by n^-1; coset shift by the multiplicative generator 22.
+  * KZG10 single check:  e(C - v*G, H) == e(W, tauH - z*H)
+    batch check with randomizers r_i:
+       e(sum r_i (C_i - v_i G + z_i W_i), H) * e(-sum r_i W_i, tauH) == 1
+"""
+import hashlib
+
+# ----------------------------------------------------------------------------- constants
+X = 0x8508C00000000001
+R = X**4 - X**2 + 1
+Q = (X - 1) ** 2 * R // 3 + X
+assert R == 0x12AB655E9A2CA55660B44D1E5C37B00159AA76FED00000010A11800000000001
+assert Q == 0x01AE3A4617C510EAC63B05C06CA1493B1A22D9F300F5138F1EF3622FBA094800170B5D44300000008508C00000000001
+
+G1_GEN = (
+    81937999373150964239938255573465948239988671502647976594219695644855304257327692006745978603320413799295628339695,
+    241266749859715473739788878240585681733927191168601896383759122102112907357779751001206799952863815012735208165030,
+)
+G2_GEN = (
+    (233578398248691099356572568220835526895379068987715365179118596935057653620464273615301663571204657964920925606294,
+     140913150380207355837477652521042157274541796891053068589147167627541651775299824604154852141315666357241556069118),
+    (63160294768292073209381361943935198908131692476676907196754037919244929611450776219210369229519898517858833747423,
+     149157405641012693445398062341192467754805999074082136895788947234480009303640899064710353187729182149407503257491),
+)
+FR_TWO_ADICITY = 47
+FR_GENERATOR = 22
+FR_ROOT = pow(FR_GENERATOR, (R - 1) >> FR_TWO_ADICITY, R)
+assert FR_ROOT == 8065159656716812877374967518403273466521432693661810619979959746626482506078
+NONRES = -5  # Fq2 = Fq[u]/(u^2+5); Fq12 = Fq[w]/(w^12+5) with u = w^6, v = w^2
+
+FR_MONT_R = (1 << 256) % R
+FQ_MONT_R = (1 << 384) % Q
+
+
+def inv(a, p):
+    return pow(a, p - 2, p)
+
+
+# ----------------------------------------------------------------------------- Fq2
+def fq2_add(a, b):
+    return ((a[0] + b[0]) % Q, (a[1] + b[1]) % Q)
+
+
+def fq2_sub(a, b):
+    return ((a[0] - b[0]) % Q, (a[1] - b[1]) % Q)
+
+
+def fq2_mul(a, b):
+    return ((a[0] * b[0] + NONRES * a[1] * b[1]) % Q, (a[0] * b[1] + a[1] * b[0]) % Q)
+
+
+def fq2_inv(a):
+    n = inv((a[0] * a[0] - NONRES * a[1] * a[1]) % Q, Q)
+    return (a[0] * n % Q, (-a[1]) * n % Q)
+
+
+def fq2_neg(a):
+    return ((-a[0]) % Q, (-a[1]) % Q)
+
+
+# ----------------------------------------------------------------------------- Fq12, power basis
+def f12_one():
+    return [1] + [0] * 11
+
+
+def f12_mul(a, b):
+    t = [0] * 23
+    for i in range(12):
+        ai = a[i]
+        if ai:
+            for j in range(12):
+                t[i + j] += ai * b[j]
+    return [(t[k] + NONRES * t[k + 12]) % Q if k < 11 else t[k] % Q for k in range(12)]
+
+
+def f12_pow(a, e):
+    r = f12_one()
+    for bit in bin(e)[2:]:
+        r = f12_mul(r, r)
+        if bit == "1":
+            r = f12_mul(r, a)
+    return r
+
+
+def f12_from_fq2(c, shift):
+    """c0 + c1*u placed at w^shift: u = w^6."""
+    out = [0] * 12
+    out[shift % 12] = c[0]
+    k = shift + 6
+    if k >= 12:
+        out[k - 12] = (out[k - 12] + NONRES * c[1]) % Q
+    else:
+        out[k] = c[1]
+    return out
+
+
+def f12_add(a, b):
+    return [(x + y) % Q for x, y in zip(a, b)]
+
+
+def f12_sub(a, b):
+    return [(x - y) % Q for x, y in zip(a, b)]
+
+
+def f12_inv(a):
+    # a^(q^12-2) is far too slow; use linear algebra-free trick: norm down via conjugates is
+    # overkill here.  Solve a * b = 1 by Gaussian elimination over Fq (12x12).
+    n = 12
+    M = [[0] * (n + 1) for _ in range(n)]
+    for j in range(n):
+        e = [0] * 12
+        e[j] = 1
+        col = f12_mul(a, e)
+        for i in range(n):
+            M[i][j] = col[i]
+    M[0][n] = 1
+    for c in range(n):
+        p = next(i for i in range(c, n) if M[i][c] % Q)
+        M[c], M[p] = M[p], M[c]
+        iv = inv(M[c][c], Q)
+        M[c] = [x * iv % Q for x in M[c]]
+        for i in range(n):
+            if i != c and M[i][c]:
+                f = M[i][c]
+                M[i] = [(x - f * y) % Q for x, y in zip(M[i], M[c])]
+    return [M[i][n] for i in range(n)]
+
+
+# ----------------------------------------------------------------------------- G1 (affine, None = infinity)
+def g1_is_on_curve(P):
+    if P is None:
+        return True
+    x, y = P
+    return (y * y - x * x * x - 1) % Q == 0
+
+
+def g1_neg(P):
+    return None if P is None else (P[0], (-P[1]) % Q)
+
+
+def g1_add(P, S):
+    if P is None:
+        return S
+    if S is None:
+        return P
+    x1, y1 = P
+    x2, y2 = S
+    if x1 == x2:
+        if (y1 + y2) % Q == 0:
+            return None
+        lam = 3 * x1 * x1 * inv(2 * y1, Q) % Q
+    else:
+        lam = (y2 - y1) * inv((x2 - x1) % Q, Q) % Q
+    x3 = (lam * lam - x1 - x2) % Q
+    return (x3, (lam * (x1 - x3) - y1) % Q)
+
+
+def g1_mul(P, k):
+    k %= R
+    acc = None
+    for bit in bin(k)[2:] if k else "":
+        acc = g1_add(acc, acc)
+        if bit == "1":
+            acc = g1_add(acc, P)
+    return acc
+
+
+def msm(bases, scalars):
+    """VariableBase::msm semantic: sum scalars[i]*bases[i] over min(len) items."""
+    acc = None
+    for P, s in zip(bases, scalars):
+        acc = g1_add(acc, g1_mul(P, s))
+    return acc
+
+
+# ----------------------------------------------------------------------------- G2 on the D-twist y^2 = x^3 + 1/u
+TWIST_B = fq2_inv((0, 1))
+
+
+def g2_is_on_curve(P):
+    if P is None:
+        return True
+    x, y = P
+    return fq2_sub(fq2_mul(y, y), fq2_add(fq2_mul(fq2_mul(x, x), x), TWIST_B)) == (0, 0)
+
+
+def g2_add(P, S):
+    if P is None:
+        return S
+    if S is None:
+        return P
+    x1, y1 = P
+    x2, y2 = S
+    if x1 == x2:
+        if fq2_add(y1, y2) == (0, 0):
+            return None
+        xx = fq2_mul(x1, x1)
+        lam = fq2_mul(fq2_add(fq2_add(xx, xx), xx), fq2_inv(fq2_add(y1, y1)))
+    else:
+        lam = fq2_mul(fq2_sub(y2, y1), fq2_inv(fq2_sub(x2, x1)))
+    x3 = fq2_sub(fq2_sub(fq2_mul(lam, lam), x1), x2)
+    return (x3, fq2_sub(fq2_mul(lam, fq2_sub(x1, x3)), y1))
+
+
+def g2_mul(P, k):
+    k %= R
+    acc = None
+    for bit in bin(k)[2:] if k else "":
+        acc = g2_add(acc, acc)
+        if bit == "1":
+            acc = g2_add(acc, P)
+    return acc
+
+
+# ----------------------------------------------------------------------------- pairing (generic, E(Fq12))
+def _untwist(Qp):
+    """psi: E'(Fq2) -> E(Fq12), (x', y') -> (x' w^2, y' w^3)."""
+    return (f12_from_fq2(Qp[0], 2), f12_from_fq2(Qp[1], 3))
+
+
+def miller_loop(P, Qp):
+    """f_{x,psi(Q)}(P): ate Miller loop over the seed x with affine lines in Fq12."""
+    if P is None or Qp is None:
+        return f12_one()
+    xq, yq = _untwist(Qp)
+    xp = [P[0]] + [0] * 11
+    yp = [P[1]] + [0] * 11
+    T = (xq, yq)
+    f = f12_one()
+
+    def line(T1, T2):
+        x1, y1 = T1
+        x2, y2 = T2
+        if x1 == x2 and y1 == y2:
+            xx = f12_mul(x1, x1)
+            lam = f12_mul(f12_add(f12_add(xx, xx), xx), f12_inv(f12_add(y1, y1)))
+        else:
+            lam = f12_mul(f12_sub(y2, y1), f12_inv(f12_sub(x2, x1)))
+        x3 = f12_sub(f12_sub(f12_mul(lam, lam), x1), x2)
+        y3 = f12_sub(f12_mul(lam, f12_sub(x1, x3)), y1)
+        # l(P) = yP - y1 - lam (xP - x1)
+        val = f12_sub(f12_sub(yp, y1), f12_mul(lam, f12_sub(xp, x1)))
+        return val, (x3, y3)
+
+    for bit in bin(X)[3:]:
+        l, T = line(T, T)
+        f = f12_mul(f12_mul(f, f), l)
+        if bit == "1":
+            l, T = line(T, (xq, yq))
+            f = f12_mul(f, l)
+    return f
+
+
+FINAL_EXP = (Q**12 - 1) // R
+# The x-chain used by optimised implementations computes the cube of the reduced pairing:
+#   3*(q^4-q^2+1)/r = (x-1)^2 (x+q) (x^2+q^2-1) + 3
+assert 3 * ((Q**4 - Q**2 + 1) // R) == (X - 1) ** 2 * (X + Q) * (X * X + Q * Q - 1) + 3
+
+
+def final_exponentiation(f, cubed=True):
+    return f12_pow(f, FINAL_EXP * (3 if cubed else 1))
+
+
+def pairing(P, Qp, cubed=True):
+    return final_exponentiation(miller_loop(P, Qp), cubed)
+
+
+def pairing_product_is_one(pairs):
+    f = f12_one()
+    for P, Qp in pairs:
+        f = f12_mul(f, miller_loop(P, Qp))
+    return final_exponentiation(f, cubed=False) == f12_one()
+
+
+# ----------------------------------------------------------------------------- NTT over Fr
+def omega(log_n):
+    return pow(FR_ROOT, 1 << (FR_TWO_ADICITY - log_n), R)
+
+
+def dft(a, w):
+    n = len(a)
+    return [sum(a[j] * pow(w, i * j, R) for j in range(n)) % R for i in range(n)]
+
+
+def ntt(a, inverse=False, coset=False):
+    """EvaluationDomain::{fft, ifft, coset_fft, coset_ifft} semantics, natural order."""
+    n = len(a)
+    log_n = n.bit_length() - 1
+    assert 1 << log_n == n
+    a = list(a)
+    w = omega(log_n)
+    if not inverse:
+        if coset:
+            g = 1
+            for i in range(n):
+                a[i] = a[i] * g % R
+                g = g * FR_GENERATOR % R
+        return _fft(a, w)
+    out = _fft(a, inv(w, R))
+    ninv = inv(n, R)
+    out = [x * ninv % R for x in out]
+    if coset:
+        gi = inv(FR_GENERATOR, R)
+        g = 1
+        for i in range(n):
+            out[i] = out[i] * g % R
+            g = g * gi % R
+    return out
+
+
+def _fft(a, w):
+    n = len(a)
+    if n == 1:
+        return a
+    ev = _fft(a[0::2], w * w % R)
+    od = _fft(a[1::2], w * w % R)
+    out = [0] * n
+    t = 1
+    for i in range(n // 2):
+        o = od[i] * t % R
+        out[i] = (ev[i] + o) % R
+        out[i + n // 2] = (ev[i] - o) % R
+        t = t * w % R
+    return out
+
+
+# ----------------------------------------------------------------------------- KZG10
+def kzg_check(vk_tau_h, C, z, v, W):
+    """e(C - v G, H) == e(W, tauH - zH), written as a pairing product."""
+    lhs = g1_add(C, g1_neg(g1_mul(G1_GEN, v)))
+    lhs = g1_add(lhs, g1_mul(W, z))
+    return pairing_product_is_one([(lhs, G2_GEN), (g1_neg(W), vk_tau_h)])
+
+
+def kzg_batch_check(vk_tau_h, Cs, zs, vs, Ws, rs):
+    total_c = None
+    total_w = None
+    gs = 0
+    for C, z, v, W, r in zip(Cs, zs, vs, Ws, rs):
+        total_c = g1_add(total_c, g1_mul(g1_add(C, g1_mul(W, z)), r))
+        gs = (gs + r * v) % R
+        total_w = g1_add(total_w, g1_mul(W, r))
+    total_c = g1_add(total_c, g1_neg(g1_mul(G1_GEN, gs)))
+    return pairing_product_is_one([(total_c, G2_GEN), (g1_neg(total_w), vk_tau_h)])
+
+
+# ----------------------------------------------------------------------------- byte / limb helpers (ABI layout)
+def to_limbs(v, n):
+    return [(v >> (64 * i)) & 0xFFFFFFFFFFFFFFFF for i in range(n)]
+
+
+def from_limbs(l):
+    return sum(int(x) << (64 * i) for i, x in enumerate(l))
+
+
+def fq_to_mont(a):
+    return a * FQ_MONT_R % Q
+
+
+def fq_from_mont(a):
+    return a * inv(FQ_MONT_R, Q) % Q
+
+
+def fr_to_mont(a):
+    return a * FR_MONT_R % R
+
+
+def fr_from_mont(a):
+    return a * inv(FR_MONT_R, R) % R
+
+
+def sha256(b):
+    return hashlib.sha256(b).digest()
+
+
+# ----------------------------------------------------------------------------- splitmix64 (shared PRNG spec)
+class SplitMix64:
+    def __init__(self, seed):
+        self.s = seed & 0xFFFFFFFFFFFFFFFF
+
+    def next(self):
+        self.s = (self.s + 0x9E3779B97F4A7C15) & 0xFFFFFFFFFFFFFFFF
+        z = self.s
+        z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & 0xFFFFFFFFFFFFFFFF
+        z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & 0xFFFFFFFFFFFFFFFF
+        return z ^ (z >> 31)
+
+    def below(self, p, limbs):
+        """Uniform-ish value < p: draw `limbs` 64-bit words (little-endian), reduce mod p."""
+        v = 0
+        for i in range(limbs):
+            v |= self.next() << (64 * i)
+        return v % p
+
+
+# ----------------------------------------------------------------------------- VarunaShaped-v1
+VS_TAG = b"MI355X-VarunaShaped-v1".ljust(32, b"\0")
+VS_INPUTS, VS_PROOF_COMMS, VS_VK_COMMS, VS_EVALS = 16, 9, 12, 21
+VS_PROOF_BYTES, VS_CIRCUIT_VK_BYTES = 2256, 1184
+
+
+def _rd_fr(b):
+    return fr_from_mont(int.from_bytes(b, "little"))
+
+
+def _rd_g1(b):
+    if not any(b):
+        return None
+    return (fq_from_mont(int.from_bytes(b[:48], "little")), fq_from_mont(int.from_bytes(b[48:96], "little")))
+
+
+def vs_parse_proof(b):
+    assert len(b) == VS_PROOF_BYTES
+    o = 16
+    d = {"circuit": int.from_bytes(b[:4], "little"), "raw": bytes(b)}
+    d["inputs"] = [_rd_fr(b[o + 32 * i:o + 32 * i + 32]) for i in range(VS_INPUTS)]
+    o += 32 * VS_INPUTS
+    d["comms"] = [_rd_g1(b[o + 96 * i:o + 96 * i + 96]) for i in range(VS_PROOF_COMMS)]
+    o += 96 * VS_PROOF_COMMS
+    d["evals"] = [_rd_fr(b[o + 32 * i:o + 32 * i + 32]) for i in range(VS_EVALS)]
+    o += 32 * VS_EVALS
+    d["w"] = [_rd_g1(b[o + 96 * i:o + 96 * i + 96]) for i in range(2)]
+    return d
+
+
+def vs_parse_circuit(b):
+    assert len(b) == VS_CIRCUIT_VK_BYTES
+    return {"comms": [_rd_g1(b[96 * i:96 * i + 96]) for i in range(VS_VK_COMMS)], "digest": bytes(b[1152:1184])}
+
+
+def vs_challenges(cvk, proof):
+    """Transcript over the in-memory (Montgomery, little-endian) bytes of the proof."""
+    raw = proof["raw"]
+    inputs = raw[16:16 + 512]
+    comms = raw[528:528 + 864]
+    evals = raw[1392:1392 + 672]
+    h = sha256(VS_TAG + cvk["digest"] + inputs + comms[:192])
+    h = sha256(h + comms[192:480])
+    zb = int.from_bytes(h[:16], "little")
+    h = sha256(h + comms[480:864])
+    zg = int.from_bytes(h[:16], "little")
+    h = sha256(h + evals)
+    xi = int.from_bytes(h[:16], "little")
+    return zb, zg, xi
+
+
+def vs_query_of(p):
+    if p < VS_PROOF_COMMS:
+        return 0 if p < 5 else 1
+    return 0 if (p - VS_PROOF_COMMS) < 6 else 1
+
+
+def vs_verify_one(tau_h, circuits, proof, r_beta, r_gamma):
+    """Per-proof verdict = public-input consistency AND the two KZG openings (randomised together)."""
+    cvk = circuits[proof["circuit"]]
+    zb, zg, xi = vs_challenges(cvk, proof)
+    z = (zb, zg)
+    r = (r_beta, r_gamma)
+    ev = proof["evals"]
+    # algebraic check
+    zn = pow(zb, VS_INPUTS, R)
+    if zn == 1:
+        return False
+    w = omega(4)
+    xhat = 0
+    for k in range(VS_INPUTS):
+        wk = pow(w, k, R)
+        xhat += proof["inputs"][k] * wk * inv((zb - wk) % R, R)
+    xhat = xhat * (zn - 1) * inv(VS_INPUTS, R) % R
+    alg_ok = ev[0] == (xhat + (zn - 1) * ev[1]) % R
+    total_c, total_w, gs = None, None, 0
+    for p in range(VS_EVALS):
+        q = vs_query_of(p)
+        cm = proof["comms"][p] if p < VS_PROOF_COMMS else cvk["comms"][p - VS_PROOF_COMMS]
+        coef = r[q] * pow(xi, p, R) % R
+        total_c = g1_add(total_c, g1_mul(cm, coef))
+        gs = (gs + coef * ev[p]) % R
+    for q in range(2):
+        total_c = g1_add(total_c, g1_mul(proof["w"][q], r[q] * z[q] % R))
+        total_w = g1_add(total_w, g1_mul(proof["w"][q], r[q]))
+    total_c = g1_add(total_c, g1_neg(g1_mul(G1_GEN, gs)))
+    return alg_ok and pairing_product_is_one([(total_c, G2_GEN), (g1_neg(total_w), tau_h)])
