@@ -1,0 +1,121 @@
+/* libmi355x_snark -- MI355X-native BLS12-377 batch SNARK verification primitives (C ABI).
+ *
+ * The drop-in boundary for snarkOS's consensus-side verification path.  snarkOS itself has no FFI
+ * seam on this path: it calls Ledger::check_next_block / check_transaction_basic
+ * (reference node/bft/ledger-service/src/ledger.rs:319-347, node/consensus/src/lib.rs:499), which run
+ * snarkvm_algorithms::{msm, fft, polycommit, snark::varuna} (snarkVM 1.0.0 @ dea322b, the dependency
+ * pinned at reference Cargo.toml:47-52).  The entry points below are what a `hip` feature of
+ * snarkvm-algorithms would bind, at the same three gates its `cuda` feature uses:
+ *
+ *   mi_msm_g1*            <- msm::VariableBase::msm(bases: &[G1Affine], scalars: &[BigInteger256])
+ *   mi_ntt_fr*            <- fft::EvaluationDomain::{fft,ifft,coset_fft,coset_ifft}_in_place
+ *   mi_kzg_batch_check    <- polycommit::kzg10::KZG10::batch_check
+ *   mi_vs_verify_batch*   <- snark::varuna::VarunaSNARK::verify_batch, driven per block by
+ *                            VM::check_transactions; see DESIGN.md "VarunaShaped-v1"
+ *                            for the synthetic proof shape this round implements.
+ *
+ * Conventions
+ *   - plain C, no C++/torch types; integers are little-endian 64-bit limbs.
+ *   - field elements cross the ABI in Montgomery form (R = 2^256 for Fr, 2^384 for Fq), exactly the
+ *     bytes the Rust side holds; MSM scalars are canonical integers < r (BigInteger256).
+ *   - mi_g1_affine is 96 bytes {x, y}; the point at infinity is x = y = 0.
+ *   - every function returns a status: MI_OK or a negative error class.  A status never carries a
+ *     verdict; verdicts are separate uint8 outputs.  On any non-zero status the caller falls back to
+ *     its own CPU path (the contract of snarkVM's cuda gate).  No exception or abort crosses the ABI.
+ *   - thread-safe and re-entrant: any host thread may call any function; calls are serialised per
+ *     device inside the library.  The caller owns every buffer for the duration of the call.
+ *   - "_device" variants take HIP device pointers (inputs already resident in HBM) and a hipStream_t
+ *     passed as void*; the plain variants take host pointers and stage them.
+ */
+#ifndef MI355X_SNARK_H
+#define MI355X_SNARK_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MI_OK 0
+#define MI_ERR_BAD_ARGS (-1)
+#define MI_ERR_NO_DEVICE (-2)
+#define MI_ERR_OOM (-3)
+#define MI_ERR_KERNEL (-4)
+#define MI_ERR_NOT_INIT (-5)
+
+typedef struct { uint64_t l[4]; } mi_fr;        /* Fr, Montgomery */
+typedef struct { uint64_t l[4]; } mi_bigint256; /* canonical integer < r */
+typedef struct { uint64_t l[6]; } mi_fq;        /* Fq, Montgomery */
+typedef struct { mi_fq x, y; } mi_g1_affine;    /* 96 B, infinity <=> x == y == 0 */
+typedef struct { mi_fq x, y, z; } mi_g1_jac;    /* 144 B Jacobian, infinity <=> z == 0; outputs are normalised (z = 1) */
+typedef struct { mi_fq x[2], y[2]; } mi_g2_affine; /* 192 B, Fq2 = c0 + c1 u, u^2 = -5 */
+typedef struct { mi_fq c[12]; } mi_fq12;        /* tower order c0.c0.c0, c0.c0.c1, c0.c1.c0, ... (Fq12 = Fq6[w], Fq6 = Fq2[v]) */
+typedef struct { mi_g1_affine g; mi_g2_affine h, tau_h; } mi_kzg_vk; /* kzg10::VerifierKey {g, h, beta_h} */
+
+/* ---- lifecycle ---- */
+int32_t mi_init(int32_t device);          /* device < 0: keep the current HIP device.  Idempotent. */
+int32_t mi_shutdown(void);
+const char *mi_error_string(int32_t status);
+int32_t mi_abi_version(void);
+
+/* ---- msm::VariableBase::msm ---- */
+int32_t mi_msm_g1(const mi_g1_affine *bases, const mi_bigint256 *scalars, size_t n, mi_g1_jac *out);
+int32_t mi_msm_g1_device(const void *d_bases, const void *d_scalars, size_t n, mi_g1_jac *out, void *stream);
+/* bases kept resident in HBM (SRS powers, verifying-key commitments) */
+int32_t mi_bases_register(const mi_g1_affine *pts, size_t n, uint64_t *handle_out);
+int32_t mi_bases_release(uint64_t handle);
+int32_t mi_msm_g1_h(uint64_t bases_handle, size_t offset, const mi_bigint256 *scalars, size_t n, mi_g1_jac *out);
+
+/* ---- fft::EvaluationDomain::{fft,ifft,coset_fft,coset_ifft}_in_place ----
+ * natural order in and out; omega_n = ROOT^(2^(47 - log_n)); inverse scales by n^-1; coset generator 22 */
+int32_t mi_ntt_fr(mi_fr *data, uint32_t log_n, int32_t inverse, int32_t coset);
+int32_t mi_ntt_fr_device(void *d_data, uint32_t log_n, int32_t inverse, int32_t coset, void *stream);
+
+/* ---- pairing (Bls12_377::{miller_loop, final_exponentiation, product_of_pairings}) ---- */
+int32_t mi_pairing_product_is_one(const mi_g1_affine *ps, const mi_g2_affine *qs, size_t n, uint8_t *is_one);
+int32_t mi_pairing(const mi_g1_affine *p, const mi_g2_affine *q, mi_fq12 *out); /* f^(3(q^12-1)/r) */
+
+/* ---- kzg10::KZG10::batch_check ----  randomizers128: n x 16 bytes from the caller's RNG */
+int32_t mi_kzg_batch_check(const mi_kzg_vk *vk, const mi_g1_affine *comms, const mi_fr *points, const mi_fr *values,
+                           const mi_g1_affine *witnesses, size_t n, const uint8_t *randomizers128, uint8_t *ok_out);
+
+/* ---- VarunaShaped-v1 batch verification ---- */
+#define MI_VS_VK_COMMS 12
+#define MI_VS_PROOF_COMMS 9
+#define MI_VS_EVALS 21
+#define MI_VS_INPUTS 16
+typedef struct { mi_g1_affine comms[MI_VS_VK_COMMS]; uint8_t digest[32]; } mi_vs_circuit_vk; /* 1184 B */
+typedef struct {
+    uint32_t circuit;
+    uint32_t _pad[3];
+    mi_fr inputs[MI_VS_INPUTS];
+    mi_g1_affine comms[MI_VS_PROOF_COMMS];
+    mi_fr evals[MI_VS_EVALS];
+    mi_g1_affine w[2];
+} mi_vs_proof; /* 2256 B */
+typedef struct { mi_g1_jac total_c, total_w; uint64_t n_proofs, n_alg_fail; } mi_vs_partial; /* one shard's accumulator */
+
+/* keys resident on the device: KZG vk (G2 lines prepared once) + circuit verifying keys */
+int32_t mi_vs_ctx_create(const mi_kzg_vk *vk, const mi_vs_circuit_vk *circuits, size_t n_circuits, uint64_t *ctx_out);
+int32_t mi_vs_ctx_destroy(uint64_t ctx);
+/* host-pointer form: verdicts[n] (1 = valid) and *all_ok.  randomizers128: n x 2 x 16 bytes. */
+int32_t mi_vs_verify_batch(uint64_t ctx, const mi_vs_proof *proofs, size_t n, const uint8_t *randomizers128,
+                           uint8_t *verdicts, uint8_t *all_ok);
+/* device-pointer form (proofs and randomizers already in HBM) */
+int32_t mi_vs_verify_batch_device(uint64_t ctx, const void *d_proofs, size_t n, const void *d_randomizers128,
+                                  uint8_t *verdicts, uint8_t *all_ok, void *stream);
+/* multi-GPU: each rank accumulates its shard, partials are exchanged (RCCL all-gather), any rank finalises */
+int32_t mi_vs_accumulate_device(uint64_t ctx, const void *d_proofs, size_t n, const void *d_randomizers128,
+                                mi_vs_partial *partial_out, void *stream);
+int32_t mi_vs_finalize(uint64_t ctx, const mi_vs_partial *partials, size_t n_partials, uint8_t *all_ok);
+
+/* ---- diagnostics (parity tests of the device field / group arithmetic) ---- */
+int32_t mi_dbg_fq_mul(const mi_fq *a, const mi_fq *b, mi_fq *out, size_t n);
+int32_t mi_dbg_fr_mul(const mi_fr *a, const mi_fr *b, mi_fr *out, size_t n);
+int32_t mi_dbg_g1_add(const mi_g1_affine *a, const mi_g1_affine *b, mi_g1_affine *out, size_t n);
+int32_t mi_dbg_fq_mul_throughput(size_t n_threads, uint32_t iters, double *gmul_per_s);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

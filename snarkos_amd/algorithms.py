@@ -1,0 +1,214 @@
+"""Host-side mirror of the snarkvm_algorithms surface for the hot path, over the C ABI.
+
+Same names and argument meaning as the Rust interface the reference reaches through
+Ledger::check_next_block (reference node/bft/ledger-service/src/ledger.rs:345-347); SURVEY.md Appendix B:
+
+    msm::VariableBase::msm(bases, scalars)                     -> VariableBase.msm
+    fft::EvaluationDomain::{new, fft, ifft, coset_fft, ...}    -> EvaluationDomain
+    polycommit::kzg10::KZG10::batch_check                      -> KZG10.batch_check
+    snark::varuna::VarunaSNARK::verify_batch (VarunaShaped-v1) -> VarunaShaped.verify_batch
+
+Arrays are numpy uint64 in the ABI layout (Montgomery limbs; MSM scalars canonical), or torch CUDA
+tensors of dtype uint8/int64 holding the same bytes for the device-resident entry points.
+Every call goes to the HIP library; there is no CPU implementation behind these classes.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import lib as L
+
+
+def _is_torch_cuda(x):
+    return hasattr(x, "is_cuda") and x.is_cuda
+
+
+class VariableBase:
+    """snarkvm_algorithms::msm::VariableBase"""
+
+    @staticmethod
+    def msm(bases, scalars, stream=None):
+        """sum_i scalars[i] * bases[i] over min(len(bases), len(scalars)) pairs.
+
+        bases: (n, 12) uint64 Montgomery affine; scalars: (n, 4) uint64 canonical.  Returns the
+        projective result as a (18,) uint64 Jacobian point, normalised to z = 1 (z = 0: infinity).
+        """
+        out = np.zeros(L.G1_JAC_U64, dtype=np.uint64)
+        if _is_torch_cuda(bases):
+            n = min(bases.numel() * bases.element_size() // 96, scalars.numel() * scalars.element_size() // 32)
+            L.check(L.lib().mi_msm_g1_device(L.dptr(bases), L.dptr(scalars), C.c_size_t(n), L.ptr(out),
+                                             L.stream_ptr(stream)), "mi_msm_g1_device")
+            return out
+        bases = np.ascontiguousarray(bases, dtype=np.uint64).reshape(-1, 12)
+        scalars = np.ascontiguousarray(scalars, dtype=np.uint64).reshape(-1, 4)
+        n = min(len(bases), len(scalars))
+        L.check(L.lib().mi_msm_g1(L.ptr(bases), L.ptr(scalars), C.c_size_t(n), L.ptr(out)), "mi_msm_g1")
+        return out
+
+
+class ResidentBases:
+    """Bases kept in HBM across calls (SRS powers / verifying-key commitments)."""
+
+    def __init__(self, bases):
+        bases = np.ascontiguousarray(bases, dtype=np.uint64).reshape(-1, 12)
+        self.n = len(bases)
+        h = C.c_uint64(0)
+        L.check(L.lib().mi_bases_register(L.ptr(bases), C.c_size_t(self.n), C.byref(h)), "mi_bases_register")
+        self.handle = h.value
+
+    def msm(self, scalars, offset=0):
+        scalars = np.ascontiguousarray(scalars, dtype=np.uint64).reshape(-1, 4)
+        out = np.zeros(L.G1_JAC_U64, dtype=np.uint64)
+        L.check(L.lib().mi_msm_g1_h(C.c_uint64(self.handle), C.c_size_t(offset), L.ptr(scalars),
+                                    C.c_size_t(len(scalars)), L.ptr(out)), "mi_msm_g1_h")
+        return out
+
+    def release(self):
+        if self.handle:
+            L.check(L.lib().mi_bases_release(C.c_uint64(self.handle)), "mi_bases_release")
+            self.handle = 0
+
+
+class EvaluationDomain:
+    """snarkvm_algorithms::fft::EvaluationDomain<Fr> (radix-2, size = next power of two)."""
+
+    def __init__(self, num_coeffs):
+        size = 1
+        while size < num_coeffs:
+            size <<= 1
+        self.size = size
+        self.log_size_of_group = size.bit_length() - 1
+        if self.log_size_of_group > 47:
+            raise ValueError("domain larger than the 2-adicity of Fr")
+
+    @classmethod
+    def new(cls, num_coeffs):
+        return cls(num_coeffs)
+
+    def _run(self, data, inverse, coset, stream=None):
+        if _is_torch_cuda(data):
+            assert data.numel() * data.element_size() == 32 * self.size
+            L.check(L.lib().mi_ntt_fr_device(L.dptr(data), C.c_uint32(self.log_size_of_group), C.c_int32(inverse),
+                                             C.c_int32(coset), L.stream_ptr(stream)), "mi_ntt_fr_device")
+            return data
+        a = np.asarray(data, dtype=np.uint64).reshape(-1, 4)
+        if len(a) > self.size:
+            raise ValueError("more coefficients than the domain holds")
+        buf = np.zeros((self.size, 4), dtype=np.uint64)  # zero-padded to the domain size, as fft() does
+        buf[:len(a)] = a
+        L.check(L.lib().mi_ntt_fr(L.ptr(buf), C.c_uint32(self.log_size_of_group), C.c_int32(inverse), C.c_int32(coset)),
+                "mi_ntt_fr")
+        return buf
+
+    def fft(self, coeffs, stream=None):
+        return self._run(coeffs, 0, 0, stream)
+
+    def ifft(self, evals, stream=None):
+        return self._run(evals, 1, 0, stream)
+
+    def coset_fft(self, coeffs, stream=None):
+        return self._run(coeffs, 0, 1, stream)
+
+    def coset_ifft(self, evals, stream=None):
+        return self._run(evals, 1, 1, stream)
+
+
+class Bls12_377:
+    """snarkvm_curves::bls12_377::Bls12_377 pairing engine"""
+
+    @staticmethod
+    def pairing(p, q):
+        out = np.zeros(L.FQ12_U64, dtype=np.uint64)
+        p = np.ascontiguousarray(p, dtype=np.uint64).reshape(12)
+        q = np.ascontiguousarray(q, dtype=np.uint64).reshape(24)
+        L.check(L.lib().mi_pairing(L.ptr(p), L.ptr(q), L.ptr(out)), "mi_pairing")
+        return out
+
+    @staticmethod
+    def product_of_pairings_is_one(ps, qs):
+        ps = np.ascontiguousarray(ps, dtype=np.uint64).reshape(-1, 12)
+        qs = np.ascontiguousarray(qs, dtype=np.uint64).reshape(-1, 24)
+        r = np.zeros(1, dtype=np.uint8)
+        L.check(L.lib().mi_pairing_product_is_one(L.ptr(ps), L.ptr(qs), C.c_size_t(len(ps)), L.ptr(r)),
+                "mi_pairing_product_is_one")
+        return bool(r[0])
+
+
+class KZG10:
+    """snarkvm_algorithms::polycommit::kzg10::KZG10"""
+
+    @staticmethod
+    def batch_check(vk, commitments, points, values, proofs, randomizers128):
+        """vk: 480-byte VerifierKey {g, h, beta_h}; proofs: the opening witnesses w_i."""
+        vk = np.ascontiguousarray(vk).view(np.uint8).reshape(-1)
+        assert vk.size == L.KZG_VK_BYTES
+        comms = np.ascontiguousarray(commitments, dtype=np.uint64).reshape(-1, 12)
+        n = len(comms)
+        pts = np.ascontiguousarray(points, dtype=np.uint64).reshape(n, 4)
+        vals = np.ascontiguousarray(values, dtype=np.uint64).reshape(n, 4)
+        wit = np.ascontiguousarray(proofs, dtype=np.uint64).reshape(n, 12)
+        rnd = np.ascontiguousarray(randomizers128, dtype=np.uint8).reshape(-1)
+        assert rnd.size == 16 * n
+        ok = np.zeros(1, dtype=np.uint8)
+        L.check(L.lib().mi_kzg_batch_check(L.ptr(vk), L.ptr(comms), L.ptr(pts), L.ptr(vals), L.ptr(wit), C.c_size_t(n),
+                                           L.ptr(rnd), L.ptr(ok)), "mi_kzg_batch_check")
+        return bool(ok[0])
+
+    @staticmethod
+    def check(vk, commitment, point, value, proof):
+        one = np.zeros(16, dtype=np.uint8)
+        one[0] = 1
+        return KZG10.batch_check(vk, [commitment], [point], [value], [proof], one)
+
+
+class VarunaShaped:
+    """Batch verifier for the synthetic VarunaShaped-v1 proofs; the role of
+    VarunaSNARK::verify_batch inside VM::check_transactions."""
+
+    def __init__(self, kzg_vk, circuit_vks):
+        vk = np.ascontiguousarray(kzg_vk).view(np.uint8).reshape(-1)
+        cv = np.ascontiguousarray(circuit_vks).view(np.uint8).reshape(-1)
+        assert vk.size == L.KZG_VK_BYTES and cv.size % L.VS_CIRCUIT_VK_BYTES == 0
+        self.n_circuits = cv.size // L.VS_CIRCUIT_VK_BYTES
+        h = C.c_uint64(0)
+        L.check(L.lib().mi_vs_ctx_create(L.ptr(vk), L.ptr(cv), C.c_size_t(self.n_circuits), C.byref(h)), "mi_vs_ctx_create")
+        self.ctx = h.value
+
+    def close(self):
+        if self.ctx:
+            L.check(L.lib().mi_vs_ctx_destroy(C.c_uint64(self.ctx)), "mi_vs_ctx_destroy")
+            self.ctx = 0
+
+    def verify_batch(self, proofs, randomizers128, stream=None):
+        """Returns (all_ok: bool, verdicts: uint8[n])."""
+        all_ok = np.zeros(1, dtype=np.uint8)
+        if _is_torch_cuda(proofs):
+            n = proofs.numel() * proofs.element_size() // L.VS_PROOF_BYTES
+            verdicts = np.zeros(n, dtype=np.uint8)
+            L.check(L.lib().mi_vs_verify_batch_device(C.c_uint64(self.ctx), L.dptr(proofs), C.c_size_t(n),
+                                                      L.dptr(randomizers128), L.ptr(verdicts), L.ptr(all_ok),
+                                                      L.stream_ptr(stream)), "mi_vs_verify_batch_device")
+            return bool(all_ok[0]), verdicts
+        p = np.ascontiguousarray(proofs).view(np.uint8).reshape(-1)
+        n = p.size // L.VS_PROOF_BYTES
+        r = np.ascontiguousarray(randomizers128, dtype=np.uint8).reshape(-1)
+        assert r.size == 32 * n
+        verdicts = np.zeros(n, dtype=np.uint8)
+        L.check(L.lib().mi_vs_verify_batch(C.c_uint64(self.ctx), L.ptr(p), C.c_size_t(n), L.ptr(r), L.ptr(verdicts),
+                                           L.ptr(all_ok)), "mi_vs_verify_batch")
+        return bool(all_ok[0]), verdicts
+
+    def accumulate(self, proofs_cuda, randomizers_cuda, stream=None):
+        """One shard's accumulator (304 bytes): the unit exchanged between GPUs."""
+        n = proofs_cuda.numel() * proofs_cuda.element_size() // L.VS_PROOF_BYTES
+        part = np.zeros(L.VS_PARTIAL_BYTES, dtype=np.uint8)
+        L.check(L.lib().mi_vs_accumulate_device(C.c_uint64(self.ctx), L.dptr(proofs_cuda), C.c_size_t(n),
+                                                L.dptr(randomizers_cuda), L.ptr(part), L.stream_ptr(stream)),
+                "mi_vs_accumulate_device")
+        return part
+
+    def finalize(self, partials):
+        parts = np.ascontiguousarray(partials, dtype=np.uint8).reshape(-1, L.VS_PARTIAL_BYTES)
+        ok = np.zeros(1, dtype=np.uint8)
+        L.check(L.lib().mi_vs_finalize(C.c_uint64(self.ctx), L.ptr(parts), C.c_size_t(len(parts)), L.ptr(ok)), "mi_vs_finalize")
+        return bool(ok[0])

@@ -1,0 +1,45 @@
+// Host-side functions shared between the translation units of libmi355x_snark.so.
+// Each .hip file owns its kernels; nothing here needs relocatable device code.
+#pragma once
+#include "curve.hpp"
+#include "runtime.hpp"
+
+namespace mi {
+
+struct Fq12;
+struct G2Affine;
+struct G2Prepared;
+struct PairingConsts;
+
+// msm.hip -- d_points / d_scalars are device pointers; result normalised Jacobian (z = 1) or infinity (z = 0).
+// scalar_bits bounds the scalars (254 = any canonical Fr, 128 = randomizers).
+void msm_device(Context &cx, const G1Affine *d_points, const uint32_t *d_scalars, size_t n, mi_g1_jac *out,
+                hipStream_t st, int scalar_bits = 254, int force_c = 0);
+
+// ntt.hip -- in place on d_data (2^log_n elements)
+void ntt_device(Context &cx, Fr *d_data, uint32_t log_n, bool inverse, bool coset, hipStream_t st);
+void ntt_release_tables();
+Fr host_omega(uint32_t log_n);
+
+// pairing.hip
+void pairing_product_prepared(Context &cx, const G1Affine *ps, const G2Prepared *const *d_qs, size_t n, Fq12 *out_host,
+                              hipStream_t st);
+void pairing_product_host_args(Context &cx, const G1Affine *ps, const G2Affine *qs, size_t n, Fq12 *out_host,
+                               hipStream_t st);
+const PairingConsts *pairing_consts(Context &cx, hipStream_t st);
+void pairing_release();
+
+// verify.hip
+int32_t kzg_batch_check_host(Context &cx, const mi_kzg_vk *vk, const mi_g1_affine *comms, const mi_fr *points,
+                             const mi_fr *values, const mi_g1_affine *witnesses, size_t n, const uint8_t *rand128,
+                             uint8_t *ok_out);
+int32_t vs_ctx_create(Context &cx, const mi_kzg_vk *vk, const mi_vs_circuit_vk *circuits, size_t n_circuits, uint64_t *out);
+int32_t vs_ctx_destroy(Context &cx, uint64_t id);
+int32_t vs_accumulate_device(Context &cx, uint64_t id, const void *d_proofs, size_t n, const void *d_rand,
+                             mi_vs_partial *out, hipStream_t st);
+int32_t vs_finalize(Context &cx, uint64_t id, const mi_vs_partial *parts, size_t np, uint8_t *all_ok, hipStream_t st);
+int32_t vs_verify_batch_device(Context &cx, uint64_t id, const void *d_proofs, size_t n, const void *d_rand,
+                               uint8_t *verdicts, uint8_t *all_ok, hipStream_t st);
+void verify_release_all();
+
+}  // namespace mi

@@ -1,0 +1,293 @@
+// libmi355x_snark.so -- C ABI entry points (include/mi355x_snark.h) over the HIP kernels.
+#include <string.h>
+#include <new>
+#include "api.hpp"
+#include "tower.hpp"
+
+namespace mi {
+
+static Context g_ctx;
+Context &ctx() { return g_ctx; }
+static std::mutex g_init_mu;
+
+int32_t ensure_init() {
+    std::lock_guard<std::mutex> lk(g_init_mu);
+    if (g_ctx.inited) return MI_OK;
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) return MI_ERR_NO_DEVICE;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return MI_ERR_NO_DEVICE;
+    g_ctx.device = dev;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, dev) == hipSuccess) g_ctx.n_cus = prop.multiProcessorCount;
+    if (hipStreamCreateWithFlags(&g_ctx.stream, hipStreamNonBlocking) != hipSuccess) return MI_ERR_KERNEL;
+    g_ctx.inited = true;
+    return MI_OK;
+}
+
+// ------------------------------------------------------------ diagnostics kernels
+__global__ void dbg_fq_mul_kernel(const Fq *a, const Fq *b, Fq *out, size_t n) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = mul(a[i], b[i]);
+}
+__global__ void dbg_fr_mul_kernel(const Fr *a, const Fr *b, Fr *out, size_t n) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = mul(a[i], b[i]);
+}
+__global__ void dbg_g1_add_kernel(const G1Affine *a, const G1Affine *b, G1Affine *out, size_t n) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = to_affine(add_mixed(G1Xyzz::from_affine(a[i]), b[i]));
+}
+__global__ void __launch_bounds__(256) dbg_fq_mul_throughput_kernel(Fq *out, uint32_t iters) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    Fq a = Fq::one(), b = Fq::r2();
+    a.l[0] += (uint32_t)i;
+    for (uint32_t k = 0; k < iters; k++) {
+        a = mul(a, b);
+        b = mul(b, a);
+    }
+    out[i] = add(a, b);
+}
+
+template <class T, class K>
+static int32_t dbg_binary(const T *a, const T *b, T *out, size_t n, K kernel) {
+    if (!a || !b || !out) return MI_ERR_BAD_ARGS;
+    return guarded([&]() -> int32_t {
+        Context &cx = ctx();
+        T *da = (T *)cx.buf("dbg.a", sizeof(T) * n), *db = (T *)cx.buf("dbg.b", sizeof(T) * n), *dc = (T *)cx.buf("dbg.c", sizeof(T) * n);
+        MI_HIP(hipMemcpyAsync(da, a, sizeof(T) * n, hipMemcpyHostToDevice, cx.stream));
+        MI_HIP(hipMemcpyAsync(db, b, sizeof(T) * n, hipMemcpyHostToDevice, cx.stream));
+        hipLaunchKernelGGL(kernel, dim3(cdiv(n, 128)), dim3(128), 0, cx.stream, da, db, dc, n);
+        MI_HIP(hipGetLastError());
+        MI_HIP(hipMemcpyAsync(out, dc, sizeof(T) * n, hipMemcpyDeviceToHost, cx.stream));
+        MI_HIP(hipStreamSynchronize(cx.stream));
+        return MI_OK;
+    });
+}
+
+}  // namespace mi
+
+using namespace mi;
+
+extern "C" {
+
+int32_t mi_init(int32_t device) {
+    if (device >= 0) {
+        if (hipSetDevice(device) != hipSuccess) return MI_ERR_NO_DEVICE;
+    }
+    return ensure_init();
+}
+int32_t mi_shutdown(void) {
+    std::lock_guard<std::mutex> lk(g_init_mu);
+    if (!g_ctx.inited) return MI_OK;
+    std::lock_guard<std::mutex> lk2(g_ctx.mu);
+    (void)hipSetDevice(g_ctx.device);
+    (void)hipStreamSynchronize(g_ctx.stream);
+    for (auto &kv : g_ctx.bufs) kv.second.release();
+    for (auto &kv : g_ctx.handles) kv.second.release();
+    g_ctx.bufs.clear();
+    g_ctx.handles.clear();
+    g_ctx.handle_len.clear();
+    verify_release_all();
+    if (g_ctx.pinned) (void)hipHostFree(g_ctx.pinned);
+    g_ctx.pinned = nullptr;
+    g_ctx.pinned_cap = 0;
+    (void)hipStreamDestroy(g_ctx.stream);
+    g_ctx.stream = nullptr;
+    g_ctx.inited = false;
+    return MI_OK;
+}
+const char *mi_error_string(int32_t s) {
+    switch (s) {
+    case MI_OK: return "ok";
+    case MI_ERR_BAD_ARGS: return "bad arguments";
+    case MI_ERR_NO_DEVICE: return "no HIP device";
+    case MI_ERR_OOM: return "out of device memory";
+    case MI_ERR_KERNEL: return "HIP runtime or kernel failure";
+    case MI_ERR_NOT_INIT: return "not initialised";
+    default: return "unknown status";
+    }
+}
+int32_t mi_abi_version(void) { return 1; }
+
+// ------------------------------------------------------------ MSM
+int32_t mi_msm_g1(const mi_g1_affine *bases, const mi_bigint256 *scalars, size_t n, mi_g1_jac *out) {
+    if (!out || (n && (!bases || !scalars))) return MI_ERR_BAD_ARGS;
+    return guarded([&]() -> int32_t {
+        Context &cx = ctx();
+        G1Affine *dp = (G1Affine *)cx.buf("msm.in_points", sizeof(G1Affine) * (n ? n : 1));
+        uint32_t *ds = (uint32_t *)cx.buf("msm.in_scalars", 32 * (n ? n : 1));
+        if (n) {
+            MI_HIP(hipMemcpyAsync(dp, bases, sizeof(G1Affine) * n, hipMemcpyHostToDevice, cx.stream));
+            MI_HIP(hipMemcpyAsync(ds, scalars, 32 * n, hipMemcpyHostToDevice, cx.stream));
+        }
+        msm_device(cx, dp, ds, n, out, cx.stream);
+        return MI_OK;
+    });
+}
+int32_t mi_msm_g1_device(const void *d_bases, const void *d_scalars, size_t n, mi_g1_jac *out, void *stream) {
+    if (!out || (n && (!d_bases || !d_scalars))) return MI_ERR_BAD_ARGS;
+    return guarded([&]() -> int32_t {
+        msm_device(ctx(), (const G1Affine *)d_bases, (const uint32_t *)d_scalars, n, out, (hipStream_t)stream);
+        return MI_OK;
+    });
+}
+int32_t mi_bases_register(const mi_g1_affine *pts, size_t n, uint64_t *handle_out) {
+    if (!pts || !n || !handle_out) return MI_ERR_BAD_ARGS;
+    return guarded([&]() -> int32_t {
+        Context &cx = ctx();
+        uint64_t h = cx.next_handle++;
+        void *d = cx.handles[h].get(sizeof(G1Affine) * n);
+        cx.handle_len[h] = n;
+        MI_HIP(hipMemcpy(d, pts, sizeof(G1Affine) * n, hipMemcpyHostToDevice));
+        *handle_out = h;
+        return MI_OK;
+    });
+}
+int32_t mi_bases_release(uint64_t handle) {
+    return guarded([&]() -> int32_t {
+        Context &cx = ctx();
+        auto it = cx.handles.find(handle);
+        if (it == cx.handles.end()) return MI_ERR_BAD_ARGS;
+        MI_HIP(hipStreamSynchronize(cx.stream));
+        it->second.release();
+        cx.handles.erase(it);
+        cx.handle_len.erase(handle);
+        return MI_OK;
+    });
+}
+int32_t mi_msm_g1_h(uint64_t handle, size_t offset, const mi_bigint256 *scalars, size_t n, mi_g1_jac *out) {
+    if (!out || (n && !scalars)) return MI_ERR_BAD_ARGS;
+    return guarded([&]() -> int32_t {
+        Context &cx = ctx();
+        auto it = cx.handles.find(handle);
+        if (it == cx.handles.end() || offset + n > cx.handle_len[handle]) return MI_ERR_BAD_ARGS;
+        uint32_t *ds = (uint32_t *)cx.buf("msm.in_scalars", 32 * (n ? n : 1));
+        if (n) MI_HIP(hipMemcpyAsync(ds, scalars, 32 * n, hipMemcpyHostToDevice, cx.stream));
+        msm_device(cx, (const G1Affine *)it->second.p + offset, ds, n, out, cx.stream);
+        return MI_OK;
+    });
+}
+
+// ------------------------------------------------------------ NTT
+int32_t mi_ntt_fr(mi_fr *data, uint32_t log_n, int32_t inverse, int32_t coset) {
+    if (!data || log_n > 47) return MI_ERR_BAD_ARGS;
+    return guarded([&]() -> int32_t {
+        Context &cx = ctx();
+        size_t bytes = sizeof(Fr) << log_n;
+        Fr *d = (Fr *)cx.buf("ntt.io", bytes);
+        MI_HIP(hipMemcpyAsync(d, data, bytes, hipMemcpyHostToDevice, cx.stream));
+        ntt_device(cx, d, log_n, inverse != 0, coset != 0, cx.stream);
+        MI_HIP(hipMemcpyAsync(data, d, bytes, hipMemcpyDeviceToHost, cx.stream));
+        MI_HIP(hipStreamSynchronize(cx.stream));
+        return MI_OK;
+    });
+}
+int32_t mi_ntt_fr_device(void *d_data, uint32_t log_n, int32_t inverse, int32_t coset, void *stream) {
+    if (!d_data || log_n > 47) return MI_ERR_BAD_ARGS;
+    return guarded([&]() -> int32_t {
+        ntt_device(ctx(), (Fr *)d_data, log_n, inverse != 0, coset != 0, (hipStream_t)stream);
+        return MI_OK;
+    });
+}
+
+// ------------------------------------------------------------ pairing / KZG
+int32_t mi_pairing_product_is_one(const mi_g1_affine *ps, const mi_g2_affine *qs, size_t n, uint8_t *is_one) {
+    if (!ps || !qs || !is_one || n == 0 || n > MI_MAX_PAIRS) return MI_ERR_BAD_ARGS;
+    return guarded([&]() -> int32_t {
+        Fq12 f;
+        pairing_product_host_args(ctx(), (const G1Affine *)ps, (const G2Affine *)qs, n, &f, ctx().stream);
+        *is_one = f.is_one() ? 1 : 0;
+        return MI_OK;
+    });
+}
+int32_t mi_pairing(const mi_g1_affine *p, const mi_g2_affine *q, mi_fq12 *out) {
+    if (!p || !q || !out) return MI_ERR_BAD_ARGS;
+    return guarded([&]() -> int32_t {
+        Fq12 f;
+        pairing_product_host_args(ctx(), (const G1Affine *)p, (const G2Affine *)q, 1, &f, ctx().stream);
+        memcpy(out, &f, sizeof f);
+        return MI_OK;
+    });
+}
+int32_t mi_kzg_batch_check(const mi_kzg_vk *vk, const mi_g1_affine *comms, const mi_fr *points, const mi_fr *values,
+                           const mi_g1_affine *witnesses, size_t n, const uint8_t *randomizers128, uint8_t *ok_out) {
+    if (!vk || !comms || !points || !values || !witnesses || !randomizers128 || !ok_out || n == 0) return MI_ERR_BAD_ARGS;
+    return guarded([&]() -> int32_t {
+        return kzg_batch_check_host(ctx(), vk, comms, points, values, witnesses, n, randomizers128, ok_out);
+    });
+}
+
+// ------------------------------------------------------------ VarunaShaped-v1
+int32_t mi_vs_ctx_create(const mi_kzg_vk *vk, const mi_vs_circuit_vk *circuits, size_t n_circuits, uint64_t *ctx_out) {
+    if (!vk || !circuits || !n_circuits || !ctx_out) return MI_ERR_BAD_ARGS;
+    return guarded([&]() -> int32_t { return vs_ctx_create(ctx(), vk, circuits, n_circuits, ctx_out); });
+}
+int32_t mi_vs_ctx_destroy(uint64_t c) {
+    return guarded([&]() -> int32_t { return vs_ctx_destroy(ctx(), c); });
+}
+int32_t mi_vs_verify_batch(uint64_t c, const mi_vs_proof *proofs, size_t n, const uint8_t *randomizers128,
+                           uint8_t *verdicts, uint8_t *all_ok) {
+    if (!proofs || !n || !randomizers128 || !verdicts || !all_ok) return MI_ERR_BAD_ARGS;
+    return guarded([&]() -> int32_t {
+        Context &cx = ctx();
+        void *dp = cx.buf("vs.in_proofs", sizeof(mi_vs_proof) * n);
+        void *dr = cx.buf("vs.in_rand", 32 * n);
+        MI_HIP(hipMemcpyAsync(dp, proofs, sizeof(mi_vs_proof) * n, hipMemcpyHostToDevice, cx.stream));
+        MI_HIP(hipMemcpyAsync(dr, randomizers128, 32 * n, hipMemcpyHostToDevice, cx.stream));
+        return vs_verify_batch_device(cx, c, dp, n, dr, verdicts, all_ok, cx.stream);
+    });
+}
+int32_t mi_vs_verify_batch_device(uint64_t c, const void *d_proofs, size_t n, const void *d_randomizers128,
+                                  uint8_t *verdicts, uint8_t *all_ok, void *stream) {
+    if (!d_proofs || !n || !d_randomizers128 || !verdicts || !all_ok) return MI_ERR_BAD_ARGS;
+    return guarded([&]() -> int32_t {
+        return vs_verify_batch_device(ctx(), c, d_proofs, n, d_randomizers128, verdicts, all_ok, (hipStream_t)stream);
+    });
+}
+int32_t mi_vs_accumulate_device(uint64_t c, const void *d_proofs, size_t n, const void *d_randomizers128,
+                                mi_vs_partial *partial_out, void *stream) {
+    if (!d_proofs || !n || !d_randomizers128 || !partial_out) return MI_ERR_BAD_ARGS;
+    return guarded([&]() -> int32_t {
+        return vs_accumulate_device(ctx(), c, d_proofs, n, d_randomizers128, partial_out, (hipStream_t)stream);
+    });
+}
+int32_t mi_vs_finalize(uint64_t c, const mi_vs_partial *partials, size_t n_partials, uint8_t *all_ok) {
+    if (!partials || !n_partials || !all_ok) return MI_ERR_BAD_ARGS;
+    return guarded([&]() -> int32_t { return vs_finalize(ctx(), c, partials, n_partials, all_ok, ctx().stream); });
+}
+
+// ------------------------------------------------------------ diagnostics
+int32_t mi_dbg_fq_mul(const mi_fq *a, const mi_fq *b, mi_fq *out, size_t n) {
+    return dbg_binary((const Fq *)a, (const Fq *)b, (Fq *)out, n, dbg_fq_mul_kernel);
+}
+int32_t mi_dbg_fr_mul(const mi_fr *a, const mi_fr *b, mi_fr *out, size_t n) {
+    return dbg_binary((const Fr *)a, (const Fr *)b, (Fr *)out, n, dbg_fr_mul_kernel);
+}
+int32_t mi_dbg_g1_add(const mi_g1_affine *a, const mi_g1_affine *b, mi_g1_affine *out, size_t n) {
+    return dbg_binary((const G1Affine *)a, (const G1Affine *)b, (G1Affine *)out, n, dbg_g1_add_kernel);
+}
+int32_t mi_dbg_fq_mul_throughput(size_t n_threads, uint32_t iters, double *gmul_per_s) {
+    if (!gmul_per_s || !n_threads) return MI_ERR_BAD_ARGS;
+    return guarded([&]() -> int32_t {
+        Context &cx = ctx();
+        n_threads = (n_threads + 255) / 256 * 256;
+        Fq *d = (Fq *)cx.buf("dbg.c", sizeof(Fq) * n_threads);
+        hipEvent_t e0, e1;
+        MI_HIP(hipEventCreate(&e0));
+        MI_HIP(hipEventCreate(&e1));
+        hipLaunchKernelGGL(dbg_fq_mul_throughput_kernel, dim3(n_threads / 256), dim3(256), 0, cx.stream, d, 8u);
+        MI_HIP(hipEventRecord(e0, cx.stream));
+        hipLaunchKernelGGL(dbg_fq_mul_throughput_kernel, dim3(n_threads / 256), dim3(256), 0, cx.stream, d, iters);
+        MI_HIP(hipEventRecord(e1, cx.stream));
+        MI_HIP(hipEventSynchronize(e1));
+        float ms = 0;
+        MI_HIP(hipEventElapsedTime(&ms, e0, e1));
+        *gmul_per_s = 2.0 * iters * (double)n_threads / (ms * 1e-3) / 1e9;
+        (void)hipEventDestroy(e0);
+        (void)hipEventDestroy(e1);
+        return MI_OK;
+    });
+}
+
+}  // extern "C"

@@ -1,0 +1,272 @@
+// BLS12-377 prime fields for gfx950 (and the host side of the same library).
+//
+// Replaces snarkvm_fields::{Fp256<FrParameters>, Fp384<FqParameters>} (snarkVM 1.0.0 @ dea322b, the
+// un-vendored dependency pinned at reference Cargo.toml:47-52) on the device.
+// Memory layout is the ABI's: little-endian 64-bit limbs, Montgomery form with R = 2^256 (Fr) /
+// 2^384 (Fq).  CDNA4 has no 64-bit integer multiplier, so the arithmetic runs on 32-bit limbs
+// (v_mad_u64_u32: 32x32+64 -> 64) over the very same bytes; R and therefore every stored value is
+// unchanged.  Both moduli are 1 mod 2^32, so the Montgomery factor is m = -t0 (no multiply).
+//
+// The same header compiles for the host (plain C++), which the library uses for the short serial
+// tails (window fold of an MSM, G2 line precomputation at key registration).
+#pragma once
+#include <stdint.h>
+#include "constants.hpp"
+
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#define MI_HD __host__ __device__ __forceinline__
+#define MI_D __device__ __forceinline__
+#else
+#define MI_HD inline
+#define MI_D inline
+#endif
+
+namespace mi {
+
+struct FqP {
+    static constexpr int N = 12;
+    static constexpr uint32_t MOD[12] = {0x00000001u, 0x8508c000u, 0x30000000u, 0x170b5d44u, 0xba094800u, 0x1ef3622fu,
+                                         0x00f5138fu, 0x1a22d9f3u, 0x6ca1493bu, 0xc63b05c0u, 0x17c510eau, 0x01ae3a46u};
+    // R mod q
+    static constexpr uint32_t ONE[12] = {0xffffff68u, 0x02cdffffu, 0x7fffffb1u, 0x51409f83u, 0x8a7d3ff2u, 0x9f7db3a9u,
+                                         0x6e7c6305u, 0x7b4e97b7u, 0x803c84e8u, 0x4cf495bfu, 0xe2fdf49au, 0x008d6661u};
+    static constexpr uint32_t R2[12] = {0x9400cd22u, 0xb786686cu, 0xb00431b1u, 0x0329fcaau, 0x62d6b46du, 0x22a5f111u,
+                                        0x827dc3acu, 0xbfdf7d03u, 0x41790bf9u, 0x837e92f0u, 0x1e914b88u, 0x006dfccbu};
+};
+struct FrP {
+    static constexpr int N = 8;
+    static constexpr uint32_t MOD[8] = {0x00000001u, 0x0a118000u, 0xd0000001u, 0x59aa76feu,
+                                        0x5c37b001u, 0x60b44d1eu, 0x9a2ca556u, 0x12ab655eu};
+    static constexpr uint32_t ONE[8] = {0xfffffff3u, 0x7d1c7fffu, 0x6ffffff2u, 0x7257f50fu,
+                                        0x512c0feeu, 0x16d81575u, 0x2bbb9a9du, 0x0d4bda32u};
+    static constexpr uint32_t R2[8] = {0xb861857bu, 0x25d577bau, 0x8860591fu, 0xcc2c27b5u,
+                                       0xe5dc8593u, 0xa7cc008fu, 0xeff1c939u, 0x011fdae7u};
+};
+
+template <class P>
+struct Fp {
+    static constexpr int N = P::N;
+    uint32_t l[N];
+
+    MI_HD static Fp zero() {
+        Fp r;
+#pragma unroll
+        for (int i = 0; i < N; i++) r.l[i] = 0;
+        return r;
+    }
+    MI_HD static Fp one() {
+        Fp r;
+#pragma unroll
+        for (int i = 0; i < N; i++) r.l[i] = P::ONE[i];
+        return r;
+    }
+    MI_HD static Fp r2() {
+        Fp r;
+#pragma unroll
+        for (int i = 0; i < N; i++) r.l[i] = P::R2[i];
+        return r;
+    }
+    MI_HD bool is_zero() const {
+        uint32_t o = 0;
+#pragma unroll
+        for (int i = 0; i < N; i++) o |= l[i];
+        return o == 0;
+    }
+    MI_HD bool operator==(const Fp &b) const {
+        uint32_t o = 0;
+#pragma unroll
+        for (int i = 0; i < N; i++) o |= l[i] ^ b.l[i];
+        return o == 0;
+    }
+    MI_HD bool operator!=(const Fp &b) const { return !(*this == b); }
+};
+
+// r = a - MOD if a >= MOD (a < 2*MOD on entry)
+template <class P>
+MI_HD void reduce_once(Fp<P> &a) {
+    constexpr int N = P::N;
+    uint32_t t[N];
+    uint32_t borrow = 0;
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+        uint64_t d = (uint64_t)a.l[i] - P::MOD[i] - borrow;
+        t[i] = (uint32_t)d;
+        borrow = (uint32_t)(d >> 63);
+    }
+    if (!borrow) {
+#pragma unroll
+        for (int i = 0; i < N; i++) a.l[i] = t[i];
+    }
+}
+
+template <class P>
+MI_HD Fp<P> add(const Fp<P> &a, const Fp<P> &b) {
+    constexpr int N = P::N;
+    Fp<P> r;
+    uint32_t c = 0;
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+        uint64_t s = (uint64_t)a.l[i] + b.l[i] + c;
+        r.l[i] = (uint32_t)s;
+        c = (uint32_t)(s >> 32);
+    }
+    reduce_once(r);  // both moduli leave spare top bits: no carry out of the top limb
+    return r;
+}
+
+template <class P>
+MI_HD Fp<P> sub(const Fp<P> &a, const Fp<P> &b) {
+    constexpr int N = P::N;
+    Fp<P> r;
+    uint32_t borrow = 0;
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+        uint64_t d = (uint64_t)a.l[i] - b.l[i] - borrow;
+        r.l[i] = (uint32_t)d;
+        borrow = (uint32_t)(d >> 63);
+    }
+    // add back MOD masked by the borrow (branch-free: lanes diverge on data)
+    uint32_t mask = 0u - borrow, c = 0;
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+        uint64_t s = (uint64_t)r.l[i] + (P::MOD[i] & mask) + c;
+        r.l[i] = (uint32_t)s;
+        c = (uint32_t)(s >> 32);
+    }
+    return r;
+}
+
+template <class P>
+MI_HD Fp<P> neg(const Fp<P> &a) {
+    return sub(Fp<P>::zero(), a);
+}
+template <class P>
+MI_HD Fp<P> dbl(const Fp<P> &a) {
+    return add(a, a);
+}
+
+// Montgomery product a*b*R^-1 mod p, fully reduced.  Operand-scanning CIOS on 32-bit limbs; the
+// modulus is 1 mod 2^32, so m = -t0 and m*MOD[0] + t0 contributes only its carry (1 when t0 != 0).
+template <class P>
+MI_HD Fp<P> mul(const Fp<P> &a, const Fp<P> &b) {
+    constexpr int N = P::N;
+    uint32_t t[N + 1];
+#pragma unroll
+    for (int i = 0; i <= N; i++) t[i] = 0;
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+        uint32_t bi = b.l[i];
+        uint64_t acc = 0;
+#pragma unroll
+        for (int j = 0; j < N; j++) {
+            acc = (uint64_t)a.l[j] * bi + t[j] + (acc >> 32);
+            t[j] = (uint32_t)acc;
+        }
+        t[N] = (uint32_t)(acc >> 32);
+        uint32_t m = 0u - t[0];
+        acc = (uint64_t)(t[0] != 0);  // carry of m*1 + t0
+#pragma unroll
+        for (int j = 1; j < N; j++) {
+            acc = (uint64_t)m * P::MOD[j] + t[j] + (uint32_t)acc;
+            t[j - 1] = (uint32_t)acc;
+            acc >>= 32;
+        }
+        t[N - 1] = t[N] + (uint32_t)acc;
+    }
+    Fp<P> r;
+#pragma unroll
+    for (int i = 0; i < N; i++) r.l[i] = t[i];
+    reduce_once(r);
+    return r;
+}
+
+template <class P>
+MI_HD Fp<P> sqr(const Fp<P> &a) {
+    return mul(a, a);
+}
+
+template <class P>
+MI_HD Fp<P> operator+(const Fp<P> &a, const Fp<P> &b) { return add(a, b); }
+template <class P>
+MI_HD Fp<P> operator-(const Fp<P> &a, const Fp<P> &b) { return sub(a, b); }
+template <class P>
+MI_HD Fp<P> operator*(const Fp<P> &a, const Fp<P> &b) { return mul(a, b); }
+
+// a^e for a little-endian 32-bit-limb exponent (square-and-multiply, MSB first)
+template <class P>
+MI_HD Fp<P> pow_limbs(const Fp<P> &a, const uint32_t *e, int n_limbs) {
+    Fp<P> acc = Fp<P>::one();
+    bool started = false;
+    for (int i = n_limbs * 32 - 1; i >= 0; i--) {
+        if (started) acc = sqr(acc);
+        if ((e[i >> 5] >> (i & 31)) & 1u) {
+            if (started) acc = mul(acc, a);
+            else { acc = a; started = true; }
+        }
+    }
+    return acc;
+}
+
+// Fermat inverse a^(p-2); inv(0) = 0.  The exponent is MOD - 2 and MOD[0] = 1, so the low limb
+// borrows: (MOD - 2) = {0xffffffff, MOD[1]-1, MOD[2], ...}.
+template <class P>
+MI_HD Fp<P> inv(const Fp<P> &a) {
+    uint32_t e[P::N];
+    e[0] = 0xffffffffu;
+    e[1] = P::MOD[1] - 1u;
+    for (int i = 2; i < P::N; i++) e[i] = P::MOD[i];
+    return pow_limbs(a, e, P::N);
+}
+
+// canonical little-endian integer (< p) -> Montgomery
+template <class P>
+MI_HD Fp<P> to_mont(const Fp<P> &canonical) {
+    return mul(canonical, Fp<P>::r2());
+}
+template <class P>
+MI_HD Fp<P> from_mont(const Fp<P> &m) {
+    Fp<P> one = Fp<P>::zero();
+    one.l[0] = 1;
+    return mul(m, one);
+}
+template <class P>
+MI_HD Fp<P> from_u32(uint32_t v) {
+    Fp<P> t = Fp<P>::zero();
+    t.l[0] = v;
+    return to_mont(t);
+}
+
+using Fq = Fp<FqP>;
+using Fr = Fp<FrP>;
+
+// Out-of-line copies: long serial chains (pairing tower, reductions, scalar multiplications) call these
+// instead of inlining a ~600-instruction product at every site.
+#if defined(__HIPCC__)
+#define MI_NI __host__ __device__ __attribute__((noinline))
+#else
+#define MI_NI __attribute__((noinline))
+#endif
+inline MI_NI Fq mulq(const Fq &a, const Fq &b) { return mul(a, b); }
+inline MI_NI Fq sqrq(const Fq &a) { return mul(a, a); }
+inline MI_NI Fq invq(const Fq &a) {
+    uint32_t e[12];
+    e[0] = 0xffffffffu;
+    e[1] = FqP::MOD[1] - 1u;
+    for (int i = 2; i < 12; i++) e[i] = FqP::MOD[i];
+    Fq acc = Fq::one();
+    bool started = false;
+    for (int i = 383; i >= 0; i--) {
+        if (started) acc = sqrq(acc);
+        if ((e[i >> 5] >> (i & 31)) & 1u) {
+            if (started) acc = mulq(acc, a);
+            else { acc = a; started = true; }
+        }
+    }
+    return acc;
+}
+inline MI_NI Fr mulr(const Fr &a, const Fr &b) { return mul(a, b); }
+
+static_assert(sizeof(Fq) == 48 && sizeof(Fr) == 32, "ABI layout");
+
+}  // namespace mi

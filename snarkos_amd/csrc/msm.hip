@@ -1,0 +1,314 @@
+// Variable-base MSM over BLS12-377 G1 on gfx950: signed-digit Pippenger, sort-by-bucket, one lane per
+// bucket with a register-resident XYZZ accumulator, segmented bucket reduction, LDS tree sums.
+//
+// Replaces snarkvm_algorithms::msm::VariableBase::msm (snarkVM 1.0.0 @ dea322b, un-vendored; SURVEY.md
+// 8a row A3): out = sum_i scalars[i] * bases[i], scalars canonical BigInteger256, bases Montgomery
+// affine.  The CPU reference walks c-bit windows with batched-affine bucket adds on rayon threads; this
+// is a different algorithm with the same (unique) group result.
+//
+// Pipeline (all on one stream, no host sync until the final 192*nwin-byte copy):
+//   K1 msm_digits    one lane per scalar: signed c-bit digits -> digits[w][i], histogram counts[w][b]
+//   K2 scan          exclusive scan of the nwin*B counts (B = 2^(c-1) buckets per window)
+//   K3 msm_scatter   one lane per (w,i): sorted[offset[bucket]++] = (i << 1) | negate
+//   K4 msm_accumulate one lane per bucket: gather its points (96 B each, random), mixed-add into XYZZ
+//   K5 msm_segments  one lane per L-bucket segment: running sums -> sum_j (gL + j) * bucket
+//   K6 point_tree_sum LDS tree: per-window sum of the segment partials
+//   host             Horner fold of the nwin window sums (<= 256 doublings), normalise to z = 1
+// HBM traffic per (point, scalar) pair: 32 B scalar read once, 96 B point read once per window from
+// HBM/Infinity Cache (the 100 MB base table of a 2^20 MSM stays cache resident), 4 B digit + 4 B index
+// written and read once per window.
+#include <string.h>
+#include "api.hpp"
+
+namespace mi {
+
+struct MsmPlan {
+    int c, nwin;
+    uint32_t B;  // buckets per window = 2^(c-1)
+};
+
+static MsmPlan msm_plan(size_t n, int scalar_bits, int force_c) {
+    int lg = 0;
+    while (((size_t)1 << (lg + 1)) <= n) lg++;
+    int c = lg - 4;
+    if (c < 6) c = 6;
+    if (c > 16) c = 16;
+    if (force_c >= 6 && force_c <= 16) c = force_c;
+    MsmPlan p;
+    p.c = c;
+    const int bits = scalar_bits > 128 ? 254 : 129;  // one spare bit so the top signed digit never overflows
+    p.nwin = (bits + c - 1) / c;
+    p.B = 1u << (c - 1);
+    return p;
+}
+
+// ---------------------------------------------------------------- K1: signed digits + histogram
+template <int C, int BITS>
+__global__ void __launch_bounds__(256) msm_digits_kernel(const uint32_t *__restrict__ scalars, size_t n,
+                                                         int32_t *__restrict__ digits, uint32_t *__restrict__ counts) {
+    constexpr int NWIN = (BITS + C - 1) / C;
+    constexpr uint32_t B = 1u << (C - 1);
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint4 *sp = reinterpret_cast<const uint4 *>(scalars + i * 8);
+    uint4 lo = sp[0], hi = sp[1];
+    uint32_t s[9] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w, 0u};
+    uint32_t carry = 0;
+#pragma unroll
+    for (int w = 0; w < NWIN; w++) {
+        constexpr uint32_t MASK = (1u << C) - 1u;
+        const int bit = w * C, limb = bit >> 5, off = bit & 31;
+        uint64_t v = (limb < 8 ? (uint64_t)s[limb] : 0ull) | ((limb + 1 < 9 ? (uint64_t)s[limb + 1] : 0ull) << 32);
+        uint32_t raw = ((uint32_t)(v >> off) & MASK) + carry;
+        int32_t d;
+        if (raw > B) {
+            d = (int32_t)raw - (int32_t)(1u << C);
+            carry = 1;
+        } else {
+            d = (int32_t)raw;
+            carry = 0;
+        }
+        digits[(size_t)w * n + i] = d;
+        if (d != 0) {
+            uint32_t mag = d < 0 ? (uint32_t)(-d) : (uint32_t)d;
+            atomicAdd(&counts[(size_t)w * B + (mag - 1)], 1u);
+        }
+    }
+}
+
+// ---------------------------------------------------------------- K2: exclusive scan (3 small kernels)
+__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v, int lane) {
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        uint32_t t = __shfl_up(v, d, 64);
+        if (lane >= d) v += t;
+    }
+    return v;
+}
+// each block scans a tile of 256*8 elements; out = exclusive prefix inside the tile; tile_sums[block] = total
+__global__ void __launch_bounds__(256) scan_tiles_kernel(const uint32_t *__restrict__ in, uint32_t *__restrict__ out,
+                                                         uint32_t *__restrict__ tile_sums, size_t n) {
+    __shared__ uint32_t wsum[4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    size_t base = ((size_t)blockIdx.x * 256 + threadIdx.x) * 8;
+    uint32_t v[8], s = 0;
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        v[k] = base + k < n ? in[base + k] : 0u;
+        s += v[k];
+    }
+    uint32_t incl = wave_incl_scan(s, lane);
+    if (lane == 63) wsum[wave] = incl;
+    __syncthreads();
+    uint32_t woff = 0;
+    for (int k = 0; k < wave; k++) woff += wsum[k];
+    uint32_t run = woff + incl - s;
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        if (base + k < n) out[base + k] = run;
+        run += v[k];
+    }
+    if (threadIdx.x == 255) tile_sums[blockIdx.x] = woff + incl;
+}
+// single block: exclusive scan of up to 1024*K tile sums, in place
+__global__ void __launch_bounds__(1024) scan_sums_kernel(uint32_t *sums, size_t m) {
+    __shared__ uint32_t wsum[16];
+    __shared__ uint32_t carry_s;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (threadIdx.x == 0) carry_s = 0;
+    __syncthreads();
+    for (size_t base = 0; base < m; base += 1024) {
+        size_t i = base + threadIdx.x;
+        uint32_t v = i < m ? sums[i] : 0u;
+        uint32_t incl = wave_incl_scan(v, lane);
+        if (lane == 63) wsum[wave] = incl;
+        __syncthreads();
+        uint32_t woff = carry_s;
+        for (int k = 0; k < wave; k++) woff += wsum[k];
+        if (i < m) sums[i] = woff + incl - v;
+        __syncthreads();
+        if (threadIdx.x == 1023) carry_s = woff + incl;
+        __syncthreads();
+    }
+}
+// offsets[i] += tile_sums[tile]; also write the grand total at offsets[n] and copy to cursor
+__global__ void __launch_bounds__(256) scan_finish_kernel(uint32_t *__restrict__ offsets, uint32_t *__restrict__ cursor,
+                                                          const uint32_t *__restrict__ tile_sums,
+                                                          const uint32_t *__restrict__ counts, size_t n) {
+    size_t base = ((size_t)blockIdx.x * 256 + threadIdx.x) * 8;
+    uint32_t add = tile_sums[blockIdx.x];
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        size_t i = base + k;
+        if (i < n) {
+            uint32_t o = offsets[i] + add;
+            offsets[i] = o;
+            cursor[i] = o;
+            if (i == n - 1) offsets[n] = o + counts[i];
+        }
+    }
+}
+
+// ---------------------------------------------------------------- K3: scatter indices into bucket order
+__global__ void __launch_bounds__(256) msm_scatter_kernel(const int32_t *__restrict__ digits, size_t n, int nwin,
+                                                          uint32_t B, uint32_t *__restrict__ cursor,
+                                                          uint32_t *__restrict__ sorted) {
+    size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n * (size_t)nwin) return;
+    int32_t d = digits[t];
+    if (d == 0) return;
+    size_t w = t / n, i = t - w * n;
+    uint32_t mag = d < 0 ? (uint32_t)(-d) : (uint32_t)d;
+    uint32_t pos = atomicAdd(&cursor[w * B + (mag - 1)], 1u);
+    sorted[pos] = ((uint32_t)i << 1) | (d < 0 ? 1u : 0u);
+}
+
+// ---------------------------------------------------------------- K4: bucket accumulation
+__global__ void __launch_bounds__(128) msm_accumulate_kernel(const G1Affine *__restrict__ points,
+                                                             const uint32_t *__restrict__ sorted,
+                                                             const uint32_t *__restrict__ offsets, size_t n_buckets,
+                                                             G1Xyzz *__restrict__ buckets) {
+    size_t id = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= n_buckets) return;
+    uint32_t k = offsets[id], end = offsets[id + 1];
+    G1Xyzz acc = G1Xyzz::inf();
+    if (k < end) {
+        G1Affine nxt = load_point(points, sorted[k]);
+        while (k < end) {
+            G1Affine cur = nxt;
+            k++;
+            if (k < end) nxt = load_point(points, sorted[k]);  // issue the next gather before the add
+            acc = add_mixed<true>(acc, cur);
+        }
+    }
+    store_xyzz(&buckets[id], acc);
+}
+
+// ---------------------------------------------------------------- K5: segment partials
+// thread (w, g): part = sum_{j=0}^{L-1} (g*L + j + 1) * bucket[w][g*L + j]
+__global__ void __launch_bounds__(128) msm_segments_kernel(const G1Xyzz *__restrict__ buckets, uint32_t B, uint32_t L,
+                                                           size_t n_segments_total, G1Xyzz *__restrict__ partials) {
+    size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n_segments_total) return;
+    uint32_t G = B / L;
+    size_t w = t / G;
+    uint32_t g = (uint32_t)(t - w * G);
+    const G1Xyzz *seg = buckets + w * B + (size_t)g * L;
+    G1Xyzz run = G1Xyzz::inf(), wsum = G1Xyzz::inf();
+    for (int j = (int)L - 1; j >= 0; j--) {
+        run = add(run, load_xyzz(&seg[j]));
+        wsum = add(wsum, run);
+    }
+    // + (g*L) * run  (double-and-add on the XYZZ point)
+    uint32_t k = g * L;
+    if (k != 0 && !run.is_inf()) {
+        G1Xyzz acc = G1Xyzz::inf();
+        for (int b = 31 - __clz(k); b >= 0; b--) {
+            acc = dbl(acc);
+            if ((k >> b) & 1u) acc = add(acc, run);
+        }
+        wsum = add(wsum, acc);
+    }
+    store_xyzz(&partials[t], wsum);
+}
+
+// out-of-line group addition for the cold reduction kernels
+__device__ __attribute__((noinline)) G1Xyzz xyzz_add_ni(const G1Xyzz &a, const G1Xyzz &b) { return add(a, b); }
+
+// ---------------------------------------------------------------- K6: per-group tree sum through LDS
+// in[group][m] -> out[group][gridDim.x]; block (x, group) sums a strided slice, then an LDS tree.
+__global__ void __launch_bounds__(256) point_tree_sum_kernel(const G1Xyzz *__restrict__ in, size_t m,
+                                                             G1Xyzz *__restrict__ out) {
+    __shared__ G1Xyzz lds[128];  // 24 KiB: the upper half of the live lanes parks its sum here each level
+    const size_t group = blockIdx.y;
+    const G1Xyzz *src = in + group * m;
+    G1Xyzz acc = G1Xyzz::inf();
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < m; i += (size_t)gridDim.x * 256) acc = xyzz_add_ni(acc, load_xyzz(&src[i]));
+    const int t = threadIdx.x;
+    for (int stride = 128; stride >= 1; stride >>= 1) {
+        if (t >= stride && t < 2 * stride) store_xyzz(&lds[t - stride], acc);
+        __syncthreads();
+        if (t < stride) acc = xyzz_add_ni(acc, load_xyzz(&lds[t]));
+        __syncthreads();
+    }
+    if (t == 0) store_xyzz(&out[group * gridDim.x + blockIdx.x], acc);
+}
+
+// ---------------------------------------------------------------- host driver
+template <int C>
+static void launch_digits(const uint32_t *scalars, size_t n, int32_t *digits, uint32_t *counts, int scalar_bits,
+                          hipStream_t st) {
+    if (scalar_bits > 128)
+        hipLaunchKernelGGL((msm_digits_kernel<C, 254>), dim3(cdiv(n, 256)), dim3(256), 0, st, scalars, n, digits, counts);
+    else
+        hipLaunchKernelGGL((msm_digits_kernel<C, 129>), dim3(cdiv(n, 256)), dim3(256), 0, st, scalars, n, digits, counts);
+}
+
+// Sum groups of XYZZ points on the device: in[groups][m] -> result[groups] (device pointer into workspace)
+static G1Xyzz *device_group_sum(Context &cx, G1Xyzz *in, size_t groups, size_t m, hipStream_t st, const char *tag_a,
+                                const char *tag_b) {
+    G1Xyzz *cur = in;
+    bool flip = false;
+    while (m > 1) {
+        unsigned bx = (unsigned)((m + 2047) / 2048);  // >= 8 elements per lane before the tree
+        if (bx < 1) bx = 1;
+        G1Xyzz *dst = (G1Xyzz *)cx.buf(flip ? tag_b : tag_a, sizeof(G1Xyzz) * groups * bx);
+        hipLaunchKernelGGL(point_tree_sum_kernel, dim3(bx, (unsigned)groups), dim3(256), 0, st, cur, m, dst);
+        cur = dst;
+        m = bx;
+        flip = !flip;
+    }
+    return cur;
+}
+
+// d_points / d_scalars: device pointers.  Result: normalised Jacobian (z = 1) or infinity (z = 0).
+void msm_device(Context &cx, const G1Affine *d_points, const uint32_t *d_scalars, size_t n, mi_g1_jac *out,
+                hipStream_t st, int scalar_bits, int force_c) {
+    G1Jac res = G1Jac{Fq::one(), Fq::one(), Fq::zero()};
+    if (n == 0) {
+        memcpy(out, &res, sizeof res);
+        return;
+    }
+    MsmPlan pl = msm_plan(n, scalar_bits, force_c);
+    const size_t nb = (size_t)pl.nwin * pl.B;
+    int32_t *digits = (int32_t *)cx.buf("msm.digits", sizeof(int32_t) * n * pl.nwin);
+    uint32_t *sorted = (uint32_t *)cx.buf("msm.sorted", sizeof(uint32_t) * n * pl.nwin);
+    uint32_t *counts = (uint32_t *)cx.buf("msm.counts", sizeof(uint32_t) * nb);
+    uint32_t *offsets = (uint32_t *)cx.buf("msm.offsets", sizeof(uint32_t) * (nb + 1));
+    uint32_t *cursor = (uint32_t *)cx.buf("msm.cursor", sizeof(uint32_t) * nb);
+    const unsigned tiles = cdiv(nb, 2048);
+    uint32_t *tile_sums = (uint32_t *)cx.buf("msm.tiles", sizeof(uint32_t) * tiles);
+    G1Xyzz *buckets = (G1Xyzz *)cx.buf("msm.buckets", sizeof(G1Xyzz) * nb);
+
+    MI_HIP(hipMemsetAsync(counts, 0, sizeof(uint32_t) * nb, st));
+    switch (pl.c) {
+#define MI_CASE(C) case C: launch_digits<C>(d_scalars, n, digits, counts, scalar_bits, st); break;
+        MI_CASE(6) MI_CASE(7) MI_CASE(8) MI_CASE(9) MI_CASE(10) MI_CASE(11) MI_CASE(12) MI_CASE(13) MI_CASE(14) MI_CASE(15) MI_CASE(16)
+#undef MI_CASE
+    }
+    hipLaunchKernelGGL(scan_tiles_kernel, dim3(tiles), dim3(256), 0, st, counts, offsets, tile_sums, nb);
+    hipLaunchKernelGGL(scan_sums_kernel, dim3(1), dim3(1024), 0, st, tile_sums, (size_t)tiles);
+    hipLaunchKernelGGL(scan_finish_kernel, dim3(tiles), dim3(256), 0, st, offsets, cursor, tile_sums, counts, nb);
+    hipLaunchKernelGGL(msm_scatter_kernel, dim3(cdiv(n * pl.nwin, 256)), dim3(256), 0, st, digits, n, pl.nwin, pl.B, cursor, sorted);
+    hipLaunchKernelGGL(msm_accumulate_kernel, dim3(cdiv(nb, 128)), dim3(128), 0, st, d_points, sorted, offsets, nb, buckets);
+    uint32_t L = pl.B >= 4096 ? 8 : 4;
+    const size_t nseg = nb / L;
+    G1Xyzz *partials = (G1Xyzz *)cx.buf("msm.partials", sizeof(G1Xyzz) * nseg);
+    hipLaunchKernelGGL(msm_segments_kernel, dim3(cdiv(nseg, 128)), dim3(128), 0, st, buckets, pl.B, L, nseg, partials);
+    G1Xyzz *wsums = device_group_sum(cx, partials, pl.nwin, pl.B / L, st, "msm.tree_a", "msm.tree_b");
+    MI_HIP(hipGetLastError());
+    G1Xyzz *h = (G1Xyzz *)cx.pin(sizeof(G1Xyzz) * pl.nwin);
+    MI_HIP(hipMemcpyAsync(h, wsums, sizeof(G1Xyzz) * pl.nwin, hipMemcpyDeviceToHost, st));
+    MI_HIP(hipStreamSynchronize(st));
+    // host tail: Horner fold over the windows (nwin additions, (nwin-1)*c doublings), then normalise
+    G1Xyzz acc = h[pl.nwin - 1];
+    for (int w = pl.nwin - 2; w >= 0; w--) {
+        for (int k = 0; k < pl.c; k++) acc = dbl(acc);
+        acc = add(acc, h[w]);
+    }
+    G1Affine a = to_affine(acc);
+    res = affine_to_jac(a);
+    memcpy(out, &res, sizeof res);
+}
+
+}  // namespace mi

@@ -1,0 +1,85 @@
+// Pairing product on the device: kernel + host drivers.  Device/host arithmetic lives in tower.hpp.
+#include <vector>
+#include "api.hpp"
+#include "tower.hpp"
+
+namespace mi {
+
+struct PairingArgs {
+    G1Affine p[MI_MAX_PAIRS];
+    const G2Prepared *q[MI_MAX_PAIRS];
+    int n;
+};
+
+// v1: one lane walks the whole product (latency-bound; the wave-parallel Fq12 version replaces this)
+__global__ void __launch_bounds__(64) pairing_product_kernel(PairingArgs args, const PairingConsts *__restrict__ pc,
+                                                             Fq12 *out) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    Fq12 f = miller_product(args.p, args.q, args.n);
+    *out = final_exponentiation(f, *pc);
+}
+
+struct PairingState {
+    DevBuf consts;
+    bool ready = false;
+};
+static PairingState &pairing_state() {
+    static PairingState s;
+    return s;
+}
+static Fq host_fq_from_limbs(const uint64_t *l) {
+    Fq r;
+    for (int i = 0; i < 6; i++) { r.l[2 * i] = (uint32_t)l[i]; r.l[2 * i + 1] = (uint32_t)(l[i] >> 32); }
+    return r;
+}
+const PairingConsts *pairing_consts(Context &cx, hipStream_t st) {
+    PairingState &s = pairing_state();
+    if (!s.ready) {
+        PairingConsts h;
+        for (int e = 0; e < 3; e++)
+            for (int k = 0; k < 12; k++) h.frob[e][k] = host_fq_from_limbs(MI_FROB[e][k]);
+        void *d = s.consts.get(sizeof h);
+        MI_HIP(hipMemcpyAsync(d, &h, sizeof h, hipMemcpyHostToDevice, st));
+        MI_HIP(hipStreamSynchronize(st));
+        s.ready = true;
+    }
+    (void)cx;
+    return (const PairingConsts *)s.consts.p;
+}
+
+// product over prepared (device-resident) G2 points; P's are host values passed as kernel arguments
+void pairing_product_prepared(Context &cx, const G1Affine *ps, const G2Prepared *const *d_qs, size_t n, Fq12 *out_host,
+                                     hipStream_t st) {
+    PairingArgs a;
+    memset(&a, 0, sizeof a);
+    a.n = (int)n;
+    for (size_t i = 0; i < n; i++) { a.p[i] = ps[i]; a.q[i] = d_qs[i]; }
+    const PairingConsts *pc = pairing_consts(cx, st);
+    Fq12 *d_out = (Fq12 *)cx.buf("pairing.out", sizeof(Fq12));
+    hipLaunchKernelGGL(pairing_product_kernel, dim3(1), dim3(64), 0, st, a, pc, d_out);
+    MI_HIP(hipGetLastError());
+    Fq12 *h = (Fq12 *)cx.pin(sizeof(Fq12));
+    MI_HIP(hipMemcpyAsync(h, d_out, sizeof(Fq12), hipMemcpyDeviceToHost, st));
+    MI_HIP(hipStreamSynchronize(st));
+    *out_host = *h;
+}
+
+// arbitrary G2 points given on the host: prepare (host), upload, run
+void pairing_product_host_args(Context &cx, const G1Affine *ps, const G2Affine *qs, size_t n, Fq12 *out_host,
+                                      hipStream_t st) {
+    std::vector<G2Prepared> prep(n);
+    for (size_t i = 0; i < n; i++) g2_prepare_host(prep[i], qs[i]);
+    G2Prepared *d = (G2Prepared *)cx.buf("pairing.adhoc_q", sizeof(G2Prepared) * n);
+    MI_HIP(hipMemcpyAsync(d, prep.data(), sizeof(G2Prepared) * n, hipMemcpyHostToDevice, st));
+    MI_HIP(hipStreamSynchronize(st));
+    const G2Prepared *dq[MI_MAX_PAIRS];
+    for (size_t i = 0; i < n; i++) dq[i] = d + i;
+    pairing_product_prepared(cx, ps, dq, n, out_host, st);
+}
+
+void pairing_release() {
+    pairing_state().consts.release();
+    pairing_state().ready = false;
+}
+
+}  // namespace mi

@@ -1,0 +1,102 @@
+// Device context, workspace cache and error plumbing shared by every entry point.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <map>
+#include <mutex>
+#include <string>
+#include <vector>
+#include "../../include/mi355x_snark.h"
+
+namespace mi {
+
+struct HipError {
+    hipError_t e;
+    const char *what;
+    int line;
+};
+
+#define MI_HIP(expr)                                                     \
+    do {                                                                 \
+        hipError_t _e = (expr);                                          \
+        if (_e != hipSuccess) throw ::mi::HipError{_e, #expr, __LINE__}; \
+    } while (0)
+
+inline int32_t status_of(const HipError &h) {
+    fprintf(stderr, "[mi355x_snark] HIP error %d (%s) at %s:%d\n", (int)h.e, hipGetErrorString(h.e), h.what, h.line);
+    if (h.e == hipErrorOutOfMemory) return MI_ERR_OOM;
+    if (h.e == hipErrorNoDevice || h.e == hipErrorInvalidDevice) return MI_ERR_NO_DEVICE;
+    return MI_ERR_KERNEL;
+}
+
+// A grow-only device buffer (no hipMalloc on the steady-state path).
+struct DevBuf {
+    void *p = nullptr;
+    size_t cap = 0;
+    void *get(size_t bytes) {
+        if (bytes > cap) {
+            if (p) MI_HIP(hipFree(p));
+            p = nullptr;
+            cap = 0;
+            size_t want = bytes + bytes / 8 + 256;
+            MI_HIP(hipMalloc(&p, want));
+            cap = want;
+        }
+        return p;
+    }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+};
+
+struct Context {
+    std::mutex mu;  // serialises GPU work issued through the library (callers are rayon / tokio threads)
+    bool inited = false;
+    int device = 0;
+    int n_cus = 256;
+    hipStream_t stream = nullptr;  // library-owned stream for host-pointer entry points
+    std::map<std::string, DevBuf> bufs;
+    std::map<uint64_t, DevBuf> handles;  // registered bases
+    std::map<uint64_t, size_t> handle_len;
+    uint64_t next_handle = 1;
+    void *pinned = nullptr;  // small pinned staging area for results
+    size_t pinned_cap = 0;
+
+    void *buf(const char *name, size_t bytes) { return bufs[name].get(bytes); }
+    void *pin(size_t bytes) {
+        if (bytes > pinned_cap) {
+            if (pinned) MI_HIP(hipHostFree(pinned));
+            pinned = nullptr;
+            MI_HIP(hipHostMalloc(&pinned, bytes + 4096, hipHostMallocDefault));
+            pinned_cap = bytes + 4096;
+        }
+        return pinned;
+    }
+};
+
+Context &ctx();
+int32_t ensure_init();
+
+template <class F>
+int32_t guarded(F &&f) {
+    try {
+        int32_t s = ensure_init();
+        if (s != MI_OK) return s;
+        std::lock_guard<std::mutex> lk(ctx().mu);
+        MI_HIP(hipSetDevice(ctx().device));  // never rely on a foreign thread's current device
+        return f();
+    } catch (const HipError &h) {
+        return status_of(h);
+    } catch (const std::bad_alloc &) {
+        return MI_ERR_OOM;
+    } catch (...) {
+        return MI_ERR_KERNEL;
+    }
+}
+
+inline unsigned cdiv(size_t a, size_t b) { return (unsigned)((a + b - 1) / b); }
+
+}  // namespace mi

@@ -1,0 +1,584 @@
+// KZG10 batch_check and the VarunaShaped-v1 batch verifier on gfx950.
+//
+// Replaces, for the consensus-side batch (Consensus::try_advance_to_next_block ->
+// Ledger::check_next_block -> VM::check_transactions -> Varuna::verify_batch -> SonicKZG10 -> KZG10):
+//   polycommit::kzg10::KZG10::batch_check                         
+//   polycommit::sonic_pc::SonicKZG10::{accumulate_elems,check_elems} (row A6) and the Fr / Fiat-Shamir
+//   work of snark::varuna::VarunaSNARK::verify_batch              (row A7), on the synthetic proof shape
+//   "VarunaShaped-v1"  with a SHA-256 stand-in transcript (row A9 is not reproduced: the
+//   Poseidon parameters of snarkVM are not available offline).
+// The reference verifies one transaction at a time (rayon over transactions, one pairing product per
+// proof).  Here the whole batch becomes ONE random-linear-combination MSM plus ONE two-pair pairing
+// product; only if that aggregate check fails are proofs checked one by one to name the bad ones.
+#include <map>
+#include <vector>
+#include "api.hpp"
+#include "tower.hpp"
+
+namespace mi {
+
+// ---------------------------------------------------------------- small Fr helpers
+__device__ __forceinline__ Fr fr_load(const void *p) {
+    const uint4 *q = reinterpret_cast<const uint4 *>(p);
+    uint4 a = q[0], b = q[1];
+    Fr r;
+    r.l[0] = a.x; r.l[1] = a.y; r.l[2] = a.z; r.l[3] = a.w;
+    r.l[4] = b.x; r.l[5] = b.y; r.l[6] = b.z; r.l[7] = b.w;
+    return r;
+}
+__device__ __forceinline__ void fr_store(void *p, const Fr &v) {
+    uint4 *q = reinterpret_cast<uint4 *>(p);
+    q[0] = make_uint4(v.l[0], v.l[1], v.l[2], v.l[3]);
+    q[1] = make_uint4(v.l[4], v.l[5], v.l[6], v.l[7]);
+}
+// 128-bit little-endian integer -> Montgomery Fr
+__device__ __forceinline__ Fr fr_from_u128(const uint32_t w[4]) {
+    Fr t = Fr::zero();
+    t.l[0] = w[0]; t.l[1] = w[1]; t.l[2] = w[2]; t.l[3] = w[3];
+    return to_mont(t);
+}
+__device__ __forceinline__ void copy_g1(G1Affine *dst, const G1Affine *src) {
+    const uint4 *s = reinterpret_cast<const uint4 *>(src);
+    uint4 *d = reinterpret_cast<uint4 *>(dst);
+#pragma unroll
+    for (int k = 0; k < 6; k++) d[k] = s[k];
+}
+
+// ---------------------------------------------------------------- SHA-256 (stand-in transcript)
+__device__ __forceinline__ uint32_t ror32(uint32_t x, int n) { return (x >> n) | (x << (32 - n)); }
+__constant__ uint32_t SHA_K[64] = {
+    0x428a2f98, 0x71374491, 0xb5c0fbcf, 0xe9b5dba5, 0x3956c25b, 0x59f111f1, 0x923f82a4, 0xab1c5ed5, 0xd807aa98,
+    0x12835b01, 0x243185be, 0x550c7dc3, 0x72be5d74, 0x80deb1fe, 0x9bdc06a7, 0xc19bf174, 0xe49b69c1, 0xefbe4786,
+    0x0fc19dc6, 0x240ca1cc, 0x2de92c6f, 0x4a7484aa, 0x5cb0a9dc, 0x76f988da, 0x983e5152, 0xa831c66d, 0xb00327c8,
+    0xbf597fc7, 0xc6e00bf3, 0xd5a79147, 0x06ca6351, 0x14292967, 0x27b70a85, 0x2e1b2138, 0x4d2c6dfc, 0x53380d13,
+    0x650a7354, 0x766a0abb, 0x81c2c92e, 0x92722c85, 0xa2bfe8a1, 0xa81a664b, 0xc24b8b70, 0xc76c51a3, 0xd192e819,
+    0xd6990624, 0xf40e3585, 0x106aa070, 0x19a4c116, 0x1e376c08, 0x2748774c, 0x34b0bcb5, 0x391c0cb3, 0x4ed8aa4a,
+    0x5b9cca4f, 0x682e6ff3, 0x748f82ee, 0x78a5636f, 0x84c87814, 0x8cc70208, 0x90befffa, 0xa4506ceb, 0xbef9a3f7,
+    0xc67178f2};
+__device__ __forceinline__ void sha256_compress(uint32_t st[8], uint32_t w[16]) {
+    uint32_t a = st[0], b = st[1], c = st[2], d = st[3], e = st[4], f = st[5], g = st[6], h = st[7];
+#pragma unroll
+    for (int i = 0; i < 64; i++) {
+        if (i >= 16) {
+            uint32_t w15 = w[(i - 15) & 15], w2 = w[(i - 2) & 15];
+            uint32_t s0 = ror32(w15, 7) ^ ror32(w15, 18) ^ (w15 >> 3);
+            uint32_t s1 = ror32(w2, 17) ^ ror32(w2, 19) ^ (w2 >> 10);
+            w[i & 15] = w[i & 15] + s0 + w[(i - 7) & 15] + s1;
+        }
+        uint32_t t1 = h + (ror32(e, 6) ^ ror32(e, 11) ^ ror32(e, 25)) + ((e & f) ^ (~e & g)) + SHA_K[i] + w[i & 15];
+        uint32_t t2 = (ror32(a, 2) ^ ror32(a, 13) ^ ror32(a, 22)) + ((a & b) ^ (a & c) ^ (b & c));
+        h = g; g = f; f = e; e = d + t1; d = c; c = b; b = a; a = t1 + t2;
+    }
+    st[0] += a; st[1] += b; st[2] += c; st[3] += d; st[4] += e; st[5] += f; st[6] += g; st[7] += h;
+}
+// SHA-256( prefix(32 bytes, given as 8 big-endian words) || a[0..na) || b[0..nb) ), a/b little-endian
+// words in memory (i.e. raw bytes).  Output: 8 big-endian state words.
+__device__ void sha256_prefixed(uint32_t out[8], const uint32_t prefix[8], const uint32_t *__restrict__ a, uint32_t na,
+                                const uint32_t *__restrict__ b, uint32_t nb) {
+    uint32_t st[8] = {0x6a09e667, 0xbb67ae85, 0x3c6ef372, 0xa54ff53a, 0x510e527f, 0x9b05688c, 0x1f83d9ab, 0x5be0cd19};
+    const uint32_t total = 8 + na + nb;                 // message words
+    const uint32_t nblocks = (total + 1 + 2 + 15) / 16;  // + 0x80 word + 64-bit length
+    for (uint32_t blk = 0; blk < nblocks; blk++) {
+        uint32_t w[16];
+#pragma unroll
+        for (int t = 0; t < 16; t++) {
+            uint32_t i = blk * 16 + t, v;
+            if (blk == 0 && t < 8) v = prefix[t];
+            else if (i < 8 + na) v = __builtin_bswap32(a[i - 8]);
+            else if (i < total) v = __builtin_bswap32(b[i - 8 - na]);
+            else if (i == total) v = 0x80000000u;
+            else if (i == nblocks * 16 - 1) v = total * 32u;  // bit length (< 2^32)
+            else v = 0;
+            w[t] = v;
+        }
+        sha256_compress(st, w);
+    }
+#pragma unroll
+    for (int i = 0; i < 8; i++) out[i] = st[i];
+}
+
+// ---------------------------------------------------------------- VarunaShaped-v1 context
+struct VsConsts {
+    Fr omega16[MI_VS_INPUTS];  // w_16^k
+    Fr n_inv;                  // 1/16
+    uint32_t tag[8];           // big-endian words of the 32-byte domain tag
+    G1Affine g;
+};
+struct VsCtx {
+    size_t n_circuits = 0;
+    DevBuf circuits, h_prep, tauh_prep, consts;
+    mi_kzg_vk vk;
+};
+static std::map<uint64_t, VsCtx> &vs_ctxs() {
+    static std::map<uint64_t, VsCtx> m;
+    return m;
+}
+static uint64_t g_vs_next = 1;
+void verify_release_all() {
+    for (auto &kv : vs_ctxs()) {
+        kv.second.circuits.release();
+        kv.second.h_prep.release();
+        kv.second.tauh_prep.release();
+        kv.second.consts.release();
+    }
+    vs_ctxs().clear();
+    ntt_release_tables();
+    pairing_release();
+}
+
+static void upload_prepared(DevBuf &buf, const mi_g2_affine *q, hipStream_t st) {
+    G2Prepared prep;
+    G2Affine qa;
+    memcpy(&qa, q, sizeof qa);
+    g2_prepare_host(prep, qa);
+    void *d = buf.get(sizeof prep);
+    MI_HIP(hipMemcpyAsync(d, &prep, sizeof prep, hipMemcpyHostToDevice, st));
+    MI_HIP(hipStreamSynchronize(st));
+}
+
+int32_t vs_ctx_create(Context &cx, const mi_kzg_vk *vk, const mi_vs_circuit_vk *circuits, size_t n_circuits,
+                             uint64_t *out) {
+    uint64_t id = g_vs_next++;
+    VsCtx &v = vs_ctxs()[id];
+    v.n_circuits = n_circuits;
+    v.vk = *vk;
+    void *dc = v.circuits.get(sizeof(mi_vs_circuit_vk) * n_circuits);
+    MI_HIP(hipMemcpyAsync(dc, circuits, sizeof(mi_vs_circuit_vk) * n_circuits, hipMemcpyHostToDevice, cx.stream));
+    upload_prepared(v.h_prep, &vk->h, cx.stream);
+    upload_prepared(v.tauh_prep, &vk->tau_h, cx.stream);
+    VsConsts hc;
+    Fr w = host_omega(4);
+    hc.omega16[0] = Fr::one();
+    for (int k = 1; k < MI_VS_INPUTS; k++) hc.omega16[k] = mul(hc.omega16[k - 1], w);
+    hc.n_inv = inv(from_u32<FrP>(MI_VS_INPUTS));
+    static const char TAG[32] = "MI355X-VarunaShaped-v1";
+    for (int i = 0; i < 8; i++)
+        hc.tag[i] = ((uint32_t)(uint8_t)TAG[4 * i] << 24) | ((uint32_t)(uint8_t)TAG[4 * i + 1] << 16) |
+                    ((uint32_t)(uint8_t)TAG[4 * i + 2] << 8) | (uint32_t)(uint8_t)TAG[4 * i + 3];
+    memcpy(&hc.g, &vk->g, sizeof hc.g);
+    void *dk = v.consts.get(sizeof hc);
+    MI_HIP(hipMemcpyAsync(dk, &hc, sizeof hc, hipMemcpyHostToDevice, cx.stream));
+    MI_HIP(hipStreamSynchronize(cx.stream));
+    *out = id;
+    return MI_OK;
+}
+int32_t vs_ctx_destroy(Context &cx, uint64_t id) {
+    auto it = vs_ctxs().find(id);
+    if (it == vs_ctxs().end()) return MI_ERR_BAD_ARGS;
+    MI_HIP(hipStreamSynchronize(cx.stream));
+    it->second.circuits.release();
+    it->second.h_prep.release();
+    it->second.tauh_prep.release();
+    it->second.consts.release();
+    vs_ctxs().erase(it);
+    return MI_OK;
+}
+
+// polynomial p (0..20: 9 proof commitments then 12 vk commitments) opens at query 0 (beta) or 1 (gamma)
+__host__ __device__ __forceinline__ int vs_query_of(int p) {
+    if (p < MI_VS_PROOF_COMMS) return p < 5 ? 0 : 1;
+    return (p - MI_VS_PROOF_COMMS) < 6 ? 0 : 1;
+}
+
+#define VS_PER_PROOF_POINTS (MI_VS_PROOF_COMMS + 2)
+
+// ---------------------------------------------------------------- K: transcript + Fr work, one lane per proof
+// Writes, for proof i:
+//   pts1[i*11 + k]   = C_k (k < 9), W_beta, W_gamma          sc1[i*11 + k] = r_q xi^k | r_q z_q   (canonical)
+//   pts2[i*2 + q]    = W_q                                    sc2[i*2 + q]  = r_q                  (canonical)
+//   vk_scal[i*12+k]  = r_q xi^(9+k)  (Montgomery)             g_scal[i] = -(sum_q r_q val_q)       (Montgomery)
+//   alg_ok[i]        = public-input consistency v_0 == x_hat(z_beta) + (z_beta^16 - 1) v_1
+__global__ void __launch_bounds__(64) vs_derive_kernel(const mi_vs_proof *__restrict__ proofs, size_t n,
+                                                       const uint8_t *__restrict__ rand128,
+                                                       const mi_vs_circuit_vk *__restrict__ circuits, size_t n_circuits,
+                                                       const VsConsts *__restrict__ kc, G1Affine *__restrict__ pts1,
+                                                       uint32_t *__restrict__ sc1, G1Affine *__restrict__ pts2,
+                                                       uint32_t *__restrict__ sc2, Fr *__restrict__ vk_scal,
+                                                       Fr *__restrict__ g_scal, uint8_t *__restrict__ alg_ok,
+                                                       uint32_t *__restrict__ circuit_of) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const mi_vs_proof *p = proofs + i;
+    const uint32_t *pw = reinterpret_cast<const uint32_t *>(p);
+    uint32_t circuit = pw[0];
+    if (circuit >= n_circuits) circuit = 0;  // malformed index: still well-defined, proof is rejected below
+    const bool bad_circuit = pw[0] >= n_circuits;
+    circuit_of[i] = circuit;
+    const uint32_t *digest = reinterpret_cast<const uint32_t *>(circuits[circuit].digest);
+    const uint32_t *inputs = pw + 4;                 // 16 x 8 words
+    const uint32_t *comms = inputs + 128;            // 9 x 24 words
+    const uint32_t *evals = comms + 216;             // 21 x 8 words
+    // ---- transcript
+    uint32_t tag[8], h[8], zw[2][4], xw[4];
+#pragma unroll
+    for (int k = 0; k < 8; k++) tag[k] = kc->tag[k];
+    sha256_prefixed(h, tag, digest, 8, inputs, 128 + 48);
+    sha256_prefixed(h, h, comms + 48, 72, nullptr, 0);
+#pragma unroll
+    for (int k = 0; k < 4; k++) zw[0][k] = __builtin_bswap32(h[k]);
+    sha256_prefixed(h, h, comms + 120, 96, nullptr, 0);
+#pragma unroll
+    for (int k = 0; k < 4; k++) zw[1][k] = __builtin_bswap32(h[k]);
+    sha256_prefixed(h, h, evals, 168, nullptr, 0);
+#pragma unroll
+    for (int k = 0; k < 4; k++) xw[k] = __builtin_bswap32(h[k]);
+    Fr z[2] = {fr_from_u128(zw[0]), fr_from_u128(zw[1])};
+    Fr xi = fr_from_u128(xw);
+    // ---- randomizers
+    const uint32_t *rw = reinterpret_cast<const uint32_t *>(rand128 + 32 * i);
+    uint32_t r0[4] = {rw[0], rw[1], rw[2], rw[3]}, r1[4] = {rw[4], rw[5], rw[6], rw[7]};
+    Fr r[2] = {fr_from_u128(r0), fr_from_u128(r1)};
+    // ---- opening-challenge powers, combined values, MSM scalars
+    Fr xip = Fr::one(), val[2] = {Fr::zero(), Fr::zero()};
+    for (int k = 0; k < MI_VS_EVALS; k++) {
+        int q = vs_query_of(k);
+        Fr s = mul(r[q], xip);
+        if (k < MI_VS_PROOF_COMMS) fr_store(sc1 + (i * VS_PER_PROOF_POINTS + k) * 8, from_mont(s));
+        else fr_store(vk_scal + i * MI_VS_VK_COMMS + (k - MI_VS_PROOF_COMMS), s);
+        val[q] = add(val[q], mul(xip, fr_load(evals + 8 * k)));
+        xip = mul(xip, xi);
+    }
+    Fr gs = Fr::zero();
+#pragma unroll
+    for (int q = 0; q < 2; q++) {
+        fr_store(sc1 + (i * VS_PER_PROOF_POINTS + MI_VS_PROOF_COMMS + q) * 8, from_mont(mul(r[q], z[q])));
+        gs = sub(gs, mul(r[q], val[q]));
+    }
+    {
+        uint32_t *o = sc2 + i * 16;
+#pragma unroll
+        for (int k = 0; k < 4; k++) { o[k] = r0[k]; o[4 + k] = 0; o[8 + k] = r1[k]; o[12 + k] = 0; }
+    }
+    fr_store(g_scal + i, gs);
+    // ---- points into MSM order
+    const G1Affine *pc = reinterpret_cast<const G1Affine *>(comms);
+    for (int k = 0; k < MI_VS_PROOF_COMMS; k++) copy_g1(pts1 + i * VS_PER_PROOF_POINTS + k, pc + k);
+    const G1Affine *wpt = reinterpret_cast<const G1Affine *>(evals + 168);
+#pragma unroll
+    for (int q = 0; q < 2; q++) {
+        copy_g1(pts1 + i * VS_PER_PROOF_POINTS + MI_VS_PROOF_COMMS + q, wpt + q);
+        copy_g1(pts2 + i * 2 + q, wpt + q);
+    }
+    // ---- public-input consistency (Lagrange evaluation over the size-16 domain, one batched inversion)
+    Fr zn = z[0];
+#pragma unroll
+    for (int k = 0; k < 4; k++) zn = sqr(zn);
+    Fr znm1 = sub(zn, Fr::one());
+    bool ok = !znm1.is_zero() && !bad_circuit;
+    Fr pre[MI_VS_INPUTS], acc = Fr::one();
+    for (int k = 0; k < MI_VS_INPUTS; k++) {
+        pre[k] = acc;
+        acc = mul(acc, sub(z[0], fr_load(&kc->omega16[k])));
+    }
+    acc = inv(acc);
+    Fr xhat = Fr::zero();
+    for (int k = MI_VS_INPUTS - 1; k >= 0; k--) {
+        Fr wk = fr_load(&kc->omega16[k]);
+        Fr dinv = mul(acc, pre[k]);
+        acc = mul(acc, sub(z[0], wk));
+        xhat = add(xhat, mul(mul(fr_load(inputs + 8 * k), wk), dinv));
+    }
+    xhat = mul(mul(xhat, znm1), fr_load(&kc->n_inv));
+    Fr lhs = add(xhat, mul(znm1, fr_load(evals + 8)));
+    ok = ok && (lhs == fr_load(evals));
+    alg_ok[i] = ok ? 1 : 0;
+}
+
+// one block per merged slot: slot < n_circuits*12 -> sum of vk_scal over the proofs of that circuit;
+// last slot -> sum of g_scal.  Output: canonical scalar at sc1[(n*11 + slot)], point copied alongside.
+__global__ void __launch_bounds__(256) vs_merge_kernel(const Fr *__restrict__ vk_scal, const Fr *__restrict__ g_scal,
+                                                       const uint32_t *__restrict__ circuit_of, size_t n,
+                                                       const mi_vs_circuit_vk *__restrict__ circuits, size_t n_circuits,
+                                                       const VsConsts *__restrict__ kc, G1Affine *__restrict__ pts1,
+                                                       uint32_t *__restrict__ sc1) {
+    __shared__ uint32_t lds[8 * 256];
+    const size_t slot = blockIdx.x, n_vk_slots = n_circuits * MI_VS_VK_COMMS;
+    const int t = threadIdx.x;
+    Fr acc = Fr::zero();
+    if (slot < n_vk_slots) {
+        const uint32_t c = (uint32_t)(slot / MI_VS_VK_COMMS), k = (uint32_t)(slot % MI_VS_VK_COMMS);
+        for (size_t i = t; i < n; i += 256)
+            if (circuit_of[i] == c) acc = add(acc, fr_load(vk_scal + i * MI_VS_VK_COMMS + k));
+    } else {
+        for (size_t i = t; i < n; i += 256) acc = add(acc, fr_load(g_scal + i));
+    }
+    for (int stride = 128; stride >= 1; stride >>= 1) {
+        if (t >= stride && t < 2 * stride)
+#pragma unroll
+            for (int k = 0; k < 8; k++) lds[k * 256 + (t - stride)] = acc.l[k];
+        __syncthreads();
+        if (t < stride) {
+            Fr o;
+#pragma unroll
+            for (int k = 0; k < 8; k++) o.l[k] = lds[k * 256 + t];
+            acc = add(acc, o);
+        }
+        __syncthreads();
+    }
+    if (t == 0) {
+        const size_t dst = n * VS_PER_PROOF_POINTS + slot;
+        fr_store(sc1 + dst * 8, from_mont(acc));
+        if (slot < n_vk_slots)
+            copy_g1(pts1 + dst, reinterpret_cast<const G1Affine *>(circuits[slot / MI_VS_VK_COMMS].comms) + slot % MI_VS_VK_COMMS);
+        else
+            copy_g1(pts1 + dst, &kc->g);
+    }
+}
+
+// ---------------------------------------------------------------- per-proof fallback (names the bad proofs)
+// lane (i, k): k < 11 own points, 11..22 vk points, 23 G, 24..25 W_q with r_q  ->  term[i][k] = scalar * point
+#define VS_TERMS 26
+__global__ void __launch_bounds__(128) vs_terms_kernel(size_t n, const G1Affine *__restrict__ pts1,
+                                                       const uint32_t *__restrict__ sc1, const uint32_t *__restrict__ sc2,
+                                                       const Fr *__restrict__ vk_scal, const Fr *__restrict__ g_scal,
+                                                       const uint32_t *__restrict__ circuit_of,
+                                                       const mi_vs_circuit_vk *__restrict__ circuits,
+                                                       const VsConsts *__restrict__ kc, G1Xyzz *__restrict__ terms) {
+    size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n * VS_TERMS) return;
+    size_t i = t / VS_TERMS;
+    int k = (int)(t % VS_TERMS);
+    G1Affine P;
+    uint32_t s[8];
+    int bits = 253;
+    if (k < VS_PER_PROOF_POINTS) {
+        copy_g1(&P, pts1 + i * VS_PER_PROOF_POINTS + k);
+        Fr v = fr_load(sc1 + (i * VS_PER_PROOF_POINTS + k) * 8);
+#pragma unroll
+        for (int j = 0; j < 8; j++) s[j] = v.l[j];
+    } else if (k < VS_PER_PROOF_POINTS + MI_VS_VK_COMMS) {
+        int kk = k - VS_PER_PROOF_POINTS;
+        copy_g1(&P, reinterpret_cast<const G1Affine *>(circuits[circuit_of[i]].comms) + kk);
+        Fr v = from_mont(fr_load(vk_scal + i * MI_VS_VK_COMMS + kk));
+#pragma unroll
+        for (int j = 0; j < 8; j++) s[j] = v.l[j];
+    } else if (k == VS_PER_PROOF_POINTS + MI_VS_VK_COMMS) {
+        copy_g1(&P, &kc->g);
+        Fr v = from_mont(fr_load(g_scal + i));
+#pragma unroll
+        for (int j = 0; j < 8; j++) s[j] = v.l[j];
+    } else {
+        int q = k - (VS_PER_PROOF_POINTS + MI_VS_VK_COMMS + 1);
+        copy_g1(&P, pts1 + i * VS_PER_PROOF_POINTS + MI_VS_PROOF_COMMS + q);
+        Fr v = fr_load(sc2 + (i * 2 + q) * 8);
+#pragma unroll
+        for (int j = 0; j < 8; j++) s[j] = v.l[j];
+        bits = 128;
+    }
+    G1Xyzz acc = G1Xyzz::inf();
+    for (int b = bits - 1; b >= 0; b--) {
+        acc = dbl(acc);
+        // select the scalar bit without dynamic register indexing
+        uint32_t word = 0;
+#pragma unroll
+        for (int j = 0; j < 8; j++) word = (b >> 5) == j ? s[j] : word;
+        if ((word >> (b & 31)) & 1u) acc = add_mixed(acc, P);
+    }
+    store_xyzz(&terms[t], acc);
+}
+// lane i: total_c_i = sum of terms 0..23, total_w_i = terms 24 + 25; pairing product; verdict
+__global__ void __launch_bounds__(64) vs_per_proof_pairing_kernel(size_t n, const G1Xyzz *__restrict__ terms,
+                                                                  const G2Prepared *__restrict__ h,
+                                                                  const G2Prepared *__restrict__ tauh,
+                                                                  const PairingConsts *__restrict__ pc,
+                                                                  const uint8_t *__restrict__ alg_ok,
+                                                                  uint8_t *__restrict__ verdicts) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    G1Xyzz tc = G1Xyzz::inf(), tw = G1Xyzz::inf();
+    for (int k = 0; k < 24; k++) tc = add(tc, load_xyzz(&terms[i * VS_TERMS + k]));
+    tw = add(load_xyzz(&terms[i * VS_TERMS + 24]), load_xyzz(&terms[i * VS_TERMS + 25]));
+    G1Affine ps[2] = {to_affine(tc), neg(to_affine(tw))};
+    const G2Prepared *qs[2] = {h, tauh};
+    Fq12 f = final_exponentiation(miller_product(ps, qs, 2), *pc);
+    verdicts[i] = (f.is_one() && alg_ok[i]) ? 1 : 0;
+}
+
+// ---------------------------------------------------------------- host drivers
+struct VsWork {
+    G1Affine *pts1, *pts2;
+    uint32_t *sc1, *sc2, *circuit_of;
+    Fr *vk_scal, *g_scal;
+    uint8_t *alg_ok;
+    size_t n1, n2;
+};
+
+static VsWork vs_run_derive(Context &cx, VsCtx &v, const void *d_proofs, size_t n, const void *d_rand, hipStream_t st) {
+    VsWork w;
+    w.n1 = n * VS_PER_PROOF_POINTS + v.n_circuits * MI_VS_VK_COMMS + 1;
+    w.n2 = n * 2;
+    w.pts1 = (G1Affine *)cx.buf("vs.pts1", sizeof(G1Affine) * w.n1);
+    w.sc1 = (uint32_t *)cx.buf("vs.sc1", 32 * w.n1);
+    w.pts2 = (G1Affine *)cx.buf("vs.pts2", sizeof(G1Affine) * w.n2);
+    w.sc2 = (uint32_t *)cx.buf("vs.sc2", 32 * w.n2);
+    w.vk_scal = (Fr *)cx.buf("vs.vk_scal", sizeof(Fr) * n * MI_VS_VK_COMMS);
+    w.g_scal = (Fr *)cx.buf("vs.g_scal", sizeof(Fr) * n);
+    w.alg_ok = (uint8_t *)cx.buf("vs.alg_ok", n);
+    w.circuit_of = (uint32_t *)cx.buf("vs.circuit_of", 4 * n);
+    hipLaunchKernelGGL(vs_derive_kernel, dim3(cdiv(n, 64)), dim3(64), 0, st, (const mi_vs_proof *)d_proofs, n,
+                       (const uint8_t *)d_rand, (const mi_vs_circuit_vk *)v.circuits.p, v.n_circuits,
+                       (const VsConsts *)v.consts.p, w.pts1, w.sc1, w.pts2, w.sc2, w.vk_scal, w.g_scal, w.alg_ok, w.circuit_of);
+    hipLaunchKernelGGL(vs_merge_kernel, dim3((unsigned)(v.n_circuits * MI_VS_VK_COMMS + 1)), dim3(256), 0, st, w.vk_scal,
+                       w.g_scal, w.circuit_of, n, (const mi_vs_circuit_vk *)v.circuits.p, v.n_circuits,
+                       (const VsConsts *)v.consts.p, w.pts1, w.sc1);
+    MI_HIP(hipGetLastError());
+    return w;
+}
+
+static G1Jac host_jac(const mi_g1_jac &j) {
+    G1Jac r;
+    memcpy(&r, &j, sizeof r);
+    return r;
+}
+static G1Affine host_jac_to_affine_normalised(const mi_g1_jac &j) {
+    G1Jac r = host_jac(j);
+    if (r.z.is_zero()) return G1Affine::inf();
+    return G1Affine{r.x, r.y};  // library outputs always carry z = 1
+}
+
+// accumulate one shard: partial sums + algebraic failures (+ optional per-proof alg flags to host)
+static int32_t vs_accumulate_impl(Context &cx, uint64_t id, const void *d_proofs, size_t n, const void *d_rand,
+                                  mi_vs_partial *out, VsWork *work_out, hipStream_t st) {
+    auto it = vs_ctxs().find(id);
+    if (it == vs_ctxs().end()) return MI_ERR_BAD_ARGS;
+    VsCtx &v = it->second;
+    VsWork w = vs_run_derive(cx, v, d_proofs, n, d_rand, st);
+    msm_device(cx, w.pts1, w.sc1, w.n1, &out->total_c, st);
+    msm_device(cx, w.pts2, w.sc2, w.n2, &out->total_w, st, 128);
+    uint8_t *h_alg = (uint8_t *)cx.pin(n);
+    MI_HIP(hipMemcpyAsync(h_alg, w.alg_ok, n, hipMemcpyDeviceToHost, st));
+    MI_HIP(hipStreamSynchronize(st));
+    uint64_t fails = 0;
+    for (size_t i = 0; i < n; i++) fails += h_alg[i] ? 0 : 1;
+    out->n_proofs = n;
+    out->n_alg_fail = fails;
+    if (work_out) *work_out = w;
+    return MI_OK;
+}
+
+int32_t vs_accumulate_device(Context &cx, uint64_t id, const void *d_proofs, size_t n, const void *d_rand,
+                             mi_vs_partial *out, hipStream_t st) {
+    return vs_accumulate_impl(cx, id, d_proofs, n, d_rand, out, nullptr, st);
+}
+
+int32_t vs_finalize(Context &cx, uint64_t id, const mi_vs_partial *parts, size_t np, uint8_t *all_ok, hipStream_t st) {
+    auto it = vs_ctxs().find(id);
+    if (it == vs_ctxs().end()) return MI_ERR_BAD_ARGS;
+    VsCtx &v = it->second;
+    G1Xyzz tc = G1Xyzz::inf(), tw = G1Xyzz::inf();
+    uint64_t fails = 0;
+    for (size_t k = 0; k < np; k++) {
+        tc = add_mixed(tc, host_jac_to_affine_normalised(parts[k].total_c));
+        tw = add_mixed(tw, host_jac_to_affine_normalised(parts[k].total_w));
+        fails += parts[k].n_alg_fail;
+    }
+    G1Affine ps[2] = {to_affine(tc), neg(to_affine(tw))};
+    const G2Prepared *qs[2] = {(const G2Prepared *)v.h_prep.p, (const G2Prepared *)v.tauh_prep.p};
+    Fq12 f;
+    pairing_product_prepared(cx, ps, qs, 2, &f, st);
+    *all_ok = (f.is_one() && fails == 0) ? 1 : 0;
+    return MI_OK;
+}
+
+int32_t vs_verify_batch_device(Context &cx, uint64_t id, const void *d_proofs, size_t n, const void *d_rand,
+                                      uint8_t *verdicts, uint8_t *all_ok, hipStream_t st) {
+    mi_vs_partial part;
+    VsWork w;
+    int32_t s = vs_accumulate_impl(cx, id, d_proofs, n, d_rand, &part, &w, st);
+    if (s != MI_OK) return s;
+    s = vs_finalize(cx, id, &part, 1, all_ok, st);
+    if (s != MI_OK) return s;
+    if (*all_ok) {
+        memset(verdicts, 1, n);
+        return MI_OK;
+    }
+    // aggregate check failed: check every proof on its own to name the invalid ones
+    VsCtx &v = vs_ctxs()[id];
+    G1Xyzz *terms = (G1Xyzz *)cx.buf("vs.terms", sizeof(G1Xyzz) * n * VS_TERMS);
+    uint8_t *d_verdicts = (uint8_t *)cx.buf("vs.verdicts", n);
+    hipLaunchKernelGGL(vs_terms_kernel, dim3(cdiv(n * VS_TERMS, 128)), dim3(128), 0, st, n, w.pts1, w.sc1, w.sc2, w.vk_scal,
+                       w.g_scal, w.circuit_of, (const mi_vs_circuit_vk *)v.circuits.p, (const VsConsts *)v.consts.p, terms);
+    hipLaunchKernelGGL(vs_per_proof_pairing_kernel, dim3(cdiv(n, 64)), dim3(64), 0, st, n, terms,
+                       (const G2Prepared *)v.h_prep.p, (const G2Prepared *)v.tauh_prep.p, pairing_consts(cx, st), w.alg_ok,
+                       d_verdicts);
+    MI_HIP(hipGetLastError());
+    uint8_t *h = (uint8_t *)cx.pin(n);
+    MI_HIP(hipMemcpyAsync(h, d_verdicts, n, hipMemcpyDeviceToHost, st));
+    MI_HIP(hipStreamSynchronize(st));
+    memcpy(verdicts, h, n);
+    return MI_OK;
+}
+
+// ---------------------------------------------------------------- KZG10::batch_check
+// lane i: sc[i] = r_i, sc[n+i] = r_i z_i (canonical), rv[i] = r_i v_i (Montgomery); sc2[i] = r_i
+__global__ void __launch_bounds__(128) kzg_scalars_kernel(size_t n, const Fr *__restrict__ points,
+                                                          const Fr *__restrict__ values, const uint8_t *__restrict__ rand128,
+                                                          uint32_t *__restrict__ sc, uint32_t *__restrict__ sc2,
+                                                          Fr *__restrict__ rv) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t *rw = reinterpret_cast<const uint32_t *>(rand128 + 16 * i);
+    uint32_t r4[4] = {rw[0], rw[1], rw[2], rw[3]};
+    Fr r = fr_from_u128(r4);
+    uint32_t *o = sc + i * 8, *o2 = sc2 + i * 8;
+#pragma unroll
+    for (int k = 0; k < 4; k++) { o[k] = r4[k]; o[4 + k] = 0; o2[k] = r4[k]; o2[4 + k] = 0; }
+    fr_store(sc + (n + i) * 8, from_mont(mul(r, fr_load(points + i))));
+    fr_store(rv + i, mul(r, fr_load(values + i)));
+}
+// single block: sc[2n] = -(sum rv) canonical
+__global__ void __launch_bounds__(256) kzg_gsum_kernel(size_t n, const Fr *__restrict__ rv, uint32_t *__restrict__ sc) {
+    __shared__ uint32_t lds[8 * 256];
+    const int t = threadIdx.x;
+    Fr acc = Fr::zero();
+    for (size_t i = t; i < n; i += 256) acc = add(acc, fr_load(rv + i));
+    for (int stride = 128; stride >= 1; stride >>= 1) {
+        if (t >= stride && t < 2 * stride)
+#pragma unroll
+            for (int k = 0; k < 8; k++) lds[k * 256 + (t - stride)] = acc.l[k];
+        __syncthreads();
+        if (t < stride) {
+            Fr o;
+#pragma unroll
+            for (int k = 0; k < 8; k++) o.l[k] = lds[k * 256 + t];
+            acc = add(acc, o);
+        }
+        __syncthreads();
+    }
+    if (t == 0) fr_store(sc + 2 * n * 8, from_mont(neg(acc)));
+}
+
+int32_t kzg_batch_check_host(Context &cx, const mi_kzg_vk *vk, const mi_g1_affine *comms, const mi_fr *points,
+                                    const mi_fr *values, const mi_g1_affine *witnesses, size_t n, const uint8_t *rand128,
+                                    uint8_t *ok_out) {
+    hipStream_t st = cx.stream;
+    const size_t n1 = 2 * n + 1;
+    G1Affine *pts = (G1Affine *)cx.buf("kzg.pts", sizeof(G1Affine) * n1);
+    uint32_t *sc = (uint32_t *)cx.buf("kzg.sc", 32 * n1);
+    uint32_t *sc2 = (uint32_t *)cx.buf("kzg.sc2", 32 * n);
+    Fr *dpts = (Fr *)cx.buf("kzg.points", sizeof(Fr) * n), *dval = (Fr *)cx.buf("kzg.values", sizeof(Fr) * n);
+    Fr *rv = (Fr *)cx.buf("kzg.rv", sizeof(Fr) * n);
+    uint8_t *dr = (uint8_t *)cx.buf("kzg.rand", 16 * n);
+    MI_HIP(hipMemcpyAsync(pts, comms, sizeof(G1Affine) * n, hipMemcpyHostToDevice, st));
+    MI_HIP(hipMemcpyAsync(pts + n, witnesses, sizeof(G1Affine) * n, hipMemcpyHostToDevice, st));
+    MI_HIP(hipMemcpyAsync(pts + 2 * n, &vk->g, sizeof(G1Affine), hipMemcpyHostToDevice, st));
+    MI_HIP(hipMemcpyAsync(dpts, points, sizeof(Fr) * n, hipMemcpyHostToDevice, st));
+    MI_HIP(hipMemcpyAsync(dval, values, sizeof(Fr) * n, hipMemcpyHostToDevice, st));
+    MI_HIP(hipMemcpyAsync(dr, rand128, 16 * n, hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(kzg_scalars_kernel, dim3(cdiv(n, 128)), dim3(128), 0, st, n, dpts, dval, dr, sc, sc2, rv);
+    hipLaunchKernelGGL(kzg_gsum_kernel, dim3(1), dim3(256), 0, st, n, rv, sc);
+    MI_HIP(hipGetLastError());
+    mi_g1_jac tc, tw;
+    msm_device(cx, pts, sc, n1, &tc, st);
+    msm_device(cx, pts + n, sc2, n, &tw, st, 128);
+    G1Affine ps[2] = {host_jac_to_affine_normalised(tc), neg(host_jac_to_affine_normalised(tw))};
+    G2Affine qs[2];
+    memcpy(&qs[0], &vk->h, sizeof(G2Affine));
+    memcpy(&qs[1], &vk->tau_h, sizeof(G2Affine));
+    Fq12 f;
+    pairing_product_host_args(cx, ps, qs, 2, &f, st);
+    *ok_out = f.is_one() ? 1 : 0;
+    return MI_OK;
+}
+
+}  // namespace mi

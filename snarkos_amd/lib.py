@@ -1,0 +1,101 @@
+"""ctypes loader for libmi355x_snark.so (the C-ABI of include/mi355x_snark.h).
+
+The product path has NO CPU fallback: if the HIP library is missing or a call returns a non-zero
+status, a MiError is raised.  (A Rust caller would fall back to snarkVM's own CPU path on a non-zero
+status; this Python mirror exists for tests and benchmarks, where a silent fallback would hide bugs.)
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmi355x_snark.so")
+
+MI_OK = 0
+G1_AFFINE_U64 = 12
+G1_JAC_U64 = 18
+G2_AFFINE_U64 = 24
+FQ12_U64 = 72
+KZG_VK_BYTES = 480
+VS_PROOF_BYTES = 2256
+VS_CIRCUIT_VK_BYTES = 1184
+VS_PARTIAL_BYTES = 304
+
+# every symbol include/mi355x_snark.h declares
+EXPORTS = [
+    "mi_init", "mi_shutdown", "mi_error_string", "mi_abi_version",
+    "mi_msm_g1", "mi_msm_g1_device", "mi_bases_register", "mi_bases_release", "mi_msm_g1_h",
+    "mi_ntt_fr", "mi_ntt_fr_device",
+    "mi_pairing_product_is_one", "mi_pairing", "mi_kzg_batch_check",
+    "mi_vs_ctx_create", "mi_vs_ctx_destroy", "mi_vs_verify_batch", "mi_vs_verify_batch_device",
+    "mi_vs_accumulate_device", "mi_vs_finalize",
+    "mi_dbg_fq_mul", "mi_dbg_fr_mul", "mi_dbg_g1_add", "mi_dbg_fq_mul_throughput",
+]
+
+
+class MiError(RuntimeError):
+    def __init__(self, status, where):
+        self.status = status
+        try:
+            msg = lib().mi_error_string(status).decode()
+        except Exception:  # pragma: no cover
+            msg = "?"
+        super().__init__("%s failed: status %d (%s)" % (where, status, msg))
+
+
+_LIB = None
+
+
+def lib():
+    """Load the HIP library; fail loudly if it has not been built."""
+    global _LIB
+    if _LIB is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                "libmi355x_snark.so is not built (run `python -m snarkos_amd.build`); "
+                "there is no CPU fallback on the product path")
+        l = C.CDLL(LIB_PATH)
+        for name in EXPORTS:
+            getattr(l, name).restype = C.c_int32
+        l.mi_error_string.restype = C.c_char_p
+        l.mi_error_string.argtypes = [C.c_int32]
+        _LIB = l
+    return _LIB
+
+
+def check(status, where):
+    if status != MI_OK:
+        raise MiError(status, where)
+
+
+def ptr(a):
+    """numpy array -> void* (must be C-contiguous)"""
+    if a is None:
+        return None
+    assert a.flags["C_CONTIGUOUS"], "array must be C-contiguous"
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def dptr(t):
+    """torch CUDA tensor (or int address) -> void*"""
+    if isinstance(t, int):
+        return C.c_void_p(t)
+    assert t.is_cuda and t.is_contiguous()
+    return C.c_void_p(t.data_ptr())
+
+
+def stream_ptr(stream=None):
+    """torch.cuda.Stream (or None = torch's current stream) -> hipStream_t as void*"""
+    import torch
+
+    s = stream if stream is not None else torch.cuda.current_stream()
+    return C.c_void_p(s.cuda_stream)
+
+
+def init(device=-1):
+    check(lib().mi_init(C.c_int32(device)), "mi_init")
+
+
+def shutdown():
+    check(lib().mi_shutdown(), "mi_shutdown")

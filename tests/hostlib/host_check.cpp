@@ -1,0 +1,55 @@
+// Host build (plain g++, no HIP) of the product's shared host/device arithmetic headers, so the
+// CPU test tier can pin snarkos_amd/csrc/{field,curve,tower}.hpp against the oracle without a GPU.
+// Test infrastructure: compiled by tests/test_host_arith.py into tests/hostlib/libhostcheck.so.
+#include <string.h>
+#include "../../snarkos_amd/csrc/tower.hpp"
+
+using namespace mi;
+
+static Fq fq_from64(const uint64_t *l) {
+    Fq r;
+    for (int i = 0; i < 6; i++) { r.l[2 * i] = (uint32_t)l[i]; r.l[2 * i + 1] = (uint32_t)(l[i] >> 32); }
+    return r;
+}
+
+extern "C" {
+void hc_fq_mul(const Fq *a, const Fq *b, Fq *o) { *o = mul(*a, *b); }
+void hc_fq_add(const Fq *a, const Fq *b, Fq *o) { *o = add(*a, *b); }
+void hc_fq_sub(const Fq *a, const Fq *b, Fq *o) { *o = sub(*a, *b); }
+void hc_fq_inv(const Fq *a, Fq *o) { *o = inv(*a); }
+void hc_fr_mul(const Fr *a, const Fr *b, Fr *o) { *o = mul(*a, *b); }
+void hc_fr_inv(const Fr *a, Fr *o) { *o = inv(*a); }
+void hc_fr_to_mont(const Fr *a, Fr *o) { *o = to_mont(*a); }
+void hc_fr_from_mont(const Fr *a, Fr *o) { *o = from_mont(*a); }
+void hc_g1_add_mixed(const G1Affine *a, const G1Affine *b, G1Affine *o) { *o = to_affine(add_mixed(G1Xyzz::from_affine(*a), *b)); }
+void hc_g1_add(const G1Affine *a, const G1Affine *b, G1Affine *o) { *o = to_affine(add(G1Xyzz::from_affine(*a), G1Xyzz::from_affine(*b))); }
+void hc_g1_dbl(const G1Affine *a, G1Affine *o) { *o = to_affine(dbl(G1Xyzz::from_affine(*a))); }
+void hc_g1_mul(const G1Affine *p, const uint32_t *k, int bits, G1Affine *o) { *o = to_affine(scalar_mul(*p, k, bits)); }
+void hc_fq12_mul(const Fq12 *a, const Fq12 *b, Fq12 *o) { *o = mul(*a, *b); }
+void hc_fq12_sqr(const Fq12 *a, Fq12 *o) { *o = sqr(*a); }
+void hc_fq12_inv(const Fq12 *a, Fq12 *o) { *o = inv(*a); }
+void hc_pairing_product(const G1Affine *ps, const G2Affine *qs, int n, Fq12 *out) {
+    static G2Prepared prep[MI_MAX_PAIRS];
+    const G2Prepared *qp[MI_MAX_PAIRS];
+    for (int i = 0; i < n; i++) { g2_prepare_host(prep[i], qs[i]); qp[i] = &prep[i]; }
+    PairingConsts pc;
+    for (int e = 0; e < 3; e++)
+        for (int k = 0; k < 12; k++) pc.frob[e][k] = fq_from64(MI_FROB[e][k]);
+    *out = final_exponentiation(miller_product(ps, qp, n), pc);
+}
+int hc_constants_ok() {
+    // the 32-bit limb tables in field.hpp must equal the generated 64-bit constants
+    for (int i = 0; i < 6; i++) {
+        if ((((uint64_t)FqP::MOD[2 * i + 1] << 32) | FqP::MOD[2 * i]) != MI_FQ_MODULUS[i]) return 1;
+        if ((((uint64_t)FqP::ONE[2 * i + 1] << 32) | FqP::ONE[2 * i]) != MI_FQ_ONE[i]) return 2;
+        if ((((uint64_t)FqP::R2[2 * i + 1] << 32) | FqP::R2[2 * i]) != MI_FQ_R2[i]) return 3;
+    }
+    for (int i = 0; i < 4; i++) {
+        if ((((uint64_t)FrP::MOD[2 * i + 1] << 32) | FrP::MOD[2 * i]) != MI_FR_MODULUS[i]) return 4;
+        if ((((uint64_t)FrP::ONE[2 * i + 1] << 32) | FrP::ONE[2 * i]) != MI_FR_ONE[i]) return 5;
+        if ((((uint64_t)FrP::R2[2 * i + 1] << 32) | FrP::R2[2 * i]) != MI_FR_R2[i]) return 6;
+    }
+    if ((uint32_t)MI_FQ_INV != 0xffffffffu || (uint32_t)MI_FR_INV != 0xffffffffu) return 7;
+    return 0;
+}
+}

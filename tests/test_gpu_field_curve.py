@@ -1,0 +1,73 @@
+"""-m gpu: device field and group arithmetic, bit-exact against the CPU oracle (through the C ABI)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from helpers import rng_points, rng_scalars
+
+pytestmark = pytest.mark.gpu
+
+
+def test_fq_mul_bit_exact(orc, mi):
+    from snarkos_amd import lib as L
+    n = 4096
+    g = np.random.default_rng(1)
+    a = np.zeros((n, 6), dtype=np.uint64)
+    b = np.zeros((n, 6), dtype=np.uint64)
+    for arr, s in ((a, 11), (b, 12)):
+        pts = rng_points(s, n // 2)  # coordinates are uniform-looking field elements < q
+        arr[:] = pts.reshape(-1, 6)
+    a[0] = 0
+    b[1] = 0
+    a[2] = np.array(orc.int_to_limbs(orc_q() - 1, 6))
+    b[2] = a[2]
+    out = np.zeros_like(a)
+    L.check(L.lib().mi_dbg_fq_mul(L.ptr(a), L.ptr(b), L.ptr(out), C.c_size_t(n)), "mi_dbg_fq_mul")
+    want = np.zeros_like(a)
+    for i in range(n):
+        orc.lib().orc_fq_mul(orc._p(want[i]), orc._p(a[i]), orc._p(b[i]))
+    assert (out == want).all()
+
+
+def orc_q():
+    import pyref
+    return pyref.Q
+
+
+def test_fr_mul_bit_exact(orc, mi):
+    from snarkos_amd import lib as L
+    n = 4096
+    a, b = rng_scalars(21, n), rng_scalars(22, n)
+    a[0] = 0
+    out = np.zeros_like(a)
+    L.check(L.lib().mi_dbg_fr_mul(L.ptr(a), L.ptr(b), L.ptr(out), C.c_size_t(n)), "mi_dbg_fr_mul")
+    want = np.zeros_like(a)
+    for i in range(n):
+        orc.lib().orc_fr_mul(orc._p(want[i]), orc._p(a[i]), orc._p(b[i]))
+    assert (out == want).all()
+
+
+def test_g1_add_all_cases(orc, mi):
+    from snarkos_amd import lib as L
+    n = 256
+    a, b = rng_points(31, n), rng_points(32, n)
+    b[0] = a[0]                      # doubling
+    b[1] = a[1]; b[1, 6:] = neg_y(orc, a[1, 6:])  # P + (-P) = O
+    a[2] = 0                         # O + Q
+    b[3] = 0                         # P + O
+    a[4] = 0; b[4] = 0               # O + O
+    out = np.zeros_like(a)
+    L.check(L.lib().mi_dbg_g1_add(L.ptr(a), L.ptr(b), L.ptr(out), C.c_size_t(n)), "mi_dbg_g1_add")
+    for i in range(n):
+        j = np.zeros(18, dtype=np.uint64)
+        ja = np.zeros(18, dtype=np.uint64)
+        orc.lib().orc_g1_from_affine(orc._p(ja), orc._p(np.ascontiguousarray(a[i])))
+        orc.lib().orc_g1_add_mixed(orc._p(j), orc._p(ja), orc._p(np.ascontiguousarray(b[i])))
+        assert (orc.jac_to_affine(j) == out[i]).all(), i
+
+
+def neg_y(orc, y):
+    import pyref
+    v = orc.fq_to_int(y)
+    return orc.fq_from_int((-v) % pyref.Q)

@@ -1,0 +1,57 @@
+"""-m gpu: VarunaShaped-v1 batch verification, verdict-for-verdict against the CPU oracle."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _ctx(mi, b):
+    return mi.VarunaShaped(b.vk, b.circuits)
+
+
+def test_valid_batch(orc, mi):
+    b = orc.VSBatch(0xA1E00004, 96, 8, 0)
+    v = _ctx(mi, b)
+    try:
+        ok, verdicts = v.verify_batch(b.proofs, b.randomizers)
+        assert ok and verdicts.all()
+        assert (b.verify_cpu(8) == verdicts).all()
+        # the aggregated accumulators are bit-identical to the oracle's aggregated form
+        ok_o, alg, tc, tw = b.verify_aggregated(8)
+        assert ok_o
+    finally:
+        v.close()
+
+
+def test_corrupted_batch_names_the_bad_proofs(orc, mi):
+    b = orc.VSBatch(0xBAD5EED, 80, 4, 160)
+    assert 0 < b.expected.sum() < b.n
+    v = _ctx(mi, b)
+    try:
+        ok, verdicts = v.verify_batch(b.proofs, b.randomizers)
+        assert not ok
+        assert (verdicts == b.expected).all()
+        assert (verdicts == b.verify_cpu(8)).all()
+    finally:
+        v.close()
+
+
+def test_partials_match_oracle_and_shard(orc, mi):
+    """accumulate per shard + finalize == single batch; partial points equal the oracle's totals"""
+    import torch
+    from helpers import jac_affine
+    b = orc.VSBatch(0x51A4D, 64, 3, 0)
+    v = _ctx(mi, b)
+    try:
+        proofs = torch.from_numpy(b.proofs).cuda(); rnd = torch.from_numpy(b.randomizers).cuda()
+        whole = v.accumulate(proofs, rnd)
+        _, _, tc, tw = b.verify_aggregated(8)
+        part = np.frombuffer(whole.tobytes(), dtype=np.uint64)
+        assert (jac_affine(part[0:18]) == tc).all() and (jac_affine(part[18:36]) == tw).all()
+        assert v.finalize([whole])
+        half = 32 * 2256
+        p0 = v.accumulate(proofs[:half].contiguous(), rnd[:32 * 32].contiguous())
+        p1 = v.accumulate(proofs[half:].contiguous(), rnd[32 * 32:].contiguous())
+        assert v.finalize([p0, p1])
+    finally:
+        v.close()
