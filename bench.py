@@ -1,0 +1,254 @@
+#!/usr/bin/env python3
+"""Benchmark of the batch SNARK verification hot path on MI355X.
+
+    python bench.py --gpus 1 --steps 20 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+Headline (BASELINE.json metric / configs[3], configs[4] at N = 8): proofs verified per second on a
+batch of 1024 synthetic VarunaShaped-v1 proofs PER GPU (weak scaling: N GPUs verify N x 1024 proofs as
+one block-validation batch: every rank accumulates its shard, the 304-byte partial accumulators are
+all-gathered over RCCL, one pairing product decides the whole batch).  A "step" is one such batch.
+Inputs (proofs, randomizers, keys) are resident in HBM before the timed region.
+
+One JSON line on rank 0, with
+  roofline     -- the dominant kernel of the timed region: algorithmic bytes / HIP-event time vs 8 TB/s
+  cpu_baseline -- the CPU oracle (a port of the reference's per-transaction verify loop) on this host
+  extra        -- MSM 2^20 points/s (configs[1]) and NTT 2^22 round trip (configs[2]) on the same GPU,
+                  and the batch with 1 % corrupted proofs (fallback that names the bad proofs)
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from snarkos_amd import algorithms as A  # noqa: E402
+from snarkos_amd import lib as L  # noqa: E402
+
+HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s spec, 6.29 TB/s measured copy)
+PROOFS_PER_GPU = 1024
+# algorithmic bytes per unit of each profiled kernel (DESIGN.md "Measurement")
+ALG_BYTES = {
+    "msm_accumulate": 128.0,        # per (point, scalar) pair: 96 B affine point + 32 B scalar
+    "vs_derive": 2256.0 + 32.0,     # per proof: the proof record + its two 128-bit randomizers
+    "pairing": 96.0 + 13264.0,      # per pair: one G1 point + one prepared G2 line table
+    "ntt_pass": 64.0,               # per element per pass: 32 B read + 32 B written
+}
+
+
+def load_fixture():
+    d = np.load(os.path.join(ROOT, "tests", "golden", "vs_batch_1024.npz"))
+    return d["vk"], d["circuits"], d["proofs"], d["randomizers"]
+
+
+def sync_all(dist_on):
+    torch.cuda.synchronize()
+    if dist_on:
+        torch.distributed.barrier()
+    torch.cuda.synchronize()
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--no-extra", action="store_true", help="skip the MSM / NTT / corrupted-batch side measurements")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    dist_on = world > 1
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if dist_on:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.distributed.init_process_group("nccl", device_id=dev)
+    L.init(local_rank)
+
+    vk, circuits, proofs, rnd = load_fixture()
+    # every rank holds its own shard of the block's proofs; randomizers differ per rank (caller RNG)
+    rnd = rnd.copy()
+    rnd[::16] ^= np.uint8(rank)
+    d_proofs = torch.from_numpy(proofs).to(dev)
+    d_rnd = torch.from_numpy(rnd).to(dev)
+    verifier = A.VarunaShaped(vk, circuits)
+    gather_buf = torch.empty(world * L.VS_PARTIAL_BYTES, dtype=torch.uint8, device=dev) if dist_on else None
+
+    def step():
+        if not dist_on:
+            ok, verdicts = verifier.verify_batch(d_proofs, d_rnd)
+            return ok
+        part = verifier.accumulate(d_proofs, d_rnd)
+        mine = torch.from_numpy(part).to(dev, non_blocking=False)
+        torch.distributed.all_gather_into_tensor(gather_buf, mine)  # RCCL over xGMI: 304 B per rank
+        return verifier.finalize(gather_buf.cpu().numpy())
+
+    for _ in range(args.warmup):
+        assert step(), "synthetic batch must verify"
+    L.prof_enable(True)
+    for k in ALG_BYTES:
+        L.prof_read(k)
+    L.prof_read("msm_total")
+    sync_all(dist_on)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        ok = step()
+    sync_all(dist_on)
+    dt = time.perf_counter() - t0
+    assert ok
+    if dist_on:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        dt = float(t.item())
+    L.prof_enable(False)
+
+    kernels = {}
+    for k, per_unit in ALG_BYTES.items():
+        ms, launches, units = L.prof_read(k)
+        if launches:
+            kernels[k] = {"total_ms": ms, "launches": launches, "avg_us": 1e3 * ms / launches,
+                          "units_per_launch": units / launches,
+                          "achieved_GBps": per_unit * units / (ms * 1e-3) / 1e9 if ms > 0 else None}
+    ms_tot, n_msm, _ = L.prof_read("msm_total")
+    if n_msm:
+        kernels["msm_total"] = {"total_ms": ms_tot, "launches": n_msm, "avg_us": 1e3 * ms_tot / n_msm}
+
+    if rank != 0:
+        if dist_on:
+            torch.distributed.destroy_process_group()
+        return
+
+    dom = max((k for k in kernels if k in ALG_BYTES), key=lambda k: kernels[k]["total_ms"])
+    pmc_path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    traffic = None
+    if os.path.exists(pmc_path):
+        try:
+            traffic = json.load(open(pmc_path)).get(dom)
+        except Exception:
+            traffic = None
+    roofline = {"bound": "hbm", "kernel": dom, "achieved": kernels[dom]["achieved_GBps"], "peak": HBM_PEAK_GBPS,
+                "unit": "GB/s", "frac": kernels[dom]["achieved_GBps"] / HBM_PEAK_GBPS,
+                "avg_launch_us": kernels[dom]["avg_us"],
+                "algorithmic_bytes_per_launch": ALG_BYTES[dom] * kernels[dom]["units_per_launch"], "traffic": traffic}
+
+    out = {
+        "metric": "varuna_proofs_verified_per_sec", "value": world * PROOFS_PER_GPU * args.steps / dt,
+        "unit": "proofs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "u32-limb Montgomery (Fq 12x32, Fr 8x32)", "data": "synthetic",
+        "config": {"workload": "configs[3]: batch verify of 1024 synthetic VarunaShaped-v1 proofs per GPU "
+                               "(KZG open + pairing check); N GPUs = one %d-proof block sharded, partials all-gathered over RCCL" % (world * PROOFS_PER_GPU),
+                   "proofs_per_gpu": PROOFS_PER_GPU, "circuits": 8, "all_valid": True, "parallelism": "shard%d" % world},
+        "roofline": roofline, "kernels": kernels,
+    }
+
+    if world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(vk, circuits, proofs, rnd)
+    if world == 1 and not args.no_extra:
+        out["extra"] = extras(dev, verifier, proofs, rnd)
+    print(json.dumps(out), flush=True)
+    if dist_on:
+        torch.distributed.destroy_process_group()
+
+
+def cpu_baseline(vk, circuits, proofs, rnd):
+    """The oracle's port of the reference shape: one proof at a time, per-proof pairing product, one
+    thread per core (the reference runs rayon over transactions on all cores)."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import orc_py as O
+
+    cores = os.cpu_count() or 1
+    b = O.VSArrays(vk, circuits, proofs, rnd)
+    b_small = O.VSArrays(vk, circuits, proofs[:64 * O.VS_PROOF_BYTES], rnd[:64 * 32])
+    b_small.verify_cpu(cores)  # warm-up (fixed-base tables, page-in)
+    t0 = time.perf_counter()
+    v = b.verify_cpu(cores)
+    dt = time.perf_counter() - t0
+    assert v.all()
+    return {"value": b.n / dt, "unit": "proofs/s", "cores": cores, "kind": "port",
+            "sample": "all 1024 proofs of the batch, oracle orc_vs_verify_batch_cpu, %d OpenMP threads, %.2f s" % (cores, dt)}
+
+
+def extras(dev, verifier, proofs, rnd):
+    ex = {}
+    st = torch.cuda.current_stream()
+    # --- configs[1]: 2^20-point G1 MSM, inputs resident
+    n = 1 << 20
+    pts = torch.empty(n * 96, dtype=torch.uint8, device=dev)
+    import ctypes as C
+    L.check(L.lib().mi_dbg_gen_points_device(C.c_uint64(0xA1E00002), C.c_size_t(n), L.dptr(pts), L.stream_ptr(st)), "gen_points")
+    g = torch.Generator(device="cpu").manual_seed(0xA1E00002)
+    sc = torch.randint(0, 1 << 62, (n, 4), dtype=torch.int64, generator=g)
+    sc[:, 3] &= (1 << 58) - 1
+    sc = sc.to(dev)
+    torch.cuda.synchronize()
+    A.VariableBase.msm(pts, sc)
+    L.prof_enable(True)
+    L.prof_read("msm_accumulate"); L.prof_read("msm_total")
+    reps = 5
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        res = A.VariableBase.msm(pts, sc)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / reps
+    ms, launches, units = L.prof_read("msm_accumulate")
+    ms_t, l_t, _ = L.prof_read("msm_total")
+    ex["msm_2^20"] = {"points_per_s": n / dt, "ms": 1e3 * dt, "accumulate_kernel_ms": ms / launches,
+                      "gpu_pipeline_ms": ms_t / l_t,
+                      "roofline_frac_hbm": 128.0 * n / dt / 1e9 / HBM_PEAK_GBPS, "result_is_infinity": bool(not res[12:].any())}
+    del pts, sc
+    # --- configs[2]: NTT 2^22 forward + inverse round trip, in place in HBM
+    log_n = 22
+    a = torch.randint(0, 1 << 62, (1 << log_n, 4), dtype=torch.int64, generator=g)
+    a[:, 3] &= (1 << 58) - 1
+    a = a.to(dev)
+    ref = a.clone()
+    d = A.EvaluationDomain(1 << log_n)
+    d.fft(a); d.ifft(a)
+    torch.cuda.synchronize()
+    assert torch.equal(a, ref), "ifft(fft(a)) != a"
+    L.prof_read("ntt_pass")
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        d.fft(a); d.ifft(a)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / reps
+    ms, launches, _ = L.prof_read("ntt_pass")
+    L.prof_enable(False)
+    assert torch.equal(a, ref)
+    ex["ntt_2^22_roundtrip"] = {"ms": 1e3 * dt, "elements_per_s": 2 * (1 << log_n) / dt, "pass_kernel_avg_ms": ms / launches,
+                                "passes_per_transform": launches // (2 * reps),
+                                "roofline_frac_hbm": 2 * 64.0 * (1 << log_n) / dt / 1e9 / HBM_PEAK_GBPS}
+    del a, ref
+    # --- the same 1024-proof batch with 1 % corrupted proofs: aggregate check fails, fallback names them
+    bad = proofs.copy()
+    idx = np.arange(5, 1024, 101)  # 11 proofs
+    ev_off = 16 + 16 * 32 + 9 * 96
+    for i in idx:
+        bad[i * L.VS_PROOF_BYTES + ev_off + 32 * 7] ^= 1  # flip one bit of evaluation 7
+    d_bad = torch.from_numpy(bad).to(dev)
+    d_rnd = torch.from_numpy(rnd).to(dev)
+    verifier.verify_batch(d_bad, d_rnd)
+    t0 = time.perf_counter()
+    ok, verdicts = verifier.verify_batch(d_bad, d_rnd)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    want = np.ones(1024, dtype=np.uint8)
+    want[idx] = 0
+    ex["batch_1pct_corrupted"] = {"proofs_per_s": 1024 / dt, "ms": 1e3 * dt, "all_ok": ok,
+                                  "verdicts_correct": bool((verdicts == want).all()), "n_bad": int(len(idx))}
+    return ex
+
+
+if __name__ == "__main__":
+    main()

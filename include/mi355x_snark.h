@@ -114,6 +114,16 @@ int32_t mi_dbg_fq_mul(const mi_fq *a, const mi_fq *b, mi_fq *out, size_t n);
 int32_t mi_dbg_fr_mul(const mi_fr *a, const mi_fr *b, mi_fr *out, size_t n);
 int32_t mi_dbg_g1_add(const mi_g1_affine *a, const mi_g1_affine *b, mi_g1_affine *out, size_t n);
 int32_t mi_dbg_fq_mul_throughput(size_t n_threads, uint32_t iters, double *gmul_per_s);
+/* synthetic inputs made on the device: out[i] = k_i * G with k_i = splitmix64(seed + i) (distinct, in-subgroup) */
+int32_t mi_dbg_gen_points_device(uint64_t seed, size_t n, void *d_out, void *stream);
+
+/* ---- profiling: HIP-event timing of the dominant kernels on the stream they are launched on ----
+ * mi_prof_enable(1) makes every later call bracket its kernels with hipEvents; mi_prof_read sums the
+ * elapsed time of all recorded launches of `kernel` ("msm_accumulate", "ntt_pass", "pairing", ...),
+ * returns the launch count and the work units (points / elements) those launches processed, and
+ * clears the records of that kernel. */
+int32_t mi_prof_enable(int32_t on);
+int32_t mi_prof_read(const char *kernel, double *total_ms, uint64_t *launches, uint64_t *units);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,90 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.json from oracle/pyref.py (independent Python big-ints), NOT from the C oracle.
+
+There is no reference-side golden material for this path (parity unpinned), so the
+committed vectors are seeded inputs -> outputs of the textbook definitions in pyref.py.  The C oracle
+and (on the GPU box) the HIP library are both checked against these files.
+Run:  python oracle/gen_golden.py
+"""
+import json
+import os
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+import pyref as P  # noqa: E402
+
+OUT = os.path.join(os.path.dirname(HERE), "tests", "golden")
+
+
+def hx(v):
+    return "%x" % v
+
+
+def pt(p):
+    return None if p is None else [hx(p[0]), hx(p[1])]
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    rng = P.SplitMix64(0xA1E00001)
+    # --- field products
+    fq = [[hx(a), hx(b), hx(a * b % P.Q)] for a, b in ((rng.below(P.Q, 7), rng.below(P.Q, 7)) for _ in range(16))]
+    fr = [[hx(a), hx(b), hx(a * b % P.R)] for a, b in ((rng.below(P.R, 5), rng.below(P.R, 5)) for _ in range(16))]
+    json.dump({"fq_mul": fq, "fr_mul": fr, "fq_mont_r": hx(P.FQ_MONT_R), "fr_mont_r": hx(P.FR_MONT_R)},
+              open(os.path.join(OUT, "field.json"), "w"), indent=0)
+    # --- G1 scalar multiples and an MSM with edge cases
+    ks = [1, 2, 3, P.R - 1, rng.below(P.R, 5), rng.below(P.R, 5)]
+    g1 = [[hx(k), pt(P.g1_mul(P.G1_GEN, k))] for k in ks]
+    n = 48
+    pk = [rng.below(P.R, 5) for _ in range(n)]
+    pts = [P.g1_mul(P.G1_GEN, k) for k in pk]
+    sc = [rng.below(P.R, 5) for _ in range(n)]
+    sc[0] = 0
+    sc[1] = P.R - 1
+    sc[2] = 1
+    pts[3] = None
+    pts[5], sc[5] = pts[4], sc[4]
+    pts[7], sc[7] = P.g1_neg(pts[6]), sc[6]
+    msm = {"points": [pt(p) for p in pts], "scalars": [hx(s) for s in sc], "result": pt(P.msm(pts, sc)),
+           "result_first_20": pt(P.msm(pts[:20], sc[:20]))}
+    json.dump({"g1_mul": g1, "msm": msm}, open(os.path.join(OUT, "g1_msm.json"), "w"), indent=0)
+    # --- NTT, 2^6, all four flavours
+    a = [rng.below(P.R, 5) for _ in range(64)]
+    ntt = {"input": [hx(x) for x in a], "omega_64": hx(P.omega(6)),
+           "fft": [hx(x) for x in P.ntt(a)], "ifft": [hx(x) for x in P.ntt(a, inverse=True)],
+           "coset_fft": [hx(x) for x in P.ntt(a, coset=True)],
+           "coset_ifft": [hx(x) for x in P.ntt(a, inverse=True, coset=True)]}
+    assert P.ntt(a) == P.dft(a, P.omega(6))
+    json.dump(ntt, open(os.path.join(OUT, "ntt.json"), "w"), indent=0)
+    # --- pairing value (cube of the reduced ate pairing) in the power basis Fq[w]/(w^12+5)
+    ka, kb = rng.below(P.R, 5), rng.below(P.R, 5)
+    p, q = P.g1_mul(P.G1_GEN, ka), P.g2_mul(P.G2_GEN, kb)
+    e = P.pairing(p, q, cubed=True)
+    pairing = {"a": hx(ka), "b": hx(kb), "p": pt(p), "q": [[hx(q[0][0]), hx(q[0][1])], [hx(q[1][0]), hx(q[1][1])]],
+               "e_cubed_power_basis": [hx(c) for c in e]}
+    json.dump(pairing, open(os.path.join(OUT, "pairing.json"), "w"), indent=0)
+    # --- KZG batch instance with a known tau
+    tau = rng.below(P.R, 5)
+    polys = [[rng.below(P.R, 5) for _ in range(4)] for _ in range(5)]
+    ev = lambda c, z: sum(ci * pow(z, i, P.R) for i, ci in enumerate(c)) % P.R  # noqa: E731
+    zs = [rng.below(P.R, 5) for _ in range(5)]
+    vs = [ev(c, z) for c, z in zip(polys, zs)]
+    cs = [P.g1_mul(P.G1_GEN, ev(c, tau)) for c in polys]
+    ws = [P.g1_mul(P.G1_GEN, (ev(c, tau) - v) * P.inv((tau - z) % P.R, P.R) % P.R) for c, z, v in zip(polys, zs, vs)]
+    rs = [rng.below(1 << 128, 2) for _ in range(5)]
+    tau_h = P.g2_mul(P.G2_GEN, tau)
+    assert P.kzg_batch_check(tau_h, cs, zs, vs, ws, rs)
+    bad = list(vs)
+    bad[2] = (bad[2] + 1) % P.R
+    assert not P.kzg_batch_check(tau_h, cs, zs, bad, ws, rs)
+    kzg = {"tau": hx(tau), "tau_h": [[hx(tau_h[0][0]), hx(tau_h[0][1])], [hx(tau_h[1][0]), hx(tau_h[1][1])]],
+           "comms": [pt(c) for c in cs], "points": [hx(z) for z in zs], "values": [hx(v) for v in vs],
+           "bad_values": [hx(v) for v in bad], "witnesses": [pt(w) for w in ws], "randomizers": [hx(r) for r in rs],
+           "verdict_good": True, "verdict_bad": False}
+    json.dump(kzg, open(os.path.join(OUT, "kzg.json"), "w"), indent=0)
+    print("golden vectors written to", OUT)
+
+
+if __name__ == "__main__":
+    main()

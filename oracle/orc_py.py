@@ -263,3 +263,17 @@ class VSBatch:
         zb, zg, xi = u64(4), u64(4), u64(4)
         lib().orc_vs_challenges(_p(np.ascontiguousarray(cvk)), _p(np.ascontiguousarray(p)), _p(zb), _p(zg), _p(xi))
         return fr_to_ints(zb)[0], fr_to_ints(zg)[0], fr_to_ints(xi)[0]
+
+
+class VSArrays(VSBatch):
+    """A VarunaShaped-v1 batch wrapped around existing ABI-layout arrays (e.g. a committed fixture)."""
+
+    def __init__(self, vk, circuits, proofs, randomizers, expected=None):  # noqa: D107
+        self.vk = np.ascontiguousarray(vk, dtype=np.uint8).reshape(-1)
+        self.circuits = np.ascontiguousarray(circuits, dtype=np.uint8).reshape(-1)
+        self.proofs = np.ascontiguousarray(proofs, dtype=np.uint8).reshape(-1)
+        self.randomizers = np.ascontiguousarray(randomizers, dtype=np.uint8).reshape(-1)
+        self.n = self.proofs.size // VS_PROOF_BYTES
+        self.n_circuits = self.circuits.size // VS_CIRCUIT_VK_BYTES
+        self.expected = expected
+        self.seed = None

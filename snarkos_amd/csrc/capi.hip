@@ -38,6 +38,30 @@ __global__ void dbg_g1_add_kernel(const G1Affine *a, const G1Affine *b, G1Affine
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) out[i] = to_affine(add_mixed(G1Xyzz::from_affine(a[i]), b[i]));
 }
+__device__ __forceinline__ uint64_t splitmix64(uint64_t x) {
+    x += 0x9E3779B97F4A7C15ull;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+    return x ^ (x >> 31);
+}
+__global__ void __launch_bounds__(128) dbg_gen_points_kernel(uint64_t seed, size_t n, G1Affine g, G1Affine *out) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint64_t k = splitmix64(seed + i) | 1ull;
+    uint32_t kw[2] = {(uint32_t)k, (uint32_t)(k >> 32)};
+    G1Xyzz acc = G1Xyzz::inf();
+    for (int b = 63; b >= 0; b--) {
+        acc = dbl(acc);
+        if ((kw[b >> 5] >> (b & 31)) & 1u) acc = add_mixed(acc, g);
+    }
+    G1Affine a = to_affine(acc);
+    uint4 *o = reinterpret_cast<uint4 *>(out + i);
+#pragma unroll
+    for (int q = 0; q < 3; q++) {
+        o[q] = make_uint4(a.x.l[4 * q], a.x.l[4 * q + 1], a.x.l[4 * q + 2], a.x.l[4 * q + 3]);
+        o[3 + q] = make_uint4(a.y.l[4 * q], a.y.l[4 * q + 1], a.y.l[4 * q + 2], a.y.l[4 * q + 3]);
+    }
+}
 __global__ void __launch_bounds__(256) dbg_fq_mul_throughput_kernel(Fq *out, uint32_t iters) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     Fq a = Fq::one(), b = Fq::r2();
@@ -286,6 +310,49 @@ int32_t mi_dbg_fq_mul_throughput(size_t n_threads, uint32_t iters, double *gmul_
         *gmul_per_s = 2.0 * iters * (double)n_threads / (ms * 1e-3) / 1e9;
         (void)hipEventDestroy(e0);
         (void)hipEventDestroy(e1);
+        return MI_OK;
+    });
+}
+
+int32_t mi_dbg_gen_points_device(uint64_t seed, size_t n, void *d_out, void *stream) {
+    if (!d_out || !n) return MI_ERR_BAD_ARGS;
+    return guarded([&]() -> int32_t {
+        G1Affine g;
+        for (int i = 0; i < 6; i++) {
+            g.x.l[2 * i] = (uint32_t)MI_G1_GEN_X[i]; g.x.l[2 * i + 1] = (uint32_t)(MI_G1_GEN_X[i] >> 32);
+            g.y.l[2 * i] = (uint32_t)MI_G1_GEN_Y[i]; g.y.l[2 * i + 1] = (uint32_t)(MI_G1_GEN_Y[i] >> 32);
+        }
+        hipLaunchKernelGGL(dbg_gen_points_kernel, dim3(cdiv(n, 128)), dim3(128), 0, (hipStream_t)stream, seed, n, g, (G1Affine *)d_out);
+        MI_HIP(hipGetLastError());
+        return MI_OK;
+    });
+}
+
+int32_t mi_prof_enable(int32_t on) {
+    return guarded([&]() -> int32_t {
+        ctx().prof.on = on != 0;
+        return MI_OK;
+    });
+}
+int32_t mi_prof_read(const char *kernel, double *total_ms, uint64_t *launches, uint64_t *units) {
+    if (!kernel || !total_ms || !launches || !units) return MI_ERR_BAD_ARGS;
+    return guarded([&]() -> int32_t {
+        auto &v = ctx().prof.recs[kernel];
+        double ms = 0;
+        uint64_t u = 0;
+        for (auto &r : v) {
+            MI_HIP(hipEventSynchronize(r.e1));
+            float t = 0;
+            MI_HIP(hipEventElapsedTime(&t, r.e0, r.e1));
+            ms += t;
+            u += r.units;
+            (void)hipEventDestroy(r.e0);
+            (void)hipEventDestroy(r.e1);
+        }
+        *total_ms = ms;
+        *launches = v.size();
+        *units = u;
+        v.clear();
         return MI_OK;
     });
 }

@@ -270,6 +270,7 @@ void msm_device(Context &cx, const G1Affine *d_points, const uint32_t *d_scalars
         return;
     }
     MsmPlan pl = msm_plan(n, scalar_bits, force_c);
+    cx.prof.begin("msm_total", st, n);
     const size_t nb = (size_t)pl.nwin * pl.B;
     int32_t *digits = (int32_t *)cx.buf("msm.digits", sizeof(int32_t) * n * pl.nwin);
     uint32_t *sorted = (uint32_t *)cx.buf("msm.sorted", sizeof(uint32_t) * n * pl.nwin);
@@ -290,7 +291,9 @@ void msm_device(Context &cx, const G1Affine *d_points, const uint32_t *d_scalars
     hipLaunchKernelGGL(scan_sums_kernel, dim3(1), dim3(1024), 0, st, tile_sums, (size_t)tiles);
     hipLaunchKernelGGL(scan_finish_kernel, dim3(tiles), dim3(256), 0, st, offsets, cursor, tile_sums, counts, nb);
     hipLaunchKernelGGL(msm_scatter_kernel, dim3(cdiv(n * pl.nwin, 256)), dim3(256), 0, st, digits, n, pl.nwin, pl.B, cursor, sorted);
+    cx.prof.begin("msm_accumulate", st, n);
     hipLaunchKernelGGL(msm_accumulate_kernel, dim3(cdiv(nb, 128)), dim3(128), 0, st, d_points, sorted, offsets, nb, buckets);
+    cx.prof.end("msm_accumulate", st);
     uint32_t L = pl.B >= 4096 ? 8 : 4;
     const size_t nseg = nb / L;
     G1Xyzz *partials = (G1Xyzz *)cx.buf("msm.partials", sizeof(G1Xyzz) * nseg);
@@ -298,6 +301,7 @@ void msm_device(Context &cx, const G1Affine *d_points, const uint32_t *d_scalars
     G1Xyzz *wsums = device_group_sum(cx, partials, pl.nwin, pl.B / L, st, "msm.tree_a", "msm.tree_b");
     MI_HIP(hipGetLastError());
     G1Xyzz *h = (G1Xyzz *)cx.pin(sizeof(G1Xyzz) * pl.nwin);
+    cx.prof.end("msm_total", st);
     MI_HIP(hipMemcpyAsync(h, wsums, sizeof(G1Xyzz) * pl.nwin, hipMemcpyDeviceToHost, st));
     MI_HIP(hipStreamSynchronize(st));
     // host tail: Horner fold over the windows (nwin additions, (nwin-1)*c doublings), then normalise

@@ -200,12 +200,14 @@ void ntt_device(Context &cx, Fr *d_data, uint32_t log_n, bool inverse, bool cose
         for (int p = 0; p < npass; p++) {
             int K = (int)(log_n - log_ns + (npass - p) - 1) / (npass - p);
             bool last = p == npass - 1;
+            cx.prof.begin("ntt_pass", st, n);
             switch (K) {
             case 1: ntt_launch_pass<1>(src, dst, tw, log_n, log_ns, inverse, last && fold_scale, n_inv, st); break;
             case 2: ntt_launch_pass<2>(src, dst, tw, log_n, log_ns, inverse, last && fold_scale, n_inv, st); break;
             case 3: ntt_launch_pass<3>(src, dst, tw, log_n, log_ns, inverse, last && fold_scale, n_inv, st); break;
             default: ntt_launch_pass<4>(src, dst, tw, log_n, log_ns, inverse, last && fold_scale, n_inv, st); break;
             }
+            cx.prof.end("ntt_pass", st);
             log_ns += K;
             Fr *t = src; src = dst; dst = t;
         }

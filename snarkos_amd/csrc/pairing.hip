@@ -56,7 +56,9 @@ void pairing_product_prepared(Context &cx, const G1Affine *ps, const G2Prepared 
     for (size_t i = 0; i < n; i++) { a.p[i] = ps[i]; a.q[i] = d_qs[i]; }
     const PairingConsts *pc = pairing_consts(cx, st);
     Fq12 *d_out = (Fq12 *)cx.buf("pairing.out", sizeof(Fq12));
+    cx.prof.begin("pairing", st, n);
     hipLaunchKernelGGL(pairing_product_kernel, dim3(1), dim3(64), 0, st, a, pc, d_out);
+    cx.prof.end("pairing", st);
     MI_HIP(hipGetLastError());
     Fq12 *h = (Fq12 *)cx.pin(sizeof(Fq12));
     MI_HIP(hipMemcpyAsync(h, d_out, sizeof(Fq12), hipMemcpyDeviceToHost, st));

@@ -52,8 +52,33 @@ struct DevBuf {
     }
 };
 
+// HIP-event records of named kernels (mi_prof_enable / mi_prof_read).
+struct ProfRecord {
+    hipEvent_t e0, e1;
+    uint64_t units;
+};
+struct Profiler {
+    bool on = false;
+    std::map<std::string, std::vector<ProfRecord>> recs;
+    // begin/end bracket one launch on `st`; no-ops when profiling is off
+    void begin(const char *name, hipStream_t st, uint64_t units) {
+        if (!on) return;
+        ProfRecord r;
+        r.units = units;
+        MI_HIP(hipEventCreate(&r.e0));
+        MI_HIP(hipEventCreate(&r.e1));
+        MI_HIP(hipEventRecord(r.e0, st));
+        recs[name].push_back(r);
+    }
+    void end(const char *name, hipStream_t st) {
+        if (!on) return;
+        MI_HIP(hipEventRecord(recs[name].back().e1, st));
+    }
+};
+
 struct Context {
     std::mutex mu;  // serialises GPU work issued through the library (callers are rayon / tokio threads)
+    Profiler prof;
     bool inited = false;
     int device = 0;
     int n_cus = 256;

@@ -415,9 +415,11 @@ static VsWork vs_run_derive(Context &cx, VsCtx &v, const void *d_proofs, size_t 
     w.g_scal = (Fr *)cx.buf("vs.g_scal", sizeof(Fr) * n);
     w.alg_ok = (uint8_t *)cx.buf("vs.alg_ok", n);
     w.circuit_of = (uint32_t *)cx.buf("vs.circuit_of", 4 * n);
+    cx.prof.begin("vs_derive", st, n);
     hipLaunchKernelGGL(vs_derive_kernel, dim3(cdiv(n, 64)), dim3(64), 0, st, (const mi_vs_proof *)d_proofs, n,
                        (const uint8_t *)d_rand, (const mi_vs_circuit_vk *)v.circuits.p, v.n_circuits,
                        (const VsConsts *)v.consts.p, w.pts1, w.sc1, w.pts2, w.sc2, w.vk_scal, w.g_scal, w.alg_ok, w.circuit_of);
+    cx.prof.end("vs_derive", st);
     hipLaunchKernelGGL(vs_merge_kernel, dim3((unsigned)(v.n_circuits * MI_VS_VK_COMMS + 1)), dim3(256), 0, st, w.vk_scal,
                        w.g_scal, w.circuit_of, n, (const mi_vs_circuit_vk *)v.circuits.p, v.n_circuits,
                        (const VsConsts *)v.consts.p, w.pts1, w.sc1);

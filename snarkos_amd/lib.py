@@ -30,7 +30,8 @@ EXPORTS = [
     "mi_pairing_product_is_one", "mi_pairing", "mi_kzg_batch_check",
     "mi_vs_ctx_create", "mi_vs_ctx_destroy", "mi_vs_verify_batch", "mi_vs_verify_batch_device",
     "mi_vs_accumulate_device", "mi_vs_finalize",
-    "mi_dbg_fq_mul", "mi_dbg_fr_mul", "mi_dbg_g1_add", "mi_dbg_fq_mul_throughput",
+    "mi_dbg_fq_mul", "mi_dbg_fr_mul", "mi_dbg_g1_add", "mi_dbg_fq_mul_throughput", "mi_dbg_gen_points_device",
+    "mi_prof_enable", "mi_prof_read",
 ]
 
 
@@ -55,6 +56,14 @@ def lib():
             raise ImportError(
                 "libmi355x_snark.so is not built (run `python -m snarkos_amd.build`); "
                 "there is no CPU fallback on the product path")
+        # The PyTorch wheel bundles its own libamdhip64.so.7 / libhsa-runtime64; two HIP runtimes in one
+        # process cannot both own the GPU ("No HIP GPUs are available" for whichever comes second).
+        # Importing torch first makes the dynamic loader resolve our NEEDED libamdhip64.so.7 to the copy
+        # torch already mapped, so device pointers and streams are shared with torch tensors.
+        try:
+            import torch  # noqa: F401
+        except Exception:  # pragma: no cover - torch is plumbing, not a requirement of the C ABI
+            pass
         l = C.CDLL(LIB_PATH)
         for name in EXPORTS:
             getattr(l, name).restype = C.c_int32
@@ -99,3 +108,14 @@ def init(device=-1):
 
 def shutdown():
     check(lib().mi_shutdown(), "mi_shutdown")
+
+
+def prof_enable(on=True):
+    check(lib().mi_prof_enable(C.c_int32(1 if on else 0)), "mi_prof_enable")
+
+
+def prof_read(kernel):
+    """-> (total_ms, launches, units) of the HIP-event records of `kernel`, then clears them"""
+    ms, n, u = C.c_double(0), C.c_uint64(0), C.c_uint64(0)
+    check(lib().mi_prof_read(kernel.encode(), C.byref(ms), C.byref(n), C.byref(u)), "mi_prof_read")
+    return ms.value, n.value, u.value

@@ -55,3 +55,29 @@ def test_partials_match_oracle_and_shard(orc, mi):
         assert v.finalize([p0, p1])
     finally:
         v.close()
+
+
+def _fixture():
+    import os
+    d = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "vs_batch_1024.npz"))
+    return d["vk"], d["circuits"], d["proofs"], d["randomizers"]
+
+
+def test_full_size_batch_1024(orc, mi):
+    """BASELINE configs[3] at full size: 1024 valid proofs, then 1 % corrupted; verdict vector vs oracle"""
+    vk, circuits, proofs, rnd = _fixture()
+    v = mi.VarunaShaped(vk, circuits)
+    try:
+        ok, verdicts = v.verify_batch(proofs, rnd)
+        assert ok and verdicts.all()
+        bad = proofs.copy()
+        idx = np.arange(5, 1024, 101)
+        for i in idx:
+            bad[i * 2256 + 16 + 512 + 864 + 32 * 7] ^= 1
+        ok, verdicts = v.verify_batch(bad, rnd)
+        want = np.ones(1024, dtype=np.uint8); want[idx] = 0
+        assert not ok and (verdicts == want).all()
+        cpu = orc.VSArrays(vk, circuits, bad, rnd).verify_cpu(16)
+        assert (cpu == want).all()
+    finally:
+        v.close()
