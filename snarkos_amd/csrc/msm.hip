@@ -143,7 +143,7 @@ __global__ void __launch_bounds__(256) scan_finish_kernel(uint32_t *__restrict__
         if (i < n) {
             uint32_t o = offsets[i] + add;
             offsets[i] = o;
-            cursor[i] = o;
+            if (cursor) cursor[i] = o;
             if (i == n - 1) offsets[n] = o + counts[i];
         }
     }
@@ -163,25 +163,86 @@ __global__ void __launch_bounds__(256) msm_scatter_kernel(const int32_t *__restr
     sorted[pos] = ((uint32_t)i << 1) | (d < 0 ? 1u : 0u);
 }
 
-// ---------------------------------------------------------------- K4: bucket accumulation
+// out-of-line group addition for the cold reduction kernels
+__device__ __attribute__((noinline)) G1Xyzz xyzz_add_ni(const G1Xyzz &a, const G1Xyzz &b) { return add(a, b); }
+
+// ---------------------------------------------------------------- K4: bucket accumulation, load-balanced
+// A bucket with more than T entries is cut into ceil(count / T) chunks, one lane each; the top window of a
+// 253-bit scalar has few distinct digits, and a skewed scalar distribution can put most points into a handful
+// of buckets, so lane-per-bucket would leave one lane walking thousands of points.
+__global__ void __launch_bounds__(256) msm_chunk_count_kernel(const uint32_t *__restrict__ counts, size_t nb, uint32_t T,
+                                                              uint32_t *__restrict__ nchunks) {
+    size_t b = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b < nb) nchunks[b] = (counts[b] + T - 1) / T;
+}
+// lane per bucket: chunk_bucket[chunk_off[b] + j] = b; buckets with more than `heavy` chunks go on the heavy list
+__global__ void __launch_bounds__(256) msm_chunk_map_kernel(const uint32_t *__restrict__ chunk_off, size_t nb,
+                                                            uint32_t *__restrict__ chunk_bucket, uint32_t heavy,
+                                                            uint32_t *__restrict__ heavy_list,
+                                                            uint32_t *__restrict__ heavy_count) {
+    size_t b = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= nb) return;
+    uint32_t lo = chunk_off[b], hi = chunk_off[b + 1];
+    for (uint32_t t = lo; t < hi; t++) chunk_bucket[t] = (uint32_t)b;
+    if (hi - lo > heavy) heavy_list[atomicAdd(heavy_count, 1u)] = (uint32_t)b;
+}
 __global__ void __launch_bounds__(128) msm_accumulate_kernel(const G1Affine *__restrict__ points,
                                                              const uint32_t *__restrict__ sorted,
-                                                             const uint32_t *__restrict__ offsets, size_t n_buckets,
-                                                             G1Xyzz *__restrict__ buckets) {
-    size_t id = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (id >= n_buckets) return;
-    uint32_t k = offsets[id], end = offsets[id + 1];
+                                                             const uint32_t *__restrict__ offsets,
+                                                             const uint32_t *__restrict__ chunk_off,
+                                                             const uint32_t *__restrict__ chunk_bucket, size_t nb,
+                                                             uint32_t T, G1Xyzz *__restrict__ chunk_partial) {
+    size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= chunk_off[nb]) return;
+    const uint32_t b = chunk_bucket[t];
+    uint32_t k = offsets[b] + ((uint32_t)t - chunk_off[b]) * T;
+    uint32_t end = offsets[b + 1];
+    if (end - k > T) end = k + T;
     G1Xyzz acc = G1Xyzz::inf();
-    if (k < end) {
-        G1Affine nxt = load_point(points, sorted[k]);
-        while (k < end) {
-            G1Affine cur = nxt;
-            k++;
-            if (k < end) nxt = load_point(points, sorted[k]);  // issue the next gather before the add
-            acc = add_mixed<true>(acc, cur);
-        }
+    G1Affine nxt = load_point(points, sorted[k]);
+    while (k < end) {
+        G1Affine cur = nxt;
+        k++;
+        if (k < end) nxt = load_point(points, sorted[k]);  // issue the next gather before the add
+        acc = add_mixed<true>(acc, cur);
     }
-    store_xyzz(&buckets[id], acc);
+    store_xyzz(&chunk_partial[t], acc);
+}
+// lane per bucket: bucket = sum of its (few) chunk partials; heavy buckets are left to the block kernel
+__global__ void __launch_bounds__(128) msm_combine_kernel(const G1Xyzz *__restrict__ chunk_partial,
+                                                          const uint32_t *__restrict__ chunk_off, size_t nb, uint32_t heavy,
+                                                          G1Xyzz *__restrict__ buckets) {
+    size_t b = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= nb) return;
+    uint32_t lo = chunk_off[b], hi = chunk_off[b + 1];
+    if (hi - lo > heavy) return;
+    G1Xyzz acc = G1Xyzz::inf();
+    if (lo < hi) acc = load_xyzz(&chunk_partial[lo]);
+    for (uint32_t t = lo + 1; t < hi; t++) acc = xyzz_add_ni(acc, load_xyzz(&chunk_partial[t]));
+    store_xyzz(&buckets[b], acc);
+}
+// block per heavy bucket: strided partial sums, then an LDS tree
+__global__ void __launch_bounds__(256) msm_combine_heavy_kernel(const G1Xyzz *__restrict__ chunk_partial,
+                                                                const uint32_t *__restrict__ chunk_off,
+                                                                const uint32_t *__restrict__ heavy_list,
+                                                                const uint32_t *__restrict__ heavy_count,
+                                                                G1Xyzz *__restrict__ buckets) {
+    __shared__ G1Xyzz lds[128];
+    const int t = threadIdx.x;
+    const uint32_t nheavy = *heavy_count;
+    for (uint32_t h = blockIdx.x; h < nheavy; h += gridDim.x) {
+        const uint32_t b = heavy_list[h];
+        const uint32_t lo = chunk_off[b], hi = chunk_off[b + 1];
+        G1Xyzz acc = G1Xyzz::inf();
+        for (uint32_t i = lo + t; i < hi; i += 256) acc = xyzz_add_ni(acc, load_xyzz(&chunk_partial[i]));
+        for (int stride = 128; stride >= 1; stride >>= 1) {
+            if (t >= stride && t < 2 * stride) store_xyzz(&lds[t - stride], acc);
+            __syncthreads();
+            if (t < stride) acc = xyzz_add_ni(acc, load_xyzz(&lds[t]));
+            __syncthreads();
+        }
+        if (t == 0) store_xyzz(&buckets[b], acc);
+    }
 }
 
 // ---------------------------------------------------------------- K5: segment partials
@@ -211,9 +272,6 @@ __global__ void __launch_bounds__(128) msm_segments_kernel(const G1Xyzz *__restr
     }
     store_xyzz(&partials[t], wsum);
 }
-
-// out-of-line group addition for the cold reduction kernels
-__device__ __attribute__((noinline)) G1Xyzz xyzz_add_ni(const G1Xyzz &a, const G1Xyzz &b) { return add(a, b); }
 
 // ---------------------------------------------------------------- K6: per-group tree sum through LDS
 // in[group][m] -> out[group][gridDim.x]; block (x, group) sums a strided slice, then an LDS tree.
@@ -282,23 +340,57 @@ void msm_device(Context &cx, const G1Affine *d_points, const uint32_t *d_scalars
     G1Xyzz *buckets = (G1Xyzz *)cx.buf("msm.buckets", sizeof(G1Xyzz) * nb);
 
     MI_HIP(hipMemsetAsync(counts, 0, sizeof(uint32_t) * nb, st));
+    cx.prof.begin("msm_digits", st, n);
     switch (pl.c) {
 #define MI_CASE(C) case C: launch_digits<C>(d_scalars, n, digits, counts, scalar_bits, st); break;
         MI_CASE(6) MI_CASE(7) MI_CASE(8) MI_CASE(9) MI_CASE(10) MI_CASE(11) MI_CASE(12) MI_CASE(13) MI_CASE(14) MI_CASE(15) MI_CASE(16)
 #undef MI_CASE
     }
+    cx.prof.end("msm_digits", st);
+    cx.prof.begin("msm_scan", st, n);
     hipLaunchKernelGGL(scan_tiles_kernel, dim3(tiles), dim3(256), 0, st, counts, offsets, tile_sums, nb);
     hipLaunchKernelGGL(scan_sums_kernel, dim3(1), dim3(1024), 0, st, tile_sums, (size_t)tiles);
     hipLaunchKernelGGL(scan_finish_kernel, dim3(tiles), dim3(256), 0, st, offsets, cursor, tile_sums, counts, nb);
+    cx.prof.end("msm_scan", st);
+    cx.prof.begin("msm_scatter", st, n);
     hipLaunchKernelGGL(msm_scatter_kernel, dim3(cdiv(n * pl.nwin, 256)), dim3(256), 0, st, digits, n, pl.nwin, pl.B, cursor, sorted);
+    cx.prof.end("msm_scatter", st);
+    // chunking: T = twice the mean bucket load of a full window, so only over-full buckets are split
+    uint32_t T = (uint32_t)(2 * ((n + pl.B - 1) / pl.B));
+    if (T < 16) T = 16;
+    const uint32_t HEAVY = 8;
+    const size_t max_chunks = nb + (n * (size_t)pl.nwin) / T + 1;
+    uint32_t *nchunks = (uint32_t *)cx.buf("msm.nchunks", sizeof(uint32_t) * nb);
+    uint32_t *chunk_off = (uint32_t *)cx.buf("msm.chunk_off", sizeof(uint32_t) * (nb + 1));
+    uint32_t *chunk_bucket = (uint32_t *)cx.buf("msm.chunk_bucket", sizeof(uint32_t) * max_chunks);
+    uint32_t *heavy_list = (uint32_t *)cx.buf("msm.heavy", sizeof(uint32_t) * (nb + 1));
+    uint32_t *heavy_count = heavy_list + nb;
+    G1Xyzz *chunk_partial = (G1Xyzz *)cx.buf("msm.chunk_partial", sizeof(G1Xyzz) * max_chunks);
+    cx.prof.begin("msm_chunks", st, n);
+    MI_HIP(hipMemsetAsync(heavy_count, 0, sizeof(uint32_t), st));
+    hipLaunchKernelGGL(msm_chunk_count_kernel, dim3(cdiv(nb, 256)), dim3(256), 0, st, counts, nb, T, nchunks);
+    hipLaunchKernelGGL(scan_tiles_kernel, dim3(tiles), dim3(256), 0, st, nchunks, chunk_off, tile_sums, nb);
+    hipLaunchKernelGGL(scan_sums_kernel, dim3(1), dim3(1024), 0, st, tile_sums, (size_t)tiles);
+    hipLaunchKernelGGL(scan_finish_kernel, dim3(tiles), dim3(256), 0, st, chunk_off, (uint32_t *)nullptr, tile_sums, nchunks, nb);
+    hipLaunchKernelGGL(msm_chunk_map_kernel, dim3(cdiv(nb, 256)), dim3(256), 0, st, chunk_off, nb, chunk_bucket, HEAVY, heavy_list, heavy_count);
+    cx.prof.end("msm_chunks", st);
     cx.prof.begin("msm_accumulate", st, n);
-    hipLaunchKernelGGL(msm_accumulate_kernel, dim3(cdiv(nb, 128)), dim3(128), 0, st, d_points, sorted, offsets, nb, buckets);
+    hipLaunchKernelGGL(msm_accumulate_kernel, dim3(cdiv(max_chunks, 128)), dim3(128), 0, st, d_points, sorted, offsets, chunk_off,
+                       chunk_bucket, nb, T, chunk_partial);
     cx.prof.end("msm_accumulate", st);
+    cx.prof.begin("msm_combine", st, n);
+    hipLaunchKernelGGL(msm_combine_kernel, dim3(cdiv(nb, 128)), dim3(128), 0, st, chunk_partial, chunk_off, nb, HEAVY, buckets);
+    hipLaunchKernelGGL(msm_combine_heavy_kernel, dim3(1024), dim3(256), 0, st, chunk_partial, chunk_off, heavy_list, heavy_count, buckets);
+    cx.prof.end("msm_combine", st);
     uint32_t L = pl.B >= 4096 ? 8 : 4;
     const size_t nseg = nb / L;
     G1Xyzz *partials = (G1Xyzz *)cx.buf("msm.partials", sizeof(G1Xyzz) * nseg);
+    cx.prof.begin("msm_segments", st, n);
     hipLaunchKernelGGL(msm_segments_kernel, dim3(cdiv(nseg, 128)), dim3(128), 0, st, buckets, pl.B, L, nseg, partials);
+    cx.prof.end("msm_segments", st);
+    cx.prof.begin("msm_tree", st, n);
     G1Xyzz *wsums = device_group_sum(cx, partials, pl.nwin, pl.B / L, st, "msm.tree_a", "msm.tree_b");
+    cx.prof.end("msm_tree", st);
     MI_HIP(hipGetLastError());
     G1Xyzz *h = (G1Xyzz *)cx.pin(sizeof(G1Xyzz) * pl.nwin);
     cx.prof.end("msm_total", st);

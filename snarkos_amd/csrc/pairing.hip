@@ -2,6 +2,7 @@
 #include <vector>
 #include "api.hpp"
 #include "tower.hpp"
+#include "pairing_wg.hpp"
 
 namespace mi {
 
@@ -11,12 +12,11 @@ struct PairingArgs {
     int n;
 };
 
-// v1: one lane walks the whole product (latency-bound; the wave-parallel Fq12 version replaces this)
-__global__ void __launch_bounds__(64) pairing_product_kernel(PairingArgs args, const PairingConsts *__restrict__ pc,
-                                                             Fq12 *out) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    Fq12 f = miller_product(args.p, args.q, args.n);
-    *out = final_exponentiation(f, *pc);
+// one workgroup of 192 lanes per pairing product (pairing_wg.hpp)
+__global__ void __launch_bounds__(PW_THREADS) pairing_product_kernel(PairingArgs args, const PairingConsts *__restrict__ pc,
+                                                                     Fq12 *out) {
+    __shared__ PwShared S;
+    pw_pairing_product(S, args.p, args.q, args.n, pc, out);
 }
 
 struct PairingState {
@@ -57,7 +57,7 @@ void pairing_product_prepared(Context &cx, const G1Affine *ps, const G2Prepared 
     const PairingConsts *pc = pairing_consts(cx, st);
     Fq12 *d_out = (Fq12 *)cx.buf("pairing.out", sizeof(Fq12));
     cx.prof.begin("pairing", st, n);
-    hipLaunchKernelGGL(pairing_product_kernel, dim3(1), dim3(64), 0, st, a, pc, d_out);
+    hipLaunchKernelGGL(pairing_product_kernel, dim3(1), dim3(PW_THREADS), 0, st, a, pc, d_out);
     cx.prof.end("pairing", st);
     MI_HIP(hipGetLastError());
     Fq12 *h = (Fq12 *)cx.pin(sizeof(Fq12));

@@ -14,6 +14,7 @@
 #include <vector>
 #include "api.hpp"
 #include "tower.hpp"
+#include "pairing_wg.hpp"
 
 namespace mi {
 
@@ -376,22 +377,32 @@ __global__ void __launch_bounds__(128) vs_terms_kernel(size_t n, const G1Affine 
     }
     store_xyzz(&terms[t], acc);
 }
-// lane i: total_c_i = sum of terms 0..23, total_w_i = terms 24 + 25; pairing product; verdict
-__global__ void __launch_bounds__(64) vs_per_proof_pairing_kernel(size_t n, const G1Xyzz *__restrict__ terms,
-                                                                  const G2Prepared *__restrict__ h,
-                                                                  const G2Prepared *__restrict__ tauh,
-                                                                  const PairingConsts *__restrict__ pc,
-                                                                  const uint8_t *__restrict__ alg_ok,
-                                                                  uint8_t *__restrict__ verdicts) {
-    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    G1Xyzz tc = G1Xyzz::inf(), tw = G1Xyzz::inf();
-    for (int k = 0; k < 24; k++) tc = add(tc, load_xyzz(&terms[i * VS_TERMS + k]));
-    tw = add(load_xyzz(&terms[i * VS_TERMS + 24]), load_xyzz(&terms[i * VS_TERMS + 25]));
-    G1Affine ps[2] = {to_affine(tc), neg(to_affine(tw))};
-    const G2Prepared *qs[2] = {h, tauh};
-    Fq12 f = final_exponentiation(miller_product(ps, qs, 2), *pc);
-    verdicts[i] = (f.is_one() && alg_ok[i]) ? 1 : 0;
+// block i (192 lanes): total_c_i = sum of terms 0..23, total_w_i = terms 24 + 25 (lanes 0 and 1), then the
+// workgroup-cooperative pairing product; verdict
+__global__ void __launch_bounds__(PW_THREADS) vs_per_proof_pairing_kernel(size_t n, const G1Xyzz *__restrict__ terms,
+                                                                          const G2Prepared *__restrict__ h,
+                                                                          const G2Prepared *__restrict__ tauh,
+                                                                          const PairingConsts *__restrict__ pc,
+                                                                          const uint8_t *__restrict__ alg_ok,
+                                                                          uint8_t *__restrict__ verdicts) {
+    __shared__ PwShared S;
+    __shared__ G1Affine ps[2];
+    __shared__ const G2Prepared *qs[2];
+    __shared__ Fq12 result;
+    const size_t i = blockIdx.x;
+    if (threadIdx.x == 0) {
+        G1Xyzz tc = G1Xyzz::inf();
+        for (int k = 0; k < 24; k++) tc = add(tc, load_xyzz(&terms[i * VS_TERMS + k]));
+        ps[0] = to_affine(tc);
+        qs[0] = h;
+        qs[1] = tauh;
+    } else if (threadIdx.x == 64) {
+        G1Xyzz tw = add(load_xyzz(&terms[i * VS_TERMS + 24]), load_xyzz(&terms[i * VS_TERMS + 25]));
+        ps[1] = neg(to_affine(tw));
+    }
+    __syncthreads();
+    pw_pairing_product(S, ps, qs, 2, pc, &result);
+    if (threadIdx.x == 0) verdicts[i] = (result.is_one() && alg_ok[i]) ? 1 : 0;
 }
 
 // ---------------------------------------------------------------- host drivers
@@ -500,7 +511,7 @@ int32_t vs_verify_batch_device(Context &cx, uint64_t id, const void *d_proofs, s
     uint8_t *d_verdicts = (uint8_t *)cx.buf("vs.verdicts", n);
     hipLaunchKernelGGL(vs_terms_kernel, dim3(cdiv(n * VS_TERMS, 128)), dim3(128), 0, st, n, w.pts1, w.sc1, w.sc2, w.vk_scal,
                        w.g_scal, w.circuit_of, (const mi_vs_circuit_vk *)v.circuits.p, (const VsConsts *)v.consts.p, terms);
-    hipLaunchKernelGGL(vs_per_proof_pairing_kernel, dim3(cdiv(n, 64)), dim3(64), 0, st, n, terms,
+    hipLaunchKernelGGL(vs_per_proof_pairing_kernel, dim3((unsigned)n), dim3(PW_THREADS), 0, st, n, terms,
                        (const G2Prepared *)v.h_prep.p, (const G2Prepared *)v.tauh_prep.p, pairing_consts(cx, st), w.alg_ok,
                        d_verdicts);
     MI_HIP(hipGetLastError());

@@ -48,6 +48,8 @@ def test_fq_ops(hc, orc):
         a = np.ascontiguousarray(a)
         hc.hc_fq_inv(_p(a), _p(out)); orc.lib().orc_fq_inv(_p(want), _p(a))
         assert (out == want).all()
+        hc.hc_fq_inv_egcd(_p(a), _p(out))
+        assert (out == want).all()
 
 
 def test_fr_ops(hc, orc):
@@ -58,6 +60,8 @@ def test_fr_ops(hc, orc):
         assert (out == want).all()
     for i in range(4):
         hc.hc_fr_inv(_p(a[i]), _p(out)); orc.lib().orc_fr_inv(_p(want), _p(a[i]))
+        assert (out == want).all()
+        hc.hc_fr_inv_egcd(_p(a[i]), _p(out))
         assert (out == want).all()
         hc.hc_fr_to_mont(_p(a[i]), _p(out)); orc.lib().orc_fr_from_canonical(_p(want), _p(a[i]))
         assert (out == want).all()

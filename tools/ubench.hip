@@ -1,0 +1,127 @@
+// Integer-ALU micro-benchmarks for gfx950: issue rates that bound the 377-bit Montgomery product.
+//   hipcc -O3 --offload-arch=gfx950 -std=c++17 -o tools/ubench tools/ubench.hip && ./tools/ubench
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include "../snarkos_amd/csrc/field.hpp"
+using namespace mi;
+
+#define CHECK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); return 1; } } while (0)
+
+template <int MODE>
+__global__ void __launch_bounds__(256) alu_kernel(uint32_t *out, int iters) {
+    uint32_t a = threadIdx.x * 2654435761u + 1, b = blockIdx.x * 40503u + 7;
+    uint64_t acc0 = a, acc1 = b, acc2 = a ^ b, acc3 = a + b;
+    uint32_t x0 = a, x1 = b, x2 = a ^ b, x3 = a + b;
+    for (int i = 0; i < iters; i++) {
+#pragma unroll
+        for (int k = 0; k < 16; k++) {
+            if (MODE == 0) {  // 4 independent v_mad_u64_u32 chains
+                asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, %0" : "+v"(acc0) : "v"(a), "v"(b) : "vcc");
+                asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, %0" : "+v"(acc1) : "v"(a), "v"(b) : "vcc");
+                asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, %0" : "+v"(acc2) : "v"(a), "v"(b) : "vcc");
+                asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, %0" : "+v"(acc3) : "v"(a), "v"(b) : "vcc");
+            } else if (MODE == 1) {  // v_add_u32
+                asm volatile("v_add_u32 %0, %0, %1" : "+v"(x0) : "v"(a));
+                asm volatile("v_add_u32 %0, %0, %1" : "+v"(x1) : "v"(a));
+                asm volatile("v_add_u32 %0, %0, %1" : "+v"(x2) : "v"(a));
+                asm volatile("v_add_u32 %0, %0, %1" : "+v"(x3) : "v"(a));
+            } else if (MODE == 2) {  // v_lshl_add_u64 (64-bit add)
+                asm volatile("v_lshl_add_u64 %0, %0, 0, %1" : "+v"(acc0) : "v"(acc3));
+                asm volatile("v_lshl_add_u64 %0, %0, 0, %1" : "+v"(acc1) : "v"(acc3));
+                asm volatile("v_lshl_add_u64 %0, %0, 0, %1" : "+v"(acc2) : "v"(acc3));
+                asm volatile("v_lshl_add_u64 %0, %0, 0, %1" : "+v"(acc3) : "v"(acc0));
+            } else if (MODE == 3) {  // v_mul_lo_u32
+                asm volatile("v_mul_lo_u32 %0, %0, %1" : "+v"(x0) : "v"(a));
+                asm volatile("v_mul_lo_u32 %0, %0, %1" : "+v"(x1) : "v"(a));
+                asm volatile("v_mul_lo_u32 %0, %0, %1" : "+v"(x2) : "v"(a));
+                asm volatile("v_mul_lo_u32 %0, %0, %1" : "+v"(x3) : "v"(a));
+            } else if (MODE == 4) {  // v_addc_co_u32 chain
+                asm volatile("v_addc_co_u32 %0, vcc, %0, %1, vcc" : "+v"(x0) : "v"(a) : "vcc");
+                asm volatile("v_addc_co_u32 %0, vcc, %0, %1, vcc" : "+v"(x1) : "v"(a) : "vcc");
+                asm volatile("v_addc_co_u32 %0, vcc, %0, %1, vcc" : "+v"(x2) : "v"(a) : "vcc");
+                asm volatile("v_addc_co_u32 %0, vcc, %0, %1, vcc" : "+v"(x3) : "v"(a) : "vcc");
+            } else if (MODE == 5) {  // v_mad_u32_u24 (24-bit multiply-add, full rate?)
+                asm volatile("v_mad_u32_u24 %0, %0, %1, %2" : "+v"(x0) : "v"(a), "v"(b));
+                asm volatile("v_mad_u32_u24 %0, %0, %1, %2" : "+v"(x1) : "v"(a), "v"(b));
+                asm volatile("v_mad_u32_u24 %0, %0, %1, %2" : "+v"(x2) : "v"(a), "v"(b));
+                asm volatile("v_mad_u32_u24 %0, %0, %1, %2" : "+v"(x3) : "v"(a), "v"(b));
+            } else if (MODE == 6) {  // v_fma_f64
+                double d0 = __longlong_as_double(acc0), d1 = __longlong_as_double(acc1), d2 = __longlong_as_double(acc2), d3 = __longlong_as_double(acc3);
+                asm volatile("v_fma_f64 %0, %0, %1, %1" : "+v"(d0) : "v"(d3));
+                asm volatile("v_fma_f64 %0, %0, %1, %1" : "+v"(d1) : "v"(d3));
+                asm volatile("v_fma_f64 %0, %0, %1, %1" : "+v"(d2) : "v"(d3));
+                asm volatile("v_fma_f64 %0, %0, %1, %1" : "+v"(d2) : "v"(d3));
+                acc0 = __double_as_longlong(d0); acc1 = __double_as_longlong(d1); acc2 = __double_as_longlong(d2);
+            } else if (MODE == 7) {  // v_mul_hi_u32
+                asm volatile("v_mul_hi_u32 %0, %0, %1" : "+v"(x0) : "v"(a));
+                asm volatile("v_mul_hi_u32 %0, %0, %1" : "+v"(x1) : "v"(a));
+                asm volatile("v_mul_hi_u32 %0, %0, %1" : "+v"(x2) : "v"(a));
+                asm volatile("v_mul_hi_u32 %0, %0, %1" : "+v"(x3) : "v"(a));
+            }
+        }
+    }
+    out[blockIdx.x * blockDim.x + threadIdx.x] = (uint32_t)(acc0 ^ acc1 ^ acc2 ^ acc3) ^ x0 ^ x1 ^ x2 ^ x3;
+}
+
+template <class F>
+__global__ void __launch_bounds__(256) fmul_kernel(F *out, int iters) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    F a = F::one(), b = F::r2();
+    a.l[0] += (uint32_t)i;
+    for (int k = 0; k < iters; k++) {
+        a = mul(a, b);
+        b = mul(b, a);
+    }
+    out[i] = add(a, b);
+}
+
+template <class K, class... A>
+static double time_kernel(K k, dim3 g, dim3 b, A... args) {
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    hipLaunchKernelGGL(k, g, b, 0, 0, args...);
+    hipDeviceSynchronize();
+    hipEventRecord(e0, 0);
+    hipLaunchKernelGGL(k, g, b, 0, 0, args...);
+    hipEventRecord(e1, 0);
+    hipEventSynchronize(e1);
+    float ms = 0;
+    hipEventElapsedTime(&ms, e0, e1);
+    return ms * 1e-3;
+}
+
+int main() {
+    uint32_t *d;
+    CHECK(hipMalloc(&d, 256u * 4096 * 48));
+    const char *names[] = {"v_mad_u64_u32", "v_add_u32", "v_lshl_add_u64", "v_mul_lo_u32", "v_addc_co_u32", "v_mad_u32_u24", "v_fma_f64", "v_mul_hi_u32"};
+    const int iters = 2000;
+    for (int waves_per_simd = 1; waves_per_simd <= 4; waves_per_simd *= 2) {
+        int blocks = 256 * waves_per_simd;  // 256 CUs x (256-thread blocks = 1 wave per SIMD each)
+        double t[8];
+        t[0] = time_kernel(alu_kernel<0>, dim3(blocks), dim3(256), d, iters);
+        t[1] = time_kernel(alu_kernel<1>, dim3(blocks), dim3(256), d, iters);
+        t[2] = time_kernel(alu_kernel<2>, dim3(blocks), dim3(256), d, iters);
+        t[3] = time_kernel(alu_kernel<3>, dim3(blocks), dim3(256), d, iters);
+        t[4] = time_kernel(alu_kernel<4>, dim3(blocks), dim3(256), d, iters);
+        t[5] = time_kernel(alu_kernel<5>, dim3(blocks), dim3(256), d, iters);
+        t[6] = time_kernel(alu_kernel<6>, dim3(blocks), dim3(256), d, iters);
+        t[7] = time_kernel(alu_kernel<7>, dim3(blocks), dim3(256), d, iters);
+        for (int m = 0; m < 8; m++) {
+            double n_inst = (double)iters * 64;  // wave-instructions per wave
+            double waves = (double)blocks * 4;
+            // cycles per wave-instruction per SIMD at an assumed 2.4 GHz, all SIMDs busy
+            double per_simd = t[m] * 2.4e9 / (n_inst * waves_per_simd);
+            printf("waves/SIMD=%d %-16s %.3f ms  %.2f cyc/wave-instr/SIMD  %.2f Tlane-op/s\n", waves_per_simd, names[m], t[m] * 1e3, per_simd,
+                   n_inst * waves * 64 / t[m] / 1e12);
+        }
+    }
+    for (int wps = 1; wps <= 8; wps *= 2) {
+        int blocks = 256 * wps;
+        double tq = time_kernel(fmul_kernel<Fq>, dim3(blocks), dim3(256), (Fq *)d, 200);
+        double tr = time_kernel(fmul_kernel<Fr>, dim3(blocks), dim3(256), (Fr *)d, 200);
+        printf("waves/SIMD=%d  Fq mul %.2f Gmul/s (%.0f ns per mul per wave)   Fr mul %.2f Gmul/s\n", wps, 400.0 * blocks * 256 / tq / 1e9,
+               tq / 400 * 1e9, 400.0 * blocks * 256 / tr / 1e9);
+    }
+    hipFree(d);
+    return 0;
+}
