@@ -13,6 +13,9 @@
 #include <stdint.h>
 #include "constants.hpp"
 
+#ifndef MI_COMBA_LANES
+#define MI_COMBA_LANES 1
+#endif
 #if defined(__HIPCC__)
 #include <hip/hip_runtime.h>
 #define MI_HD __host__ __device__ __forceinline__
@@ -26,6 +29,7 @@ namespace mi {
 
 struct FqP {
     static constexpr int N = 12;
+    static constexpr uint64_t INV64 = MI_FQ_INV;
     static constexpr uint32_t MOD[12] = {0x00000001u, 0x8508c000u, 0x30000000u, 0x170b5d44u, 0xba094800u, 0x1ef3622fu,
                                          0x00f5138fu, 0x1a22d9f3u, 0x6ca1493bu, 0xc63b05c0u, 0x17c510eau, 0x01ae3a46u};
     // R mod q
@@ -36,6 +40,7 @@ struct FqP {
 };
 struct FrP {
     static constexpr int N = 8;
+    static constexpr uint64_t INV64 = MI_FR_INV;
     static constexpr uint32_t MOD[8] = {0x00000001u, 0x0a118000u, 0xd0000001u, 0x59aa76feu,
                                         0x5c37b001u, 0x60b44d1eu, 0x9a2ca556u, 0x12ab655eu};
     static constexpr uint32_t ONE[8] = {0xfffffff3u, 0x7d1c7fffu, 0x6ffffff2u, 0x7257f50fu,
@@ -46,6 +51,7 @@ struct FrP {
 
 template <class P>
 struct Fp {
+    using Params = P;
     static constexpr int N = P::N;
     uint32_t l[N];
 
@@ -148,8 +154,48 @@ MI_HD Fp<P> dbl(const Fp<P> &a) {
 
 // Montgomery product a*b*R^-1 mod p, fully reduced.  Operand-scanning CIOS on 32-bit limbs; the
 // modulus is 1 mod 2^32, so m = -t0 and m*MOD[0] + t0 contributes only its carry (1 when t0 != 0).
+#if !defined(__HIP_DEVICE_COMPILE__)
+// host build of the same product: 64-bit limbs and a 128-bit accumulator (the short serial tails that run on
+// the host -- window fold, G2 line preparation -- are ~3x faster this way than with the 32-bit limb code)
 template <class P>
-MI_HD Fp<P> mul(const Fp<P> &a, const Fp<P> &b) {
+inline Fp<P> mul_host64(const Fp<P> &a, const Fp<P> &b) {
+    constexpr int M = P::N / 2;
+    uint64_t A[M], B[M], Q[M], t[M + 1];
+    for (int i = 0; i < M; i++) {
+        A[i] = ((uint64_t)a.l[2 * i + 1] << 32) | a.l[2 * i];
+        B[i] = ((uint64_t)b.l[2 * i + 1] << 32) | b.l[2 * i];
+        Q[i] = ((uint64_t)P::MOD[2 * i + 1] << 32) | P::MOD[2 * i];
+        t[i] = 0;
+    }
+    t[M] = 0;
+    for (int i = 0; i < M; i++) {
+        unsigned __int128 acc;
+        uint64_t carry = 0;
+        for (int j = 0; j < M; j++) {
+            acc = (unsigned __int128)A[j] * B[i] + t[j] + carry;
+            t[j] = (uint64_t)acc;
+            carry = (uint64_t)(acc >> 64);
+        }
+        t[M] = carry;
+        uint64_t m = t[0] * P::INV64;
+        acc = (unsigned __int128)m * Q[0] + t[0];
+        carry = (uint64_t)(acc >> 64);
+        for (int j = 1; j < M; j++) {
+            acc = (unsigned __int128)m * Q[j] + t[j] + carry;
+            t[j - 1] = (uint64_t)acc;
+            carry = (uint64_t)(acc >> 64);
+        }
+        t[M - 1] = t[M] + carry;
+    }
+    Fp<P> r;
+    for (int i = 0; i < M; i++) { r.l[2 * i] = (uint32_t)t[i]; r.l[2 * i + 1] = (uint32_t)(t[i] >> 32); }
+    reduce_once(r);
+    return r;
+}
+#endif
+
+template <class P>
+MI_HD Fp<P> mul32(const Fp<P> &a, const Fp<P> &b) {
     constexpr int N = P::N;
     uint32_t t[N + 1];
 #pragma unroll
@@ -179,6 +225,28 @@ MI_HD Fp<P> mul(const Fp<P> &a, const Fp<P> &b) {
     for (int i = 0; i < N; i++) r.l[i] = t[i];
     reduce_once(r);
     return r;
+}
+
+}  // namespace mi
+#if defined(__HIP_DEVICE_COMPILE__)
+// Device product: finely integrated product scanning (Comba), generated fully unrolled by tools/gen_comba.py.
+// Column k sums a_i b_(k-i) and m_i p_(k-i) into a 96-bit accumulator {ovf, acc}: v_mad_u64_u32 adds the 64-bit
+// product into acc and leaves the carry in VCC, v_addc_co_u32 folds it into ovf: 2 VALU instructions per limb
+// product and no register shuffling, against ~4.4 for the compiler's code from mul32 (v_mad + 64-bit add + two
+// v_mov to build the zero-extended addend).  LANES = 2 splits each column over two accumulators.
+#include "comba_gen.hpp"
+#endif
+namespace mi {
+
+template <class P>
+MI_HD Fp<P> mul(const Fp<P> &a, const Fp<P> &b) {
+#if !defined(__HIP_DEVICE_COMPILE__)
+    return mul_host64(a, b);
+#elif defined(MI_MUL32)
+    return mul32(a, b);
+#else
+    return mul_comba_gen<P, MI_COMBA_LANES>(a, b);
+#endif
 }
 
 template <class P>

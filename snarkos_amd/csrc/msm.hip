@@ -292,6 +292,33 @@ __global__ void __launch_bounds__(256) point_tree_sum_kernel(const G1Xyzz *__res
     if (t == 0) store_xyzz(&out[group * gridDim.x + blockIdx.x], acc);
 }
 
+// ---------------------------------------------------------------- small-MSM reduction: per-bit subset sums
+// sum_b mag(b) * bucket_b = sum_bit 2^bit * (sum of the buckets whose magnitude has that bit set).  Group
+// g = w * c + bit (which is also the bit position of 2^(c w + bit) in the scalar) sums, straight from the chunk
+// partials of window w, those whose bucket magnitude has `bit` set: log depth instead of a running sum, at
+// c/2 times the additions -- the right trade when the whole MSM is latency bound (n <= 2^17).
+__global__ void __launch_bounds__(256) msm_bit_sums_kernel(const G1Xyzz *__restrict__ chunk_partial,
+                                                           const uint32_t *__restrict__ chunk_off,
+                                                           const uint32_t *__restrict__ chunk_bucket, uint32_t B, int c,
+                                                           G1Xyzz *__restrict__ out) {
+    __shared__ G1Xyzz lds[128];
+    const uint32_t g = blockIdx.y, w = g / (uint32_t)c, bit = g - w * (uint32_t)c;
+    const uint32_t lo = chunk_off[(size_t)w * B], hi = chunk_off[(size_t)(w + 1) * B];
+    const int t = threadIdx.x;
+    G1Xyzz acc = G1Xyzz::inf();
+    for (uint32_t e = lo + blockIdx.x * 256 + t; e < hi; e += gridDim.x * 256) {
+        const uint32_t mag = chunk_bucket[e] - w * B + 1;
+        if ((mag >> bit) & 1u) acc = xyzz_add_ni(acc, load_xyzz(&chunk_partial[e]));
+    }
+    for (int stride = 128; stride >= 1; stride >>= 1) {
+        if (t >= stride && t < 2 * stride) store_xyzz(&lds[t - stride], acc);
+        __syncthreads();
+        if (t < stride) acc = xyzz_add_ni(acc, load_xyzz(&lds[t]));
+        __syncthreads();
+    }
+    if (t == 0) store_xyzz(&out[(size_t)g * gridDim.x + blockIdx.x], acc);
+}
+
 // ---------------------------------------------------------------- host driver
 template <int C>
 static void launch_digits(const uint32_t *scalars, size_t n, int32_t *digits, uint32_t *counts, int scalar_bits,
@@ -355,9 +382,13 @@ void msm_device(Context &cx, const G1Affine *d_points, const uint32_t *d_scalars
     cx.prof.begin("msm_scatter", st, n);
     hipLaunchKernelGGL(msm_scatter_kernel, dim3(cdiv(n * pl.nwin, 256)), dim3(256), 0, st, digits, n, pl.nwin, pl.B, cursor, sorted);
     cx.prof.end("msm_scatter", st);
-    // chunking: T = twice the mean bucket load of a full window, so only over-full buckets are split
+    // chunking: T = twice the mean bucket load of a full window, so only over-full buckets are split.  A small MSM
+    // is latency bound (one mixed addition is ~15k instructions), so it takes short chunks and the log-depth
+    // reduction below instead.
+    const bool small = n <= ((size_t)1 << 17);
     uint32_t T = (uint32_t)(2 * ((n + pl.B - 1) / pl.B));
     if (T < 16) T = 16;
+    if (small) T = 8;
     const uint32_t HEAVY = 8;
     const size_t max_chunks = nb + (n * (size_t)pl.nwin) / T + 1;
     uint32_t *nchunks = (uint32_t *)cx.buf("msm.nchunks", sizeof(uint32_t) * nb);
@@ -378,6 +409,31 @@ void msm_device(Context &cx, const G1Affine *d_points, const uint32_t *d_scalars
     hipLaunchKernelGGL(msm_accumulate_kernel, dim3(cdiv(max_chunks, 128)), dim3(128), 0, st, d_points, sorted, offsets, chunk_off,
                        chunk_bucket, nb, T, chunk_partial);
     cx.prof.end("msm_accumulate", st);
+    if (small) {
+        // per-bit subset sums straight from the chunk partials, then a Horner walk over bit positions on the host
+        const size_t groups = (size_t)pl.nwin * pl.c;
+        const size_t per_win = pl.B + n / T + 1;
+        unsigned bx = (unsigned)((per_win + 2047) / 2048);
+        G1Xyzz *bits0 = (G1Xyzz *)cx.buf("msm.bits0", sizeof(G1Xyzz) * groups * bx);
+        cx.prof.begin("msm_bitsums", st, n);
+        hipLaunchKernelGGL(msm_bit_sums_kernel, dim3(bx, (unsigned)groups), dim3(256), 0, st, chunk_partial, chunk_off, chunk_bucket,
+                           pl.B, pl.c, bits0);
+        G1Xyzz *bits = device_group_sum(cx, bits0, groups, bx, st, "msm.tree_a", "msm.tree_b");
+        cx.prof.end("msm_bitsums", st);
+        MI_HIP(hipGetLastError());
+        G1Xyzz *hb = (G1Xyzz *)cx.pin(sizeof(G1Xyzz) * groups);
+        cx.prof.end("msm_total", st);
+        MI_HIP(hipMemcpyAsync(hb, bits, sizeof(G1Xyzz) * groups, hipMemcpyDeviceToHost, st));
+        MI_HIP(hipStreamSynchronize(st));
+        G1Xyzz acc = G1Xyzz::inf();
+        for (size_t g = groups; g-- > 0;) {
+            acc = dbl(acc);
+            if (!hb[g].is_inf()) acc = add(acc, hb[g]);
+        }
+        res = affine_to_jac(to_affine(acc));
+        memcpy(out, &res, sizeof res);
+        return;
+    }
     cx.prof.begin("msm_combine", st, n);
     hipLaunchKernelGGL(msm_combine_kernel, dim3(cdiv(nb, 128)), dim3(128), 0, st, chunk_partial, chunk_off, nb, HEAVY, buckets);
     hipLaunchKernelGGL(msm_combine_heavy_kernel, dim3(1024), dim3(256), 0, st, chunk_partial, chunk_off, heavy_list, heavy_count, buckets);

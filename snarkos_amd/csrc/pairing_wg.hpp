@@ -15,115 +15,98 @@ namespace mi {
 
 constexpr int PW_THREADS = 192;
 
-struct PB {
+struct alignas(16) PB {
     Fq c[12];  // coefficient of w^k
 };
 
-struct PwShared {
+struct alignas(16) PwShared {
     PB f, t, a, b, c, d, x, y;
-    Fq prod[144];
-    Fq line[MI_MAX_PAIRS][5];  // coefficients at w^0, w^1, w^3, w^7, w^9
-    Fq px[MI_MAX_PAIRS], py[MI_MAX_PAIRS];
+    alignas(16) Fq line[MI_MAX_PAIRS][8];  // per pair: coefficients at w^0, w^1, w^3, w^7, w^9 (+ padding)
+    alignas(16) Fq px[MI_MAX_PAIRS], py[MI_MAX_PAIRS];
 };
 
-// ---- LDS <-> register copies through 32-bit words (LDS objects are only 4-byte aligned as far as we assume)
+// ---- LDS <-> register copies, 16 bytes at a time (PwShared members are 16-byte aligned)
 __device__ __forceinline__ Fq lds_load(const Fq *p) {
+    const uint4 *q = reinterpret_cast<const uint4 *>(p);
+    uint4 v0 = q[0], v1 = q[1], v2 = q[2];
     Fq r;
-#pragma unroll
-    for (int i = 0; i < 12; i++) r.l[i] = p->l[i];
+    r.l[0] = v0.x; r.l[1] = v0.y; r.l[2] = v0.z; r.l[3] = v0.w;
+    r.l[4] = v1.x; r.l[5] = v1.y; r.l[6] = v1.z; r.l[7] = v1.w;
+    r.l[8] = v2.x; r.l[9] = v2.y; r.l[10] = v2.z; r.l[11] = v2.w;
     return r;
 }
 __device__ __forceinline__ void lds_store(Fq *p, const Fq &v) {
-#pragma unroll
-    for (int i = 0; i < 12; i++) p->l[i] = v.l[i];
+    uint4 *q = reinterpret_cast<uint4 *>(p);
+    q[0] = make_uint4(v.l[0], v.l[1], v.l[2], v.l[3]);
+    q[1] = make_uint4(v.l[4], v.l[5], v.l[6], v.l[7]);
+    q[2] = make_uint4(v.l[8], v.l[9], v.l[10], v.l[11]);
 }
 
-// acc (384-bit, no reduction) += v
-__device__ __forceinline__ void wide_add(uint32_t acc[12], const Fq &v) {
-    uint32_t c = 0;
-#pragma unroll
-    for (int i = 0; i < 12; i++) {
-        uint64_t s = (uint64_t)acc[i] + v.l[i] + c;
-        acc[i] = (uint32_t)s;
-        c = (uint32_t)(s >> 32);
-    }
+// position (power of w) of the s-th stored coefficient of the right operand: dense 0..11, line {0,1,3,7,9}
+template <int M>
+__device__ __forceinline__ int pb_pos(int s) {
+    if (M == 12) return s;
+    return s == 0 ? 0 : s == 1 ? 1 : s == 2 ? 3 : s == 3 ? 7 : 9;
 }
-// (lo - 5 hi) mod q for lo < 12q, hi < 12q:  lo + 64q - 5hi in (4q, 76q), then binary conditional subtraction
-__device__ __forceinline__ Fq pb_reduce(const uint32_t lo[12], const uint32_t hi[12]) {
-    uint32_t t[12], v[12];
-    uint32_t c = 0;
+
+// out = A * B, B given compactly as its M stored coefficients bc[0..M).  All PW_THREADS lanes must call.
+// Lane (k = t / 16, s = t % 16): the 16-lane row k produces coefficient k.  Lane s < M multiplies
+// a_((k - pos(s)) mod 12) by bc[s], turns a wrapped product (degree >= 12) into -5 * product, and the row
+// sums its <= 12 reduced values with a 4-step xor-shuffle tree of lazy 384-bit additions (12 q < 2^381);
+// one binary reduction per coefficient.  out may alias A or bc (reads finish before the barrier).
+template <int M>
+__device__ __attribute__((noinline)) void pb_mul_t(PwShared &S, PB *out, const PB *A, const Fq *bc) {
+    const int t = threadIdx.x, k = t >> 4, s = t & 15;
+    uint32_t acc[12];
 #pragma unroll
-    for (int i = 0; i < 12; i++) {  // t = 5 * hi = (hi << 2) + hi
-        uint32_t sh = (hi[i] << 2) | (i ? (hi[i - 1] >> 30) : 0u);
-        uint64_t s = (uint64_t)sh + hi[i] + c;
-        t[i] = (uint32_t)s;
-        c = (uint32_t)(s >> 32);
-    }
-    c = 0;
+    for (int i = 0; i < 12; i++) acc[i] = 0;
+    if (s < M) {
+        int i = k - pb_pos<M>(s);
+        const bool wrap = i < 0;
+        if (wrap) i += 12;
+        Fq p = mul(lds_load(&A->c[i]), lds_load(&bc[s]));
+        if (wrap) p = neg(add(dbl(dbl(p)), p));  // w^12 = -5
 #pragma unroll
-    for (int i = 0; i < 12; i++) {  // v = lo + (q << 6)
-        uint32_t q6 = (FqP::MOD[i] << 6) | (i ? (FqP::MOD[i - 1] >> 26) : 0u);
-        uint64_t s = (uint64_t)lo[i] + q6 + c;
-        v[i] = (uint32_t)s;
-        c = (uint32_t)(s >> 32);
-    }
-    uint32_t borrow = 0;
-#pragma unroll
-    for (int i = 0; i < 12; i++) {  // v -= t
-        uint64_t d = (uint64_t)v[i] - t[i] - borrow;
-        v[i] = (uint32_t)d;
-        borrow = (uint32_t)(d >> 63);
+        for (int j = 0; j < 12; j++) acc[j] = p.l[j];
     }
 #pragma unroll
-    for (int s = 6; s >= 0; s--) {  // if v >= (q << s): v -= q << s
-        uint32_t d[12];
-        borrow = 0;
+    for (int d = 8; d >= 1; d >>= 1) {
+        uint32_t o[12];
 #pragma unroll
-        for (int i = 0; i < 12; i++) {
-            uint32_t qs = s ? ((FqP::MOD[i] << s) | (i ? (FqP::MOD[i - 1] >> (32 - s)) : 0u)) : FqP::MOD[i];
-            uint64_t dd = (uint64_t)v[i] - qs - borrow;
-            d[i] = (uint32_t)dd;
+        for (int j = 0; j < 12; j++) o[j] = (uint32_t)__shfl_xor((int)acc[j], d, 16);
+        uint32_t c = 0;
+#pragma unroll
+        for (int j = 0; j < 12; j++) {
+            uint64_t sum = (uint64_t)acc[j] + o[j] + c;
+            acc[j] = (uint32_t)sum;
+            c = (uint32_t)(sum >> 32);
+        }
+    }
+    // acc < 12 q: subtract 8q, 4q, 2q, q where possible
+#pragma unroll
+    for (int sh = 3; sh >= 0; sh--) {
+        uint32_t d[12], borrow = 0;
+#pragma unroll
+        for (int j = 0; j < 12; j++) {
+            uint32_t qs = sh ? ((FqP::MOD[j] << sh) | (j ? (FqP::MOD[j - 1] >> (32 - sh)) : 0u)) : FqP::MOD[j];
+            uint64_t dd = (uint64_t)acc[j] - qs - borrow;
+            d[j] = (uint32_t)dd;
             borrow = (uint32_t)(dd >> 63);
         }
 #pragma unroll
-        for (int i = 0; i < 12; i++) v[i] = borrow ? v[i] : d[i];
-    }
-    Fq r;
-#pragma unroll
-    for (int i = 0; i < 12; i++) r.l[i] = v[i];
-    return r;
-}
-
-// out = A * B where B has m non-zero coefficients at positions pos[0..m) held compactly in bc[0..m).
-// All PW_THREADS lanes must call.  out may alias A (products are read before the barrier).
-__device__ __attribute__((noinline)) void pb_mul_generic(PwShared &S, PB *out, const PB *A, const Fq *bc, const int *pos, int m) {
-    const int t = threadIdx.x;
-    if (t < 12 * m) {
-        const int i = t / m, jj = t - i * m;
-        lds_store(&S.prod[t], mul(lds_load(&A->c[i]), lds_load(&bc[jj])));
+        for (int j = 0; j < 12; j++) acc[j] = borrow ? acc[j] : d[j];
     }
     __syncthreads();
-    if (t < 12) {
-        uint32_t lo[12], hi[12];
+    if (s == 0) {
+        Fq r;
 #pragma unroll
-        for (int i = 0; i < 12; i++) { lo[i] = 0; hi[i] = 0; }
-        for (int jj = 0; jj < m; jj++) {
-            int i = t - pos[jj];
-            if (i >= 0) wide_add(lo, lds_load(&S.prod[i * m + jj]));
-            else wide_add(hi, lds_load(&S.prod[(i + 12) * m + jj]));
-        }
-        lds_store(&out->c[t], pb_reduce(lo, hi));
+        for (int j = 0; j < 12; j++) r.l[j] = acc[j];
+        lds_store(&out->c[k], r);
     }
     __syncthreads();
 }
-__device__ __forceinline__ void pb_mul(PwShared &S, PB *out, const PB *A, const PB *B) {
-    const int pos[12] = {0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11};
-    pb_mul_generic(S, out, A, B->c, pos, 12);
-}
-__device__ __forceinline__ void pb_mul_line(PwShared &S, PB *out, const PB *A, const Fq *line5) {
-    const int pos[5] = {0, 1, 3, 7, 9};
-    pb_mul_generic(S, out, A, line5, pos, 5);
-}
+__device__ __forceinline__ void pb_mul(PwShared &S, PB *out, const PB *A, const PB *B) { pb_mul_t<12>(S, out, A, B->c); }
+__device__ __forceinline__ void pb_mul_line(PwShared &S, PB *out, const PB *A, const Fq *line5) { pb_mul_t<5>(S, out, A, line5); }
 // out = frobenius^e(A): c_k *= gamma_e^k
 __device__ __forceinline__ void pb_frob(PwShared &S, PB *out, const PB *A, const Fq *gamma /* global, 12 */) {
     const int t = threadIdx.x;

@@ -14,6 +14,8 @@ static Fq fq_from64(const uint64_t *l) {
 
 extern "C" {
 void hc_fq_mul(const Fq *a, const Fq *b, Fq *o) { *o = mul(*a, *b); }
+void hc_fq_mul32(const Fq *a, const Fq *b, Fq *o) { *o = mul32(*a, *b); }
+void hc_fr_mul32(const Fr *a, const Fr *b, Fr *o) { *o = mul32(*a, *b); }
 void hc_fq_add(const Fq *a, const Fq *b, Fq *o) { *o = add(*a, *b); }
 void hc_fq_sub(const Fq *a, const Fq *b, Fq *o) { *o = sub(*a, *b); }
 void hc_fq_inv(const Fq *a, Fq *o) { *o = inv(*a); }

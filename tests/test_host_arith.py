@@ -40,6 +40,8 @@ def test_fq_ops(hc, orc):
     out, want = np.zeros(6, dtype=np.uint64), np.zeros(6, dtype=np.uint64)
     for i in range(len(vals)):
         a = np.ascontiguousarray(vals[i]); b = np.ascontiguousarray(vals[(i * 7 + 3) % len(vals)])
+        hc.hc_fq_mul32(_p(a), _p(b), _p(out)); orc.lib().orc_fq_mul(_p(want), _p(a), _p(b))
+        assert (out == want).all(), ("mul32 (the device limb algorithm)", i)
         for name in ("mul", "add", "sub"):
             getattr(hc, "hc_fq_" + name)(_p(a), _p(b), _p(out))
             getattr(orc.lib(), "orc_fq_" + name)(_p(want), _p(a), _p(b))
@@ -57,6 +59,8 @@ def test_fr_ops(hc, orc):
     out, want = np.zeros(4, dtype=np.uint64), np.zeros(4, dtype=np.uint64)
     for i in range(64):
         hc.hc_fr_mul(_p(a[i]), _p(b[i]), _p(out)); orc.lib().orc_fr_mul(_p(want), _p(a[i]), _p(b[i]))
+        assert (out == want).all()
+        hc.hc_fr_mul32(_p(a[i]), _p(b[i]), _p(out))
         assert (out == want).all()
     for i in range(4):
         hc.hc_fr_inv(_p(a[i]), _p(out)); orc.lib().orc_fr_inv(_p(want), _p(a[i]))

@@ -18,7 +18,7 @@ r = C.c_double(0)
 for nt in (256 * 256, 256 * 1024):
     L.check(L.lib().mi_dbg_fq_mul_throughput(C.c_size_t(nt), C.c_uint32(200), C.byref(r)), "tp")
     print("fq mul throughput threads=%d: %.2f Gmul/s" % (nt, r.value), flush=True)
-names = ["msm_total", "msm_accumulate", "msm_digits", "msm_scan", "msm_scatter", "msm_chunks", "msm_combine", "msm_segments", "msm_tree"]
+names = ["msm_total", "msm_accumulate", "msm_digits", "msm_scan", "msm_scatter", "msm_chunks", "msm_combine", "msm_segments", "msm_tree", "msm_bitsums"]
 for lg in (10, 12, 13, 14, 16, 18, 20):
     n = 1 << lg
     pts = torch.empty(n * 96, dtype=torch.uint8, device=dev)

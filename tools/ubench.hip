@@ -2,6 +2,7 @@
 //   hipcc -O3 --offload-arch=gfx950 -std=c++17 -o tools/ubench tools/ubench.hip && ./tools/ubench
 #include <hip/hip_runtime.h>
 #include <stdio.h>
+#include <type_traits>
 #include "../snarkos_amd/csrc/field.hpp"
 using namespace mi;
 
@@ -63,14 +64,24 @@ __global__ void __launch_bounds__(256) alu_kernel(uint32_t *out, int iters) {
     out[blockIdx.x * blockDim.x + threadIdx.x] = (uint32_t)(acc0 ^ acc1 ^ acc2 ^ acc3) ^ x0 ^ x1 ^ x2 ^ x3;
 }
 
-template <class F>
+template <class F, int V>
+__device__ __forceinline__ F vmul(const F &a, const F &b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (V == 0) return mul32(a, b);
+    if (V == 1) return mul_comba_gen<typename F::Params, 1>(a, b);
+    return mul_comba_gen<typename F::Params, 2>(a, b);
+#else
+    return mul32(a, b);
+#endif
+}
+template <class F, int V>
 __global__ void __launch_bounds__(256) fmul_kernel(F *out, int iters) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     F a = F::one(), b = F::r2();
     a.l[0] += (uint32_t)i;
     for (int k = 0; k < iters; k++) {
-        a = mul(a, b);
-        b = mul(b, a);
+        a = vmul<F, V>(a, b);
+        b = vmul<F, V>(b, a);
     }
     out[i] = add(a, b);
 }
@@ -117,10 +128,17 @@ int main() {
     }
     for (int wps = 1; wps <= 8; wps *= 2) {
         int blocks = 256 * wps;
-        double tq = time_kernel(fmul_kernel<Fq>, dim3(blocks), dim3(256), (Fq *)d, 200);
-        double tr = time_kernel(fmul_kernel<Fr>, dim3(blocks), dim3(256), (Fr *)d, 200);
-        printf("waves/SIMD=%d  Fq mul %.2f Gmul/s (%.0f ns per mul per wave)   Fr mul %.2f Gmul/s\n", wps, 400.0 * blocks * 256 / tq / 1e9,
-               tq / 400 * 1e9, 400.0 * blocks * 256 / tr / 1e9);
+        double tq[3], tr[3];
+        tq[0] = time_kernel(fmul_kernel<Fq, 0>, dim3(blocks), dim3(256), (Fq *)d, 200);
+        tq[1] = time_kernel(fmul_kernel<Fq, 1>, dim3(blocks), dim3(256), (Fq *)d, 200);
+        tq[2] = time_kernel(fmul_kernel<Fq, 2>, dim3(blocks), dim3(256), (Fq *)d, 200);
+        tr[0] = time_kernel(fmul_kernel<Fr, 0>, dim3(blocks), dim3(256), (Fr *)d, 200);
+        tr[1] = time_kernel(fmul_kernel<Fr, 1>, dim3(blocks), dim3(256), (Fr *)d, 200);
+        tr[2] = time_kernel(fmul_kernel<Fr, 2>, dim3(blocks), dim3(256), (Fr *)d, 200);
+        const char *vn[3] = {"cios32", "comba1", "comba2"};
+        for (int v = 0; v < 3; v++)
+            printf("waves/SIMD=%d %s  Fq mul %.2f Gmul/s (%.0f ns per mul per wave)   Fr mul %.2f Gmul/s\n", wps, vn[v],
+                   400.0 * blocks * 256 / tq[v] / 1e9, tq[v] / 400 * 1e9, 400.0 * blocks * 256 / tr[v] / 1e9);
     }
     hipFree(d);
     return 0;
