@@ -31,6 +31,7 @@ sys.path.insert(0, ROOT)
 
 from snarkos_amd import algorithms as A  # noqa: E402
 from snarkos_amd import lib as L  # noqa: E402
+from snarkos_amd import sharding  # noqa: E402
 
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s spec, 6.29 TB/s measured copy)
 PROOFS_PER_GPU = 1024
@@ -82,16 +83,14 @@ def main():
     d_proofs = torch.from_numpy(proofs).to(dev)
     d_rnd = torch.from_numpy(rnd).to(dev)
     verifier = A.VarunaShaped(vk, circuits)
-    gather_buf = torch.empty(world * L.VS_PARTIAL_BYTES, dtype=torch.uint8, device=dev) if dist_on else None
 
     def step():
         if not dist_on:
             ok, verdicts = verifier.verify_batch(d_proofs, d_rnd)
             return ok
-        part = verifier.accumulate(d_proofs, d_rnd)
-        mine = torch.from_numpy(part).to(dev, non_blocking=False)
-        torch.distributed.all_gather_into_tensor(gather_buf, mine)  # RCCL over xGMI: 304 B per rank
-        return verifier.finalize(gather_buf.cpu().numpy())
+        # this rank's shard is already resident; partials (304 B per rank) are all-gathered over RCCL/xGMI
+        return sharding.verify_sharded(d_proofs, d_rnd, verifier.accumulate, verifier.finalize, torch.distributed, dev,
+                                       pre_sharded=True)
 
     for _ in range(args.warmup):
         assert step(), "synthetic batch must verify"
@@ -161,13 +160,32 @@ def main():
         torch.distributed.destroy_process_group()
 
 
+def usable_cores():
+    """Cores this process may actually use: affinity mask, capped by the cgroup CPU quota if there is one."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(int(txt[0]) / int(txt[1]))))
+            else:
+                q = int(txt[0])
+                if q > 0:
+                    per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                    n = min(n, max(1, q // per))
+        except Exception:
+            pass
+    return n
+
+
 def cpu_baseline(vk, circuits, proofs, rnd):
     """The oracle's port of the reference shape: one proof at a time, per-proof pairing product, one
     thread per core (the reference runs rayon over transactions on all cores)."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import orc_py as O
 
-    cores = os.cpu_count() or 1
+    cores = usable_cores()
     b = O.VSArrays(vk, circuits, proofs, rnd)
     b_small = O.VSArrays(vk, circuits, proofs[:64 * O.VS_PROOF_BYTES], rnd[:64 * 32])
     b_small.verify_cpu(cores)  # warm-up (fixed-base tables, page-in)

@@ -265,6 +265,53 @@ class VSBatch:
         return fr_to_ints(zb)[0], fr_to_ints(zg)[0], fr_to_ints(xi)[0]
 
 
+def g1_add_affine(a, b):
+    ja, j = u64(18), u64(18)
+    lib().orc_g1_from_affine(_p(ja), _p(np.ascontiguousarray(a, dtype=np.uint64)))
+    lib().orc_g1_add_mixed(_p(j), _p(ja), _p(np.ascontiguousarray(b, dtype=np.uint64)))
+    return jac_to_affine(j)
+
+
+def vs_partial_from_oracle(batch, threads=1):
+    """The 304-byte mi_vs_partial the HIP library would produce for this shard, computed by the oracle."""
+    _, alg, tc, tw = batch.verify_aggregated(threads)
+    one = int_to_limbs((1 << 384) % 0x01AE3A4617C510EAC63B05C06CA1493B1A22D9F300F5138F1EF3622FBA094800170B5D44300000008508C00000000001, 6)
+    part = np.zeros(38, dtype=np.uint64)
+    for k, pt in enumerate((tc, tw)):
+        if pt.any():
+            part[18 * k:18 * k + 12] = pt
+            part[18 * k + 12:18 * k + 18] = one
+        else:
+            part[18 * k:18 * k + 6] = one
+            part[18 * k + 6:18 * k + 12] = one
+    part[36] = batch.n
+    part[37] = int((alg == 0).sum())
+    return part.view(np.uint8).copy()
+
+
+def vs_finalize_with_oracle(vk, partials):
+    """Sum the partial accumulators and run the single pairing product: all_ok for the whole batch."""
+    parts = np.ascontiguousarray(partials, dtype=np.uint8).reshape(-1, 304).view(np.uint64)
+    tc, tw, fails = u64(12), u64(12), 0
+    for p in parts:
+        for acc, off in ((tc, 0), (tw, 18)):
+            pt = p[off:off + 12] if p[off + 12:off + 18].any() else u64(12)
+            acc[:] = g1_add_affine(acc, pt)
+        fails += int(p[37])
+    vkb = np.ascontiguousarray(vk).view(np.uint8).reshape(-1)
+    h = np.frombuffer(vkb[96:288].tobytes(), dtype=np.uint64).copy()
+    tau_h = np.frombuffer(vkb[288:480].tobytes(), dtype=np.uint64).copy()
+    ps = np.stack([tc, tw])
+    lib().orc_g1_neg_affine(_p(ps[1]), _p(np.ascontiguousarray(tw)))
+    if not tw.any():
+        ps[1] = 0
+    prep = [C.create_string_buffer(16 + 70 * 192 + 64) for _ in range(2)]
+    lib().orc_g2_prepare(prep[0], _p(h))
+    lib().orc_g2_prepare(prep[1], _p(tau_h))
+    qs = (C.c_void_p * 2)(C.addressof(prep[0]), C.addressof(prep[1]))
+    return lib().orc_pairing_product_is_one(_p(ps), qs, C.c_size_t(2)) == 1 and fails == 0
+
+
 class VSArrays(VSBatch):
     """A VarunaShaped-v1 batch wrapped around existing ABI-layout arrays (e.g. a committed fixture)."""
 

@@ -1,0 +1,56 @@
+"""Multi-GPU sharding of one block-validation batch.
+
+Proofs are independent until the final accumulator, so a batch of N proofs is cut into contiguous shards,
+one per rank (one process per GPU).  Each rank folds its shard into a 304-byte `mi_vs_partial`
+(two G1 accumulators + counts); the only exchange is an all-gather of those partials (RCCL over xGMI on the
+GPU box, gloo in the CPU tests), after which any rank adds the partials and runs the single pairing product.
+RCCL has no elliptic-curve reduction operator, hence gather + local add instead of a reduce.
+
+The arithmetic is injected (`accumulate`, `finalize`), so the protocol is the same object on both tiers: the
+product passes the HIP library's entry points, the CPU tests pass the oracle's.
+"""
+import numpy as np
+
+PARTIAL_BYTES = 304
+PROOF_BYTES = 2256
+
+
+def shard_bounds(n_items, world, rank):
+    """Contiguous shard [lo, hi) of rank: sizes differ by at most one, earlier ranks take the remainder."""
+    base, rem = divmod(n_items, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def gather_partials(partial, dist=None, device=None):
+    """All-gather one 304-byte partial per rank -> (world, 304) uint8 array on every rank."""
+    partial = np.ascontiguousarray(partial, dtype=np.uint8).reshape(PARTIAL_BYTES)
+    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+        return partial.reshape(1, PARTIAL_BYTES)
+    import torch
+
+    world = dist.get_world_size()
+    mine = torch.from_numpy(partial.copy())
+    if device is not None:
+        mine = mine.to(device)
+    out = torch.empty(world * PARTIAL_BYTES, dtype=torch.uint8, device=mine.device)
+    dist.all_gather_into_tensor(out, mine)
+    return out.cpu().numpy().reshape(world, PARTIAL_BYTES)
+
+
+def verify_sharded(proofs, randomizers, accumulate, finalize, dist=None, device=None, pre_sharded=False):
+    """Verify one batch across the ranks of `dist`.
+
+    proofs / randomizers: the whole batch (every rank holds it; rank r works on shard r), or with
+    pre_sharded=True this rank's shard only.  accumulate(proofs_shard, randomizers_shard) -> 304-byte partial;
+    finalize((world, 304) partials) -> bool.  Returns all_ok (identical on every rank).
+    """
+    world = dist.get_world_size() if dist is not None and dist.is_initialized() else 1
+    rank = dist.get_rank() if world > 1 else 0
+    if not pre_sharded:
+        n = len(proofs) // PROOF_BYTES
+        lo, hi = shard_bounds(n, world, rank)
+        proofs = proofs[lo * PROOF_BYTES:hi * PROOF_BYTES]
+        randomizers = randomizers[lo * 32:hi * 32]
+    part = accumulate(proofs, randomizers)
+    return bool(finalize(gather_partials(part, dist, device)))
