@@ -88,6 +88,33 @@ struct Fp {
     MI_HD bool operator!=(const Fp &b) const { return !(*this == b); }
 };
 
+// add / subtract with carry, one instruction per limb on the device (v_addc_co_u32 / v_subb_co_u32 chains)
+#if defined(__clang__)
+MI_HD uint32_t addc32(uint32_t a, uint32_t b, uint32_t cin, uint32_t *cout) {
+    unsigned c;
+    uint32_t r = __builtin_addc(a, b, cin, &c);
+    *cout = c;
+    return r;
+}
+MI_HD uint32_t subc32(uint32_t a, uint32_t b, uint32_t bin, uint32_t *bout) {
+    unsigned c;
+    uint32_t r = __builtin_subc(a, b, bin, &c);
+    *bout = c;
+    return r;
+}
+#else
+MI_HD uint32_t addc32(uint32_t a, uint32_t b, uint32_t cin, uint32_t *cout) {
+    uint64_t s = (uint64_t)a + b + cin;
+    *cout = (uint32_t)(s >> 32);
+    return (uint32_t)s;
+}
+MI_HD uint32_t subc32(uint32_t a, uint32_t b, uint32_t bin, uint32_t *bout) {
+    uint64_t d = (uint64_t)a - b - bin;
+    *bout = (uint32_t)(d >> 63);
+    return (uint32_t)d;
+}
+#endif
+
 // r = a - MOD if a >= MOD (a < 2*MOD on entry)
 template <class P>
 MI_HD void reduce_once(Fp<P> &a) {
@@ -95,15 +122,9 @@ MI_HD void reduce_once(Fp<P> &a) {
     uint32_t t[N];
     uint32_t borrow = 0;
 #pragma unroll
-    for (int i = 0; i < N; i++) {
-        uint64_t d = (uint64_t)a.l[i] - P::MOD[i] - borrow;
-        t[i] = (uint32_t)d;
-        borrow = (uint32_t)(d >> 63);
-    }
-    if (!borrow) {
+    for (int i = 0; i < N; i++) t[i] = subc32(a.l[i], P::MOD[i], borrow, &borrow);
 #pragma unroll
-        for (int i = 0; i < N; i++) a.l[i] = t[i];
-    }
+    for (int i = 0; i < N; i++) a.l[i] = borrow ? a.l[i] : t[i];
 }
 
 template <class P>
@@ -112,11 +133,7 @@ MI_HD Fp<P> add(const Fp<P> &a, const Fp<P> &b) {
     Fp<P> r;
     uint32_t c = 0;
 #pragma unroll
-    for (int i = 0; i < N; i++) {
-        uint64_t s = (uint64_t)a.l[i] + b.l[i] + c;
-        r.l[i] = (uint32_t)s;
-        c = (uint32_t)(s >> 32);
-    }
+    for (int i = 0; i < N; i++) r.l[i] = addc32(a.l[i], b.l[i], c, &c);
     reduce_once(r);  // both moduli leave spare top bits: no carry out of the top limb
     return r;
 }
@@ -127,19 +144,12 @@ MI_HD Fp<P> sub(const Fp<P> &a, const Fp<P> &b) {
     Fp<P> r;
     uint32_t borrow = 0;
 #pragma unroll
-    for (int i = 0; i < N; i++) {
-        uint64_t d = (uint64_t)a.l[i] - b.l[i] - borrow;
-        r.l[i] = (uint32_t)d;
-        borrow = (uint32_t)(d >> 63);
-    }
+    for (int i = 0; i < N; i++) r.l[i] = subc32(a.l[i], b.l[i], borrow, &borrow);
     // add back MOD masked by the borrow (branch-free: lanes diverge on data)
-    uint32_t mask = 0u - borrow, c = 0;
+    const uint32_t mask = 0u - borrow;
+    uint32_t c = 0;
 #pragma unroll
-    for (int i = 0; i < N; i++) {
-        uint64_t s = (uint64_t)r.l[i] + (P::MOD[i] & mask) + c;
-        r.l[i] = (uint32_t)s;
-        c = (uint32_t)(s >> 32);
-    }
+    for (int i = 0; i < N; i++) r.l[i] = addc32(r.l[i], P::MOD[i] & mask, c, &c);
     return r;
 }
 

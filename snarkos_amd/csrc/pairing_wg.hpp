@@ -51,9 +51,9 @@ __device__ __forceinline__ int pb_pos(int s) {
 
 // out = A * B, B given compactly as its M stored coefficients bc[0..M).  All PW_THREADS lanes must call.
 // Lane (k = t / 16, s = t % 16): the 16-lane row k produces coefficient k.  Lane s < M multiplies
-// a_((k - pos(s)) mod 12) by bc[s], turns a wrapped product (degree >= 12) into -5 * product, and the row
-// sums its <= 12 reduced values with a 4-step xor-shuffle tree of lazy 384-bit additions (12 q < 2^381);
-// one binary reduction per coefficient.  out may alias A or bc (reads finish before the barrier).
+// a_((k - pos(s)) mod 12) by bc[s], turns a wrapped product p (degree >= 12) into 8q - 5p, and the row sums its
+// <= 12 values with a 4-step xor-shuffle tree of lazy 384-bit additions (< 100 q < 2^384); one binary
+// reduction (conditional subtraction of 64q .. q) per coefficient.  out may alias A or bc (reads finish before the barrier).
 template <int M>
 __device__ __attribute__((noinline)) void pb_mul_t(PwShared &S, PB *out, const PB *A, const Fq *bc) {
     const int t = threadIdx.x, k = t >> 4, s = t & 15;
@@ -65,33 +65,33 @@ __device__ __attribute__((noinline)) void pb_mul_t(PwShared &S, PB *out, const P
         const bool wrap = i < 0;
         if (wrap) i += 12;
         Fq p = mul(lds_load(&A->c[i]), lds_load(&bc[s]));
-        if (wrap) p = neg(add(dbl(dbl(p)), p));  // w^12 = -5
 #pragma unroll
         for (int j = 0; j < 12; j++) acc[j] = p.l[j];
+        if (wrap) {  // w^12 = -5: contribute 8q - 5p (in (3q, 8q]) instead of a reduced -5p; the row sum stays < 2^384
+            uint32_t t5[12], c = 0, bw = 0;
+#pragma unroll
+            for (int j = 0; j < 12; j++) t5[j] = addc32((p.l[j] << 2) | (j ? (p.l[j - 1] >> 30) : 0u), p.l[j], c, &c);
+#pragma unroll
+            for (int j = 0; j < 12; j++) {
+                const uint32_t q8 = (FqP::MOD[j] << 3) | (j ? (FqP::MOD[j - 1] >> 29) : 0u);
+                acc[j] = subc32(q8, t5[j], bw, &bw);
+            }
+        }
     }
 #pragma unroll
     for (int d = 8; d >= 1; d >>= 1) {
-        uint32_t o[12];
-#pragma unroll
-        for (int j = 0; j < 12; j++) o[j] = (uint32_t)__shfl_xor((int)acc[j], d, 16);
         uint32_t c = 0;
 #pragma unroll
-        for (int j = 0; j < 12; j++) {
-            uint64_t sum = (uint64_t)acc[j] + o[j] + c;
-            acc[j] = (uint32_t)sum;
-            c = (uint32_t)(sum >> 32);
-        }
+        for (int j = 0; j < 12; j++) acc[j] = addc32(acc[j], (uint32_t)__shfl_xor((int)acc[j], d, 16), c, &c);
     }
-    // acc < 12 q: subtract 8q, 4q, 2q, q where possible
+    // acc < 100 q < 2^384: subtract 64q, 32q, ..., q where possible
 #pragma unroll
-    for (int sh = 3; sh >= 0; sh--) {
+    for (int sh = 6; sh >= 0; sh--) {
         uint32_t d[12], borrow = 0;
 #pragma unroll
         for (int j = 0; j < 12; j++) {
-            uint32_t qs = sh ? ((FqP::MOD[j] << sh) | (j ? (FqP::MOD[j - 1] >> (32 - sh)) : 0u)) : FqP::MOD[j];
-            uint64_t dd = (uint64_t)acc[j] - qs - borrow;
-            d[j] = (uint32_t)dd;
-            borrow = (uint32_t)(dd >> 63);
+            const uint32_t qs = sh ? ((FqP::MOD[j] << sh) | (j ? (FqP::MOD[j - 1] >> (32 - sh)) : 0u)) : FqP::MOD[j];
+            d[j] = subc32(acc[j], qs, borrow, &borrow);
         }
 #pragma unroll
         for (int j = 0; j < 12; j++) acc[j] = borrow ? acc[j] : d[j];
