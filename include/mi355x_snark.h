@@ -108,6 +108,11 @@ int32_t mi_vs_verify_batch_device(uint64_t ctx, const void *d_proofs, size_t n, 
 int32_t mi_vs_accumulate_device(uint64_t ctx, const void *d_proofs, size_t n, const void *d_randomizers128,
                                 mi_vs_partial *partial_out, void *stream);
 int32_t mi_vs_finalize(uint64_t ctx, const mi_vs_partial *partials, size_t n_partials, uint8_t *all_ok);
+/* pipelined form: the pairing product of batch i runs on the context's own stream while the caller accumulates
+ * batch i+1 (VM::check_transactions walks a block in chunks of <= 1000 executions; mempool admission streams).
+ * At most 4 tickets may be outstanding; tickets must be waited for in any order before the context is destroyed. */
+int32_t mi_vs_finalize_async(uint64_t ctx, const mi_vs_partial *partials, size_t n_partials, uint64_t *ticket_out);
+int32_t mi_vs_finalize_wait(uint64_t ctx, uint64_t ticket, uint8_t *all_ok);
 
 /* ---- diagnostics (parity tests of the device field / group arithmetic) ---- */
 int32_t mi_dbg_fq_mul(const mi_fq *a, const mi_fq *b, mi_fq *out, size_t n);

@@ -207,6 +207,34 @@ class VarunaShaped:
                 "mi_vs_accumulate_device")
         return part
 
+    def finalize_async(self, partials):
+        """Enqueue the pairing product for these partials on the context's own stream; returns a ticket."""
+        parts = np.ascontiguousarray(partials, dtype=np.uint8).reshape(-1, L.VS_PARTIAL_BYTES)
+        t = C.c_uint64(0)
+        L.check(L.lib().mi_vs_finalize_async(C.c_uint64(self.ctx), L.ptr(parts), C.c_size_t(len(parts)), C.byref(t)),
+                "mi_vs_finalize_async")
+        return t.value
+
+    def finalize_wait(self, ticket):
+        ok = np.zeros(1, dtype=np.uint8)
+        L.check(L.lib().mi_vs_finalize_wait(C.c_uint64(self.ctx), C.c_uint64(ticket), L.ptr(ok)), "mi_vs_finalize_wait")
+        return bool(ok[0])
+
+    def verify_stream(self, batches, gather=None, depth=3):
+        """Pipelined verification of a stream of batches (chunks of a block, or mempool traffic): yields all_ok per
+        batch, in order.  Up to `depth` (<= 4) pairing products are in flight, each on its own stream, while the
+        following batches are accumulated.  `batches` yields (proofs_cuda, randomizers_cuda); `gather` (optional)
+        maps this rank's partial to the list of all ranks' partials (multi-GPU)."""
+        pending = []
+        for proofs, rnd in batches:
+            part = self.accumulate(proofs, rnd)
+            parts = gather(part) if gather is not None else [part]
+            pending.append(self.finalize_async(parts))
+            if len(pending) >= max(1, min(depth, 4)):
+                yield self.finalize_wait(pending.pop(0))
+        while pending:
+            yield self.finalize_wait(pending.pop(0))
+
     def finalize(self, partials):
         parts = np.ascontiguousarray(partials, dtype=np.uint8).reshape(-1, L.VS_PARTIAL_BYTES)
         ok = np.zeros(1, dtype=np.uint8)

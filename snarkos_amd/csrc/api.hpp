@@ -13,6 +13,16 @@ struct PairingConsts;
 
 // msm.hip -- d_points / d_scalars are device pointers; result normalised Jacobian (z = 1) or infinity (z = 0).
 // scalar_bits bounds the scalars (254 = any canonical Fr, 128 = randomizers).
+struct G1Xyzz;
+struct MsmJob {
+    size_t n = 0, groups = 0;
+    int c = 0, nwin = 0;
+    bool per_bit = false;
+    G1Xyzz *h = nullptr;  // pinned host copy of the window / bit sums
+};
+void msm_enqueue(Context &cx, const G1Affine *d_points, const uint32_t *d_scalars, size_t n, hipStream_t st, int scalar_bits,
+                 int slot, MsmJob *job, int force_c = 0);
+void msm_finish(Context &cx, MsmJob *job, hipStream_t st, mi_g1_jac *out);
 void msm_device(Context &cx, const G1Affine *d_points, const uint32_t *d_scalars, size_t n, mi_g1_jac *out,
                 hipStream_t st, int scalar_bits = 254, int force_c = 0);
 
@@ -26,6 +36,7 @@ void pairing_product_prepared(Context &cx, const G1Affine *ps, const G2Prepared 
                               hipStream_t st);
 void pairing_product_host_args(Context &cx, const G1Affine *ps, const G2Affine *qs, size_t n, Fq12 *out_host,
                                hipStream_t st);
+void pairing_launch(Context &cx, const G1Affine *ps, const G2Prepared *const *d_qs, size_t n, Fq12 *d_out, hipStream_t st);
 const PairingConsts *pairing_consts(Context &cx, hipStream_t st);
 void pairing_release();
 
@@ -38,6 +49,8 @@ int32_t vs_ctx_destroy(Context &cx, uint64_t id);
 int32_t vs_accumulate_device(Context &cx, uint64_t id, const void *d_proofs, size_t n, const void *d_rand,
                              mi_vs_partial *out, hipStream_t st);
 int32_t vs_finalize(Context &cx, uint64_t id, const mi_vs_partial *parts, size_t np, uint8_t *all_ok, hipStream_t st);
+int32_t vs_finalize_async(Context &cx, uint64_t id, const mi_vs_partial *parts, size_t np, uint64_t *ticket);
+int32_t vs_finalize_wait(Context &cx, uint64_t id, uint64_t ticket, uint8_t *all_ok);
 int32_t vs_verify_batch_device(Context &cx, uint64_t id, const void *d_proofs, size_t n, const void *d_rand,
                                uint8_t *verdicts, uint8_t *all_ok, hipStream_t st);
 void verify_release_all();

@@ -21,6 +21,8 @@ int32_t ensure_init() {
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, dev) == hipSuccess) g_ctx.n_cus = prop.multiProcessorCount;
     if (hipStreamCreateWithFlags(&g_ctx.stream, hipStreamNonBlocking) != hipSuccess) return MI_ERR_KERNEL;
+    if (hipStreamCreateWithFlags(&g_ctx.stream2, hipStreamNonBlocking) != hipSuccess) return MI_ERR_KERNEL;
+    if (hipEventCreateWithFlags(&g_ctx.fork_event, hipEventDisableTiming) != hipSuccess) return MI_ERR_KERNEL;
     g_ctx.inited = true;
     return MI_OK;
 }
@@ -118,6 +120,14 @@ int32_t mi_shutdown(void) {
     g_ctx.pinned_cap = 0;
     (void)hipStreamDestroy(g_ctx.stream);
     g_ctx.stream = nullptr;
+    (void)hipStreamSynchronize(g_ctx.stream2);
+    (void)hipStreamDestroy(g_ctx.stream2);
+    g_ctx.stream2 = nullptr;
+    (void)hipEventDestroy(g_ctx.fork_event);
+    g_ctx.fork_event = nullptr;
+    for (auto &kv : g_ctx.pins)
+        if (kv.second.first) (void)hipHostFree(kv.second.first);
+    g_ctx.pins.clear();
     g_ctx.inited = false;
     return MI_OK;
 }
@@ -279,6 +289,15 @@ int32_t mi_vs_accumulate_device(uint64_t c, const void *d_proofs, size_t n, cons
 int32_t mi_vs_finalize(uint64_t c, const mi_vs_partial *partials, size_t n_partials, uint8_t *all_ok) {
     if (!partials || !n_partials || !all_ok) return MI_ERR_BAD_ARGS;
     return guarded([&]() -> int32_t { return vs_finalize(ctx(), c, partials, n_partials, all_ok, ctx().stream); });
+}
+
+int32_t mi_vs_finalize_async(uint64_t c, const mi_vs_partial *partials, size_t n_partials, uint64_t *ticket_out) {
+    if (!partials || !n_partials || !ticket_out) return MI_ERR_BAD_ARGS;
+    return guarded([&]() -> int32_t { return vs_finalize_async(ctx(), c, partials, n_partials, ticket_out); });
+}
+int32_t mi_vs_finalize_wait(uint64_t c, uint64_t ticket, uint8_t *all_ok) {
+    if (!all_ok) return MI_ERR_BAD_ARGS;
+    return guarded([&]() -> int32_t { return vs_finalize_wait(ctx(), c, ticket, all_ok); });
 }
 
 // ------------------------------------------------------------ diagnostics

@@ -17,6 +17,7 @@
 // HBM traffic per (point, scalar) pair: 32 B scalar read once, 96 B point read once per window from
 // HBM/Infinity Cache (the 100 MB base table of a 2^20 MSM stays cache resident), 4 B digit + 4 B index
 // written and read once per window.
+#include <stdio.h>
 #include <string.h>
 #include "api.hpp"
 
@@ -346,25 +347,30 @@ static G1Xyzz *device_group_sum(Context &cx, G1Xyzz *in, size_t groups, size_t m
     return cur;
 }
 
-// d_points / d_scalars: device pointers.  Result: normalised Jacobian (z = 1) or infinity (z = 0).
-void msm_device(Context &cx, const G1Affine *d_points, const uint32_t *d_scalars, size_t n, mi_g1_jac *out,
-                hipStream_t st, int scalar_bits, int force_c) {
-    G1Jac res = G1Jac{Fq::one(), Fq::one(), Fq::zero()};
-    if (n == 0) {
-        memcpy(out, &res, sizeof res);
-        return;
-    }
+// Enqueue the whole device pipeline of one MSM on `st` (no host synchronisation); `slot` names the workspace set,
+// so two MSMs with different slots may run on two streams at once.  msm_finish() waits and folds on the host.
+void msm_enqueue(Context &cx, const G1Affine *d_points, const uint32_t *d_scalars, size_t n, hipStream_t st, int scalar_bits,
+                 int slot, MsmJob *job, int force_c) {
+    job->n = n;
+    job->groups = 0;
+    if (n == 0) return;
+    char ws[32];
+    auto W = [&](const char *name) {
+        snprintf(ws, sizeof ws, "msm%d.%s", slot, name);
+        return ws;
+    };
     MsmPlan pl = msm_plan(n, scalar_bits, force_c);
+    job->c = pl.c;
+    job->nwin = pl.nwin;
     cx.prof.begin("msm_total", st, n);
     const size_t nb = (size_t)pl.nwin * pl.B;
-    int32_t *digits = (int32_t *)cx.buf("msm.digits", sizeof(int32_t) * n * pl.nwin);
-    uint32_t *sorted = (uint32_t *)cx.buf("msm.sorted", sizeof(uint32_t) * n * pl.nwin);
-    uint32_t *counts = (uint32_t *)cx.buf("msm.counts", sizeof(uint32_t) * nb);
-    uint32_t *offsets = (uint32_t *)cx.buf("msm.offsets", sizeof(uint32_t) * (nb + 1));
-    uint32_t *cursor = (uint32_t *)cx.buf("msm.cursor", sizeof(uint32_t) * nb);
+    int32_t *digits = (int32_t *)cx.buf(W("digits"), sizeof(int32_t) * n * pl.nwin);
+    uint32_t *sorted = (uint32_t *)cx.buf(W("sorted"), sizeof(uint32_t) * n * pl.nwin);
+    uint32_t *counts = (uint32_t *)cx.buf(W("counts"), sizeof(uint32_t) * nb);
+    uint32_t *offsets = (uint32_t *)cx.buf(W("offsets"), sizeof(uint32_t) * (nb + 1));
+    uint32_t *cursor = (uint32_t *)cx.buf(W("cursor"), sizeof(uint32_t) * nb);
     const unsigned tiles = cdiv(nb, 2048);
-    uint32_t *tile_sums = (uint32_t *)cx.buf("msm.tiles", sizeof(uint32_t) * tiles);
-    G1Xyzz *buckets = (G1Xyzz *)cx.buf("msm.buckets", sizeof(G1Xyzz) * nb);
+    uint32_t *tile_sums = (uint32_t *)cx.buf(W("tiles"), sizeof(uint32_t) * tiles);
 
     MI_HIP(hipMemsetAsync(counts, 0, sizeof(uint32_t) * nb, st));
     cx.prof.begin("msm_digits", st, n);
@@ -383,20 +389,20 @@ void msm_device(Context &cx, const G1Affine *d_points, const uint32_t *d_scalars
     hipLaunchKernelGGL(msm_scatter_kernel, dim3(cdiv(n * pl.nwin, 256)), dim3(256), 0, st, digits, n, pl.nwin, pl.B, cursor, sorted);
     cx.prof.end("msm_scatter", st);
     // chunking: T = twice the mean bucket load of a full window, so only over-full buckets are split.  A small MSM
-    // is latency bound (one mixed addition is ~15k instructions), so it takes short chunks and the log-depth
+    // is latency bound (one mixed addition is ~10k instructions), so it takes short chunks and the log-depth
     // reduction below instead.
-    const bool small = n <= ((size_t)1 << 17);
+    const bool small = n <= ((size_t)1 << 16);
     uint32_t T = (uint32_t)(2 * ((n + pl.B - 1) / pl.B));
     if (T < 16) T = 16;
     if (small) T = 8;
     const uint32_t HEAVY = 8;
     const size_t max_chunks = nb + (n * (size_t)pl.nwin) / T + 1;
-    uint32_t *nchunks = (uint32_t *)cx.buf("msm.nchunks", sizeof(uint32_t) * nb);
-    uint32_t *chunk_off = (uint32_t *)cx.buf("msm.chunk_off", sizeof(uint32_t) * (nb + 1));
-    uint32_t *chunk_bucket = (uint32_t *)cx.buf("msm.chunk_bucket", sizeof(uint32_t) * max_chunks);
-    uint32_t *heavy_list = (uint32_t *)cx.buf("msm.heavy", sizeof(uint32_t) * (nb + 1));
+    uint32_t *nchunks = (uint32_t *)cx.buf(W("nchunks"), sizeof(uint32_t) * nb);
+    uint32_t *chunk_off = (uint32_t *)cx.buf(W("chunk_off"), sizeof(uint32_t) * (nb + 1));
+    uint32_t *chunk_bucket = (uint32_t *)cx.buf(W("chunk_bucket"), sizeof(uint32_t) * max_chunks);
+    uint32_t *heavy_list = (uint32_t *)cx.buf(W("heavy"), sizeof(uint32_t) * (nb + 1));
     uint32_t *heavy_count = heavy_list + nb;
-    G1Xyzz *chunk_partial = (G1Xyzz *)cx.buf("msm.chunk_partial", sizeof(G1Xyzz) * max_chunks);
+    G1Xyzz *chunk_partial = (G1Xyzz *)cx.buf(W("chunk_partial"), sizeof(G1Xyzz) * max_chunks);
     cx.prof.begin("msm_chunks", st, n);
     MI_HIP(hipMemsetAsync(heavy_count, 0, sizeof(uint32_t), st));
     hipLaunchKernelGGL(msm_chunk_count_kernel, dim3(cdiv(nb, 256)), dim3(256), 0, st, counts, nb, T, nchunks);
@@ -409,58 +415,79 @@ void msm_device(Context &cx, const G1Affine *d_points, const uint32_t *d_scalars
     hipLaunchKernelGGL(msm_accumulate_kernel, dim3(cdiv(max_chunks, 128)), dim3(128), 0, st, d_points, sorted, offsets, chunk_off,
                        chunk_bucket, nb, T, chunk_partial);
     cx.prof.end("msm_accumulate", st);
+    G1Xyzz *result;
+    char ta[32], tb[32];
+    snprintf(ta, sizeof ta, "msm%d.tree_a", slot);
+    snprintf(tb, sizeof tb, "msm%d.tree_b", slot);
     if (small) {
-        // per-bit subset sums straight from the chunk partials, then a Horner walk over bit positions on the host
-        const size_t groups = (size_t)pl.nwin * pl.c;
+        // per-bit subset sums straight from the chunk partials; the host walks the bit positions (Horner)
+        job->groups = (size_t)pl.nwin * pl.c;
+        job->per_bit = true;
         const size_t per_win = pl.B + n / T + 1;
         unsigned bx = (unsigned)((per_win + 2047) / 2048);
-        G1Xyzz *bits0 = (G1Xyzz *)cx.buf("msm.bits0", sizeof(G1Xyzz) * groups * bx);
+        G1Xyzz *bits0 = (G1Xyzz *)cx.buf(W("bits0"), sizeof(G1Xyzz) * job->groups * bx);
         cx.prof.begin("msm_bitsums", st, n);
-        hipLaunchKernelGGL(msm_bit_sums_kernel, dim3(bx, (unsigned)groups), dim3(256), 0, st, chunk_partial, chunk_off, chunk_bucket,
-                           pl.B, pl.c, bits0);
-        G1Xyzz *bits = device_group_sum(cx, bits0, groups, bx, st, "msm.tree_a", "msm.tree_b");
+        hipLaunchKernelGGL(msm_bit_sums_kernel, dim3(bx, (unsigned)job->groups), dim3(256), 0, st, chunk_partial, chunk_off,
+                           chunk_bucket, pl.B, pl.c, bits0);
+        result = device_group_sum(cx, bits0, job->groups, bx, st, ta, tb);
         cx.prof.end("msm_bitsums", st);
-        MI_HIP(hipGetLastError());
-        G1Xyzz *hb = (G1Xyzz *)cx.pin(sizeof(G1Xyzz) * groups);
-        cx.prof.end("msm_total", st);
-        MI_HIP(hipMemcpyAsync(hb, bits, sizeof(G1Xyzz) * groups, hipMemcpyDeviceToHost, st));
-        MI_HIP(hipStreamSynchronize(st));
-        G1Xyzz acc = G1Xyzz::inf();
-        for (size_t g = groups; g-- > 0;) {
-            acc = dbl(acc);
-            if (!hb[g].is_inf()) acc = add(acc, hb[g]);
-        }
-        res = affine_to_jac(to_affine(acc));
+    } else {
+        G1Xyzz *buckets = (G1Xyzz *)cx.buf(W("buckets"), sizeof(G1Xyzz) * nb);
+        cx.prof.begin("msm_combine", st, n);
+        hipLaunchKernelGGL(msm_combine_kernel, dim3(cdiv(nb, 128)), dim3(128), 0, st, chunk_partial, chunk_off, nb, HEAVY, buckets);
+        hipLaunchKernelGGL(msm_combine_heavy_kernel, dim3(1024), dim3(256), 0, st, chunk_partial, chunk_off, heavy_list, heavy_count, buckets);
+        cx.prof.end("msm_combine", st);
+        uint32_t L = pl.B >= 4096 ? 8 : 4;
+        const size_t nseg = nb / L;
+        G1Xyzz *partials = (G1Xyzz *)cx.buf(W("partials"), sizeof(G1Xyzz) * nseg);
+        cx.prof.begin("msm_segments", st, n);
+        hipLaunchKernelGGL(msm_segments_kernel, dim3(cdiv(nseg, 128)), dim3(128), 0, st, buckets, pl.B, L, nseg, partials);
+        cx.prof.end("msm_segments", st);
+        cx.prof.begin("msm_tree", st, n);
+        result = device_group_sum(cx, partials, pl.nwin, pl.B / L, st, ta, tb);
+        cx.prof.end("msm_tree", st);
+        job->groups = pl.nwin;
+        job->per_bit = false;
+    }
+    MI_HIP(hipGetLastError());
+    cx.prof.end("msm_total", st);
+    job->h = (G1Xyzz *)cx.pin_named(W("pin"), sizeof(G1Xyzz) * job->groups);
+    MI_HIP(hipMemcpyAsync(job->h, result, sizeof(G1Xyzz) * job->groups, hipMemcpyDeviceToHost, st));
+}
+
+// wait for the job's stream, fold on the host (Horner over windows or bit positions), normalise to z = 1
+void msm_finish(Context &cx, MsmJob *job, hipStream_t st, mi_g1_jac *out) {
+    (void)cx;
+    G1Jac res = G1Jac{Fq::one(), Fq::one(), Fq::zero()};
+    if (job->n == 0) {
         memcpy(out, &res, sizeof res);
         return;
     }
-    cx.prof.begin("msm_combine", st, n);
-    hipLaunchKernelGGL(msm_combine_kernel, dim3(cdiv(nb, 128)), dim3(128), 0, st, chunk_partial, chunk_off, nb, HEAVY, buckets);
-    hipLaunchKernelGGL(msm_combine_heavy_kernel, dim3(1024), dim3(256), 0, st, chunk_partial, chunk_off, heavy_list, heavy_count, buckets);
-    cx.prof.end("msm_combine", st);
-    uint32_t L = pl.B >= 4096 ? 8 : 4;
-    const size_t nseg = nb / L;
-    G1Xyzz *partials = (G1Xyzz *)cx.buf("msm.partials", sizeof(G1Xyzz) * nseg);
-    cx.prof.begin("msm_segments", st, n);
-    hipLaunchKernelGGL(msm_segments_kernel, dim3(cdiv(nseg, 128)), dim3(128), 0, st, buckets, pl.B, L, nseg, partials);
-    cx.prof.end("msm_segments", st);
-    cx.prof.begin("msm_tree", st, n);
-    G1Xyzz *wsums = device_group_sum(cx, partials, pl.nwin, pl.B / L, st, "msm.tree_a", "msm.tree_b");
-    cx.prof.end("msm_tree", st);
-    MI_HIP(hipGetLastError());
-    G1Xyzz *h = (G1Xyzz *)cx.pin(sizeof(G1Xyzz) * pl.nwin);
-    cx.prof.end("msm_total", st);
-    MI_HIP(hipMemcpyAsync(h, wsums, sizeof(G1Xyzz) * pl.nwin, hipMemcpyDeviceToHost, st));
     MI_HIP(hipStreamSynchronize(st));
-    // host tail: Horner fold over the windows (nwin additions, (nwin-1)*c doublings), then normalise
-    G1Xyzz acc = h[pl.nwin - 1];
-    for (int w = pl.nwin - 2; w >= 0; w--) {
-        for (int k = 0; k < pl.c; k++) acc = dbl(acc);
-        acc = add(acc, h[w]);
+    const G1Xyzz *h = job->h;
+    G1Xyzz acc = G1Xyzz::inf();
+    if (job->per_bit) {
+        for (size_t g = job->groups; g-- > 0;) {
+            acc = dbl(acc);
+            if (!h[g].is_inf()) acc = add(acc, h[g]);
+        }
+    } else {
+        acc = h[job->nwin - 1];
+        for (int w = job->nwin - 2; w >= 0; w--) {
+            for (int k = 0; k < job->c; k++) acc = dbl(acc);
+            acc = add(acc, h[w]);
+        }
     }
-    G1Affine a = to_affine(acc);
-    res = affine_to_jac(a);
+    res = affine_to_jac(to_affine(acc));
     memcpy(out, &res, sizeof res);
+}
+
+// d_points / d_scalars: device pointers.  Result: normalised Jacobian (z = 1) or infinity (z = 0).
+void msm_device(Context &cx, const G1Affine *d_points, const uint32_t *d_scalars, size_t n, mi_g1_jac *out,
+                hipStream_t st, int scalar_bits, int force_c) {
+    MsmJob job;
+    msm_enqueue(cx, d_points, d_scalars, n, st, scalar_bits, 0, &job, force_c);
+    msm_finish(cx, &job, st, out);
 }
 
 }  // namespace mi

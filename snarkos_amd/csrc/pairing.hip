@@ -48,18 +48,23 @@ const PairingConsts *pairing_consts(Context &cx, hipStream_t st) {
 }
 
 // product over prepared (device-resident) G2 points; P's are host values passed as kernel arguments
-void pairing_product_prepared(Context &cx, const G1Affine *ps, const G2Prepared *const *d_qs, size_t n, Fq12 *out_host,
-                                     hipStream_t st) {
+// enqueue one pairing product on `st`; the result lands in d_out (device)
+void pairing_launch(Context &cx, const G1Affine *ps, const G2Prepared *const *d_qs, size_t n, Fq12 *d_out, hipStream_t st) {
     PairingArgs a;
     memset(&a, 0, sizeof a);
     a.n = (int)n;
     for (size_t i = 0; i < n; i++) { a.p[i] = ps[i]; a.q[i] = d_qs[i]; }
     const PairingConsts *pc = pairing_consts(cx, st);
-    Fq12 *d_out = (Fq12 *)cx.buf("pairing.out", sizeof(Fq12));
     cx.prof.begin("pairing", st, n);
     hipLaunchKernelGGL(pairing_product_kernel, dim3(1), dim3(PW_THREADS), 0, st, a, pc, d_out);
     cx.prof.end("pairing", st);
     MI_HIP(hipGetLastError());
+}
+
+void pairing_product_prepared(Context &cx, const G1Affine *ps, const G2Prepared *const *d_qs, size_t n, Fq12 *out_host,
+                                     hipStream_t st) {
+    Fq12 *d_out = (Fq12 *)cx.buf("pairing.out", sizeof(Fq12));
+    pairing_launch(cx, ps, d_qs, n, d_out, st);
     Fq12 *h = (Fq12 *)cx.pin(sizeof(Fq12));
     MI_HIP(hipMemcpyAsync(h, d_out, sizeof(Fq12), hipMemcpyDeviceToHost, st));
     MI_HIP(hipStreamSynchronize(st));

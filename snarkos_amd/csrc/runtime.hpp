@@ -90,7 +90,20 @@ struct Context {
     void *pinned = nullptr;  // small pinned staging area for results
     size_t pinned_cap = 0;
 
+    std::map<std::string, std::pair<void *, size_t>> pins;  // named pinned staging buffers
+    hipStream_t stream2 = nullptr;                         // second library stream (concurrent MSMs)
+    hipEvent_t fork_event = nullptr;
     void *buf(const char *name, size_t bytes) { return bufs[name].get(bytes); }
+    void *pin_named(const char *name, size_t bytes) {
+        auto &e = pins[name];
+        if (bytes > e.second) {
+            if (e.first) MI_HIP(hipHostFree(e.first));
+            e.first = nullptr;
+            MI_HIP(hipHostMalloc(&e.first, bytes + 4096, hipHostMallocDefault));
+            e.second = bytes + 4096;
+        }
+        return e.first;
+    }
     void *pin(size_t bytes) {
         if (bytes > pinned_cap) {
             if (pinned) MI_HIP(hipHostFree(pinned));

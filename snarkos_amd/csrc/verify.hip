@@ -105,23 +105,43 @@ struct VsConsts {
     uint32_t tag[8];           // big-endian words of the 32-byte domain tag
     G1Affine g;
 };
+#define VS_SLOTS 4
+struct VsSlot {  // one in-flight pairing product (pipelined finalize)
+    uint64_t ticket = 0;
+    bool busy = false;
+    uint64_t fails = 0;
+    hipEvent_t done = nullptr;
+    hipStream_t stream = nullptr;  // each slot has its own stream: products of different batches run side by side
+    Fq12 *d_out = nullptr;
+    Fq12 *h_out = nullptr;  // pinned
+};
 struct VsCtx {
     size_t n_circuits = 0;
     DevBuf circuits, h_prep, tauh_prep, consts;
     mi_kzg_vk vk;
+    VsSlot slots[VS_SLOTS];  // pairing products run on the slots' streams, beside the next batches' accumulation
+    uint64_t next_ticket = 1;
 };
+static void vs_ctx_free(VsCtx &v) {
+    v.circuits.release();
+    v.h_prep.release();
+    v.tauh_prep.release();
+    v.consts.release();
+    for (auto &sl : v.slots) {
+        if (sl.done) (void)hipEventDestroy(sl.done);
+        if (sl.stream) (void)hipStreamDestroy(sl.stream);
+        if (sl.d_out) (void)hipFree(sl.d_out);
+        if (sl.h_out) (void)hipHostFree(sl.h_out);
+        sl = VsSlot();
+    }
+}
 static std::map<uint64_t, VsCtx> &vs_ctxs() {
     static std::map<uint64_t, VsCtx> m;
     return m;
 }
 static uint64_t g_vs_next = 1;
 void verify_release_all() {
-    for (auto &kv : vs_ctxs()) {
-        kv.second.circuits.release();
-        kv.second.h_prep.release();
-        kv.second.tauh_prep.release();
-        kv.second.consts.release();
-    }
+    for (auto &kv : vs_ctxs()) vs_ctx_free(kv.second);
     vs_ctxs().clear();
     ntt_release_tables();
     pairing_release();
@@ -160,6 +180,13 @@ int32_t vs_ctx_create(Context &cx, const mi_kzg_vk *vk, const mi_vs_circuit_vk *
     void *dk = v.consts.get(sizeof hc);
     MI_HIP(hipMemcpyAsync(dk, &hc, sizeof hc, hipMemcpyHostToDevice, cx.stream));
     MI_HIP(hipStreamSynchronize(cx.stream));
+    for (auto &sl : v.slots) {
+        MI_HIP(hipStreamCreateWithFlags(&sl.stream, hipStreamNonBlocking));
+        MI_HIP(hipEventCreateWithFlags(&sl.done, hipEventDisableTiming));
+        MI_HIP(hipMalloc((void **)&sl.d_out, sizeof(Fq12)));
+        MI_HIP(hipHostMalloc((void **)&sl.h_out, sizeof(Fq12), hipHostMallocDefault));
+    }
+    (void)pairing_consts(cx, cx.stream);  // upload the Frobenius table before any pipelined launch
     *out = id;
     return MI_OK;
 }
@@ -167,10 +194,9 @@ int32_t vs_ctx_destroy(Context &cx, uint64_t id) {
     auto it = vs_ctxs().find(id);
     if (it == vs_ctxs().end()) return MI_ERR_BAD_ARGS;
     MI_HIP(hipStreamSynchronize(cx.stream));
-    it->second.circuits.release();
-    it->second.h_prep.release();
-    it->second.tauh_prep.release();
-    it->second.consts.release();
+    for (auto &sl : it->second.slots)
+        if (sl.stream) MI_HIP(hipStreamSynchronize(sl.stream));
+    vs_ctx_free(it->second);
     vs_ctxs().erase(it);
     return MI_OK;
 }
@@ -271,7 +297,7 @@ __global__ void __launch_bounds__(64) vs_derive_kernel(const mi_vs_proof *__rest
         pre[k] = acc;
         acc = mul(acc, sub(z[0], fr_load(&kc->omega16[k])));
     }
-    acc = inv(acc);
+    acc = inv(acc);  // Fermat: branch-free, every lane of the wave walks the same exponent
     Fr xhat = Fr::zero();
     for (int k = MI_VS_INPUTS - 1; k >= 0; k--) {
         Fr wk = fr_load(&kc->omega16[k]);
@@ -456,11 +482,16 @@ static int32_t vs_accumulate_impl(Context &cx, uint64_t id, const void *d_proofs
     if (it == vs_ctxs().end()) return MI_ERR_BAD_ARGS;
     VsCtx &v = it->second;
     VsWork w = vs_run_derive(cx, v, d_proofs, n, d_rand, st);
-    msm_device(cx, w.pts1, w.sc1, w.n1, &out->total_c, st);
-    msm_device(cx, w.pts2, w.sc2, w.n2, &out->total_w, st, 128);
+    // the two MSMs (H side and tau-H side) are independent: second one on the library's second stream
+    MsmJob j1, j2;
+    MI_HIP(hipEventRecord(cx.fork_event, st));
+    MI_HIP(hipStreamWaitEvent(cx.stream2, cx.fork_event, 0));
+    msm_enqueue(cx, w.pts1, w.sc1, w.n1, st, 254, 0, &j1);
+    msm_enqueue(cx, w.pts2, w.sc2, w.n2, cx.stream2, 128, 1, &j2);
     uint8_t *h_alg = (uint8_t *)cx.pin(n);
     MI_HIP(hipMemcpyAsync(h_alg, w.alg_ok, n, hipMemcpyDeviceToHost, st));
-    MI_HIP(hipStreamSynchronize(st));
+    msm_finish(cx, &j2, cx.stream2, &out->total_w);
+    msm_finish(cx, &j1, st, &out->total_c);
     uint64_t fails = 0;
     for (size_t i = 0; i < n; i++) fails += h_alg[i] ? 0 : 1;
     out->n_proofs = n;
@@ -491,6 +522,48 @@ int32_t vs_finalize(Context &cx, uint64_t id, const mi_vs_partial *parts, size_t
     pairing_product_prepared(cx, ps, qs, 2, &f, st);
     *all_ok = (f.is_one() && fails == 0) ? 1 : 0;
     return MI_OK;
+}
+
+// pipelined finalize: sum the partials on the host, enqueue the pairing product on the context's own stream and
+// return a ticket; the caller goes on to accumulate the next batch while the product runs
+static int32_t vs_slot_wait(VsSlot &sl, uint8_t *all_ok) {
+    MI_HIP(hipEventSynchronize(sl.done));
+    if (all_ok) *all_ok = (sl.h_out->is_one() && sl.fails == 0) ? 1 : 0;
+    sl.busy = false;
+    return MI_OK;
+}
+int32_t vs_finalize_async(Context &cx, uint64_t id, const mi_vs_partial *parts, size_t np, uint64_t *ticket) {
+    auto it = vs_ctxs().find(id);
+    if (it == vs_ctxs().end()) return MI_ERR_BAD_ARGS;
+    VsCtx &v = it->second;
+    const uint64_t tk = v.next_ticket++;
+    VsSlot &sl = v.slots[tk % VS_SLOTS];
+    if (sl.busy) return MI_ERR_BAD_ARGS;  // more than VS_SLOTS products in flight: wait for a ticket first
+    G1Xyzz tc = G1Xyzz::inf(), tw = G1Xyzz::inf();
+    uint64_t fails = 0;
+    for (size_t k = 0; k < np; k++) {
+        tc = add_mixed(tc, host_jac_to_affine_normalised(parts[k].total_c));
+        tw = add_mixed(tw, host_jac_to_affine_normalised(parts[k].total_w));
+        fails += parts[k].n_alg_fail;
+    }
+    G1Affine ps[2] = {to_affine(tc), neg(to_affine(tw))};
+    const G2Prepared *qs[2] = {(const G2Prepared *)v.h_prep.p, (const G2Prepared *)v.tauh_prep.p};
+    pairing_launch(cx, ps, qs, 2, sl.d_out, sl.stream);
+    MI_HIP(hipMemcpyAsync(sl.h_out, sl.d_out, sizeof(Fq12), hipMemcpyDeviceToHost, sl.stream));
+    MI_HIP(hipEventRecord(sl.done, sl.stream));
+    sl.ticket = tk;
+    sl.busy = true;
+    sl.fails = fails;
+    *ticket = tk;
+    return MI_OK;
+}
+int32_t vs_finalize_wait(Context &cx, uint64_t id, uint64_t ticket, uint8_t *all_ok) {
+    (void)cx;
+    auto it = vs_ctxs().find(id);
+    if (it == vs_ctxs().end()) return MI_ERR_BAD_ARGS;
+    VsSlot &sl = it->second.slots[ticket % VS_SLOTS];
+    if (!sl.busy || sl.ticket != ticket) return MI_ERR_BAD_ARGS;
+    return vs_slot_wait(sl, all_ok);
 }
 
 int32_t vs_verify_batch_device(Context &cx, uint64_t id, const void *d_proofs, size_t n, const void *d_rand,

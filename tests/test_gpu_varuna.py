@@ -81,3 +81,22 @@ def test_full_size_batch_1024(orc, mi):
         assert (cpu == want).all()
     finally:
         v.close()
+
+
+def test_pipelined_stream_matches_batchwise(orc, mi):
+    """verify_stream (pairing of batch i overlapped with accumulation of batch i+1) gives the same all_ok sequence
+    as verifying each batch on its own, including a failing batch in the middle of the stream"""
+    import torch
+    good = orc.VSBatch(0x57EA, 48, 3, 0)
+    v = _ctx(mi, good)
+    try:
+        gp = torch.from_numpy(good.proofs).cuda(); gr = torch.from_numpy(good.randomizers).cuda()
+        bad_np = good.proofs.copy(); bad_np[7 * 2256 + 16 + 512 + 864 + 32 * 9] ^= 1
+        bp = torch.from_numpy(bad_np).cuda()
+        seq = [(gp, gr), (gp, gr), (bp, gr), (gp, gr), (bp, gr), (gp, gr), (gp, gr)]
+        want = [True, True, False, True, False, True, True]
+        assert list(v.verify_stream(iter(seq))) == want
+        assert [v.verify_batch(p, r)[0] for p, r in seq] == want
+        assert list(v.verify_stream(iter([]))) == []
+    finally:
+        v.close()
