@@ -46,7 +46,8 @@ static MsmPlan msm_plan(size_t n, int scalar_bits, int force_c) {
 // ---------------------------------------------------------------- K1: signed digits + histogram
 template <int C, int BITS>
 __global__ void __launch_bounds__(256) msm_digits_kernel(const uint32_t *__restrict__ scalars, size_t n,
-                                                         int32_t *__restrict__ digits, uint32_t *__restrict__ counts) {
+                                                         int32_t *__restrict__ digits, uint32_t *__restrict__ ranks,
+                                                         uint32_t *__restrict__ counts) {
     constexpr int NWIN = (BITS + C - 1) / C;
     constexpr uint32_t B = 1u << (C - 1);
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -72,7 +73,8 @@ __global__ void __launch_bounds__(256) msm_digits_kernel(const uint32_t *__restr
         digits[(size_t)w * n + i] = d;
         if (d != 0) {
             uint32_t mag = d < 0 ? (uint32_t)(-d) : (uint32_t)d;
-            atomicAdd(&counts[(size_t)w * B + (mag - 1)], 1u);
+            // the histogram atomic also hands this entry its rank inside the bucket, so the scatter needs no atomics
+            ranks[(size_t)w * n + i] = atomicAdd(&counts[(size_t)w * B + (mag - 1)], 1u);
         }
     }
 }
@@ -151,21 +153,22 @@ __global__ void __launch_bounds__(256) scan_finish_kernel(uint32_t *__restrict__
 }
 
 // ---------------------------------------------------------------- K3: scatter indices into bucket order
-__global__ void __launch_bounds__(256) msm_scatter_kernel(const int32_t *__restrict__ digits, size_t n, int nwin,
-                                                          uint32_t B, uint32_t *__restrict__ cursor,
-                                                          uint32_t *__restrict__ sorted) {
+__global__ void __launch_bounds__(256) msm_scatter_kernel(const int32_t *__restrict__ digits,
+                                                          const uint32_t *__restrict__ ranks, size_t n, int nwin, uint32_t B,
+                                                          const uint32_t *__restrict__ offsets, uint32_t *__restrict__ sorted) {
     size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= n * (size_t)nwin) return;
     int32_t d = digits[t];
     if (d == 0) return;
     size_t w = t / n, i = t - w * n;
     uint32_t mag = d < 0 ? (uint32_t)(-d) : (uint32_t)d;
-    uint32_t pos = atomicAdd(&cursor[w * B + (mag - 1)], 1u);
+    uint32_t pos = offsets[w * B + (mag - 1)] + ranks[t];
     sorted[pos] = ((uint32_t)i << 1) | (d < 0 ? 1u : 0u);
 }
 
 // out-of-line group addition for the cold reduction kernels
-__device__ __attribute__((noinline)) G1Xyzz xyzz_add_ni(const G1Xyzz &a, const G1Xyzz &b) { return add(a, b); }
+// (group law inlined, field products out of line and register-passed: curve.hpp fm<false>)
+__device__ __forceinline__ G1Xyzz xyzz_add_ni(const G1Xyzz &a, const G1Xyzz &b) { return add<false>(a, b); }
 
 // ---------------------------------------------------------------- K4: bucket accumulation, load-balanced
 // A bucket with more than T entries is cut into ceil(count / T) chunks, one lane each; the top window of a
@@ -187,14 +190,67 @@ __global__ void __launch_bounds__(256) msm_chunk_map_kernel(const uint32_t *__re
     for (uint32_t t = lo; t < hi; t++) chunk_bucket[t] = (uint32_t)b;
     if (hi - lo > heavy) heavy_list[atomicAdd(heavy_count, 1u)] = (uint32_t)b;
 }
+// ---- order the chunks by length (longest first) so the 64 lanes of a wave walk equally long chunks ----
+__device__ __forceinline__ uint32_t chunk_len(uint32_t t, const uint32_t *__restrict__ offsets,
+                                              const uint32_t *__restrict__ chunk_off, const uint32_t *__restrict__ chunk_bucket,
+                                              uint32_t T) {
+    const uint32_t b = chunk_bucket[t];
+    const uint32_t k = offsets[b] + (t - chunk_off[b]) * T, end = offsets[b + 1];
+    return end - k > T ? T : end - k;
+}
+// hist[T - len]++ (bin 0 = full chunks); per-block LDS histogram, one global atomic per used bin
+__global__ void __launch_bounds__(256) msm_len_hist_kernel(const uint32_t *__restrict__ offsets,
+                                                           const uint32_t *__restrict__ chunk_off,
+                                                           const uint32_t *__restrict__ chunk_bucket, size_t nb, uint32_t T,
+                                                           uint32_t *__restrict__ hist) {
+    extern __shared__ uint32_t lh[];
+    for (uint32_t i = threadIdx.x; i <= T; i += 256) lh[i] = 0;
+    __syncthreads();
+    size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < chunk_off[nb]) atomicAdd(&lh[T - chunk_len((uint32_t)t, offsets, chunk_off, chunk_bucket, T)], 1u);
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i <= T; i += 256)
+        if (lh[i]) atomicAdd(&hist[i], lh[i]);
+}
+// single block: exclusive scan of the T+1 bins into cursor[]
+__global__ void __launch_bounds__(64) msm_len_scan_kernel(const uint32_t *__restrict__ hist, uint32_t T, uint32_t *__restrict__ cursor) {
+    if (threadIdx.x == 0) {
+        uint32_t run = 0;
+        for (uint32_t i = 0; i <= T; i++) { cursor[i] = run; run += hist[i]; }
+    }
+}
+// order[cursor[bin]++] = chunk id, with block-local ranks so only one global atomic per (block, bin)
+__global__ void __launch_bounds__(256) msm_len_scatter_kernel(const uint32_t *__restrict__ offsets,
+                                                              const uint32_t *__restrict__ chunk_off,
+                                                              const uint32_t *__restrict__ chunk_bucket, size_t nb, uint32_t T,
+                                                              uint32_t *__restrict__ cursor, uint32_t *__restrict__ order) {
+    extern __shared__ uint32_t lh[];  // [0, T]: local counts, then [T+1, 2T+1]: global base of this block's run
+    for (uint32_t i = threadIdx.x; i < 2 * (T + 1); i += 256) lh[i] = 0;
+    __syncthreads();
+    size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool live = t < chunk_off[nb];
+    uint32_t bin = 0, rank = 0;
+    if (live) {
+        bin = T - chunk_len((uint32_t)t, offsets, chunk_off, chunk_bucket, T);
+        rank = atomicAdd(&lh[bin], 1u);
+    }
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i <= T; i += 256)
+        if (lh[i]) lh[T + 1 + i] = atomicAdd(&cursor[i], lh[i]);
+    __syncthreads();
+    if (live) order[lh[T + 1 + bin] + rank] = (uint32_t)t;
+}
+
 __global__ void __launch_bounds__(128) msm_accumulate_kernel(const G1Affine *__restrict__ points,
                                                              const uint32_t *__restrict__ sorted,
                                                              const uint32_t *__restrict__ offsets,
                                                              const uint32_t *__restrict__ chunk_off,
-                                                             const uint32_t *__restrict__ chunk_bucket, size_t nb,
+                                                             const uint32_t *__restrict__ chunk_bucket,
+                                                             const uint32_t *__restrict__ order, size_t nb,
                                                              uint32_t T, G1Xyzz *__restrict__ chunk_partial) {
     size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= chunk_off[nb]) return;
+    if (order) t = order[t];
     const uint32_t b = chunk_bucket[t];
     uint32_t k = offsets[b] + ((uint32_t)t - chunk_off[b]) * T;
     uint32_t end = offsets[b + 1];
@@ -322,12 +378,12 @@ __global__ void __launch_bounds__(256) msm_bit_sums_kernel(const G1Xyzz *__restr
 
 // ---------------------------------------------------------------- host driver
 template <int C>
-static void launch_digits(const uint32_t *scalars, size_t n, int32_t *digits, uint32_t *counts, int scalar_bits,
-                          hipStream_t st) {
+static void launch_digits(const uint32_t *scalars, size_t n, int32_t *digits, uint32_t *ranks, uint32_t *counts,
+                          int scalar_bits, hipStream_t st) {
     if (scalar_bits > 128)
-        hipLaunchKernelGGL((msm_digits_kernel<C, 254>), dim3(cdiv(n, 256)), dim3(256), 0, st, scalars, n, digits, counts);
+        hipLaunchKernelGGL((msm_digits_kernel<C, 254>), dim3(cdiv(n, 256)), dim3(256), 0, st, scalars, n, digits, ranks, counts);
     else
-        hipLaunchKernelGGL((msm_digits_kernel<C, 129>), dim3(cdiv(n, 256)), dim3(256), 0, st, scalars, n, digits, counts);
+        hipLaunchKernelGGL((msm_digits_kernel<C, 129>), dim3(cdiv(n, 256)), dim3(256), 0, st, scalars, n, digits, ranks, counts);
 }
 
 // Sum groups of XYZZ points on the device: in[groups][m] -> result[groups] (device pointer into workspace)
@@ -368,14 +424,14 @@ void msm_enqueue(Context &cx, const G1Affine *d_points, const uint32_t *d_scalar
     uint32_t *sorted = (uint32_t *)cx.buf(W("sorted"), sizeof(uint32_t) * n * pl.nwin);
     uint32_t *counts = (uint32_t *)cx.buf(W("counts"), sizeof(uint32_t) * nb);
     uint32_t *offsets = (uint32_t *)cx.buf(W("offsets"), sizeof(uint32_t) * (nb + 1));
-    uint32_t *cursor = (uint32_t *)cx.buf(W("cursor"), sizeof(uint32_t) * nb);
+    uint32_t *ranks = (uint32_t *)cx.buf(W("ranks"), sizeof(uint32_t) * n * pl.nwin);
     const unsigned tiles = cdiv(nb, 2048);
     uint32_t *tile_sums = (uint32_t *)cx.buf(W("tiles"), sizeof(uint32_t) * tiles);
 
     MI_HIP(hipMemsetAsync(counts, 0, sizeof(uint32_t) * nb, st));
     cx.prof.begin("msm_digits", st, n);
     switch (pl.c) {
-#define MI_CASE(C) case C: launch_digits<C>(d_scalars, n, digits, counts, scalar_bits, st); break;
+#define MI_CASE(C) case C: launch_digits<C>(d_scalars, n, digits, ranks, counts, scalar_bits, st); break;
         MI_CASE(6) MI_CASE(7) MI_CASE(8) MI_CASE(9) MI_CASE(10) MI_CASE(11) MI_CASE(12) MI_CASE(13) MI_CASE(14) MI_CASE(15) MI_CASE(16)
 #undef MI_CASE
     }
@@ -383,10 +439,10 @@ void msm_enqueue(Context &cx, const G1Affine *d_points, const uint32_t *d_scalar
     cx.prof.begin("msm_scan", st, n);
     hipLaunchKernelGGL(scan_tiles_kernel, dim3(tiles), dim3(256), 0, st, counts, offsets, tile_sums, nb);
     hipLaunchKernelGGL(scan_sums_kernel, dim3(1), dim3(1024), 0, st, tile_sums, (size_t)tiles);
-    hipLaunchKernelGGL(scan_finish_kernel, dim3(tiles), dim3(256), 0, st, offsets, cursor, tile_sums, counts, nb);
+    hipLaunchKernelGGL(scan_finish_kernel, dim3(tiles), dim3(256), 0, st, offsets, (uint32_t *)nullptr, tile_sums, counts, nb);
     cx.prof.end("msm_scan", st);
     cx.prof.begin("msm_scatter", st, n);
-    hipLaunchKernelGGL(msm_scatter_kernel, dim3(cdiv(n * pl.nwin, 256)), dim3(256), 0, st, digits, n, pl.nwin, pl.B, cursor, sorted);
+    hipLaunchKernelGGL(msm_scatter_kernel, dim3(cdiv(n * pl.nwin, 256)), dim3(256), 0, st, digits, ranks, n, pl.nwin, pl.B, offsets, sorted);
     cx.prof.end("msm_scatter", st);
     // chunking: T = twice the mean bucket load of a full window, so only over-full buckets are split.  A small MSM
     // is latency bound (one mixed addition is ~10k instructions), so it takes short chunks and the log-depth
@@ -410,10 +466,22 @@ void msm_enqueue(Context &cx, const G1Affine *d_points, const uint32_t *d_scalar
     hipLaunchKernelGGL(scan_sums_kernel, dim3(1), dim3(1024), 0, st, tile_sums, (size_t)tiles);
     hipLaunchKernelGGL(scan_finish_kernel, dim3(tiles), dim3(256), 0, st, chunk_off, (uint32_t *)nullptr, tile_sums, nchunks, nb);
     hipLaunchKernelGGL(msm_chunk_map_kernel, dim3(cdiv(nb, 256)), dim3(256), 0, st, chunk_off, nb, chunk_bucket, HEAVY, heavy_list, heavy_count);
+    uint32_t *order = nullptr;
+    if (!small) {
+        order = (uint32_t *)cx.buf(W("order"), sizeof(uint32_t) * max_chunks);
+        uint32_t *lhist = (uint32_t *)cx.buf(W("lenhist"), sizeof(uint32_t) * 2 * (T + 1));
+        uint32_t *lcursor = lhist + (T + 1);
+        MI_HIP(hipMemsetAsync(lhist, 0, sizeof(uint32_t) * (T + 1), st));
+        hipLaunchKernelGGL(msm_len_hist_kernel, dim3(cdiv(max_chunks, 256)), dim3(256), sizeof(uint32_t) * (T + 1), st, offsets,
+                           chunk_off, chunk_bucket, nb, T, lhist);
+        hipLaunchKernelGGL(msm_len_scan_kernel, dim3(1), dim3(64), 0, st, lhist, T, lcursor);
+        hipLaunchKernelGGL(msm_len_scatter_kernel, dim3(cdiv(max_chunks, 256)), dim3(256), sizeof(uint32_t) * 2 * (T + 1), st,
+                           offsets, chunk_off, chunk_bucket, nb, T, lcursor, order);
+    }
     cx.prof.end("msm_chunks", st);
     cx.prof.begin("msm_accumulate", st, n);
     hipLaunchKernelGGL(msm_accumulate_kernel, dim3(cdiv(max_chunks, 128)), dim3(128), 0, st, d_points, sorted, offsets, chunk_off,
-                       chunk_bucket, nb, T, chunk_partial);
+                       chunk_bucket, order, nb, T, chunk_partial);
     cx.prof.end("msm_accumulate", st);
     G1Xyzz *result;
     char ta[32], tb[32];
