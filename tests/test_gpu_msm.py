@@ -77,3 +77,33 @@ def test_msm_resident_bases(orc, mi):
         assert (jac_affine(rb.msm(scalars[:1000], offset=500)) == orc.msm_pippenger(bases[500:1500], scalars[:1000], threads=8)).all()
     finally:
         rb.release()
+
+
+def test_msm_full_size_2_20_bit_exact(orc, mi):
+    """BASELINE configs[1]: 2^20-point MSM on the GPU, bit-exact against the CPU oracle's Pippenger"""
+    import ctypes as C
+    import torch
+    from snarkos_amd import lib as L
+    n = 1 << 20
+    pts = torch.empty(n * 96, dtype=torch.uint8, device="cuda")
+    L.check(L.lib().mi_dbg_gen_points_device(C.c_uint64(0xA1E00002), C.c_size_t(n), L.dptr(pts), L.stream_ptr()), "gen_points")
+    scalars = rng_scalars(0xA1E00002, n)
+    d_sc = torch.from_numpy(scalars.view(np.int64)).cuda()
+    got = jac_affine(mi.VariableBase.msm(pts, d_sc))
+    bases = pts.cpu().numpy().view(np.uint64).reshape(n, 12)
+    # generated points are on the curve (spot check) and the oracle agrees on the sum
+    for i in (0, 1, n // 2, n - 1):
+        assert orc.lib().orc_g1_is_on_curve(orc._p(np.ascontiguousarray(bases[i])))
+    want = orc.msm_pippenger(bases, scalars, threads=16)
+    assert (got == want).all()
+
+
+def test_msm_skewed_scalars_large(orc, mi):
+    """adversarial load: 2^16 points, only 3 distinct scalars (three buckets per window hold everything)"""
+    n = 1 << 16
+    bases = rng_points(55, 1 << 10)
+    bases = np.tile(bases, (n >> 10, 1))
+    three = rng_scalars(56, 3)
+    scalars = three[np.arange(n) % 3]
+    got = jac_affine(mi.VariableBase.msm(bases, np.ascontiguousarray(scalars)))
+    assert (got == orc.msm_pippenger(bases, np.ascontiguousarray(scalars), threads=16)).all()

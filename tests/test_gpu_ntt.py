@@ -45,3 +45,14 @@ def test_ntt_roundtrip_large(orc, mi):
         x = pow(w, j, pyref.R)
         want = sum(c * pow(x, i, pyref.R) for i, c in enumerate(coeffs)) % pyref.R
         assert orc.fr_to_ints(fb[j:j + 1])[0] == want
+
+
+def test_ntt_full_size_2_22_vs_oracle(orc, mi):
+    """BASELINE configs[2]: domain 2^22, forward transform bit-exact against the CPU oracle, then the round trip"""
+    log_n = 22
+    n = 1 << log_n
+    a = rng_fr_mont(2022, n)
+    d = mi.EvaluationDomain(n)
+    f = d.fft(a)
+    assert (f == orc.ntt(a, threads=16)).all()
+    assert (d.ifft(f) == a).all()
