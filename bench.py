@@ -67,18 +67,24 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-extra", action="store_true", help="skip the MSM / NTT / corrupted-batch side measurements")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for rehearsals on one GPU)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     dist_on = world > 1
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    dev_index = local_rank % max(1, torch.cuda.device_count())  # rehearsals may put several ranks on one GPU
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if dist_on:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.distributed.init_process_group("nccl", device_id=dev)
-    L.init(local_rank)
+        if args.backend == "nccl":
+            torch.distributed.init_process_group("nccl", device_id=dev)
+        else:
+            torch.distributed.init_process_group(args.backend)
+    L.init(dev_index)
+    gather_dev = dev if args.backend == "nccl" else None
 
     vk, circuits, proofs, rnd = load_fixture()
     # every rank holds its own shard of the block's proofs; randomizers differ per rank (caller RNG)
@@ -91,7 +97,7 @@ def main():
     # The K batches are verified as a stream (chunks of a block / mempool traffic): the pairing product of batch i
     # runs on the library's second stream while batch i+1 is accumulated.  Every batch is fully verified inside
     # the timed region; "latency_ms" below is one batch on its own, unpipelined.
-    gather = (lambda part: sharding.gather_partials(part, torch.distributed, dev)) if dist_on else None
+    gather = (lambda part: sharding.gather_partials(part, torch.distributed, gather_dev)) if dist_on else None
 
     def run(k):
         oks = list(verifier.verify_stream(((d_proofs, d_rnd) for _ in range(k)), gather))
@@ -109,7 +115,7 @@ def main():
     sync_all(dist_on)
     dt = time.perf_counter() - t0
     if dist_on:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        t = torch.tensor([dt], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = float(t.item())
     L.prof_enable(False)

@@ -437,13 +437,21 @@ void orc_g1_batch_to_affine(orc_g1_affine *r, const orc_g1_jac *a, size_t n) {
     free(pre);
 }
 void orc_g1_mul(orc_g1_jac *r, const orc_g1_affine *p, const orc_bigint256 *k) {
-    orc_g1_jac acc;
-    orc_g1_affine inf;
+    /* 4-bit fixed windows from the top set bit: 15 precomputed multiples, one mixed addition per non-zero nibble */
+    orc_g1_jac acc, tabj[15];
+    orc_g1_affine tab[15], inf;
     memset(&inf, 0, sizeof inf);
     orc_g1_from_affine(&acc, &inf);
-    for (int i = 255; i >= 0; i--) {
-        orc_g1_double(&acc, &acc);
-        if ((k->l[i / 64] >> (i % 64)) & 1) orc_g1_add_mixed(&acc, &acc, p);
+    int top = 255;
+    while (top >= 0 && !((k->l[top / 64] >> (top % 64)) & 1)) top--;
+    if (top < 0 || (fq_is_zero(F(&p->x)) && fq_is_zero(F(&p->y)))) { *r = acc; return; }
+    orc_g1_from_affine(&tabj[0], p);
+    for (int i = 1; i < 15; i++) orc_g1_add_mixed(&tabj[i], &tabj[i - 1], p);
+    orc_g1_batch_to_affine(tab, tabj, 15);
+    for (int w = top / 4; w >= 0; w--) {
+        for (int d = 0; d < 4; d++) orc_g1_double(&acc, &acc);
+        unsigned nib = (unsigned)(k->l[(4 * w) / 64] >> ((4 * w) % 64)) & 15u;
+        if (nib) orc_g1_add_mixed(&acc, &acc, &tab[nib - 1]);
     }
     *r = acc;
 }
