@@ -71,3 +71,31 @@ def neg_y(orc, y):
     import pyref
     v = orc.fq_to_int(y)
     return orc.fq_from_int((-v) % pyref.Q)
+
+
+def test_entry_points_are_thread_safe(orc, mi):
+    """callers are rayon / tokio threads: concurrent calls from several host threads must all be exact"""
+    import threading
+    from helpers import jac_affine, rng_fr_mont
+    bases, scalars = rng_points(71, 600), rng_scalars(72, 600)
+    want_msm = orc.msm_pippenger(bases, scalars, threads=4)
+    a = rng_fr_mont(73, 1 << 10)
+    want_ntt = orc.ntt(a, threads=4)
+    errors = []
+
+    def worker(kind):
+        try:
+            for _ in range(4):
+                if kind == 0:
+                    assert (jac_affine(mi.VariableBase.msm(bases, scalars)) == want_msm).all()
+                else:
+                    assert (mi.EvaluationDomain(1 << 10).fft(a) == want_ntt).all()
+        except Exception as e:  # noqa: BLE001
+            errors.append(repr(e))
+
+    threads = [threading.Thread(target=worker, args=(i % 2,)) for i in range(6)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
