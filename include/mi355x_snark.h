@@ -111,6 +111,11 @@ int32_t mi_vs_finalize(uint64_t ctx, const mi_vs_partial *partials, size_t n_par
 /* pipelined form: the pairing product of batch i runs on the context's own stream while the caller accumulates
  * batch i+1 (VM::check_transactions walks a block in chunks of <= 1000 executions; mempool admission streams).
  * At most 4 tickets may be outstanding; tickets must be waited for in any order before the context is destroyed. */
+/* split accumulate: _begin enqueues the shard's kernels and returns at once, _end waits and folds on the host.
+ * Two may be open at a time, so batch k+1 runs on the GPU while batch k is folded and finalised. */
+int32_t mi_vs_accumulate_begin(uint64_t ctx, const void *d_proofs, size_t n, const void *d_randomizers128, void *stream,
+                               uint64_t *handle_out);
+int32_t mi_vs_accumulate_end(uint64_t ctx, uint64_t handle, mi_vs_partial *partial_out);
 int32_t mi_vs_finalize_async(uint64_t ctx, const mi_vs_partial *partials, size_t n_partials, uint64_t *ticket_out);
 int32_t mi_vs_finalize_wait(uint64_t ctx, uint64_t ticket, uint8_t *all_ok);
 
@@ -123,7 +128,8 @@ int32_t mi_dbg_fq_mul_throughput(size_t n_threads, uint32_t iters, double *gmul_
 int32_t mi_dbg_gen_points_device(uint64_t seed, size_t n, void *d_out, void *stream);
 
 /* ---- profiling: HIP-event timing of the dominant kernels on the stream they are launched on ----
- * mi_prof_enable(1) makes every later call bracket its kernels with hipEvents; mi_prof_read sums the
+ * mi_prof_enable(1) brackets the headline kernels (pairing, msm_accumulate, vs_derive, ntt_pass and the whole MSM
+ * pipeline) with hipEvents, mi_prof_enable(2) every section, 0 switches it off; mi_prof_read sums the
  * elapsed time of all recorded launches of `kernel` ("msm_accumulate", "ntt_pass", "pairing", ...),
  * returns the launch count and the work units (points / elements) those launches processed, and
  * clears the records of that kernel. */

@@ -207,6 +207,20 @@ class VarunaShaped:
                 "mi_vs_accumulate_device")
         return part
 
+    def accumulate_begin(self, proofs_cuda, randomizers_cuda, stream=None):
+        """Enqueue one shard's accumulation (derive + both MSMs) without waiting; returns a handle."""
+        n = proofs_cuda.numel() * proofs_cuda.element_size() // L.VS_PROOF_BYTES
+        h = C.c_uint64(0)
+        L.check(L.lib().mi_vs_accumulate_begin(C.c_uint64(self.ctx), L.dptr(proofs_cuda), C.c_size_t(n),
+                                               L.dptr(randomizers_cuda), L.stream_ptr(stream), C.byref(h)),
+                "mi_vs_accumulate_begin")
+        return h.value
+
+    def accumulate_end(self, handle):
+        part = np.zeros(L.VS_PARTIAL_BYTES, dtype=np.uint8)
+        L.check(L.lib().mi_vs_accumulate_end(C.c_uint64(self.ctx), C.c_uint64(handle), L.ptr(part)), "mi_vs_accumulate_end")
+        return part
+
     def finalize_async(self, partials):
         """Enqueue the pairing product for these partials on the context's own stream; returns a ticket."""
         parts = np.ascontiguousarray(partials, dtype=np.uint8).reshape(-1, L.VS_PARTIAL_BYTES)
@@ -220,18 +234,29 @@ class VarunaShaped:
         L.check(L.lib().mi_vs_finalize_wait(C.c_uint64(self.ctx), C.c_uint64(ticket), L.ptr(ok)), "mi_vs_finalize_wait")
         return bool(ok[0])
 
-    def verify_stream(self, batches, gather=None, depth=3):
+    def verify_stream(self, batches, gather=None, depth=4):
         """Pipelined verification of a stream of batches (chunks of a block, or mempool traffic): yields all_ok per
         batch, in order.  Up to `depth` (<= 4) pairing products are in flight, each on its own stream, while the
         following batches are accumulated.  `batches` yields (proofs_cuda, randomizers_cuda); `gather` (optional)
         maps this rank's partial to the list of all ranks' partials (multi-GPU)."""
         pending = []
-        for proofs, rnd in batches:
-            part = self.accumulate(proofs, rnd)
+        depth = max(1, min(depth, 4))
+
+        def close(handle):  # fold batch `handle`, exchange partials, start its pairing product
+            part = self.accumulate_end(handle)
             parts = gather(part) if gather is not None else [part]
             pending.append(self.finalize_async(parts))
-            if len(pending) >= max(1, min(depth, 4)):
-                yield self.finalize_wait(pending.pop(0))
+
+        prev = None
+        for proofs, rnd in batches:
+            cur = self.accumulate_begin(proofs, rnd)  # batch k+1 on the GPU ...
+            if prev is not None:
+                close(prev)                           # ... while batch k is folded on the host
+                if len(pending) >= depth:
+                    yield self.finalize_wait(pending.pop(0))
+            prev = cur
+        if prev is not None:
+            close(prev)
         while pending:
             yield self.finalize_wait(pending.pop(0))
 

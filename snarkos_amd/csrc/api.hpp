@@ -19,10 +19,12 @@ struct MsmJob {
     int c = 0, nwin = 0;
     bool per_bit = false;
     G1Xyzz *h = nullptr;  // pinned host copy of the window / bit sums
+    hipEvent_t done = nullptr;  // recorded after the copy into h
 };
 void msm_enqueue(Context &cx, const G1Affine *d_points, const uint32_t *d_scalars, size_t n, hipStream_t st, int scalar_bits,
-                 int slot, MsmJob *job, int force_c = 0);
+                 int slot, MsmJob *job, int force_c = 0, int pin_parity = 0);
 void msm_finish(Context &cx, MsmJob *job, hipStream_t st, mi_g1_jac *out);
+void msm_release_graphs();
 void msm_device(Context &cx, const G1Affine *d_points, const uint32_t *d_scalars, size_t n, mi_g1_jac *out,
                 hipStream_t st, int scalar_bits = 254, int force_c = 0);
 
@@ -48,6 +50,9 @@ int32_t vs_ctx_create(Context &cx, const mi_kzg_vk *vk, const mi_vs_circuit_vk *
 int32_t vs_ctx_destroy(Context &cx, uint64_t id);
 int32_t vs_accumulate_device(Context &cx, uint64_t id, const void *d_proofs, size_t n, const void *d_rand,
                              mi_vs_partial *out, hipStream_t st);
+int32_t vs_accumulate_begin(Context &cx, uint64_t id, const void *d_proofs, size_t n, const void *d_rand, hipStream_t st,
+                            uint64_t *handle);
+int32_t vs_accumulate_end(Context &cx, uint64_t id, uint64_t handle, mi_vs_partial *out);
 int32_t vs_finalize(Context &cx, uint64_t id, const mi_vs_partial *parts, size_t np, uint8_t *all_ok, hipStream_t st);
 int32_t vs_finalize_async(Context &cx, uint64_t id, const mi_vs_partial *parts, size_t np, uint64_t *ticket);
 int32_t vs_finalize_wait(Context &cx, uint64_t id, uint64_t ticket, uint8_t *all_ok);

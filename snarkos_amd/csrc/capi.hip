@@ -114,6 +114,7 @@ int32_t mi_shutdown(void) {
     g_ctx.bufs.clear();
     g_ctx.handles.clear();
     g_ctx.handle_len.clear();
+    msm_release_graphs();
     verify_release_all();
     if (g_ctx.pinned) (void)hipHostFree(g_ctx.pinned);
     g_ctx.pinned = nullptr;
@@ -125,6 +126,8 @@ int32_t mi_shutdown(void) {
     g_ctx.stream2 = nullptr;
     (void)hipEventDestroy(g_ctx.fork_event);
     g_ctx.fork_event = nullptr;
+    for (auto &kv : g_ctx.events) (void)hipEventDestroy(kv.second);
+    g_ctx.events.clear();
     for (auto &kv : g_ctx.pins)
         if (kv.second.first) (void)hipHostFree(kv.second.first);
     g_ctx.pins.clear();
@@ -291,6 +294,17 @@ int32_t mi_vs_finalize(uint64_t c, const mi_vs_partial *partials, size_t n_parti
     return guarded([&]() -> int32_t { return vs_finalize(ctx(), c, partials, n_partials, all_ok, ctx().stream); });
 }
 
+int32_t mi_vs_accumulate_begin(uint64_t c, const void *d_proofs, size_t n, const void *d_randomizers128, void *stream,
+                               uint64_t *handle_out) {
+    if (!d_proofs || !n || !d_randomizers128 || !handle_out) return MI_ERR_BAD_ARGS;
+    return guarded([&]() -> int32_t {
+        return vs_accumulate_begin(ctx(), c, d_proofs, n, d_randomizers128, (hipStream_t)stream, handle_out);
+    });
+}
+int32_t mi_vs_accumulate_end(uint64_t c, uint64_t handle, mi_vs_partial *partial_out) {
+    if (!partial_out) return MI_ERR_BAD_ARGS;
+    return guarded([&]() -> int32_t { return vs_accumulate_end(ctx(), c, handle, partial_out); });
+}
 int32_t mi_vs_finalize_async(uint64_t c, const mi_vs_partial *partials, size_t n_partials, uint64_t *ticket_out) {
     if (!partials || !n_partials || !ticket_out) return MI_ERR_BAD_ARGS;
     return guarded([&]() -> int32_t { return vs_finalize_async(ctx(), c, partials, n_partials, ticket_out); });
@@ -349,7 +363,7 @@ int32_t mi_dbg_gen_points_device(uint64_t seed, size_t n, void *d_out, void *str
 
 int32_t mi_prof_enable(int32_t on) {
     return guarded([&]() -> int32_t {
-        ctx().prof.on = on != 0;
+        ctx().prof.level = on < 0 ? 0 : (on > 2 ? 2 : on);
         return MI_OK;
     });
 }
@@ -365,8 +379,8 @@ int32_t mi_prof_read(const char *kernel, double *total_ms, uint64_t *launches, u
             MI_HIP(hipEventElapsedTime(&t, r.e0, r.e1));
             ms += t;
             u += r.units;
-            (void)hipEventDestroy(r.e0);
-            (void)hipEventDestroy(r.e1);
+            ctx().prof.pool.push_back(r.e0);
+            ctx().prof.pool.push_back(r.e1);
         }
         *total_ms = ms;
         *launches = v.size();

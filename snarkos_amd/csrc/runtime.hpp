@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <string.h>
 #include <map>
 #include <mutex>
 #include <string>
@@ -58,20 +59,36 @@ struct ProfRecord {
     uint64_t units;
 };
 struct Profiler {
-    bool on = false;
+    int level = 0;  // 0 off; 1 the headline kernels only (cheap enough to leave on in a timed region); 2 every section
     std::map<std::string, std::vector<ProfRecord>> recs;
+    std::vector<hipEvent_t> pool;  // recycled events: creating one costs microseconds
+    static bool headline(const char *name) {
+        return !strcmp(name, "pairing") || !strcmp(name, "msm_accumulate") || !strcmp(name, "vs_derive") ||
+               !strcmp(name, "ntt_pass") || !strcmp(name, "msm_total");
+    }
+    bool active(const char *name) const { return level >= 2 || (level == 1 && headline(name)); }
+    hipEvent_t get() {
+        if (!pool.empty()) {
+            hipEvent_t e = pool.back();
+            pool.pop_back();
+            return e;
+        }
+        hipEvent_t e;
+        MI_HIP(hipEventCreate(&e));
+        return e;
+    }
     // begin/end bracket one launch on `st`; no-ops when profiling is off
     void begin(const char *name, hipStream_t st, uint64_t units) {
-        if (!on) return;
+        if (!active(name)) return;
         ProfRecord r;
         r.units = units;
-        MI_HIP(hipEventCreate(&r.e0));
-        MI_HIP(hipEventCreate(&r.e1));
+        r.e0 = get();
+        r.e1 = get();
         MI_HIP(hipEventRecord(r.e0, st));
         recs[name].push_back(r);
     }
     void end(const char *name, hipStream_t st) {
-        if (!on) return;
+        if (!active(name)) return;
         MI_HIP(hipEventRecord(recs[name].back().e1, st));
     }
 };
@@ -93,6 +110,15 @@ struct Context {
     std::map<std::string, std::pair<void *, size_t>> pins;  // named pinned staging buffers
     hipStream_t stream2 = nullptr;                         // second library stream (concurrent MSMs)
     hipEvent_t fork_event = nullptr;
+    std::map<std::string, hipEvent_t> events;  // named events (completion of an enqueued job)
+    hipEvent_t event_named(const char *name) {
+        auto it = events.find(name);
+        if (it != events.end()) return it->second;
+        hipEvent_t e;
+        MI_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        events[name] = e;
+        return e;
+    }
     void *buf(const char *name, size_t bytes) { return bufs[name].get(bytes); }
     void *pin_named(const char *name, size_t bytes) {
         auto &e = pins[name];

@@ -107,6 +107,7 @@ struct VsConsts {
     G1Affine g;
 };
 #define VS_SLOTS 4
+struct VsAccFwd;
 struct VsSlot {  // one in-flight pairing product (pipelined finalize)
     uint64_t ticket = 0;
     bool busy = false;
@@ -121,6 +122,17 @@ struct VsCtx {
     DevBuf circuits, h_prep, tauh_prep, consts;
     mi_kzg_vk vk;
     VsSlot slots[VS_SLOTS];  // pairing products run on the slots' streams, beside the next batches' accumulation
+    struct VsAcc {           // an accumulation whose kernels are enqueued but whose host fold is still to come
+        bool open = false;
+        uint64_t handle = 0;
+        size_t n = 0;
+        hipStream_t st = nullptr;
+        MsmJob j1, j2;
+        uint8_t *h_alg = nullptr;
+    } acc[2];
+    uint64_t next_acc = 2;
+    hipStream_t acc_st[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};  // per batch parity: H-side / tau-H-side
+    hipEvent_t acc_ev[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};
     uint64_t next_ticket = 1;
 };
 static void vs_ctx_free(VsCtx &v) {
@@ -135,6 +147,13 @@ static void vs_ctx_free(VsCtx &v) {
         if (sl.h_out) (void)hipHostFree(sl.h_out);
         sl = VsSlot();
     }
+    for (int p = 0; p < 2; p++)
+        for (int k = 0; k < 2; k++) {
+            if (v.acc_st[p][k]) (void)hipStreamDestroy(v.acc_st[p][k]);
+            if (v.acc_ev[p][k]) (void)hipEventDestroy(v.acc_ev[p][k]);
+            v.acc_st[p][k] = nullptr;
+            v.acc_ev[p][k] = nullptr;
+        }
 }
 static std::map<uint64_t, VsCtx> &vs_ctxs() {
     static std::map<uint64_t, VsCtx> m;
@@ -187,6 +206,11 @@ int32_t vs_ctx_create(Context &cx, const mi_kzg_vk *vk, const mi_vs_circuit_vk *
         MI_HIP(hipMalloc((void **)&sl.d_out, sizeof(Fq12)));
         MI_HIP(hipHostMalloc((void **)&sl.h_out, sizeof(Fq12), hipHostMallocDefault));
     }
+    for (int p = 0; p < 2; p++)
+        for (int k = 0; k < 2; k++) {
+            MI_HIP(hipStreamCreateWithFlags(&v.acc_st[p][k], hipStreamNonBlocking));
+            MI_HIP(hipEventCreateWithFlags(&v.acc_ev[p][k], hipEventDisableTiming));
+        }
     (void)pairing_consts(cx, cx.stream);  // upload the Frobenius table before any pipelined launch
     *out = id;
     return MI_OK;
@@ -197,6 +221,9 @@ int32_t vs_ctx_destroy(Context &cx, uint64_t id) {
     MI_HIP(hipStreamSynchronize(cx.stream));
     for (auto &sl : it->second.slots)
         if (sl.stream) MI_HIP(hipStreamSynchronize(sl.stream));
+    for (int p = 0; p < 2; p++)
+        for (int k = 0; k < 2; k++)
+            if (it->second.acc_st[p][k]) MI_HIP(hipStreamSynchronize(it->second.acc_st[p][k]));
     vs_ctx_free(it->second);
     vs_ctxs().erase(it);
     return MI_OK;
@@ -444,18 +471,25 @@ struct VsWork {
     size_t n1, n2;
 };
 
-static VsWork vs_run_derive(Context &cx, VsCtx &v, const void *d_proofs, size_t n, const void *d_rand, hipStream_t st) {
+static VsWork vs_run_derive(Context &cx, VsCtx &v, const void *d_proofs, size_t n, const void *d_rand, hipStream_t st,
+                            int parity = 0) {
     VsWork w;
     w.n1 = n * VS_PER_PROOF_POINTS + v.n_circuits * MI_VS_VK_COMMS + 1;
     w.n2 = n * 2;
-    w.pts1 = (G1Affine *)cx.buf("vs.pts1", sizeof(G1Affine) * w.n1);
-    w.sc1 = (uint32_t *)cx.buf("vs.sc1", 32 * w.n1);
-    w.pts2 = (G1Affine *)cx.buf("vs.pts2", sizeof(G1Affine) * w.n2);
-    w.sc2 = (uint32_t *)cx.buf("vs.sc2", 32 * w.n2);
-    w.vk_scal = (Fr *)cx.buf("vs.vk_scal", sizeof(Fr) * n * MI_VS_VK_COMMS);
-    w.g_scal = (Fr *)cx.buf("vs.g_scal", sizeof(Fr) * n);
-    w.alg_ok = (uint8_t *)cx.buf("vs.alg_ok", n);
-    w.circuit_of = (uint32_t *)cx.buf("vs.circuit_of", 4 * n);
+    // every operand array exists twice (parity of the batch): two batches are in flight on different streams
+    char nm[32];
+    auto W = [&](const char *name) {
+        snprintf(nm, sizeof nm, "vs%d.%s", parity, name);
+        return nm;
+    };
+    w.pts1 = (G1Affine *)cx.buf(W("pts1"), sizeof(G1Affine) * w.n1);
+    w.sc1 = (uint32_t *)cx.buf(W("sc1"), 32 * w.n1);
+    w.pts2 = (G1Affine *)cx.buf(W("pts2"), sizeof(G1Affine) * w.n2);
+    w.sc2 = (uint32_t *)cx.buf(W("sc2"), 32 * w.n2);
+    w.vk_scal = (Fr *)cx.buf(W("vk_scal"), sizeof(Fr) * n * MI_VS_VK_COMMS);
+    w.g_scal = (Fr *)cx.buf(W("g_scal"), sizeof(Fr) * n);
+    w.alg_ok = (uint8_t *)cx.buf(W("alg_ok"), n);
+    w.circuit_of = (uint32_t *)cx.buf(W("circuit_of"), 4 * n);
     cx.prof.begin("vs_derive", st, n);
     hipLaunchKernelGGL(vs_derive_kernel, dim3(cdiv(n, 64)), dim3(64), 0, st, (const mi_vs_proof *)d_proofs, n,
                        (const uint8_t *)d_rand, (const mi_vs_circuit_vk *)v.circuits.p, v.n_circuits,
@@ -480,27 +514,49 @@ static G1Affine host_jac_to_affine_normalised(const mi_g1_jac &j) {
 }
 
 // accumulate one shard: partial sums + algebraic failures (+ optional per-proof alg flags to host)
-static int32_t vs_accumulate_impl(Context &cx, uint64_t id, const void *d_proofs, size_t n, const void *d_rand,
-                                  mi_vs_partial *out, VsWork *work_out, hipStream_t st) {
-    auto it = vs_ctxs().find(id);
-    if (it == vs_ctxs().end()) return MI_ERR_BAD_ARGS;
-    VsCtx &v = it->second;
-    VsWork w = vs_run_derive(cx, v, d_proofs, n, d_rand, st);
-    // the two MSMs (H side and tau-H side) are independent: second one on the library's second stream
-    MsmJob j1, j2;
-    MI_HIP(hipEventRecord(cx.fork_event, st));
-    MI_HIP(hipStreamWaitEvent(cx.stream2, cx.fork_event, 0));
-    msm_enqueue(cx, w.pts1, w.sc1, w.n1, st, 254, 0, &j1);
-    msm_enqueue(cx, w.pts2, w.sc2, w.n2, cx.stream2, 128, 1, &j2);
-    uint8_t *h_alg = (uint8_t *)cx.pin(n);
-    MI_HIP(hipMemcpyAsync(h_alg, w.alg_ok, n, hipMemcpyDeviceToHost, st));
+// accumulate = begin (enqueue derive + both MSMs, no host synchronisation) + end (wait, fold on the host).
+// Two begin/end pairs may be open at once (parity p = handle & 1): the device workspaces are reused in stream
+// order, only the pinned result buffers are per parity, so batch k+1's kernels run while batch k is folded.
+static int32_t vs_accumulate_begin_impl(Context &cx, VsCtx &v, const void *d_proofs, size_t n, const void *d_rand,
+                                        hipStream_t st, uint64_t *handle, VsWork *work_out) {
+    const uint64_t hd = v.next_acc++;
+    VsCtx::VsAcc &a = v.acc[hd & 1];
+    if (a.open) return MI_ERR_BAD_ARGS;  // at most two accumulations in flight
+    // Batches alternate between two stream pairs, so batch k+1's derive and MSMs run beside batch k's.  The inputs
+    // were produced on the caller's stream: order ours behind it.
+    const int par = (int)(hd & 1);
+    hipStream_t sa = v.acc_st[par][0], sb = v.acc_st[par][1];
+    MI_HIP(hipEventRecord(v.acc_ev[par][0], st));
+    MI_HIP(hipStreamWaitEvent(sa, v.acc_ev[par][0], 0));
+    VsWork w = vs_run_derive(cx, v, d_proofs, n, d_rand, sa, par);
+    MI_HIP(hipEventRecord(v.acc_ev[par][1], sa));
+    MI_HIP(hipStreamWaitEvent(sb, v.acc_ev[par][1], 0));
+    char nm[32];
+    snprintf(nm, sizeof nm, "vs.alg_pin%d", par);
+    a.h_alg = (uint8_t *)cx.pin_named(nm, n);
+    MI_HIP(hipMemcpyAsync(a.h_alg, w.alg_ok, n, hipMemcpyDeviceToHost, sa));  // ahead of MSM 1: its done-event covers it
+    msm_enqueue(cx, w.pts2, w.sc2, w.n2, sb, 128, 4 + 2 * par + 1, &a.j2, 0, par);  // the short one first
+    msm_enqueue(cx, w.pts1, w.sc1, w.n1, sa, 254, 4 + 2 * par, &a.j1, 0, par);
+    st = sa;
+    a.n = n;
+    a.st = st;
+    a.handle = hd;
+    a.open = true;
+    if (work_out) *work_out = w;
+    *handle = hd;
+    return MI_OK;
+}
+static int32_t vs_accumulate_end_impl(Context &cx, VsCtx &v, uint64_t handle, mi_vs_partial *out) {
+    VsCtx::VsAcc &a = v.acc[handle & 1];
+    if (!a.open || a.handle != handle) return MI_ERR_BAD_ARGS;
+    a.open = false;
     // the two host folds (~250 doublings + ~250 additions each) run on two host threads
     int32_t st2 = MI_OK;
     const int dev = cx.device;
     std::thread fold2([&]() {
         try {
             MI_HIP(hipSetDevice(dev));
-            msm_finish(cx, &j2, cx.stream2, &out->total_w);
+            msm_finish(cx, &a.j2, nullptr, &out->total_w);
         } catch (const HipError &h) {
             st2 = status_of(h);
         } catch (...) {
@@ -508,7 +564,7 @@ static int32_t vs_accumulate_impl(Context &cx, uint64_t id, const void *d_proofs
         }
     });
     try {
-        msm_finish(cx, &j1, st, &out->total_c);
+        msm_finish(cx, &a.j1, a.st, &out->total_c);
     } catch (...) {
         fold2.join();
         throw;
@@ -516,11 +572,30 @@ static int32_t vs_accumulate_impl(Context &cx, uint64_t id, const void *d_proofs
     fold2.join();
     if (st2 != MI_OK) return st2;
     uint64_t fails = 0;
-    for (size_t i = 0; i < n; i++) fails += h_alg[i] ? 0 : 1;
-    out->n_proofs = n;
+    for (size_t i = 0; i < a.n; i++) fails += a.h_alg[i] ? 0 : 1;
+    out->n_proofs = a.n;
     out->n_alg_fail = fails;
-    if (work_out) *work_out = w;
     return MI_OK;
+}
+static int32_t vs_accumulate_impl(Context &cx, uint64_t id, const void *d_proofs, size_t n, const void *d_rand,
+                                  mi_vs_partial *out, VsWork *work_out, hipStream_t st) {
+    auto it = vs_ctxs().find(id);
+    if (it == vs_ctxs().end()) return MI_ERR_BAD_ARGS;
+    uint64_t hd;
+    int32_t s = vs_accumulate_begin_impl(cx, it->second, d_proofs, n, d_rand, st, &hd, work_out);
+    if (s != MI_OK) return s;
+    return vs_accumulate_end_impl(cx, it->second, hd, out);
+}
+int32_t vs_accumulate_begin(Context &cx, uint64_t id, const void *d_proofs, size_t n, const void *d_rand, hipStream_t st,
+                            uint64_t *handle) {
+    auto it = vs_ctxs().find(id);
+    if (it == vs_ctxs().end()) return MI_ERR_BAD_ARGS;
+    return vs_accumulate_begin_impl(cx, it->second, d_proofs, n, d_rand, st, handle, nullptr);
+}
+int32_t vs_accumulate_end(Context &cx, uint64_t id, uint64_t handle, mi_vs_partial *out) {
+    auto it = vs_ctxs().find(id);
+    if (it == vs_ctxs().end()) return MI_ERR_BAD_ARGS;
+    return vs_accumulate_end_impl(cx, it->second, handle, out);
 }
 
 int32_t vs_accumulate_device(Context &cx, uint64_t id, const void *d_proofs, size_t n, const void *d_rand,

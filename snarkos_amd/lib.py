@@ -29,7 +29,7 @@ EXPORTS = [
     "mi_ntt_fr", "mi_ntt_fr_device",
     "mi_pairing_product_is_one", "mi_pairing", "mi_kzg_batch_check",
     "mi_vs_ctx_create", "mi_vs_ctx_destroy", "mi_vs_verify_batch", "mi_vs_verify_batch_device",
-    "mi_vs_accumulate_device", "mi_vs_finalize", "mi_vs_finalize_async", "mi_vs_finalize_wait",
+    "mi_vs_accumulate_device", "mi_vs_accumulate_begin", "mi_vs_accumulate_end", "mi_vs_finalize", "mi_vs_finalize_async", "mi_vs_finalize_wait",
     "mi_dbg_fq_mul", "mi_dbg_fr_mul", "mi_dbg_g1_add", "mi_dbg_fq_mul_throughput", "mi_dbg_gen_points_device",
     "mi_prof_enable", "mi_prof_read",
 ]
@@ -110,8 +110,9 @@ def shutdown():
     check(lib().mi_shutdown(), "mi_shutdown")
 
 
-def prof_enable(on=True):
-    check(lib().mi_prof_enable(C.c_int32(1 if on else 0)), "mi_prof_enable")
+def prof_enable(level=1):
+    """0 / False: off; 1 / True: headline kernels only; 2: every section"""
+    check(lib().mi_prof_enable(C.c_int32(int(level))), "mi_prof_enable")
 
 
 def prof_read(kernel):

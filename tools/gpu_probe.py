@@ -28,7 +28,7 @@ for lg in (10, 12, 13, 14, 16, 18, 20):
     sc = sc.to(dev)
     torch.cuda.synchronize()
     A.VariableBase.msm(pts, sc)
-    L.prof_enable(True)
+    L.prof_enable(2)
     for k in names:
         L.prof_read(k)
     t0 = time.perf_counter()
