@@ -145,20 +145,32 @@ __device__ __attribute__((noinline)) void pb_exp_by_x(PwShared &S, PB *out, cons
     }
     pb_copy(S, out, &S.y);
 }
-// out = A^-1: one lane, tower formulas (the only serial piece: ~180 products + one binary-EGCD inversion)
-__device__ __attribute__((noinline)) void pb_inv(PwShared &S, PB *out, const PB *A) {
-    if (threadIdx.x == 0) {
-        Fq12 f;
-        Fq *fc = &f.c0.c0.c0;
-        for (int i = 0; i < 2; i++)
-            for (int j = 0; j < 3; j++)
-                for (int b = 0; b < 2; b++) fc[(i * 3 + j) * 2 + b] = lds_load(&A->c[i + 2 * j + 6 * b]);
-        Fq12 g = inv(f);
-        const Fq *gc = &g.c0.c0.c0;
-        for (int i = 0; i < 2; i++)
-            for (int j = 0; j < 3; j++)
-                for (int b = 0; b < 2; b++) lds_store(&out->c[i + 2 * j + 6 * b], gc[(i * 3 + j) * 2 + b]);
-    }
+// out = A^-1 by the norm to Fq: A^-1 = Abar / N, Abar = prod_{e=1..11} frob_e(A), N = A * Abar in Fq.
+// Frobenius is diagonal here, so this stays in the workgroup-wide rounds; the one serial step is a binary-EGCD
+// inversion in Fq on a single lane.  With U = A frob1(A) frob2(A) (e = 0,1,2) and P2 = A frob1(A):
+//   W = U * frob3(U) * frob6(U) * frob9(P2)   covers e = 0..10,   Abar = frob1(W),   frob6 = conj, frob9 = conj o frob3.
+// Uses S.x, S.y, S.c, S.d as scratch (callers invert before they use those).
+__device__ __attribute__((noinline)) void pb_inv(PwShared &S, PB *out, const PB *A, const PairingConsts *pc) {
+    pb_frob(S, &S.x, A, pc->frob[0]);         // x = frob1(A)
+    pb_mul(S, &S.c, A, &S.x);                 // c = P2 = A frob1(A)
+    pb_frob(S, &S.x, A, pc->frob[1]);         // x = frob2(A)
+    pb_mul(S, &S.d, &S.c, &S.x);              // d = U
+    pb_frob(S, &S.x, &S.d, pc->frob[2]);      // x = frob3(U)
+    pb_mul(S, &S.y, &S.d, &S.x);              // y = U frob3(U)
+    pb_conj(S, &S.x, &S.d);                   // x = frob6(U)
+    pb_mul(S, &S.y, &S.y, &S.x);              // y = U frob3(U) frob6(U)
+    pb_frob(S, &S.x, &S.c, pc->frob[2]);      // x = frob3(P2)
+    pb_conj(S, &S.x, &S.x);                   // x = frob9(P2)
+    pb_mul(S, &S.y, &S.y, &S.x);              // y = W
+    pb_frob(S, &S.x, &S.y, pc->frob[0]);      // x = Abar
+    pb_mul(S, &S.y, A, &S.x);                 // y = N (coefficient 0; the others vanish)
+    const int t = threadIdx.x;
+    if (t == 0) lds_store(&S.y.c[1], invq(lds_load(&S.y.c[0])));  // 1/N parked in y.c[1]
+    __syncthreads();
+    Fq v;
+    if (t < 12) v = mul(lds_load(&S.x.c[t]), lds_load(&S.y.c[1]));
+    __syncthreads();
+    if (t < 12) lds_store(&out->c[t], v);
     __syncthreads();
 }
 
@@ -193,7 +205,7 @@ __device__ __attribute__((noinline)) void pw_miller(PwShared &S, const G2Prepare
 // S.f <- S.f ^ (3 (q^12 - 1) / r)
 __device__ __attribute__((noinline)) void pw_final_exp(PwShared &S, const PairingConsts *pc) {
     // easy part
-    pb_inv(S, &S.a, &S.f);
+    pb_inv(S, &S.a, &S.f, pc);
     pb_conj(S, &S.t, &S.f);
     pb_mul(S, &S.t, &S.t, &S.a);
     pb_frob(S, &S.a, &S.t, pc->frob[1]);
