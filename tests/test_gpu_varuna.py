@@ -100,3 +100,35 @@ def test_pipelined_stream_matches_batchwise(orc, mi):
         assert list(v.verify_stream(iter([]))) == []
     finally:
         v.close()
+
+
+@pytest.mark.parametrize("n", [1, 3])
+def test_tiny_batches(orc, mi, n):
+    good = orc.VSBatch(0x71 + n, n, 2, 0)
+    v = _ctx(mi, good)
+    try:
+        ok, verdicts = v.verify_batch(good.proofs, good.randomizers)
+        assert ok and verdicts.all()
+        bad = good.proofs.copy()
+        bad[(n - 1) * 2256 + 16 + 512 + 864 + 32 * 4] ^= 2
+        ok, verdicts = v.verify_batch(bad, good.randomizers)
+        want = orc.VSArrays(good.vk, good.circuits, bad, good.randomizers).verify_cpu(2)
+        assert not ok and (verdicts == want).all() and verdicts[n - 1] == 0
+    finally:
+        v.close()
+
+
+def test_proof_with_points_at_infinity(orc, mi):
+    """a commitment or a witness replaced by the point at infinity: both verifiers must agree proof by proof"""
+    b = orc.VSBatch(0x1F, 12, 2, 0)
+    proofs = b.proofs.copy()
+    proofs[2 * 2256 + 16 + 512 + 96 * 3:2 * 2256 + 16 + 512 + 96 * 4] = 0      # C_3 of proof 2 -> infinity
+    proofs[7 * 2256 + 16 + 512 + 864 + 672:7 * 2256 + 16 + 512 + 864 + 672 + 96] = 0  # W_beta of proof 7 -> infinity
+    v = _ctx(mi, b)
+    try:
+        ok, verdicts = v.verify_batch(proofs, b.randomizers)
+        want = orc.VSArrays(b.vk, b.circuits, proofs, b.randomizers).verify_cpu(4)
+        assert (verdicts == want).all() and ok == bool(want.all())
+        assert want[2] == 0 and want[7] == 0 and want.sum() == 10
+    finally:
+        v.close()

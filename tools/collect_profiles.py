@@ -32,13 +32,15 @@ def short(name):
 
 for pat, out in (("stats/*/*_kernel_stats.csv", "%s_rocprofv3_kernel_stats.csv" % tag), ("bench.json", "%s_bench.json" % tag),
                  ("stats_bench.json", "%s_bench_under_rocprofv3.json" % tag)):
-    for f in glob.glob(os.path.join(src, pat)):
-        shutil.copy(f, os.path.join(dst, out))
+    files = sorted(glob.glob(os.path.join(src, pat)), key=os.path.getmtime)
+    if files:
+        shutil.copy(files[-1], os.path.join(dst, out))  # newest run only
 
 per = {}
 for sub, cn in (("pmc_fetch", "FETCH_SIZE"), ("pmc_write", "WRITE_SIZE")):
     agg = collections.defaultdict(list)
-    for f in glob.glob(os.path.join(src, sub, "*", "*_counter_collection.csv")):
+    files = sorted(glob.glob(os.path.join(src, sub, "*", "*_counter_collection.csv")), key=os.path.getmtime)
+    for f in files[-1:]:
         for r in csv.DictReader(open(f)):
             if r["Counter_Name"] == cn:
                 agg[short(r["Kernel_Name"])].append(float(r["Counter_Value"]))
