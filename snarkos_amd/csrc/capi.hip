@@ -148,8 +148,11 @@ const char *mi_error_string(int32_t s) {
 int32_t mi_abi_version(void) { return 1; }
 
 // ------------------------------------------------------------ MSM
+// entries per MSM are indexed with 32 bits (index << 1 | sign; offsets over all windows): n <= 2^27
+static const size_t MI_MSM_MAX_N = (size_t)1 << 27;
+
 int32_t mi_msm_g1(const mi_g1_affine *bases, const mi_bigint256 *scalars, size_t n, mi_g1_jac *out) {
-    if (!out || (n && (!bases || !scalars))) return MI_ERR_BAD_ARGS;
+    if (!out || (n && (!bases || !scalars)) || n > MI_MSM_MAX_N) return MI_ERR_BAD_ARGS;
     return guarded([&]() -> int32_t {
         Context &cx = ctx();
         G1Affine *dp = (G1Affine *)cx.buf("msm.in_points", sizeof(G1Affine) * (n ? n : 1));
@@ -163,7 +166,7 @@ int32_t mi_msm_g1(const mi_g1_affine *bases, const mi_bigint256 *scalars, size_t
     });
 }
 int32_t mi_msm_g1_device(const void *d_bases, const void *d_scalars, size_t n, mi_g1_jac *out, void *stream) {
-    if (!out || (n && (!d_bases || !d_scalars))) return MI_ERR_BAD_ARGS;
+    if (!out || (n && (!d_bases || !d_scalars)) || n > MI_MSM_MAX_N) return MI_ERR_BAD_ARGS;
     return guarded([&]() -> int32_t {
         msm_device(ctx(), (const G1Affine *)d_bases, (const uint32_t *)d_scalars, n, out, (hipStream_t)stream);
         return MI_OK;
@@ -194,7 +197,7 @@ int32_t mi_bases_release(uint64_t handle) {
     });
 }
 int32_t mi_msm_g1_h(uint64_t handle, size_t offset, const mi_bigint256 *scalars, size_t n, mi_g1_jac *out) {
-    if (!out || (n && !scalars)) return MI_ERR_BAD_ARGS;
+    if (!out || (n && !scalars) || n > MI_MSM_MAX_N) return MI_ERR_BAD_ARGS;
     return guarded([&]() -> int32_t {
         Context &cx = ctx();
         auto it = cx.handles.find(handle);
@@ -208,7 +211,7 @@ int32_t mi_msm_g1_h(uint64_t handle, size_t offset, const mi_bigint256 *scalars,
 
 // ------------------------------------------------------------ NTT
 int32_t mi_ntt_fr(mi_fr *data, uint32_t log_n, int32_t inverse, int32_t coset) {
-    if (!data || log_n > 47) return MI_ERR_BAD_ARGS;
+    if (!data || log_n > 30) return MI_ERR_BAD_ARGS;  // 2^30 x 32 B = 32 GiB per buffer; the coset tables cover 30 bits
     return guarded([&]() -> int32_t {
         Context &cx = ctx();
         size_t bytes = sizeof(Fr) << log_n;
@@ -221,7 +224,7 @@ int32_t mi_ntt_fr(mi_fr *data, uint32_t log_n, int32_t inverse, int32_t coset) {
     });
 }
 int32_t mi_ntt_fr_device(void *d_data, uint32_t log_n, int32_t inverse, int32_t coset, void *stream) {
-    if (!d_data || log_n > 47) return MI_ERR_BAD_ARGS;
+    if (!d_data || log_n > 30) return MI_ERR_BAD_ARGS;
     return guarded([&]() -> int32_t {
         ntt_device(ctx(), (Fr *)d_data, log_n, inverse != 0, coset != 0, (hipStream_t)stream);
         return MI_OK;

@@ -43,6 +43,9 @@ def test_error_strings_and_bad_args():
     out = np.zeros(18, dtype=np.uint64)
     assert l.mi_msm_g1(None, None, C.c_size_t(4), L.ptr(out)) == -1       # MI_ERR_BAD_ARGS
     assert l.mi_ntt_fr(None, C.c_uint32(4), 0, 0) == -1
+    buf = np.zeros(4, dtype=np.uint64)
+    assert l.mi_ntt_fr(L.ptr(buf), C.c_uint32(31), 0, 0) == -1            # domain too large
+    assert l.mi_msm_g1(L.ptr(buf), L.ptr(buf), C.c_size_t(1 << 28), L.ptr(out)) == -1  # more entries than 32-bit indices hold
 
 
 def test_no_cpu_fallback_without_a_gpu():

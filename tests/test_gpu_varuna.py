@@ -132,3 +132,31 @@ def test_proof_with_points_at_infinity(orc, mi):
         assert want[2] == 0 and want[7] == 0 and want.sum() == 10
     finally:
         v.close()
+
+
+def test_block_of_8192_proofs_as_eight_shards(orc, mi):
+    """BASELINE configs[4] at full size on one GPU: the 8192-proof block is eight 1024-proof shards (the committed
+    fixture under eight different randomizer sets); each shard is accumulated as a rank would, the eight 304-byte
+    partials are finalised with ONE pairing product.  Properties: all-valid block accepts; one corrupted proof in
+    one shard makes the block reject; the shard partials add up to the single-shot accumulator of the oracle."""
+    import torch
+    from helpers import jac_affine
+    vk, circuits, proofs, rnd = _fixture()
+    v = mi.VarunaShaped(vk, circuits)
+    try:
+        d_proofs = torch.from_numpy(proofs).cuda()
+        parts, oracle_tc = [], None
+        for s in range(8):
+            r = rnd.copy(); r[::16] ^= np.uint8(s + 1)
+            parts.append(v.accumulate(d_proofs, torch.from_numpy(r).cuda()))
+            if s == 3:  # spot-check one shard's accumulators against the oracle's aggregated form
+                _, _, tc, tw = orc.VSArrays(vk, circuits, proofs, r).verify_aggregated(16)
+                p64 = np.frombuffer(parts[-1].tobytes(), dtype=np.uint64)
+                assert (jac_affine(p64[0:18]) == tc).all() and (jac_affine(p64[18:36]) == tw).all()
+        assert v.finalize(parts)
+        bad = proofs.copy(); bad[777 * 2256 + 16 + 512 + 864 + 32 * 11] ^= 1
+        r = rnd.copy(); r[::16] ^= np.uint8(6)
+        parts[5] = v.accumulate(torch.from_numpy(bad).cuda(), torch.from_numpy(r).cuda())
+        assert not v.finalize(parts)
+    finally:
+        v.close()
