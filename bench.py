@@ -276,6 +276,20 @@ def extras(dev, verifier, proofs, rnd):
                                 "passes_per_transform": launches // (2 * reps),
                                 "roofline_frac_hbm": 2 * 64.0 * (1 << log_n) / dt / 1e9 / HBM_PEAK_GBPS}
     del a, ref
+    # --- row A9: Poseidon sponge over Fq, 65536 independent sponges absorbing 64 elements each (32 permutations)
+    npos, mpos = 1 << 16, 64
+    x = torch.randint(0, 1 << 62, (npos, mpos, 6), dtype=torch.int64, generator=g)
+    x[:, :, 5] &= (1 << 55) - 1  # < q
+    x = x.to(dev)
+    A.PoseidonSponge.hash_many(x, 2)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    A.PoseidonSponge.hash_many(x, 2)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    ex["poseidon_fq"] = {"sponges": npos, "absorbed_each": mpos, "ms": 1e3 * dt, "permutations_per_s": npos * (mpos // 2) / dt,
+                         "fq_products_per_s": npos * (mpos // 2) * 626 / dt}
+    del x
     # --- the same 1024-proof batch with 1 % corrupted proofs: aggregate check fails, fallback names them
     bad = proofs.copy()
     idx = np.arange(5, 1024, 101)  # 11 proofs

@@ -119,6 +119,14 @@ int32_t mi_vs_accumulate_end(uint64_t ctx, uint64_t handle, mi_vs_partial *parti
 int32_t mi_vs_finalize_async(uint64_t ctx, const mi_vs_partial *partials, size_t n_partials, uint64_t *ticket_out);
 int32_t mi_vs_finalize_wait(uint64_t ctx, uint64_t ticket, uint8_t *all_ok);
 
+/* ---- crypto_hash::PoseidonSponge<Fq, 2, 1>, many independent sponges at once ----
+ * Structure as snarkVM's (width 3, S-box x^17, 8 full + 31 partial rounds); the round constants and MDS matrix
+ * are this library's own (tools/gen_constants.py): snarkVM's are not available offline, so this is the kernel a
+ * real Fiat-Shamir transcript would run on, not a bit-compatible one.  Each of the n sponges absorbs m Fq elements
+ * (two per permutation) and squeezes k.  inputs: n x m, outputs: n x k, Montgomery. */
+int32_t mi_poseidon_fq_hash_many(const mi_fq *inputs, size_t n, size_t m, size_t k, mi_fq *outputs);
+int32_t mi_poseidon_fq_hash_many_device(const void *d_inputs, size_t n, size_t m, size_t k, void *d_outputs, void *stream);
+
 /* ---- diagnostics (parity tests of the device field / group arithmetic) ---- */
 int32_t mi_dbg_fq_mul(const mi_fq *a, const mi_fq *b, mi_fq *out, size_t n);
 int32_t mi_dbg_fr_mul(const mi_fr *a, const mi_fr *b, mi_fr *out, size_t n);

@@ -83,6 +83,13 @@ def main():
            "bad_values": [hx(v) for v in bad], "witnesses": [pt(w) for w in ws], "randomizers": [hx(r) for r in rs],
            "verdict_good": True, "verdict_bad": False}
     json.dump(kzg, open(os.path.join(OUT, "kzg.json"), "w"), indent=0)
+    # --- Poseidon sponge over Fq (own parameters, see pyref.poseidon_params)
+    cases = []
+    for m, k in ((0, 1), (1, 1), (2, 2), (5, 3)):
+        ins = [rng.below(P.Q, 7) for _ in range(m)]
+        cases.append({"inputs": [hx(x) for x in ins], "outputs": [hx(x) for x in P.poseidon_hash(ins, k)]})
+    perm = P.poseidon_permute([1, 2, 3])
+    json.dump({"permute_1_2_3": [hx(x) for x in perm], "sponge": cases}, open(os.path.join(OUT, "poseidon.json"), "w"), indent=0)
     print("golden vectors written to", OUT)
 
 

@@ -99,6 +99,12 @@ int orc_kzg_batch_check(const orc_kzg_vk *vk, const orc_g1_affine *comms, const 
                         const orc_fr *values, const orc_g1_affine *witnesses, size_t n,
                         const uint8_t *randomizers128);
 
+/* ---- Poseidon sponge over Fq (crypto_hash::PoseidonSponge<Fq,2,1>) ----
+ * width 3, S-box x^17, 4 + 31 + 4 rounds; constants generated by tools/gen_constants.py (snarkVM's are not
+ * available offline: parity unpinned).  inputs: n x m Montgomery Fq, outputs: n x k. */
+void orc_poseidon_permute(orc_fq state[3]);
+void orc_poseidon_hash_many(const orc_fq *inputs, size_t n, size_t m, size_t k, orc_fq *outputs, int threads);
+
 /* ---- SHA-256 (stand-in Fiat-Shamir transcript) ---- */
 void orc_sha256(uint8_t out[32], const uint8_t *data, size_t len);
 

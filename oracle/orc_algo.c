@@ -214,6 +214,56 @@ int orc_kzg_batch_check(const orc_kzg_vk *vk, const orc_g1_affine *comms, const 
     return ok;
 }
 
+/* ------------------------------------------------------------------ Poseidon over Fq */
+static void fq_pow17(fq_t *r, const fq_t *x) {
+    fq_t x2, x4, x8, x16;
+    fq_sqr(&x2, x);
+    fq_sqr(&x4, &x2);
+    fq_sqr(&x8, &x4);
+    fq_sqr(&x16, &x8);
+    fq_mul(r, &x16, x);
+}
+void orc_poseidon_permute(orc_fq st[3]) {
+    for (int r = 0; r < ORC_POSEIDON_ROUNDS; r++) {
+        for (int i = 0; i < 3; i++) fq_add(&st[i], &st[i], (const fq_t *)ORC_POSEIDON_ARK[r][i]);
+        if (r < ORC_POSEIDON_FULL_HALF || r >= ORC_POSEIDON_FULL_HALF + ORC_POSEIDON_PARTIAL) {
+            for (int i = 0; i < 3; i++) fq_pow17(&st[i], &st[i]);
+        } else {
+            fq_pow17(&st[0], &st[0]);
+        }
+        fq_t o[3], t;
+        for (int i = 0; i < 3; i++) {
+            fq_zero(&o[i]);
+            for (int j = 0; j < 3; j++) {
+                fq_mul(&t, (const fq_t *)ORC_POSEIDON_MDS[i][j], &st[j]);
+                fq_add(&o[i], &o[i], &t);
+            }
+        }
+        for (int i = 0; i < 3; i++) st[i] = o[i];
+    }
+}
+void orc_poseidon_hash_many(const orc_fq *inputs, size_t n, size_t m, size_t k, orc_fq *outputs, int threads) {
+    if (threads < 1) threads = 1;
+#pragma omp parallel for schedule(static) num_threads(threads)
+    for (size_t s = 0; s < n; s++) {
+        orc_fq st[3];
+        memset(st, 0, sizeof st);
+        const orc_fq *in = inputs + s * m;
+        for (size_t i = 0; i < m; i += 2) {
+            fq_add(&st[1], &st[1], &in[i]);
+            if (i + 1 < m) fq_add(&st[2], &st[2], &in[i + 1]);
+            orc_poseidon_permute(st);
+        }
+        if (m == 0) orc_poseidon_permute(st);
+        size_t produced = 0;
+        while (produced < k) {
+            outputs[s * k + produced++] = st[1];
+            if (produced < k) outputs[s * k + produced++] = st[2];
+            if (produced < k) orc_poseidon_permute(st);
+        }
+    }
+}
+
 /* ------------------------------------------------------------------ SHA-256 (FIPS 180-4) */
 static const uint32_t K256[64] = {
     0x428a2f98, 0x71374491, 0xb5c0fbcf, 0xe9b5dba5, 0x3956c25b, 0x59f111f1, 0x923f82a4, 0xab1c5ed5, 0xd807aa98,

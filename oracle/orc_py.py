@@ -223,6 +223,15 @@ def kzg_batch_check(vk, comms, points, values, witnesses, randomizers):
                                           C.c_size_t(n), _p(rnd)))
 
 
+def poseidon_hash_many(inputs, k, threads=1):
+    """inputs: (n, m, 6) Montgomery Fq -> (n, k, 6)"""
+    a = np.ascontiguousarray(inputs, dtype=np.uint64)
+    n, m = a.shape[0], a.shape[1]
+    out = u64((n, k, 6))
+    lib().orc_poseidon_hash_many(_p(a), C.c_size_t(n), C.c_size_t(m), C.c_size_t(k), _p(out), C.c_int(threads))
+    return out
+
+
 def sha256(b):
     out = np.zeros(32, dtype=np.uint8)
     buf = np.frombuffer(bytes(b), dtype=np.uint8).copy() if len(b) else np.zeros(1, dtype=np.uint8)

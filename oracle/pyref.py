@@ -500,3 +500,62 @@ def vs_verify_one(tau_h, circuits, proof, r_beta, r_gamma):
         total_w = g1_add(total_w, g1_mul(proof["w"][q], r[q]))
     total_c = g1_add(total_c, g1_neg(g1_mul(G1_GEN, gs)))
     return alg_ok and pairing_product_is_one([(total_c, G2_GEN), (g1_neg(total_w), tau_h)])
+
+
+# ----------------------------------------------------------------------------- Poseidon sponge over Fq (row A9)
+# Structure as recalled for snarkVM's PoseidonSponge<Fq, RATE = 2, CAPACITY = 1>: width 3, S-box x^17, 8 full +
+# 31 partial rounds.  snarkVM's round constants and MDS matrix are NOT available offline, so the parameters here
+# are generated by a documented procedure of our own (SHA-256 counter stream, Cauchy matrix): same shape and cost,
+# different numbers -> parity unpinned, like the rest of the path.
+POSEIDON_T, POSEIDON_RF, POSEIDON_RP, POSEIDON_ALPHA = 3, 8, 31, 17
+POSEIDON_TAG = b"MI355X-Poseidon-BLS12-377-Fq-v1"
+
+
+def poseidon_params():
+    rounds = POSEIDON_RF + POSEIDON_RP
+    ark = []
+    for r in range(rounds):
+        row = []
+        for i in range(POSEIDON_T):
+            seed = POSEIDON_TAG + bytes([r, i])
+            v = int.from_bytes(sha256(seed + b"\x00") + sha256(seed + b"\x01"), "little") % Q
+            row.append(v)
+        ark.append(row)
+    mds = [[inv((i + POSEIDON_T + j) % Q, Q) for j in range(POSEIDON_T)] for i in range(POSEIDON_T)]  # 1/(x_i + y_j), x_i = i, y_j = T + j
+    return ark, mds
+
+
+def poseidon_permute(state, params=None):
+    ark, mds = params or poseidon_params()
+    st = list(state)
+    half = POSEIDON_RF // 2
+    for r in range(POSEIDON_RF + POSEIDON_RP):
+        st = [(x + c) % Q for x, c in zip(st, ark[r])]
+        if r < half or r >= half + POSEIDON_RP:
+            st = [pow(x, POSEIDON_ALPHA, Q) for x in st]
+        else:
+            st[0] = pow(st[0], POSEIDON_ALPHA, Q)
+        st = [sum(mds[i][j] * st[j] for j in range(POSEIDON_T)) % Q for i in range(POSEIDON_T)]
+    return st
+
+
+def poseidon_hash(inputs, n_out, params=None):
+    """Sponge: state = [capacity, rate0, rate1]; absorb two elements per permutation (the last block may hold one),
+    one permutation after the last block, then squeeze rate0, rate1, permute, ..."""
+    params = params or poseidon_params()
+    st = [0, 0, 0]
+    for i in range(0, len(inputs), 2):
+        st[1] = (st[1] + inputs[i]) % Q
+        if i + 1 < len(inputs):
+            st[2] = (st[2] + inputs[i + 1]) % Q
+        st = poseidon_permute(st, params)
+    if not inputs:
+        st = poseidon_permute(st, params)
+    out = []
+    while len(out) < n_out:
+        out.append(st[1])
+        if len(out) < n_out:
+            out.append(st[2])
+        if len(out) < n_out:
+            st = poseidon_permute(st, params)
+    return out

@@ -134,6 +134,29 @@ class Bls12_377:
         return bool(r[0])
 
 
+class PoseidonSponge:
+    """snarkvm_algorithms::crypto_hash::PoseidonSponge<Fq, 2, 1>, many independent sponges per call
+    (own round constants: see include/mi355x_snark.h)."""
+
+    @staticmethod
+    def hash_many(inputs, k, stream=None):
+        """inputs: (n, m, 6) uint64 Montgomery Fq (or a CUDA tensor of the same bytes plus n, m via its shape);
+        returns (n, k, 6)."""
+        if _is_torch_cuda(inputs):
+            import torch
+            n, m = inputs.shape[0], inputs.shape[1]
+            out = torch.empty((n, k, 6), dtype=inputs.dtype, device=inputs.device)
+            L.check(L.lib().mi_poseidon_fq_hash_many_device(L.dptr(inputs), C.c_size_t(n), C.c_size_t(m), C.c_size_t(k),
+                                                            L.dptr(out), L.stream_ptr(stream)), "mi_poseidon_fq_hash_many_device")
+            return out
+        a = np.ascontiguousarray(inputs, dtype=np.uint64)
+        n, m = a.shape[0], a.shape[1]
+        out = np.zeros((n, k, 6), dtype=np.uint64)
+        L.check(L.lib().mi_poseidon_fq_hash_many(L.ptr(a), C.c_size_t(n), C.c_size_t(m), C.c_size_t(k), L.ptr(out)),
+                "mi_poseidon_fq_hash_many")
+        return out
+
+
 class KZG10:
     """snarkvm_algorithms::polycommit::kzg10::KZG10"""
 

@@ -75,6 +75,79 @@ __global__ void __launch_bounds__(256) dbg_fq_mul_throughput_kernel(Fq *out, uin
     out[i] = add(a, b);
 }
 
+// ------------------------------------------------------------ Poseidon sponge over Fq, one lane per sponge
+struct PoseidonConsts {
+    Fq ark[MI_POSEIDON_ROUNDS][3];
+    Fq mds[3][3];
+};
+__device__ __forceinline__ Fq pow17(const Fq &x) {
+    Fq x2 = mul(x, x), x4 = mul(x2, x2), x8 = mul(x4, x4), x16 = mul(x8, x8);
+    return mul(x16, x);
+}
+__device__ __attribute__((noinline)) void poseidon_permute(Fq st[3], const PoseidonConsts *__restrict__ pc) {
+    for (int r = 0; r < MI_POSEIDON_ROUNDS; r++) {
+#pragma unroll
+        for (int i = 0; i < 3; i++) st[i] = add(st[i], pc->ark[r][i]);
+        const bool full = r < MI_POSEIDON_FULL_HALF || r >= MI_POSEIDON_FULL_HALF + MI_POSEIDON_PARTIAL;
+        st[0] = pow17(st[0]);
+        if (full) {  // wave-uniform branch
+            st[1] = pow17(st[1]);
+            st[2] = pow17(st[2]);
+        }
+        Fq o[3];
+#pragma unroll
+        for (int i = 0; i < 3; i++) o[i] = add(add(mul(pc->mds[i][0], st[0]), mul(pc->mds[i][1], st[1])), mul(pc->mds[i][2], st[2]));
+#pragma unroll
+        for (int i = 0; i < 3; i++) st[i] = o[i];
+    }
+}
+__global__ void __launch_bounds__(64) poseidon_hash_many_kernel(const Fq *__restrict__ in, size_t n, size_t m, size_t k,
+                                                                 const PoseidonConsts *__restrict__ pc, Fq *__restrict__ out) {
+    size_t s = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= n) return;
+    Fq st[3] = {Fq::zero(), Fq::zero(), Fq::zero()};
+    const Fq *x = in + s * m;
+    for (size_t i = 0; i < m; i += 2) {
+        st[1] = add(st[1], x[i]);
+        if (i + 1 < m) st[2] = add(st[2], x[i + 1]);
+        poseidon_permute(st, pc);
+    }
+    if (m == 0) poseidon_permute(st, pc);
+    size_t produced = 0;
+    while (produced < k) {
+        out[s * k + produced++] = st[1];
+        if (produced < k) out[s * k + produced++] = st[2];
+        if (produced < k) poseidon_permute(st, pc);
+    }
+}
+static const PoseidonConsts *poseidon_consts(Context &cx, hipStream_t st) {
+    static bool ready = false;
+    PoseidonConsts *d = (PoseidonConsts *)cx.buf("poseidon.consts", sizeof(PoseidonConsts));
+    if (!ready) {
+        static PoseidonConsts h;
+        auto cv = [](const uint64_t *l) {
+            Fq r;
+            for (int i = 0; i < 6; i++) { r.l[2 * i] = (uint32_t)l[i]; r.l[2 * i + 1] = (uint32_t)(l[i] >> 32); }
+            return r;
+        };
+        for (int r = 0; r < MI_POSEIDON_ROUNDS; r++)
+            for (int i = 0; i < 3; i++) h.ark[r][i] = cv(MI_POSEIDON_ARK[r][i]);
+        for (int i = 0; i < 3; i++)
+            for (int j = 0; j < 3; j++) h.mds[i][j] = cv(MI_POSEIDON_MDS[i][j]);
+        MI_HIP(hipMemcpyAsync(d, &h, sizeof h, hipMemcpyHostToDevice, st));
+        MI_HIP(hipStreamSynchronize(st));
+        ready = true;
+    }
+    return d;
+}
+static void poseidon_device(Context &cx, const Fq *d_in, size_t n, size_t m, size_t k, Fq *d_out, hipStream_t st) {
+    const PoseidonConsts *pc = poseidon_consts(cx, st);
+    cx.prof.begin("poseidon", st, n);
+    hipLaunchKernelGGL(poseidon_hash_many_kernel, dim3(cdiv(n, 64)), dim3(64), 0, st, d_in, n, m, k, pc, d_out);
+    cx.prof.end("poseidon", st);
+    MI_HIP(hipGetLastError());
+}
+
 template <class T, class K>
 static int32_t dbg_binary(const T *a, const T *b, T *out, size_t n, K kernel) {
     if (!a || !b || !out) return MI_ERR_BAD_ARGS;
@@ -255,6 +328,28 @@ int32_t mi_kzg_batch_check(const mi_kzg_vk *vk, const mi_g1_affine *comms, const
     if (!vk || !comms || !points || !values || !witnesses || !randomizers128 || !ok_out || n == 0) return MI_ERR_BAD_ARGS;
     return guarded([&]() -> int32_t {
         return kzg_batch_check_host(ctx(), vk, comms, points, values, witnesses, n, randomizers128, ok_out);
+    });
+}
+
+// ------------------------------------------------------------ Poseidon
+int32_t mi_poseidon_fq_hash_many(const mi_fq *inputs, size_t n, size_t m, size_t k, mi_fq *outputs) {
+    if (!n || !k || !outputs || (m && !inputs)) return MI_ERR_BAD_ARGS;
+    return guarded([&]() -> int32_t {
+        Context &cx = ctx();
+        Fq *din = (Fq *)cx.buf("poseidon.in", sizeof(Fq) * n * (m ? m : 1));
+        Fq *dout = (Fq *)cx.buf("poseidon.out", sizeof(Fq) * n * k);
+        if (m) MI_HIP(hipMemcpyAsync(din, inputs, sizeof(Fq) * n * m, hipMemcpyHostToDevice, cx.stream));
+        poseidon_device(cx, din, n, m, k, dout, cx.stream);
+        MI_HIP(hipMemcpyAsync(outputs, dout, sizeof(Fq) * n * k, hipMemcpyDeviceToHost, cx.stream));
+        MI_HIP(hipStreamSynchronize(cx.stream));
+        return MI_OK;
+    });
+}
+int32_t mi_poseidon_fq_hash_many_device(const void *d_inputs, size_t n, size_t m, size_t k, void *d_outputs, void *stream) {
+    if (!n || !k || !d_outputs || (m && !d_inputs)) return MI_ERR_BAD_ARGS;
+    return guarded([&]() -> int32_t {
+        poseidon_device(ctx(), (const Fq *)d_inputs, n, m, k, (Fq *)d_outputs, (hipStream_t)stream);
+        return MI_OK;
     });
 }
 

@@ -28,6 +28,7 @@ EXPORTS = [
     "mi_msm_g1", "mi_msm_g1_device", "mi_bases_register", "mi_bases_release", "mi_msm_g1_h",
     "mi_ntt_fr", "mi_ntt_fr_device",
     "mi_pairing_product_is_one", "mi_pairing", "mi_kzg_batch_check",
+    "mi_poseidon_fq_hash_many", "mi_poseidon_fq_hash_many_device",
     "mi_vs_ctx_create", "mi_vs_ctx_destroy", "mi_vs_verify_batch", "mi_vs_verify_batch_device",
     "mi_vs_accumulate_device", "mi_vs_accumulate_begin", "mi_vs_accumulate_end", "mi_vs_finalize", "mi_vs_finalize_async", "mi_vs_finalize_wait",
     "mi_dbg_fq_mul", "mi_dbg_fr_mul", "mi_dbg_g1_add", "mi_dbg_fq_mul_throughput", "mi_dbg_gen_points_device",
