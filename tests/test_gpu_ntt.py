@@ -56,3 +56,15 @@ def test_ntt_full_size_2_22_vs_oracle(orc, mi):
     f = d.fft(a)
     assert (f == orc.ntt(a, threads=16)).all()
     assert (d.ifft(f) == a).all()
+
+
+@pytest.mark.parametrize("log_n", [11, 12, 13, 14, 15, 17, 18, 19, 20, 21])
+def test_ntt_lds_passes_all_splits(orc, mi, log_n):
+    """every pass-width combination of the LDS-tiled kernel (4..9 bits per pass), all four transform flavours"""
+    n = 1 << log_n
+    a = rng_fr_mont(700 + log_n, n)
+    d = mi.EvaluationDomain(n)
+    for inverse, coset, fn in ((0, 0, d.fft), (1, 0, d.ifft), (0, 1, d.coset_fft), (1, 1, d.coset_ifft)):
+        if log_n > 17 and coset:
+            continue  # the oracle's coset scaling is serial; the coset kernels do not depend on the pass split
+        assert (fn(a) == orc.ntt(a, inverse=bool(inverse), coset=bool(coset), threads=16)).all(), (log_n, inverse, coset)
