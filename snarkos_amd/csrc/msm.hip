@@ -626,12 +626,12 @@ void msm_finish(Context &cx, MsmJob *job, hipStream_t st, mi_g1_jac *out) {
         // balances 9-product doublings against 14-product additions
         const size_t G = job->groups, mid = G - (G * 38) / 100;
         G1Xyzz hi_part;
-        std::thread th([&]() {
+        std::future<void> th = worker_pool().submit([&]() {
             hi_part = fold_bits(h, mid, G);
             for (size_t k = 0; k < mid; k++) hi_part = dbl(hi_part);
         });
         G1Xyzz lo_part = fold_bits(h, 0, mid);
-        th.join();
+        th.get();
         acc = add(hi_part, lo_part);
     } else {
         acc = h[job->nwin - 1];

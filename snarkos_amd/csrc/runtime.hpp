@@ -4,8 +4,14 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <string.h>
+#include <condition_variable>
+#include <deque>
+#include <functional>
+#include <future>
 #include <map>
+#include <memory>
 #include <mutex>
+#include <thread>
 #include <string>
 #include <vector>
 #include "../../include/mi355x_snark.h"
@@ -29,6 +35,57 @@ inline int32_t status_of(const HipError &h) {
     if (h.e == hipErrorOutOfMemory) return MI_ERR_OOM;
     if (h.e == hipErrorNoDevice || h.e == hipErrorInvalidDevice) return MI_ERR_NO_DEVICE;
     return MI_ERR_KERNEL;
+}
+
+// A few persistent host workers for the short host-side folds (spawning a std::thread per fold costs tens of
+// microseconds, several times per batch).  submit() returns a future; tasks must not throw.
+class WorkerPool {
+  public:
+    explicit WorkerPool(int n) {
+        for (int i = 0; i < n; i++)
+            threads_.emplace_back([this] {
+                for (;;) {
+                    std::function<void()> job;
+                    {
+                        std::unique_lock<std::mutex> lk(mu_);
+                        cv_.wait(lk, [this] { return stop_ || !q_.empty(); });
+                        if (stop_ && q_.empty()) return;
+                        job = std::move(q_.front());
+                        q_.pop_front();
+                    }
+                    job();
+                }
+            });
+    }
+    ~WorkerPool() {
+        {
+            std::lock_guard<std::mutex> lk(mu_);
+            stop_ = true;
+        }
+        cv_.notify_all();
+        for (auto &t : threads_) t.join();
+    }
+    std::future<void> submit(std::function<void()> f) {
+        auto task = std::make_shared<std::packaged_task<void()>>(std::move(f));
+        std::future<void> fut = task->get_future();
+        {
+            std::lock_guard<std::mutex> lk(mu_);
+            q_.emplace_back([task] { (*task)(); });
+        }
+        cv_.notify_one();
+        return fut;
+    }
+
+  private:
+    std::vector<std::thread> threads_;
+    std::deque<std::function<void()>> q_;
+    std::mutex mu_;
+    std::condition_variable cv_;
+    bool stop_ = false;
+};
+inline WorkerPool &worker_pool() {
+    static WorkerPool p(4);
+    return p;
 }
 
 // A grow-only device buffer (no hipMalloc on the steady-state path).

@@ -553,7 +553,7 @@ static int32_t vs_accumulate_end_impl(Context &cx, VsCtx &v, uint64_t handle, mi
     // the two host folds (~250 doublings + ~250 additions each) run on two host threads
     int32_t st2 = MI_OK;
     const int dev = cx.device;
-    std::thread fold2([&]() {
+    std::future<void> fold2 = worker_pool().submit([&]() {
         try {
             MI_HIP(hipSetDevice(dev));
             msm_finish(cx, &a.j2, nullptr, &out->total_w);
@@ -566,10 +566,10 @@ static int32_t vs_accumulate_end_impl(Context &cx, VsCtx &v, uint64_t handle, mi
     try {
         msm_finish(cx, &a.j1, a.st, &out->total_c);
     } catch (...) {
-        fold2.join();
+        fold2.get();
         throw;
     }
-    fold2.join();
+    fold2.get();
     if (st2 != MI_OK) return st2;
     uint64_t fails = 0;
     for (size_t i = 0; i < a.n; i++) fails += a.h_alg[i] ? 0 : 1;
