@@ -61,6 +61,9 @@ int32_t mi_abi_version(void);
 /* ---- msm::VariableBase::msm ---- */
 int32_t mi_msm_g1(const mi_g1_affine *bases, const mi_bigint256 *scalars, size_t n, mi_g1_jac *out);
 int32_t mi_msm_g1_device(const void *d_bases, const void *d_scalars, size_t n, mi_g1_jac *out, void *stream);
+/* sum of n partial results (each a normalised output of mi_msm_g1*: z = 1, or z = 0 for infinity): the combine step
+ * of an MSM whose points are split across GPUs; host arithmetic, n is the number of ranks */
+int32_t mi_g1_sum(const mi_g1_jac *partials, size_t n, mi_g1_jac *out);
 /* bases kept resident in HBM (SRS powers, verifying-key commitments) */
 int32_t mi_bases_register(const mi_g1_affine *pts, size_t n, uint64_t *handle_out);
 int32_t mi_bases_release(uint64_t handle);

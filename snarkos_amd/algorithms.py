@@ -45,6 +45,14 @@ class VariableBase:
         L.check(L.lib().mi_msm_g1(L.ptr(bases), L.ptr(scalars), C.c_size_t(n), L.ptr(out)), "mi_msm_g1")
         return out
 
+    @staticmethod
+    def sum_partials(partials):
+        """Add per-rank MSM results ((k, 18) uint64, each as returned by msm): the combine step of a sharded MSM."""
+        partials = np.ascontiguousarray(partials, dtype=np.uint64).reshape(-1, L.G1_JAC_U64)
+        out = np.zeros(L.G1_JAC_U64, dtype=np.uint64)
+        L.check(L.lib().mi_g1_sum(L.ptr(partials), C.c_size_t(len(partials)), L.ptr(out)), "mi_g1_sum")
+        return out
+
 
 class ResidentBases:
     """Bases kept in HBM across calls (SRS powers / verifying-key commitments)."""

@@ -245,6 +245,23 @@ int32_t mi_msm_g1_device(const void *d_bases, const void *d_scalars, size_t n, m
         return MI_OK;
     });
 }
+int32_t mi_g1_sum(const mi_g1_jac *partials, size_t n, mi_g1_jac *out) {
+    if (!out || (n && !partials)) return MI_ERR_BAD_ARGS;
+    return guarded([&]() -> int32_t {
+        G1Xyzz acc = G1Xyzz::inf();
+        const Fq one = Fq::one();
+        for (size_t i = 0; i < n; i++) {
+            G1Jac p;
+            memcpy(&p, &partials[i], sizeof p);
+            if (p.z.is_zero()) continue;
+            if (!(p.z == one)) return MI_ERR_BAD_ARGS;  // not a normalised result
+            acc = add_mixed(acc, G1Affine{p.x, p.y});
+        }
+        G1Jac res = affine_to_jac(to_affine(acc));
+        memcpy(out, &res, sizeof res);
+        return MI_OK;
+    });
+}
 int32_t mi_bases_register(const mi_g1_affine *pts, size_t n, uint64_t *handle_out) {
     if (!pts || !n || !handle_out) return MI_ERR_BAD_ARGS;
     return guarded([&]() -> int32_t {

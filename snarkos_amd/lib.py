@@ -25,7 +25,7 @@ VS_PARTIAL_BYTES = 304
 # every symbol include/mi355x_snark.h declares
 EXPORTS = [
     "mi_init", "mi_shutdown", "mi_error_string", "mi_abi_version",
-    "mi_msm_g1", "mi_msm_g1_device", "mi_bases_register", "mi_bases_release", "mi_msm_g1_h",
+    "mi_msm_g1", "mi_msm_g1_device", "mi_g1_sum", "mi_bases_register", "mi_bases_release", "mi_msm_g1_h",
     "mi_ntt_fr", "mi_ntt_fr_device",
     "mi_pairing_product_is_one", "mi_pairing", "mi_kzg_batch_check",
     "mi_poseidon_fq_hash_many", "mi_poseidon_fq_hash_many_device",

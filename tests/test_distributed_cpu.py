@@ -46,3 +46,7 @@ def test_sharded_valid_batch(world):
 
 def test_sharded_batch_with_a_bad_proof():
     _run(2, 13)  # the corrupted proof lands in rank 1's shard; both ranks must reject
+
+
+def test_sharded_msm():
+    _run(3, -2)  # points split 101/100/100 across three ranks, 144-byte partial sums all-gathered

@@ -107,3 +107,29 @@ def test_msm_skewed_scalars_large(orc, mi):
     scalars = three[np.arange(n) % 3]
     got = jac_affine(mi.VariableBase.msm(bases, np.ascontiguousarray(scalars)))
     assert (got == orc.msm_pippenger(bases, np.ascontiguousarray(scalars), threads=16)).all()
+
+
+def test_msm_points_split_across_ranks(orc, mi):
+    """one MSM with its points cut into shards (here: three 'ranks' on one GPU, uneven, one of them
+    empty-handed), partial sums combined by mi_g1_sum: bit-exact with the unsharded MSM and with the oracle."""
+    from snarkos_amd import sharding
+    n = 5000
+    bases, scalars = rng_points(31, n), rng_scalars(32, n)
+    parts = []
+    for r in range(3):
+        lo, hi = sharding.shard_bounds(n, 3, r)
+        parts.append(mi.VariableBase.msm(bases[lo:hi], scalars[lo:hi]))
+    parts.append(mi.VariableBase.msm(bases[:0], scalars[:0]))           # infinity partial
+    neg = bases[:1].copy(); neg[0, 6:] = orc.fq_from_int((-orc.fq_to_int(bases[0, 6:])) % __import__("pyref").Q)
+    parts.append(mi.VariableBase.msm(bases[:1], scalars[:1]))           # P and -P: cancel
+    parts.append(mi.VariableBase.msm(neg, scalars[:1]))
+    got = jac_affine(mi.VariableBase.sum_partials(np.stack(parts)))
+    assert (got == jac_affine(mi.VariableBase.msm(bases, scalars))).all()
+    assert (got == orc.msm_pippenger(bases, scalars, threads=8)).all()
+    # doubling inside the sum (the same partial twice) and the empty sum
+    twice = jac_affine(mi.VariableBase.sum_partials(np.stack([parts[0], parts[0]])))
+    assert (twice == orc.g1_add_affine(jac_affine(parts[0]), jac_affine(parts[0]))).all()
+    assert not jac_affine(mi.VariableBase.sum_partials(np.zeros((0, 18), dtype=np.uint64))).any()
+    # the protocol object, world = 1
+    whole = sharding.msm_sharded(bases, scalars, mi.VariableBase.msm, mi.VariableBase.sum_partials)
+    assert (jac_affine(whole) == got).all()
