@@ -23,9 +23,9 @@ import os
 import sys
 import time
 
-# streams of this process (torch's, the library's two, one per in-flight pairing product) should not share
+# streams of this process (torch's, 8 accumulation lanes, 8 in-flight pairing products) should not share
 # hardware queues: a 3 ms pairing kernel must not sit in front of the next batch's MSM kernels
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "32")
 
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
@@ -63,10 +63,12 @@ def sync_all(dist_on):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-extra", action="store_true", help="skip the MSM / NTT / corrupted-batch side measurements")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--acc-depth", type=int, default=8, help="batches accumulating on the GPU before the oldest is folded (<= 8)")
+    ap.add_argument("--products", type=int, default=8, help="pairing products in flight (<= 8)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for rehearsals on one GPU)")
     args = ap.parse_args()
 
@@ -100,7 +102,7 @@ def main():
     gather = (lambda part: sharding.gather_partials(part, torch.distributed, gather_dev)) if dist_on else None
 
     def run(k):
-        oks = list(verifier.verify_stream(((d_proofs, d_rnd) for _ in range(k)), gather))
+        oks = list(verifier.verify_stream(((d_proofs, d_rnd) for _ in range(k)), gather, depth=args.products, acc_depth=args.acc_depth))
         assert len(oks) == k and all(oks), "synthetic batch must verify"
 
     if args.warmup:

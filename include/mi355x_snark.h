@@ -115,7 +115,8 @@ int32_t mi_vs_finalize(uint64_t ctx, const mi_vs_partial *partials, size_t n_par
  * batch i+1 (VM::check_transactions walks a block in chunks of <= 1000 executions; mempool admission streams).
  * At most 4 tickets may be outstanding; tickets must be waited for in any order before the context is destroyed. */
 /* split accumulate: _begin enqueues the shard's kernels and returns at once, _end waits and folds on the host.
- * Two may be open at a time, so batch k+1 runs on the GPU while batch k is folded and finalised. */
+ * Up to 4 may be open at a time (each has its own stream pair and workspaces), so the next batches run on the GPU
+ * while batch k is folded and finalised. */
 int32_t mi_vs_accumulate_begin(uint64_t ctx, const void *d_proofs, size_t n, const void *d_randomizers128, void *stream,
                                uint64_t *handle_out);
 int32_t mi_vs_accumulate_end(uint64_t ctx, uint64_t handle, mi_vs_partial *partial_out);

@@ -265,31 +265,75 @@ class VarunaShaped:
         L.check(L.lib().mi_vs_finalize_wait(C.c_uint64(self.ctx), C.c_uint64(ticket), L.ptr(ok)), "mi_vs_finalize_wait")
         return bool(ok[0])
 
-    def verify_stream(self, batches, gather=None, depth=4):
+    def verify_stream(self, batches, gather=None, depth=8, acc_depth=8):
         """Pipelined verification of a stream of batches (chunks of a block, or mempool traffic): yields all_ok per
-        batch, in order.  Up to `depth` (<= 4) pairing products are in flight, each on its own stream, while the
-        following batches are accumulated.  `batches` yields (proofs_cuda, randomizers_cuda); `gather` (optional)
-        maps this rank's partial to the list of all ranks' partials (multi-GPU)."""
-        pending = []
-        depth = max(1, min(depth, 4))
+        batch, in order.
 
-        def close(handle):  # fold batch `handle`, exchange partials, start its pairing product
-            part = self.accumulate_end(handle)
-            parts = gather(part) if gather is not None else [part]
-            pending.append(self.finalize_async(parts))
+        Two host threads drive the GPU: the caller's enqueues batch k (derive + both MSMs on one of `acc_depth` <= 8
+        stream lanes) while a closer thread folds batch k-1.. on the host, exchanges partials (`gather`, optional:
+        maps this rank's partial to the list of all ranks' partials -- every collective is issued from that one
+        thread, in batch order) and starts its pairing product; up to `depth` (<= 8) products are in flight, each
+        on its own stream.  `batches` yields (proofs_cuda, randomizers_cuda).  The library's entry points drop the
+        context lock around their host-side waits and folds, so the two threads overlap.
+        """
+        import queue
+        import threading
 
-        prev = None
-        for proofs, rnd in batches:
-            cur = self.accumulate_begin(proofs, rnd)  # batch k+1 on the GPU ...
-            if prev is not None:
-                close(prev)                           # ... while batch k is folded on the host
-                if len(pending) >= depth:
-                    yield self.finalize_wait(pending.pop(0))
-            prev = cur
-        if prev is not None:
-            close(prev)
-        while pending:
-            yield self.finalize_wait(pending.pop(0))
+        depth = max(1, min(depth, 8))
+        acc_depth = max(1, min(acc_depth, 8))
+        lanes = threading.Semaphore(acc_depth)
+        handles, results = queue.Queue(), queue.Queue()
+        END = object()
+
+        def closer():
+            pending = []
+            try:
+                while True:
+                    h = handles.get()
+                    if h is END:
+                        break
+                    part = self.accumulate_end(h)         # wait for the GPU, fold on the host
+                    lanes.release()
+                    parts = gather(part) if gather is not None else [part]
+                    if len(pending) >= depth:
+                        results.put(self.finalize_wait(pending.pop(0)))
+                    pending.append(self.finalize_async(parts))
+                while pending:
+                    results.put(self.finalize_wait(pending.pop(0)))
+                results.put(END)
+            except BaseException as e:  # surfaced by the generator
+                lanes.release()
+                results.put(e)
+
+        th = threading.Thread(target=closer, name="mi-snark-closer", daemon=True)
+        th.start()
+        failed = None
+        try:
+            for proofs, rnd in batches:
+                lanes.acquire()
+                handles.put(self.accumulate_begin(proofs, rnd))
+                while True:
+                    try:
+                        r = results.get_nowait()
+                    except queue.Empty:
+                        break
+                    if isinstance(r, BaseException):
+                        failed = r
+                        raise r
+                    yield r
+            handles.put(END)
+            while True:
+                r = results.get()
+                if r is END:
+                    break
+                if isinstance(r, BaseException):
+                    failed = r
+                    raise r
+                yield r
+        finally:
+            if failed is None and th.is_alive():
+                handles.put(END)
+            th.join(timeout=60)
 
     def finalize(self, partials):
         parts = np.ascontiguousarray(partials, dtype=np.uint8).reshape(-1, L.VS_PARTIAL_BYTES)

@@ -15,15 +15,17 @@ struct PairingConsts;
 // scalar_bits bounds the scalars (254 = any canonical Fr, 128 = randomizers).
 struct G1Xyzz;
 struct MsmJob {
-    size_t n = 0, groups = 0;
+    size_t n = 0, groups = 0;  // groups: sums per problem
     int c = 0, nwin = 0;
+    int problems = 1;  // 2: two MSMs sharing one launch sequence (msm_enqueue's split), h holds problems * groups sums
     bool per_bit = false;
     G1Xyzz *h = nullptr;  // pinned host copy of the window / bit sums
     hipEvent_t done = nullptr;  // recorded after the copy into h
 };
 void msm_enqueue(Context &cx, const G1Affine *d_points, const uint32_t *d_scalars, size_t n, hipStream_t st, int scalar_bits,
-                 int slot, MsmJob *job, int force_c = 0, int pin_parity = 0);
-void msm_finish(Context &cx, MsmJob *job, hipStream_t st, mi_g1_jac *out);
+                 int slot, MsmJob *job, int force_c = 0, int pin_parity = 0, size_t split = 0);
+// out_b: the second problem's result when the job was enqueued with a split
+void msm_finish(Context &cx, MsmJob *job, hipStream_t st, mi_g1_jac *out, mi_g1_jac *out_b = nullptr);
 void msm_release_graphs();
 void msm_device(Context &cx, const G1Affine *d_points, const uint32_t *d_scalars, size_t n, mi_g1_jac *out,
                 hipStream_t st, int scalar_bits = 254, int force_c = 0);

@@ -50,11 +50,13 @@ static MsmPlan msm_plan(size_t n, int scalar_bits, int force_c) {
 template <int C, int BITS>
 __global__ void __launch_bounds__(256) msm_digits_kernel(const uint32_t *__restrict__ scalars, size_t n,
                                                          int32_t *__restrict__ digits, uint32_t *__restrict__ ranks,
-                                                         uint32_t *__restrict__ counts) {
+                                                         uint32_t *__restrict__ counts_all, size_t split) {
     constexpr int NWIN = (BITS + C - 1) / C;
     constexpr uint32_t B = 1u << (C - 1);
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
+    // two problems in one launch: points [split, n) use a second set of NWIN windows (buckets NWIN*B ...)
+    uint32_t *__restrict__ counts = counts_all + (i >= split ? (size_t)NWIN * B : 0);
     const uint4 *sp = reinterpret_cast<const uint4 *>(scalars + i * 8);
     uint4 lo = sp[0], hi = sp[1];
     uint32_t s[9] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w, 0u};
@@ -158,12 +160,14 @@ __global__ void __launch_bounds__(256) scan_finish_kernel(uint32_t *__restrict__
 // ---------------------------------------------------------------- K3: scatter indices into bucket order
 __global__ void __launch_bounds__(256) msm_scatter_kernel(const int32_t *__restrict__ digits,
                                                           const uint32_t *__restrict__ ranks, size_t n, int nwin, uint32_t B,
-                                                          const uint32_t *__restrict__ offsets, uint32_t *__restrict__ sorted) {
+                                                          const uint32_t *__restrict__ offsets, uint32_t *__restrict__ sorted,
+                                                          size_t split) {
     size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= n * (size_t)nwin) return;
     int32_t d = digits[t];
     if (d == 0) return;
     size_t w = t / n, i = t - w * n;
+    if (i >= split) w += nwin;  // second problem: its own windows
     uint32_t mag = d < 0 ? (uint32_t)(-d) : (uint32_t)d;
     uint32_t pos = offsets[w * B + (mag - 1)] + ranks[t];
     sorted[pos] = ((uint32_t)i << 1) | (d < 0 ? 1u : 0u);
@@ -177,6 +181,48 @@ __device__ __forceinline__ G1Xyzz xyzz_add_ni(const G1Xyzz &a, const G1Xyzz &b) 
 // A bucket with more than T entries is cut into ceil(count / T) chunks, one lane each; the top window of a
 // 253-bit scalar has few distinct digits, and a skewed scalar distribution can put most points into a handful
 // of buckets, so lane-per-bucket would leave one lane walking thousands of points.
+// Small MSMs: ONE workgroup turns the bucket histogram into everything the later kernels index by -- bucket offsets
+// (exclusive scan of counts), chunk offsets (exclusive scan of ceil(count / T)) -- and clears the histogram for the
+// next MSM in this workspace.  Replaces 2 memsets + 8 launches of the general path: a 10 k-point MSM is bound by
+// launch latency, not by work.
+__global__ void __launch_bounds__(1024) msm_plan_small_kernel(uint32_t *__restrict__ counts, size_t nb, uint32_t T,
+                                                              uint32_t *__restrict__ offsets, uint32_t *__restrict__ chunk_off) {
+    __shared__ uint32_t w1[16], w2[16];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const size_t per = (nb + 1023) / 1024;
+    size_t lo = (size_t)threadIdx.x * per, hi = lo + per;
+    if (lo > nb) lo = nb;
+    if (hi > nb) hi = nb;
+    uint32_t s1 = 0, s2 = 0;
+    for (size_t b = lo; b < hi; b++) {
+        const uint32_t c = counts[b];
+        s1 += c;
+        s2 += (c + T - 1) / T;
+    }
+    const uint32_t i1 = wave_incl_scan(s1, lane), i2 = wave_incl_scan(s2, lane);
+    if (lane == 63) {
+        w1[wave] = i1;
+        w2[wave] = i2;
+    }
+    __syncthreads();
+    uint32_t o1 = i1 - s1, o2 = i2 - s2;
+    for (int k = 0; k < wave; k++) {
+        o1 += w1[k];
+        o2 += w2[k];
+    }
+    for (size_t b = lo; b < hi; b++) {
+        const uint32_t c = counts[b];
+        offsets[b] = o1;
+        chunk_off[b] = o2;
+        o1 += c;
+        o2 += (c + T - 1) / T;
+        counts[b] = 0;
+    }
+    if (threadIdx.x == 1023) {  // its range is the last (possibly empty) one: o1 / o2 are the grand totals
+        offsets[nb] = o1;
+        chunk_off[nb] = o2;
+    }
+}
 __global__ void __launch_bounds__(256) msm_chunk_count_kernel(const uint32_t *__restrict__ counts, size_t nb, uint32_t T,
                                                               uint32_t *__restrict__ nchunks) {
     size_t b = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -248,13 +294,26 @@ __global__ void __launch_bounds__(128) msm_accumulate_kernel(const G1Affine *__r
                                                              const uint32_t *__restrict__ sorted,
                                                              const uint32_t *__restrict__ offsets,
                                                              const uint32_t *__restrict__ chunk_off,
-                                                             const uint32_t *__restrict__ chunk_bucket,
+                                                             uint32_t *__restrict__ chunk_bucket,
                                                              const uint32_t *__restrict__ order, size_t nb,
-                                                             uint32_t T, G1Xyzz *__restrict__ chunk_partial) {
+                                                             uint32_t T, G1Xyzz *__restrict__ chunk_partial, int find_bucket) {
     size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= chunk_off[nb]) return;
     if (order) t = order[t];
-    const uint32_t b = chunk_bucket[t];
+    uint32_t b;
+    if (find_bucket) {
+        // small path: no chunk map was built; bisect chunk_off (chunk_off[b] <= t < chunk_off[b + 1]) and record the
+        // bucket for the reduction kernel
+        uint32_t lo = 0, hi = (uint32_t)nb;
+        while (hi - lo > 1) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if (chunk_off[mid] <= (uint32_t)t) lo = mid; else hi = mid;
+        }
+        b = lo;
+        chunk_bucket[t] = b;
+    } else {
+        b = chunk_bucket[t];
+    }
     uint32_t k = offsets[b] + ((uint32_t)t - chunk_off[b]) * T;
     uint32_t end = offsets[b + 1];
     if (end - k > T) end = k + T;
@@ -357,36 +416,54 @@ __global__ void __launch_bounds__(256) point_tree_sum_kernel(const G1Xyzz *__res
 // g = w * c + bit (which is also the bit position of 2^(c w + bit) in the scalar) sums, straight from the chunk
 // partials of window w, those whose bucket magnitude has `bit` set: log depth instead of a running sum, at
 // c/2 times the additions -- the right trade when the whole MSM is latency bound (n <= 2^17).
-__global__ void __launch_bounds__(256) msm_bit_sums_kernel(const G1Xyzz *__restrict__ chunk_partial,
-                                                           const uint32_t *__restrict__ chunk_off,
-                                                           const uint32_t *__restrict__ chunk_bucket, uint32_t B, int c,
-                                                           G1Xyzz *__restrict__ out) {
-    __shared__ G1Xyzz lds[128];
-    const uint32_t g = blockIdx.y, w = g / (uint32_t)c, bit = g - w * (uint32_t)c;
+// One WAVE per group (window, bit): every lane walks its stride class of the window's chunk list, skipping entries
+// whose bucket magnitude lacks the bit without holding the other lanes up (the wave only synchronises on additions),
+// then 6 shuffle levels.  A quarter of the waves of the 256-lane version and no barrier: the whole verifier is bound
+// by wave-slots x time of this reduction, not by its latency.  `out` may be pinned host memory (results go straight
+// to the folding thread, no copy kernel).
+__device__ __forceinline__ G1Xyzz xyzz_shfl_down(const G1Xyzz &a, int delta) {
+    G1Xyzz r;
+    const Fq *src[4] = {&a.x, &a.y, &a.zz, &a.zzz};
+    Fq *dst[4] = {&r.x, &r.y, &r.zz, &r.zzz};
+#pragma unroll
+    for (int q = 0; q < 4; q++)
+#pragma unroll
+        for (int k = 0; k < 12; k++) dst[q]->l[k] = __shfl_down(src[q]->l[k], delta, 64);
+    return r;
+}
+__global__ void __launch_bounds__(64) msm_bit_sums_wave_kernel(const G1Xyzz *__restrict__ chunk_partial,
+                                                               const uint32_t *__restrict__ chunk_off,
+                                                               const uint32_t *__restrict__ chunk_bucket, uint32_t B, int c,
+                                                               G1Xyzz *__restrict__ out) {
+    const uint32_t g = blockIdx.x, w = g / (uint32_t)c, bit = g - w * (uint32_t)c;
     const uint32_t lo = chunk_off[(size_t)w * B], hi = chunk_off[(size_t)(w + 1) * B];
-    const int t = threadIdx.x;
+    const int lane = threadIdx.x;
     G1Xyzz acc = G1Xyzz::inf();
-    for (uint32_t e = lo + blockIdx.x * 256 + t; e < hi; e += gridDim.x * 256) {
-        const uint32_t mag = chunk_bucket[e] - w * B + 1;
-        if ((mag >> bit) & 1u) acc = xyzz_add_ni(acc, load_xyzz(&chunk_partial[e]));
+    uint32_t e = lo + lane;
+    for (;;) {
+        while (e < hi && !(((chunk_bucket[e] - w * B + 1) >> bit) & 1u)) e += 64;
+        if (__ballot(e < hi) == 0ull) break;
+        if (e < hi) {
+            acc = xyzz_add_ni(acc, load_xyzz(&chunk_partial[e]));
+            e += 64;
+        }
     }
-    for (int stride = 128; stride >= 1; stride >>= 1) {
-        if (t >= stride && t < 2 * stride) store_xyzz(&lds[t - stride], acc);
-        __syncthreads();
-        if (t < stride) acc = xyzz_add_ni(acc, load_xyzz(&lds[t]));
-        __syncthreads();
+#pragma unroll 1
+    for (int stride = 32; stride >= 1; stride >>= 1) {
+        G1Xyzz other = xyzz_shfl_down(acc, stride);
+        if (lane < stride) acc = xyzz_add_ni(acc, other);
     }
-    if (t == 0) store_xyzz(&out[(size_t)g * gridDim.x + blockIdx.x], acc);
+    if (lane == 0) store_xyzz(&out[g], acc);
 }
 
 // ---------------------------------------------------------------- host driver
 template <int C>
 static void launch_digits(const uint32_t *scalars, size_t n, int32_t *digits, uint32_t *ranks, uint32_t *counts,
-                          int scalar_bits, hipStream_t st) {
+                          int scalar_bits, size_t split, hipStream_t st) {
     if (scalar_bits > 128)
-        hipLaunchKernelGGL((msm_digits_kernel<C, 254>), dim3(cdiv(n, 256)), dim3(256), 0, st, scalars, n, digits, ranks, counts);
+        hipLaunchKernelGGL((msm_digits_kernel<C, 254>), dim3(cdiv(n, 256)), dim3(256), 0, st, scalars, n, digits, ranks, counts, split);
     else
-        hipLaunchKernelGGL((msm_digits_kernel<C, 129>), dim3(cdiv(n, 256)), dim3(256), 0, st, scalars, n, digits, ranks, counts);
+        hipLaunchKernelGGL((msm_digits_kernel<C, 129>), dim3(cdiv(n, 256)), dim3(256), 0, st, scalars, n, digits, ranks, counts, split);
 }
 
 // Sum groups of XYZZ points on the device: in[groups][m] -> result[groups] (device pointer into workspace)
@@ -406,12 +483,24 @@ static G1Xyzz *device_group_sum(Context &cx, G1Xyzz *in, size_t groups, size_t m
     return cur;
 }
 
+struct CleanMark {
+    uint64_t gen = 0;
+    size_t nb = 0;
+    const void *p = nullptr;
+};
+static std::map<int, CleanMark> &clean_marks() {
+    static std::map<int, CleanMark> m;
+    return m;
+}
+
 // Enqueue the whole device pipeline of one MSM on `st` (no host synchronisation); `slot` names the workspace set,
 // so two MSMs with different slots may run on two streams at once.  msm_finish() waits and folds on the host.
 static void msm_enqueue_eager(Context &cx, const G1Affine *d_points, const uint32_t *d_scalars, size_t n, hipStream_t st,
-                              int scalar_bits, int slot, MsmJob *job, int force_c, int pin_parity, bool record_done) {
+                              int scalar_bits, int slot, MsmJob *job, int force_c, int pin_parity, bool record_done,
+                              size_t split) {
     job->n = n;
     job->groups = 0;
+    job->problems = 1;
     if (n == 0) return;
     char ws[32];
     auto W = [&](const char *name) {
@@ -421,56 +510,78 @@ static void msm_enqueue_eager(Context &cx, const G1Affine *d_points, const uint3
     MsmPlan pl = msm_plan(n, scalar_bits, force_c);
     job->c = pl.c;
     job->nwin = pl.nwin;
+    // A small MSM is latency bound (one mixed addition is ~10k instructions; its ~17 dependent launches cost more
+    // than their work): it takes short chunks, one fused planning kernel and the log-depth reduction below.
+    const bool small = n <= ((size_t)1 << 16);
+    const int problems = (split > 0 && split < n) ? 2 : 1;
+    if (problems == 2 && !small) throw HipError{hipErrorInvalidValue, "msm split needs n <= 2^16", __LINE__};
+    if (problems == 1) split = n;
+    job->problems = problems;
     cx.prof.begin("msm_total", st, n);
-    const size_t nb = (size_t)pl.nwin * pl.B;
+    const size_t nb = (size_t)problems * pl.nwin * pl.B;  // all buckets (both problems' windows)
+    const int vwin = problems * pl.nwin;
     int32_t *digits = (int32_t *)cx.buf(W("digits"), sizeof(int32_t) * n * pl.nwin);
     uint32_t *sorted = (uint32_t *)cx.buf(W("sorted"), sizeof(uint32_t) * n * pl.nwin);
-    uint32_t *counts = (uint32_t *)cx.buf(W("counts"), sizeof(uint32_t) * nb);
+    DevBuf &counts_buf = cx.bufs[W("counts")];
+    uint32_t *counts = (uint32_t *)counts_buf.get(sizeof(uint32_t) * nb);
     uint32_t *offsets = (uint32_t *)cx.buf(W("offsets"), sizeof(uint32_t) * (nb + 1));
     uint32_t *ranks = (uint32_t *)cx.buf(W("ranks"), sizeof(uint32_t) * n * pl.nwin);
     const unsigned tiles = cdiv(nb, 2048);
     uint32_t *tile_sums = (uint32_t *)cx.buf(W("tiles"), sizeof(uint32_t) * tiles);
 
-    MI_HIP(hipMemsetAsync(counts, 0, sizeof(uint32_t) * nb, st));
+    // the small path's planning kernel leaves the histogram cleared: skip the memset when this workspace's last
+    // user was that kernel, on the same allocation, over at least as many buckets
+    CleanMark &mark = clean_marks()[slot];
+    const bool clean = small && mark.gen == counts_buf.gen && mark.nb >= nb && mark.p == counts;
+    mark = CleanMark();
+    if (!clean) MI_HIP(hipMemsetAsync(counts, 0, sizeof(uint32_t) * nb, st));
+    HostSpan hs_launch("msm.launches");
     cx.prof.begin("msm_digits", st, n);
     switch (pl.c) {
-#define MI_CASE(C) case C: launch_digits<C>(d_scalars, n, digits, ranks, counts, scalar_bits, st); break;
+#define MI_CASE(C) case C: launch_digits<C>(d_scalars, n, digits, ranks, counts, scalar_bits, split, st); break;
         MI_CASE(6) MI_CASE(7) MI_CASE(8) MI_CASE(9) MI_CASE(10) MI_CASE(11) MI_CASE(12) MI_CASE(13) MI_CASE(14) MI_CASE(15) MI_CASE(16)
 #undef MI_CASE
     }
     cx.prof.end("msm_digits", st);
-    cx.prof.begin("msm_scan", st, n);
-    hipLaunchKernelGGL(scan_tiles_kernel, dim3(tiles), dim3(256), 0, st, counts, offsets, tile_sums, nb);
-    hipLaunchKernelGGL(scan_sums_kernel, dim3(1), dim3(1024), 0, st, tile_sums, (size_t)tiles);
-    hipLaunchKernelGGL(scan_finish_kernel, dim3(tiles), dim3(256), 0, st, offsets, (uint32_t *)nullptr, tile_sums, counts, nb);
-    cx.prof.end("msm_scan", st);
-    cx.prof.begin("msm_scatter", st, n);
-    hipLaunchKernelGGL(msm_scatter_kernel, dim3(cdiv(n * pl.nwin, 256)), dim3(256), 0, st, digits, ranks, n, pl.nwin, pl.B, offsets, sorted);
-    cx.prof.end("msm_scatter", st);
-    // chunking: T = twice the mean bucket load of a full window, so only over-full buckets are split.  A small MSM
-    // is latency bound (one mixed addition is ~10k instructions), so it takes short chunks and the log-depth
-    // reduction below instead.
-    const bool small = n <= ((size_t)1 << 16);
+    // chunking: T = twice the mean bucket load of a full window, so only over-full buckets are split
     uint32_t T = (uint32_t)(2 * ((n + pl.B - 1) / pl.B));
     if (T < 16) T = 16;
-    if (small) T = 8;
+    if (small) T = 16;
     const uint32_t HEAVY = 8;
     const size_t max_chunks = nb + (n * (size_t)pl.nwin) / T + 1;
-    uint32_t *nchunks = (uint32_t *)cx.buf(W("nchunks"), sizeof(uint32_t) * nb);
     uint32_t *chunk_off = (uint32_t *)cx.buf(W("chunk_off"), sizeof(uint32_t) * (nb + 1));
     uint32_t *chunk_bucket = (uint32_t *)cx.buf(W("chunk_bucket"), sizeof(uint32_t) * max_chunks);
-    uint32_t *heavy_list = (uint32_t *)cx.buf(W("heavy"), sizeof(uint32_t) * (nb + 1));
-    uint32_t *heavy_count = heavy_list + nb;
     G1Xyzz *chunk_partial = (G1Xyzz *)cx.buf(W("chunk_partial"), sizeof(G1Xyzz) * max_chunks);
-    cx.prof.begin("msm_chunks", st, n);
-    MI_HIP(hipMemsetAsync(heavy_count, 0, sizeof(uint32_t), st));
-    hipLaunchKernelGGL(msm_chunk_count_kernel, dim3(cdiv(nb, 256)), dim3(256), 0, st, counts, nb, T, nchunks);
-    hipLaunchKernelGGL(scan_tiles_kernel, dim3(tiles), dim3(256), 0, st, nchunks, chunk_off, tile_sums, nb);
-    hipLaunchKernelGGL(scan_sums_kernel, dim3(1), dim3(1024), 0, st, tile_sums, (size_t)tiles);
-    hipLaunchKernelGGL(scan_finish_kernel, dim3(tiles), dim3(256), 0, st, chunk_off, (uint32_t *)nullptr, tile_sums, nchunks, nb);
-    hipLaunchKernelGGL(msm_chunk_map_kernel, dim3(cdiv(nb, 256)), dim3(256), 0, st, chunk_off, nb, chunk_bucket, HEAVY, heavy_list, heavy_count);
-    uint32_t *order = nullptr;
-    if (!small) {
+    uint32_t *heavy_list = nullptr, *heavy_count = nullptr, *order = nullptr;
+    if (small) {
+        cx.prof.begin("msm_scan", st, n);
+        hipLaunchKernelGGL(msm_plan_small_kernel, dim3(1), dim3(1024), 0, st, counts, nb, T, offsets, chunk_off);
+        cx.prof.end("msm_scan", st);
+        mark.gen = counts_buf.gen;
+        mark.nb = nb;
+        mark.p = counts;
+        cx.prof.begin("msm_scatter", st, n);
+        hipLaunchKernelGGL(msm_scatter_kernel, dim3(cdiv(n * pl.nwin, 256)), dim3(256), 0, st, digits, ranks, n, pl.nwin, pl.B, offsets, sorted, split);
+        cx.prof.end("msm_scatter", st);
+    } else {
+        cx.prof.begin("msm_scan", st, n);
+        hipLaunchKernelGGL(scan_tiles_kernel, dim3(tiles), dim3(256), 0, st, counts, offsets, tile_sums, nb);
+        hipLaunchKernelGGL(scan_sums_kernel, dim3(1), dim3(1024), 0, st, tile_sums, (size_t)tiles);
+        hipLaunchKernelGGL(scan_finish_kernel, dim3(tiles), dim3(256), 0, st, offsets, (uint32_t *)nullptr, tile_sums, counts, nb);
+        cx.prof.end("msm_scan", st);
+        cx.prof.begin("msm_scatter", st, n);
+        hipLaunchKernelGGL(msm_scatter_kernel, dim3(cdiv(n * pl.nwin, 256)), dim3(256), 0, st, digits, ranks, n, pl.nwin, pl.B, offsets, sorted, split);
+        cx.prof.end("msm_scatter", st);
+        uint32_t *nchunks = (uint32_t *)cx.buf(W("nchunks"), sizeof(uint32_t) * nb);
+        heavy_list = (uint32_t *)cx.buf(W("heavy"), sizeof(uint32_t) * (nb + 1));
+        heavy_count = heavy_list + nb;
+        cx.prof.begin("msm_chunks", st, n);
+        MI_HIP(hipMemsetAsync(heavy_count, 0, sizeof(uint32_t), st));
+        hipLaunchKernelGGL(msm_chunk_count_kernel, dim3(cdiv(nb, 256)), dim3(256), 0, st, counts, nb, T, nchunks);
+        hipLaunchKernelGGL(scan_tiles_kernel, dim3(tiles), dim3(256), 0, st, nchunks, chunk_off, tile_sums, nb);
+        hipLaunchKernelGGL(scan_sums_kernel, dim3(1), dim3(1024), 0, st, tile_sums, (size_t)tiles);
+        hipLaunchKernelGGL(scan_finish_kernel, dim3(tiles), dim3(256), 0, st, chunk_off, (uint32_t *)nullptr, tile_sums, nchunks, nb);
+        hipLaunchKernelGGL(msm_chunk_map_kernel, dim3(cdiv(nb, 256)), dim3(256), 0, st, chunk_off, nb, chunk_bucket, HEAVY, heavy_list, heavy_count);
         order = (uint32_t *)cx.buf(W("order"), sizeof(uint32_t) * max_chunks);
         uint32_t *lhist = (uint32_t *)cx.buf(W("lenhist"), sizeof(uint32_t) * 2 * (T + 1));
         uint32_t *lcursor = lhist + (T + 1);
@@ -480,11 +591,11 @@ static void msm_enqueue_eager(Context &cx, const G1Affine *d_points, const uint3
         hipLaunchKernelGGL(msm_len_scan_kernel, dim3(1), dim3(64), 0, st, lhist, T, lcursor);
         hipLaunchKernelGGL(msm_len_scatter_kernel, dim3(cdiv(max_chunks, 256)), dim3(256), sizeof(uint32_t) * 2 * (T + 1), st,
                            offsets, chunk_off, chunk_bucket, nb, T, lcursor, order);
+        cx.prof.end("msm_chunks", st);
     }
-    cx.prof.end("msm_chunks", st);
     cx.prof.begin("msm_accumulate", st, n);
     hipLaunchKernelGGL(msm_accumulate_kernel, dim3(cdiv(max_chunks, 128)), dim3(128), 0, st, d_points, sorted, offsets, chunk_off,
-                       chunk_bucket, order, nb, T, chunk_partial);
+                       chunk_bucket, order, nb, T, chunk_partial, small ? 1 : 0);
     cx.prof.end("msm_accumulate", st);
     G1Xyzz *result;
     char ta[32], tb[32];
@@ -492,16 +603,17 @@ static void msm_enqueue_eager(Context &cx, const G1Affine *d_points, const uint3
     snprintf(tb, sizeof tb, "msm%d.tree_b", slot);
     if (small) {
         // per-bit subset sums straight from the chunk partials; the host walks the bit positions (Horner)
-        job->groups = (size_t)pl.nwin * pl.c;
+        job->groups = (size_t)pl.nwin * pl.c;  // per problem
         job->per_bit = true;
-        const size_t per_win = pl.B + n / T + 1;
-        unsigned bx = (unsigned)((per_win + 2047) / 2048);
-        G1Xyzz *bits0 = (G1Xyzz *)cx.buf(W("bits0"), sizeof(G1Xyzz) * job->groups * bx);
+        const size_t all_groups = (size_t)vwin * pl.c;
+        char pn[32];
+        snprintf(pn, sizeof pn, "msm%d.pin%d", slot, pin_parity);
+        job->h = (G1Xyzz *)cx.pin_named(pn, sizeof(G1Xyzz) * all_groups);
         cx.prof.begin("msm_bitsums", st, n);
-        hipLaunchKernelGGL(msm_bit_sums_kernel, dim3(bx, (unsigned)job->groups), dim3(256), 0, st, chunk_partial, chunk_off,
-                           chunk_bucket, pl.B, pl.c, bits0);
-        result = device_group_sum(cx, bits0, job->groups, bx, st, ta, tb);
+        hipLaunchKernelGGL(msm_bit_sums_wave_kernel, dim3((unsigned)all_groups), dim3(64), 0, st, chunk_partial, chunk_off,
+                           chunk_bucket, pl.B, pl.c, job->h);  // straight into pinned host memory
         cx.prof.end("msm_bitsums", st);
+        result = nullptr;
     } else {
         G1Xyzz *buckets = (G1Xyzz *)cx.buf(W("buckets"), sizeof(G1Xyzz) * nb);
         cx.prof.begin("msm_combine", st, n);
@@ -524,8 +636,10 @@ static void msm_enqueue_eager(Context &cx, const G1Affine *d_points, const uint3
     cx.prof.end("msm_total", st);
     char pn[32];
     snprintf(pn, sizeof pn, "msm%d.pin%d", slot, pin_parity);
-    job->h = (G1Xyzz *)cx.pin_named(pn, sizeof(G1Xyzz) * job->groups);
-    MI_HIP(hipMemcpyAsync(job->h, result, sizeof(G1Xyzz) * job->groups, hipMemcpyDeviceToHost, st));
+    if (result) {  // the window sums of the large path: copy out
+        job->h = (G1Xyzz *)cx.pin_named(pn, sizeof(G1Xyzz) * job->groups * problems);
+        MI_HIP(hipMemcpyAsync(job->h, result, sizeof(G1Xyzz) * job->groups * problems, hipMemcpyDeviceToHost, st));
+    }
     job->done = cx.event_named(pn);
     if (record_done) MI_HIP(hipEventRecord(job->done, st));
 }
@@ -562,10 +676,10 @@ void msm_release_graphs() {
 }
 
 void msm_enqueue(Context &cx, const G1Affine *d_points, const uint32_t *d_scalars, size_t n, hipStream_t st, int scalar_bits,
-                 int slot, MsmJob *job, int force_c, int pin_parity) {
-    const bool graphable = msm_graphs_enabled() && cx.prof.level == 0 && force_c == 0 && n > 0 && n <= ((size_t)1 << 16);
+                 int slot, MsmJob *job, int force_c, int pin_parity, size_t split) {
+    const bool graphable = msm_graphs_enabled() && cx.prof.level == 0 && force_c == 0 && n > 0 && n <= ((size_t)1 << 16) && split == 0;
     if (!graphable) {
-        msm_enqueue_eager(cx, d_points, d_scalars, n, st, scalar_bits, slot, job, force_c, pin_parity, true);
+        msm_enqueue_eager(cx, d_points, d_scalars, n, st, scalar_bits, slot, job, force_c, pin_parity, true, split);
         return;
     }
     MsmGraph &g = msm_graphs()[slot];
@@ -574,14 +688,14 @@ void msm_enqueue(Context &cx, const G1Affine *d_points, const uint32_t *d_scalar
         if (g.exec) (void)hipGraphExecDestroy(g.exec);
         g = MsmGraph();
         g.pts = d_points; g.sc = d_scalars; g.n = n; g.bits = scalar_bits; g.parity = pin_parity; g.seen = 1;
-        msm_enqueue_eager(cx, d_points, d_scalars, n, st, scalar_bits, slot, job, force_c, pin_parity, true);
+        msm_enqueue_eager(cx, d_points, d_scalars, n, st, scalar_bits, slot, job, force_c, pin_parity, true, 0);
         return;
     }
     if (!g.exec) {  // second sighting: capture the identical launch sequence
         hipGraph_t graph = nullptr;
         MI_HIP(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
         try {
-            msm_enqueue_eager(cx, d_points, d_scalars, n, st, scalar_bits, slot, &g.job, force_c, pin_parity, false);
+            msm_enqueue_eager(cx, d_points, d_scalars, n, st, scalar_bits, slot, &g.job, force_c, pin_parity, false, 0);
         } catch (...) {
             (void)hipStreamEndCapture(st, &graph);
             if (graph) (void)hipGraphDestroy(graph);
@@ -610,29 +724,55 @@ static G1Xyzz fold_bits(const G1Xyzz *h, size_t lo, size_t hi) {
     }
     return acc;
 }
-void msm_finish(Context &cx, MsmJob *job, hipStream_t st, mi_g1_jac *out) {
+// one problem's per-bit sums -> its point: two host threads, the top ~38 % of the live bit positions (then shifted
+// down by doublings only) and the rest; balances 9-product doublings against 14-product additions
+static G1Xyzz fold_per_bit(const G1Xyzz *h, size_t G) {
+    while (G > 0 && h[G - 1].is_inf()) G--;  // short scalars leave the top positions empty
+    if (G == 0) return G1Xyzz::inf();
+    const size_t mid = G - (G * 38) / 100;
+    G1Xyzz hi_part;
+    std::future<void> th = worker_pool().submit([&]() {
+        hi_part = fold_bits(h, mid, G);
+        for (size_t k = 0; k < mid; k++) hi_part = dbl(hi_part);
+    });
+    G1Xyzz lo_part = fold_bits(h, 0, mid);
+    th.get();
+    return add(hi_part, lo_part);
+}
+void msm_finish(Context &cx, MsmJob *job, hipStream_t st, mi_g1_jac *out, mi_g1_jac *out_b) {
     (void)cx;
+    (void)st;
     G1Jac res = G1Jac{Fq::one(), Fq::one(), Fq::zero()};
     if (job->n == 0) {
         memcpy(out, &res, sizeof res);
+        if (out_b) memcpy(out_b, &res, sizeof res);
         return;
     }
-    (void)st;
-    MI_HIP(hipEventSynchronize(job->done));  // this job only: later work on the same stream is not waited for
+    {
+        HostSpan hs("finish.wait");
+        MI_HIP(hipEventSynchronize(job->done));  // this job only: later work on the same stream is not waited for
+    }
+    HostSpan hs_fold("finish.fold");
     const G1Xyzz *h = job->h;
     G1Xyzz acc;
     if (job->per_bit) {
-        // two host threads: the top ~38 % of the bit positions (then shifted down by doublings only) and the rest;
-        // balances 9-product doublings against 14-product additions
-        const size_t G = job->groups, mid = G - (G * 38) / 100;
-        G1Xyzz hi_part;
-        std::future<void> th = worker_pool().submit([&]() {
-            hi_part = fold_bits(h, mid, G);
-            for (size_t k = 0; k < mid; k++) hi_part = dbl(hi_part);
-        });
-        G1Xyzz lo_part = fold_bits(h, 0, mid);
-        th.get();
-        acc = add(hi_part, lo_part);
+        if (job->problems == 2) {
+            // the second problem folds on a pool thread of its own (which splits again)
+            G1Jac res_b = res;
+            std::future<void> tb = worker_pool().submit([&]() { res_b = affine_to_jac(to_affine(fold_per_bit(h + job->groups, job->groups))); });
+            try {
+                acc = fold_per_bit(h, job->groups);
+                res = affine_to_jac(to_affine(acc));
+            } catch (...) {
+                tb.get();
+                throw;
+            }
+            tb.get();
+            memcpy(out, &res, sizeof res);
+            if (out_b) memcpy(out_b, &res_b, sizeof res_b);
+            return;
+        }
+        acc = fold_per_bit(h, job->groups);
     } else {
         acc = h[job->nwin - 1];
         for (int w = job->nwin - 2; w >= 0; w--) {

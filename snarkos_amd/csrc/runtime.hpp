@@ -8,6 +8,7 @@
 #include <deque>
 #include <functional>
 #include <future>
+#include <chrono>
 #include <map>
 #include <memory>
 #include <mutex>
@@ -92,8 +93,10 @@ inline WorkerPool &worker_pool() {
 struct DevBuf {
     void *p = nullptr;
     size_t cap = 0;
+    uint64_t gen = 0;  // bumped by every (re)allocation: content-carrying users compare it
     void *get(size_t bytes) {
         if (bytes > cap) {
+            gen++;
             if (p) MI_HIP(hipFree(p));
             p = nullptr;
             cap = 0;
@@ -107,6 +110,44 @@ struct DevBuf {
         if (p) (void)hipFree(p);
         p = nullptr;
         cap = 0;
+    }
+};
+
+// Host-side wall-clock accounting of code sections (MI_SNARK_HOSTPROF=1; report on stderr at mi_shutdown / exit).
+struct HostProf {
+    struct Acc { double s = 0; uint64_t n = 0; };
+    std::map<std::string, Acc> acc;
+    std::mutex mu;
+    bool on = false;
+    HostProf() {
+        const char *e = getenv("MI_SNARK_HOSTPROF");
+        on = e && e[0] == '1';
+    }
+    ~HostProf() { report(); }
+    void report() {
+        if (!on) return;
+        for (auto &kv : acc)
+            fprintf(stderr, "[hostprof] %-28s %8.1f us/call x %llu\n", kv.first.c_str(), 1e6 * kv.second.s / (double)kv.second.n,
+                    (unsigned long long)kv.second.n);
+        acc.clear();
+    }
+};
+inline HostProf &host_prof() {
+    static HostProf h;
+    return h;
+}
+struct HostSpan {
+    const char *name;
+    std::chrono::steady_clock::time_point t0;
+    explicit HostSpan(const char *nm) : name(nm) {
+        if (host_prof().on) t0 = std::chrono::steady_clock::now();
+    }
+    ~HostSpan() {
+        if (!host_prof().on) return;
+        std::lock_guard<std::mutex> lk(host_prof().mu);
+        auto &a = host_prof().acc[name];
+        a.s += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        a.n++;
     }
 };
 
@@ -201,12 +242,30 @@ struct Context {
 Context &ctx();
 int32_t ensure_init();
 
+// The context mutex guards the context's maps and the verifier contexts' bookkeeping.  Entry points hold it for
+// their whole body, except around long host-side waits and folds (Unlocked below), so that one host thread can
+// enqueue batch k+1 while another folds batch k and a third waits for a pairing product.
+inline thread_local std::unique_lock<std::mutex> *tl_ctx_lock = nullptr;
+struct Unlocked {
+    std::unique_lock<std::mutex> *lk;
+    Unlocked() : lk(tl_ctx_lock) {
+        if (lk) lk->unlock();
+    }
+    ~Unlocked() {
+        if (lk) lk->lock();
+    }
+};
 template <class F>
 int32_t guarded(F &&f) {
+    struct Reset {
+        ~Reset() { tl_ctx_lock = nullptr; }
+    };
     try {
         int32_t s = ensure_init();
         if (s != MI_OK) return s;
-        std::lock_guard<std::mutex> lk(ctx().mu);
+        std::unique_lock<std::mutex> lk(ctx().mu);
+        Reset reset;  // destroyed before lk
+        tl_ctx_lock = &lk;
         MI_HIP(hipSetDevice(ctx().device));  // never rely on a foreign thread's current device
         return f();
     } catch (const HipError &h) {

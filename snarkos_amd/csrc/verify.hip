@@ -106,7 +106,8 @@ struct VsConsts {
     uint32_t tag[8];           // big-endian words of the 32-byte domain tag
     G1Affine g;
 };
-#define VS_SLOTS 4
+#define VS_SLOTS 8
+#define VS_ACC_DEPTH 8  // accumulations (derive + both MSMs) that may be enqueued before the oldest is folded
 struct VsAccFwd;
 struct VsSlot {  // one in-flight pairing product (pipelined finalize)
     uint64_t ticket = 0;
@@ -128,11 +129,13 @@ struct VsCtx {
         size_t n = 0;
         hipStream_t st = nullptr;
         MsmJob j1, j2;
+        bool fused = false;  // j1 carries both MSMs
+        bool closing = false;
         uint8_t *h_alg = nullptr;
-    } acc[2];
+    } acc[VS_ACC_DEPTH];
     uint64_t next_acc = 2;
-    hipStream_t acc_st[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};  // per batch parity: H-side / tau-H-side
-    hipEvent_t acc_ev[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};
+    hipStream_t acc_st[VS_ACC_DEPTH] = {};  // one stream per accumulation lane
+    hipEvent_t acc_ev[VS_ACC_DEPTH] = {};
     uint64_t next_ticket = 1;
 };
 static void vs_ctx_free(VsCtx &v) {
@@ -147,13 +150,12 @@ static void vs_ctx_free(VsCtx &v) {
         if (sl.h_out) (void)hipHostFree(sl.h_out);
         sl = VsSlot();
     }
-    for (int p = 0; p < 2; p++)
-        for (int k = 0; k < 2; k++) {
-            if (v.acc_st[p][k]) (void)hipStreamDestroy(v.acc_st[p][k]);
-            if (v.acc_ev[p][k]) (void)hipEventDestroy(v.acc_ev[p][k]);
-            v.acc_st[p][k] = nullptr;
-            v.acc_ev[p][k] = nullptr;
-        }
+    for (int p = 0; p < VS_ACC_DEPTH; p++) {
+        if (v.acc_st[p]) (void)hipStreamDestroy(v.acc_st[p]);
+        if (v.acc_ev[p]) (void)hipEventDestroy(v.acc_ev[p]);
+        v.acc_st[p] = nullptr;
+        v.acc_ev[p] = nullptr;
+    }
 }
 static std::map<uint64_t, VsCtx> &vs_ctxs() {
     static std::map<uint64_t, VsCtx> m;
@@ -206,11 +208,10 @@ int32_t vs_ctx_create(Context &cx, const mi_kzg_vk *vk, const mi_vs_circuit_vk *
         MI_HIP(hipMalloc((void **)&sl.d_out, sizeof(Fq12)));
         MI_HIP(hipHostMalloc((void **)&sl.h_out, sizeof(Fq12), hipHostMallocDefault));
     }
-    for (int p = 0; p < 2; p++)
-        for (int k = 0; k < 2; k++) {
-            MI_HIP(hipStreamCreateWithFlags(&v.acc_st[p][k], hipStreamNonBlocking));
-            MI_HIP(hipEventCreateWithFlags(&v.acc_ev[p][k], hipEventDisableTiming));
-        }
+    for (int p = 0; p < VS_ACC_DEPTH; p++) {
+        MI_HIP(hipStreamCreateWithFlags(&v.acc_st[p], hipStreamNonBlocking));
+        MI_HIP(hipEventCreateWithFlags(&v.acc_ev[p], hipEventDisableTiming));
+    }
     (void)pairing_consts(cx, cx.stream);  // upload the Frobenius table before any pipelined launch
     *out = id;
     return MI_OK;
@@ -221,9 +222,8 @@ int32_t vs_ctx_destroy(Context &cx, uint64_t id) {
     MI_HIP(hipStreamSynchronize(cx.stream));
     for (auto &sl : it->second.slots)
         if (sl.stream) MI_HIP(hipStreamSynchronize(sl.stream));
-    for (int p = 0; p < 2; p++)
-        for (int k = 0; k < 2; k++)
-            if (it->second.acc_st[p][k]) MI_HIP(hipStreamSynchronize(it->second.acc_st[p][k]));
+    for (int p = 0; p < VS_ACC_DEPTH; p++)
+        if (it->second.acc_st[p]) MI_HIP(hipStreamSynchronize(it->second.acc_st[p]));
     vs_ctx_free(it->second);
     vs_ctxs().erase(it);
     return MI_OK;
@@ -482,10 +482,11 @@ static VsWork vs_run_derive(Context &cx, VsCtx &v, const void *d_proofs, size_t 
         snprintf(nm, sizeof nm, "vs%d.%s", parity, name);
         return nm;
     };
-    w.pts1 = (G1Affine *)cx.buf(W("pts1"), sizeof(G1Affine) * w.n1);
-    w.sc1 = (uint32_t *)cx.buf(W("sc1"), 32 * w.n1);
-    w.pts2 = (G1Affine *)cx.buf(W("pts2"), sizeof(G1Affine) * w.n2);
-    w.sc2 = (uint32_t *)cx.buf(W("sc2"), 32 * w.n2);
+    // one array for both MSMs' operands (H side first, tau-H side behind it): they run as ONE launch sequence
+    w.pts1 = (G1Affine *)cx.buf(W("pts"), sizeof(G1Affine) * (w.n1 + w.n2));
+    w.sc1 = (uint32_t *)cx.buf(W("sc"), 32 * (w.n1 + w.n2));
+    w.pts2 = w.pts1 + w.n1;
+    w.sc2 = w.sc1 + 8 * w.n1;
     w.vk_scal = (Fr *)cx.buf(W("vk_scal"), sizeof(Fr) * n * MI_VS_VK_COMMS);
     w.g_scal = (Fr *)cx.buf(W("g_scal"), sizeof(Fr) * n);
     w.alg_ok = (uint8_t *)cx.buf(W("alg_ok"), n);
@@ -515,28 +516,45 @@ static G1Affine host_jac_to_affine_normalised(const mi_g1_jac &j) {
 
 // accumulate one shard: partial sums + algebraic failures (+ optional per-proof alg flags to host)
 // accumulate = begin (enqueue derive + both MSMs, no host synchronisation) + end (wait, fold on the host).
-// Two begin/end pairs may be open at once (parity p = handle & 1): the device workspaces are reused in stream
-// order, only the pinned result buffers are per parity, so batch k+1's kernels run while batch k is folded.
+// VS_ACC_DEPTH begin/end pairs may be open at once (lane p = handle % VS_ACC_DEPTH): every lane has its own stream
+// pair, device workspaces and pinned result buffers, so the next batches' kernels run while batch k is folded.
 static int32_t vs_accumulate_begin_impl(Context &cx, VsCtx &v, const void *d_proofs, size_t n, const void *d_rand,
                                         hipStream_t st, uint64_t *handle, VsWork *work_out) {
     const uint64_t hd = v.next_acc++;
-    VsCtx::VsAcc &a = v.acc[hd & 1];
-    if (a.open) return MI_ERR_BAD_ARGS;  // at most two accumulations in flight
+    VsCtx::VsAcc &a = v.acc[hd % VS_ACC_DEPTH];
+    if (a.open) return MI_ERR_BAD_ARGS;  // at most VS_ACC_DEPTH accumulations in flight
     // Batches alternate between two stream pairs, so batch k+1's derive and MSMs run beside batch k's.  The inputs
     // were produced on the caller's stream: order ours behind it.
-    const int par = (int)(hd & 1);
-    hipStream_t sa = v.acc_st[par][0], sb = v.acc_st[par][1];
-    MI_HIP(hipEventRecord(v.acc_ev[par][0], st));
-    MI_HIP(hipStreamWaitEvent(sa, v.acc_ev[par][0], 0));
-    VsWork w = vs_run_derive(cx, v, d_proofs, n, d_rand, sa, par);
-    MI_HIP(hipEventRecord(v.acc_ev[par][1], sa));
-    MI_HIP(hipStreamWaitEvent(sb, v.acc_ev[par][1], 0));
+    const int par = (int)(hd % VS_ACC_DEPTH);
+    hipStream_t sa = v.acc_st[par];
+    {
+        HostSpan hs("begin.order");
+        MI_HIP(hipEventRecord(v.acc_ev[par], st));
+        MI_HIP(hipStreamWaitEvent(sa, v.acc_ev[par], 0));
+    }
+    VsWork w;
+    {
+        HostSpan hs("begin.derive");
+        w = vs_run_derive(cx, v, d_proofs, n, d_rand, sa, par);
+    }
     char nm[32];
     snprintf(nm, sizeof nm, "vs.alg_pin%d", par);
     a.h_alg = (uint8_t *)cx.pin_named(nm, n);
-    MI_HIP(hipMemcpyAsync(a.h_alg, w.alg_ok, n, hipMemcpyDeviceToHost, sa));  // ahead of MSM 1: its done-event covers it
-    msm_enqueue(cx, w.pts2, w.sc2, w.n2, sb, 128, 4 + 2 * par + 1, &a.j2, 0, par);  // the short one first
-    msm_enqueue(cx, w.pts1, w.sc1, w.n1, sa, 254, 4 + 2 * par, &a.j1, 0, par);
+    {
+        HostSpan hs("begin.alg_copy");
+        MI_HIP(hipMemcpyAsync(a.h_alg, w.alg_ok, n, hipMemcpyDeviceToHost, sa));  // ahead of the MSMs: their done-event covers it
+    }
+    HostSpan hs_msm("begin.msm_enqueue");
+    // both MSMs (H side: 11n + 12 circuits + 1 points; tau-H side: 2n points, 128-bit scalars) share one launch
+    // sequence: the second is the first's extra set of windows (msm_enqueue's split)
+    if (w.n1 + w.n2 <= ((size_t)1 << 16)) {
+        msm_enqueue(cx, w.pts1, w.sc1, w.n1 + w.n2, sa, 254, 4 + 2 * par, &a.j1, 0, par, w.n1);
+        a.fused = true;
+    } else {
+        msm_enqueue(cx, w.pts2, w.sc2, w.n2, sa, 128, 4 + 2 * par + 1, &a.j2, 0, par);
+        msm_enqueue(cx, w.pts1, w.sc1, w.n1, sa, 254, 4 + 2 * par, &a.j1, 0, par);
+        a.fused = false;
+    }
     st = sa;
     a.n = n;
     a.st = st;
@@ -547,32 +565,26 @@ static int32_t vs_accumulate_begin_impl(Context &cx, VsCtx &v, const void *d_pro
     return MI_OK;
 }
 static int32_t vs_accumulate_end_impl(Context &cx, VsCtx &v, uint64_t handle, mi_vs_partial *out) {
-    VsCtx::VsAcc &a = v.acc[handle & 1];
-    if (!a.open || a.handle != handle) return MI_ERR_BAD_ARGS;
-    a.open = false;
-    // the two host folds (~250 doublings + ~250 additions each) run on two host threads
-    int32_t st2 = MI_OK;
-    const int dev = cx.device;
-    std::future<void> fold2 = worker_pool().submit([&]() {
-        try {
-            MI_HIP(hipSetDevice(dev));
-            msm_finish(cx, &a.j2, nullptr, &out->total_w);
-        } catch (const HipError &h) {
-            st2 = status_of(h);
-        } catch (...) {
-            st2 = MI_ERR_KERNEL;
-        }
-    });
+    VsCtx::VsAcc &a = v.acc[handle % VS_ACC_DEPTH];
+    if (!a.open || a.handle != handle || a.closing) return MI_ERR_BAD_ARGS;
+    a.closing = true;  // the lane stays taken until the fold is done; the context lock is not held meanwhile
+    // host folds (~250 doublings + ~250 additions for 254-bit scalars, half that for the randomizer side), each
+    // split over two pool threads
+    uint64_t fails = 0;
     try {
-        msm_finish(cx, &a.j1, a.st, &out->total_c);
+        Unlocked unlocked;
+        if (a.fused) {
+            msm_finish(cx, &a.j1, a.st, &out->total_c, &out->total_w);
+        } else {
+            msm_finish(cx, &a.j2, a.st, &out->total_w);
+            msm_finish(cx, &a.j1, a.st, &out->total_c);
+        }
+        for (size_t i = 0; i < a.n; i++) fails += a.h_alg[i] ? 0 : 1;
     } catch (...) {
-        fold2.get();
+        a.open = a.closing = false;
         throw;
     }
-    fold2.get();
-    if (st2 != MI_OK) return st2;
-    uint64_t fails = 0;
-    for (size_t i = 0; i < a.n; i++) fails += a.h_alg[i] ? 0 : 1;
+    a.open = a.closing = false;
     out->n_proofs = a.n;
     out->n_alg_fail = fails;
     return MI_OK;
@@ -625,7 +637,10 @@ int32_t vs_finalize(Context &cx, uint64_t id, const mi_vs_partial *parts, size_t
 // pipelined finalize: sum the partials on the host, enqueue the pairing product on the context's own stream and
 // return a ticket; the caller goes on to accumulate the next batch while the product runs
 static int32_t vs_slot_wait(VsSlot &sl, uint8_t *all_ok) {
-    MI_HIP(hipEventSynchronize(sl.done));
+    {
+        Unlocked unlocked;  // other threads keep enqueueing and folding while this one waits for the product
+        MI_HIP(hipEventSynchronize(sl.done));
+    }
     if (all_ok) *all_ok = (sl.h_out->is_one() && sl.fails == 0) ? 1 : 0;
     sl.busy = false;
     return MI_OK;
@@ -637,6 +652,7 @@ int32_t vs_finalize_async(Context &cx, uint64_t id, const mi_vs_partial *parts, 
     const uint64_t tk = v.next_ticket++;
     VsSlot &sl = v.slots[tk % VS_SLOTS];
     if (sl.busy) return MI_ERR_BAD_ARGS;  // more than VS_SLOTS products in flight: wait for a ticket first
+    HostSpan hs("finalize_async");
     G1Xyzz tc = G1Xyzz::inf(), tw = G1Xyzz::inf();
     uint64_t fails = 0;
     for (size_t k = 0; k < np; k++) {

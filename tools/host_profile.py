@@ -1,6 +1,6 @@
 """Where does the host thread spend its time per batch in the pipelined loop?  (ad-hoc probe)"""
 import os, sys, time
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "12")
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 import numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -20,7 +20,7 @@ for k in range(K):
     if prev is not None:
         t = time.perf_counter(); part = v.accumulate_end(prev); T["end"] += time.perf_counter() - t
         t = time.perf_counter(); pending.append(v.finalize_async([part])); T["fin_async"] += time.perf_counter() - t
-        if len(pending) >= 3:
+        if len(pending) >= 4:
             t = time.perf_counter(); assert v.finalize_wait(pending.pop(0)); T["wait"] += time.perf_counter() - t
     prev = cur
 part = v.accumulate_end(prev); pending.append(v.finalize_async([part]))
