@@ -96,10 +96,15 @@ def main():
     d_rnd = torch.from_numpy(rnd).to(dev)
     verifier = A.VarunaShaped(vk, circuits)
 
-    # The K batches are verified as a stream (chunks of a block / mempool traffic): the pairing product of batch i
-    # runs on the library's second stream while batch i+1 is accumulated.  Every batch is fully verified inside
-    # the timed region; "latency_ms" below is one batch on its own, unpipelined.
-    gather = (lambda part: sharding.gather_partials(part, torch.distributed, gather_dev)) if dist_on else None
+    # The K batches are verified as a stream (chunks of a block / mempool traffic): up to 8 batches are accumulating
+    # on their own stream lanes while earlier ones are folded on host threads and up to 8 pairing products run on
+    # their own streams.  Every batch is fully verified inside the timed region; "latency_ms" below is one batch on
+    # its own, unpipelined.
+    def gather_all(part):  # runs on verify_stream's finisher thread: every collective comes from that one thread
+        torch.cuda.set_device(dev_index)
+        return sharding.gather_partials(part, torch.distributed, gather_dev)
+
+    gather = gather_all if dist_on else None
 
     def run(k):
         oks = list(verifier.verify_stream(((d_proofs, d_rnd) for _ in range(k)), gather, depth=args.products, acc_depth=args.acc_depth))
@@ -107,7 +112,7 @@ def main():
 
     if args.warmup:
         run(args.warmup)
-    # ---- timed region: exactly K batches, no profiling hooks (the MSM pipelines replay as hipGraphs)
+    # ---- timed region: exactly K batches, no profiling hooks
     L.prof_enable(0)
     sync_all(dist_on)
     t0 = time.perf_counter()
@@ -119,8 +124,8 @@ def main():
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = float(t.item())
     # ---- the same K batches again with HIP-event brackets around the headline kernels, on the streams they run on
-    # (brackets switch the MSM pipelines from graph replay to eager launches, so they stay out of the timed region;
-    # kernel durations are the same either way and agree with profiles/*_rocprofv3_kernel_stats.csv)
+    # (the brackets cost host time, so they stay out of the timed region; kernel durations agree with
+    # profiles/*_rocprofv3_kernel_stats.csv)
     L.prof_enable(1)
     for k in ALG_BYTES:
         L.prof_read(k)

@@ -265,35 +265,67 @@ class VarunaShaped:
         L.check(L.lib().mi_vs_finalize_wait(C.c_uint64(self.ctx), C.c_uint64(ticket), L.ptr(ok)), "mi_vs_finalize_wait")
         return bool(ok[0])
 
-    def verify_stream(self, batches, gather=None, depth=8, acc_depth=8):
+    def verify_stream(self, batches, gather=None, depth=8, acc_depth=8, fold_threads=2):
         """Pipelined verification of a stream of batches (chunks of a block, or mempool traffic): yields all_ok per
         batch, in order.
 
-        Two host threads drive the GPU: the caller's enqueues batch k (derive + both MSMs on one of `acc_depth` <= 8
-        stream lanes) while a closer thread folds batch k-1.. on the host, exchanges partials (`gather`, optional:
-        maps this rank's partial to the list of all ranks' partials -- every collective is issued from that one
-        thread, in batch order) and starts its pairing product; up to `depth` (<= 8) products are in flight, each
-        on its own stream.  `batches` yields (proofs_cuda, randomizers_cuda).  The library's entry points drop the
-        context lock around their host-side waits and folds, so the two threads overlap.
+        Three host stages drive the GPU.  The caller's thread enqueues batch k (derive + both MSMs on one of
+        `acc_depth` <= 8 stream lanes); `fold_threads` threads wait for accumulations and fold them on the host
+        (accumulate_end); one finisher thread takes the partials in batch order, exchanges them (`gather`,
+        optional: maps this rank's partial to the list of all ranks' partials -- every collective is issued from
+        that one thread) and starts the pairing product; up to `depth` (<= 8) products are in flight, each on its own
+        stream.  `batches` yields (proofs_cuda, randomizers_cuda).  The library's entry points drop the context lock
+        around their host-side waits and folds, so the stages overlap.
         """
         import queue
         import threading
 
         depth = max(1, min(depth, 8))
         acc_depth = max(1, min(acc_depth, 8))
+        fold_threads = max(1, min(fold_threads, 4))
         lanes = threading.Semaphore(acc_depth)
         handles, results = queue.Queue(), queue.Queue()
+        parts_ready, parts_cv = {}, threading.Condition()
         END = object()
+        state = {"n": None, "err": None}
 
-        def closer():
-            pending = []
+        def fail(e):
+            with parts_cv:
+                if state["err"] is None:
+                    state["err"] = e
+                parts_cv.notify_all()
+            lanes.release()
+            results.put(e)
+
+        def folder():
             try:
                 while True:
-                    h = handles.get()
-                    if h is END:
-                        break
-                    part = self.accumulate_end(h)         # wait for the GPU, fold on the host
+                    item = handles.get()
+                    if item is END:
+                        handles.put(END)  # for the other folders
+                        return
+                    seq, h = item
+                    part = self.accumulate_end(h)  # wait for the GPU, fold on the host
                     lanes.release()
+                    with parts_cv:
+                        parts_ready[seq] = part
+                        parts_cv.notify_all()
+            except BaseException as e:
+                fail(e)
+
+        def finisher():
+            pending, seq = [], 0
+            try:
+                while True:
+                    with parts_cv:
+                        while seq not in parts_ready and state["err"] is None and state["n"] != seq:
+                            parts_cv.wait()
+                        if state["err"] is not None:
+                            return
+                        if seq not in parts_ready:
+                            break  # all batches taken
+                        part = parts_ready.pop(seq)
+                    seq += 1
                     parts = gather(part) if gather is not None else [part]
                     if len(pending) >= depth:
                         results.put(self.finalize_wait(pending.pop(0)))
@@ -301,39 +333,49 @@ class VarunaShaped:
                 while pending:
                     results.put(self.finalize_wait(pending.pop(0)))
                 results.put(END)
-            except BaseException as e:  # surfaced by the generator
-                lanes.release()
-                results.put(e)
+            except BaseException as e:
+                fail(e)
 
-        th = threading.Thread(target=closer, name="mi-snark-closer", daemon=True)
-        th.start()
-        failed = None
+        threads = [threading.Thread(target=folder, name="mi-snark-fold%d" % i, daemon=True) for i in range(fold_threads)]
+        threads.append(threading.Thread(target=finisher, name="mi-snark-finish", daemon=True))
+        for th in threads:
+            th.start()
+
+        def close_input(n):
+            with parts_cv:
+                if state["n"] is None:
+                    state["n"] = n
+                parts_cv.notify_all()
+            handles.put(END)
+
+        n = 0
         try:
             for proofs, rnd in batches:
                 lanes.acquire()
-                handles.put(self.accumulate_begin(proofs, rnd))
+                if state["err"] is not None:
+                    raise state["err"]
+                handles.put((n, self.accumulate_begin(proofs, rnd)))
+                n += 1
                 while True:
                     try:
                         r = results.get_nowait()
                     except queue.Empty:
                         break
                     if isinstance(r, BaseException):
-                        failed = r
                         raise r
                     yield r
-            handles.put(END)
+            close_input(n)
             while True:
                 r = results.get()
                 if r is END:
                     break
                 if isinstance(r, BaseException):
-                    failed = r
                     raise r
                 yield r
         finally:
-            if failed is None and th.is_alive():
-                handles.put(END)
-            th.join(timeout=60)
+            close_input(n)
+            for th in threads:
+                th.join(timeout=60)
 
     def finalize(self, partials):
         parts = np.ascontiguousarray(partials, dtype=np.uint8).reshape(-1, L.VS_PARTIAL_BYTES)

@@ -724,21 +724,26 @@ static G1Xyzz fold_bits(const G1Xyzz *h, size_t lo, size_t hi) {
     }
     return acc;
 }
-// one problem's per-bit sums -> its point: two host threads, the top ~38 % of the live bit positions (then shifted
-// down by doublings only) and the rest; balances 9-product doublings against 14-product additions
-static G1Xyzz fold_per_bit(const G1Xyzz *h, size_t G) {
-    while (G > 0 && h[G - 1].is_inf()) G--;  // short scalars leave the top positions empty
-    if (G == 0) return G1Xyzz::inf();
-    const size_t mid = G - (G * 38) / 100;
-    G1Xyzz hi_part;
-    std::future<void> th = worker_pool().submit([&]() {
-        hi_part = fold_bits(h, mid, G);
-        for (size_t k = 0; k < mid; k++) hi_part = dbl(hi_part);
-    });
-    G1Xyzz lo_part = fold_bits(h, 0, mid);
-    th.get();
-    return add(hi_part, lo_part);
-}
+// One problem's per-bit sums -> its point, as two independent halves: the top ~38 % of the live bit positions
+// (folded, then shifted down by doublings only) and the rest; balances 9-product doublings against 14-product
+// additions.  The halves of all problems of a job run side by side on the pool (no task waits for another).
+struct FoldSplit {
+    const G1Xyzz *h;
+    size_t G, mid;
+    G1Xyzz hi, lo;
+    FoldSplit(const G1Xyzz *h_, size_t G_) : h(h_), G(G_) {
+        while (G > 0 && h[G - 1].is_inf()) G--;  // short scalars leave the top positions empty
+        mid = G - (G * 38) / 100;
+        hi = lo = G1Xyzz::inf();
+    }
+    void run_hi() {
+        hi = fold_bits(h, mid, G);
+        if (!hi.is_inf())
+            for (size_t k = 0; k < mid; k++) hi = dbl(hi);
+    }
+    void run_lo() { lo = fold_bits(h, 0, mid); }
+    G1Jac result() const { return affine_to_jac(to_affine(add(hi, lo))); }
+};
 void msm_finish(Context &cx, MsmJob *job, hipStream_t st, mi_g1_jac *out, mi_g1_jac *out_b) {
     (void)cx;
     (void)st;
@@ -756,23 +761,37 @@ void msm_finish(Context &cx, MsmJob *job, hipStream_t st, mi_g1_jac *out, mi_g1_
     const G1Xyzz *h = job->h;
     G1Xyzz acc;
     if (job->per_bit) {
+        FoldSplit fa(h, job->groups), fb(h + job->groups, job->problems == 2 ? job->groups : 0);
+        std::future<void> t1 = worker_pool().submit([&]() { fa.run_hi(); });
+        std::future<void> t2, t3;
         if (job->problems == 2) {
-            // the second problem folds on a pool thread of its own (which splits again)
-            G1Jac res_b = res;
-            std::future<void> tb = worker_pool().submit([&]() { res_b = affine_to_jac(to_affine(fold_per_bit(h + job->groups, job->groups))); });
-            try {
-                acc = fold_per_bit(h, job->groups);
-                res = affine_to_jac(to_affine(acc));
-            } catch (...) {
-                tb.get();
-                throw;
-            }
-            tb.get();
-            memcpy(out, &res, sizeof res);
-            if (out_b) memcpy(out_b, &res_b, sizeof res_b);
-            return;
+            t2 = worker_pool().submit([&]() { fb.run_lo(); });
+            t3 = worker_pool().submit([&]() { fb.run_hi(); });
         }
-        acc = fold_per_bit(h, job->groups);
+        std::exception_ptr err;
+        try {
+            fa.run_lo();
+        } catch (...) {
+            err = std::current_exception();
+        }
+        for (std::future<void> *t : {&t1, &t2, &t3})
+            if (t->valid()) {
+                try {
+                    t->get();
+                } catch (...) {
+                    if (!err) err = std::current_exception();
+                }
+            }
+        if (err) std::rethrow_exception(err);
+        // normalise (one Fq inversion each) side by side
+        G1Jac res_b = res;
+        std::future<void> tn;
+        if (job->problems == 2 && out_b) tn = worker_pool().submit([&]() { res_b = fb.result(); });
+        res = fa.result();
+        if (tn.valid()) tn.get();
+        memcpy(out, &res, sizeof res);
+        if (job->problems == 2 && out_b) memcpy(out_b, &res_b, sizeof res_b);
+        return;
     } else {
         acc = h[job->nwin - 1];
         for (int w = job->nwin - 2; w >= 0; w--) {

@@ -85,7 +85,7 @@ class WorkerPool {
     bool stop_ = false;
 };
 inline WorkerPool &worker_pool() {
-    static WorkerPool p(4);
+    static WorkerPool p(8);
     return p;
 }
 

@@ -516,16 +516,22 @@ static G1Affine host_jac_to_affine_normalised(const mi_g1_jac &j) {
 
 // accumulate one shard: partial sums + algebraic failures (+ optional per-proof alg flags to host)
 // accumulate = begin (enqueue derive + both MSMs, no host synchronisation) + end (wait, fold on the host).
-// VS_ACC_DEPTH begin/end pairs may be open at once (lane p = handle % VS_ACC_DEPTH): every lane has its own stream
+// VS_ACC_DEPTH begin/end pairs may be open at once (lane p = handle & 0xff): every lane has its own stream
 // pair, device workspaces and pinned result buffers, so the next batches' kernels run while batch k is folded.
 static int32_t vs_accumulate_begin_impl(Context &cx, VsCtx &v, const void *d_proofs, size_t n, const void *d_rand,
                                         hipStream_t st, uint64_t *handle, VsWork *work_out) {
-    const uint64_t hd = v.next_acc++;
-    VsCtx::VsAcc &a = v.acc[hd % VS_ACC_DEPTH];
-    if (a.open) return MI_ERR_BAD_ARGS;  // at most VS_ACC_DEPTH accumulations in flight
-    // Batches alternate between two stream pairs, so batch k+1's derive and MSMs run beside batch k's.  The inputs
-    // were produced on the caller's stream: order ours behind it.
-    const int par = (int)(hd % VS_ACC_DEPTH);
+    // any free lane (ends may complete out of order when several host threads fold); the handle names its lane
+    int par = -1;
+    for (int p = 0; p < VS_ACC_DEPTH; p++)
+        if (!v.acc[p].open) {
+            par = p;
+            break;
+        }
+    if (par < 0) return MI_ERR_BAD_ARGS;  // at most VS_ACC_DEPTH accumulations in flight
+    const uint64_t hd = (v.next_acc++ << 8) | (uint64_t)par;
+    VsCtx::VsAcc &a = v.acc[par];
+    // Each lane has its own stream, so the next batches' derive and MSMs run beside this one's.  The inputs were
+    // produced on the caller's stream: order ours behind it.
     hipStream_t sa = v.acc_st[par];
     {
         HostSpan hs("begin.order");
@@ -565,7 +571,8 @@ static int32_t vs_accumulate_begin_impl(Context &cx, VsCtx &v, const void *d_pro
     return MI_OK;
 }
 static int32_t vs_accumulate_end_impl(Context &cx, VsCtx &v, uint64_t handle, mi_vs_partial *out) {
-    VsCtx::VsAcc &a = v.acc[handle % VS_ACC_DEPTH];
+    if ((handle & 0xff) >= VS_ACC_DEPTH) return MI_ERR_BAD_ARGS;
+    VsCtx::VsAcc &a = v.acc[handle & 0xff];
     if (!a.open || a.handle != handle || a.closing) return MI_ERR_BAD_ARGS;
     a.closing = true;  // the lane stays taken until the fold is done; the context lock is not held meanwhile
     // host folds (~250 doublings + ~250 additions for 254-bit scalars, half that for the randomizer side), each

@@ -102,6 +102,51 @@ def test_pipelined_stream_matches_batchwise(orc, mi):
         v.close()
 
 
+def test_pipeline_lanes_out_of_order_and_threads(orc, mi):
+    """the split API under the conditions verify_stream creates: eight accumulations open at once (a ninth is
+    refused), ended out of order and from several host threads; partials bit-exact with the oracle's; a long
+    stream (more batches than lanes and product slots) through every thread count"""
+    import threading
+    import torch
+    from snarkos_amd.lib import MiError
+    good = orc.VSBatch(0x57EB, 40, 3, 0)
+    v = _ctx(mi, good)
+    try:
+        gp = torch.from_numpy(good.proofs).cuda(); gr = torch.from_numpy(good.randomizers).cuda()
+        bad_np = good.proofs.copy(); bad_np[11 * 2256 + 16 + 512 + 864 + 32 * 3] ^= 4
+        bp = torch.from_numpy(bad_np).cuda()
+        as_bytes = lambda a: np.frombuffer(np.ascontiguousarray(a).tobytes(), dtype=np.uint8)
+        want_good = as_bytes(orc.vs_partial_from_oracle(good, threads=8))
+        want_bad = as_bytes(orc.vs_partial_from_oracle(orc.VSArrays(good.vk, good.circuits, bad_np, good.randomizers), threads=8))
+        hs = [v.accumulate_begin(bp if k == 5 else gp, gr) for k in range(8)]
+        with pytest.raises(MiError):
+            v.accumulate_begin(gp, gr)  # all lanes taken
+        got = {}
+
+        def end(ks):
+            for k in ks:
+                got[k] = v.accumulate_end(hs[k])
+
+        ts = [threading.Thread(target=end, args=(ks,)) for ks in ([7, 2, 5], [0, 6], [3, 1, 4])]
+        for t in ts:
+            t.start()
+        for t in ts:
+            t.join()
+        for k in range(8):
+            assert (got[k] == (want_bad if k == 5 else want_good)).all(), k
+        with pytest.raises(MiError):
+            v.accumulate_end(hs[0])  # already ended
+        h = v.accumulate_begin(gp, gr)  # lanes are free again
+        assert (v.accumulate_end(h) == want_good).all()
+        seq = [(bp, gr) if k % 7 == 3 else (gp, gr) for k in range(30)]
+        want = [k % 7 != 3 for k in range(30)]
+        for threads in (1, 2, 3):
+            assert list(v.verify_stream(iter(seq), fold_threads=threads)) == want
+        assert list(v.verify_stream(iter(seq), depth=1, acc_depth=1)) == want
+    finally:
+        v.close()
+
+
 @pytest.mark.parametrize("n", [1, 3])
 def test_tiny_batches(orc, mi, n):
     good = orc.VSBatch(0x71 + n, n, 2, 0)
