@@ -13,6 +13,7 @@ tensors of dtype uint8/int64 holding the same bytes for the device-resident entr
 Every call goes to the HIP library; there is no CPU implementation behind these classes.
 """
 import ctypes as C
+import os
 
 import numpy as np
 
@@ -204,6 +205,12 @@ class VarunaShaped:
         h = C.c_uint64(0)
         L.check(L.lib().mi_vs_ctx_create(L.ptr(vk), L.ptr(cv), C.c_size_t(self.n_circuits), C.byref(h)), "mi_vs_ctx_create")
         self.ctx = h.value
+        # accumulation lanes of this context (the library reads the same variable when it creates the context)
+        try:
+            lanes = int(os.environ.get("MI_SNARK_VS_LANES", L.VS_DEFAULT_LANES))
+        except ValueError:
+            lanes = L.VS_DEFAULT_LANES
+        self.lanes = lanes if 1 <= lanes <= L.VS_MAX_OPEN_ACCUMULATIONS else L.VS_DEFAULT_LANES
 
     def close(self):
         if self.ctx:
@@ -265,12 +272,12 @@ class VarunaShaped:
         L.check(L.lib().mi_vs_finalize_wait(C.c_uint64(self.ctx), C.c_uint64(ticket), L.ptr(ok)), "mi_vs_finalize_wait")
         return bool(ok[0])
 
-    def verify_stream(self, batches, gather=None, depth=8, acc_depth=8, fold_threads=2):
+    def verify_stream(self, batches, gather=None, depth=8, acc_depth=12, fold_threads=3):
         """Pipelined verification of a stream of batches (chunks of a block, or mempool traffic): yields all_ok per
         batch, in order.
 
         Three host stages drive the GPU.  The caller's thread enqueues batch k (derive + both MSMs on one of
-        `acc_depth` <= 8 stream lanes); `fold_threads` threads wait for accumulations and fold them on the host
+        `acc_depth` <= 14 stream lanes); `fold_threads` threads wait for accumulations and fold them on the host
         (accumulate_end); one finisher thread takes the partials in batch order, exchanges them (`gather`,
         optional: maps this rank's partial to the list of all ranks' partials -- every collective is issued from
         that one thread) and starts the pairing product; up to `depth` (<= 8) products are in flight, each on its own
@@ -281,7 +288,7 @@ class VarunaShaped:
         import threading
 
         depth = max(1, min(depth, 8))
-        acc_depth = max(1, min(acc_depth, 8))
+        acc_depth = max(1, min(acc_depth, self.lanes))
         fold_threads = max(1, min(fold_threads, 4))
         lanes = threading.Semaphore(acc_depth)
         handles, results = queue.Queue(), queue.Queue()

@@ -21,8 +21,6 @@ int32_t ensure_init() {
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, dev) == hipSuccess) g_ctx.n_cus = prop.multiProcessorCount;
     if (hipStreamCreateWithFlags(&g_ctx.stream, hipStreamNonBlocking) != hipSuccess) return MI_ERR_KERNEL;
-    if (hipStreamCreateWithFlags(&g_ctx.stream2, hipStreamNonBlocking) != hipSuccess) return MI_ERR_KERNEL;
-    if (hipEventCreateWithFlags(&g_ctx.fork_event, hipEventDisableTiming) != hipSuccess) return MI_ERR_KERNEL;
     g_ctx.inited = true;
     return MI_OK;
 }
@@ -194,11 +192,6 @@ int32_t mi_shutdown(void) {
     g_ctx.pinned_cap = 0;
     (void)hipStreamDestroy(g_ctx.stream);
     g_ctx.stream = nullptr;
-    (void)hipStreamSynchronize(g_ctx.stream2);
-    (void)hipStreamDestroy(g_ctx.stream2);
-    g_ctx.stream2 = nullptr;
-    (void)hipEventDestroy(g_ctx.fork_event);
-    g_ctx.fork_event = nullptr;
     for (auto &kv : g_ctx.events) (void)hipEventDestroy(kv.second);
     g_ctx.events.clear();
     for (auto &kv : g_ctx.pins)

@@ -248,6 +248,10 @@ MI_HD Fp<P> mul32(const Fp<P> &a, const Fp<P> &b) {
 #endif
 namespace mi {
 
+// Fq product WITHOUT the final conditional subtraction (device: result < q (1 + q/R) for canonical inputs, to be
+// summed lazily and reduced once); the host build returns the reduced product.
+MI_HD Fp<FqP> mul_nr(const Fp<FqP> &a, const Fp<FqP> &b);
+
 template <class P>
 MI_HD Fp<P> mul(const Fp<P> &a, const Fp<P> &b) {
 #if !defined(__HIP_DEVICE_COMPILE__)
@@ -256,6 +260,13 @@ MI_HD Fp<P> mul(const Fp<P> &a, const Fp<P> &b) {
     return mul32(a, b);
 #else
     return mul_comba_gen<P, MI_COMBA_LANES>(a, b);
+#endif
+}
+MI_HD Fp<FqP> mul_nr(const Fp<FqP> &a, const Fp<FqP> &b) {
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(MI_MUL32)
+    return mul_comba_nr_gen<FqP>(a, b);
+#else
+    return mul(a, b);
 #endif
 }
 

@@ -23,6 +23,9 @@ struct alignas(16) PwShared {
     PB f, t, a, b, c, d, x, y;
     alignas(16) Fq line[MI_MAX_PAIRS][8];  // per pair: coefficients at w^0, w^1, w^3, w^7, w^9 (+ padding)
     alignas(16) Fq px[MI_MAX_PAIRS], py[MI_MAX_PAIRS];
+    // two-pair fast path: every line of the Miller loop evaluated at its P up front, [step][pair][w^1, w^3, w^7, w^9]
+    // (the w^0 coefficient is py[pair]); 26 KB
+    alignas(16) Fq lines2[MI_MILLER_LINES][2][4];
 };
 
 // ---- LDS <-> register copies, 16 bytes at a time (PwShared members are 16-byte aligned)
@@ -105,7 +108,146 @@ __device__ __attribute__((noinline)) void pb_mul_t(PwShared &S, PB *out, const P
     }
     __syncthreads();
 }
-__device__ __forceinline__ void pb_mul(PwShared &S, PB *out, const PB *A, const PB *B) { pb_mul_t<12>(S, out, A, B->c); }
+// ---------------------------------------------------------------------------------------------------------------
+// The dense round, second version (every round of the final exponentiation and of the two-pair Miller loop).
+//   * products are taken without their final conditional subtraction (< 1.007 q); a wrapped product p contributes
+//     6q - 5p; a row's lazy sum stays < 67 q < 2^384;
+//   * the row sum is an inclusive scan over the 16-lane row with DPP row_shr:1/2/4/8 -- no LDS traffic; lane 11 ends
+//     with the sum of lanes 0..11;
+//   * one reduction: quotient estimate from the top limb (k <= floor(acc / q) <= k + 1), acc - k q, one conditional
+//     subtraction;
+//   * the four spare lanes of every row (s = 12..15) can carry a second, independent product in the same round: the
+//     product of two sparse line functions (5 x 5 coefficients -> 10 non-zero rows of at most 4 products each, table
+//     below), summed after the first two scan steps in lane 15.
+struct Q6 {
+    uint32_t l[12];
+};
+constexpr Q6 pw_make_q6() {
+    Q6 r{};
+    uint64_t c = 0;
+    for (int j = 0; j < 12; j++) {
+        const uint64_t v = (uint64_t)FqP::MOD[j] * 6u + c;
+        r.l[j] = (uint32_t)v;
+        c = v >> 32;
+    }
+    return r;
+}
+// line x line: for output row k, up to four products l1[i] * l2[j] (stored-coefficient indices; positions 0,1,3,7,9);
+// code = i | j << 3 | wrapped << 6 | valid << 7
+#define PW_LL(i, j, w) (uint8_t)((i) | ((j) << 3) | ((w) << 6) | 0x80)
+__device__ const uint8_t PW_LL_TABLE[12][4] = {
+    {PW_LL(0, 0, 0), PW_LL(2, 4, 1), PW_LL(4, 2, 1), 0},               // w^0: 0+0, 3+9, 9+3
+    {PW_LL(0, 1, 0), PW_LL(1, 0, 0), 0, 0},                            // w^1
+    {PW_LL(1, 1, 0), PW_LL(3, 3, 1), 0, 0},                            // w^2: 1+1, 7+7
+    {PW_LL(0, 2, 0), PW_LL(2, 0, 0), 0, 0},                            // w^3
+    {PW_LL(1, 2, 0), PW_LL(2, 1, 0), PW_LL(3, 4, 1), PW_LL(4, 3, 1)},  // w^4: 1+3, 3+1, 7+9, 9+7
+    {0, 0, 0, 0},                                                      // w^5
+    {PW_LL(2, 2, 0), PW_LL(4, 4, 1), 0, 0},                            // w^6: 3+3, 9+9
+    {PW_LL(0, 3, 0), PW_LL(3, 0, 0), 0, 0},                            // w^7
+    {PW_LL(1, 3, 0), PW_LL(3, 1, 0), 0, 0},                            // w^8
+    {PW_LL(0, 4, 0), PW_LL(4, 0, 0), 0, 0},                            // w^9
+    {PW_LL(1, 4, 0), PW_LL(4, 1, 0), PW_LL(2, 3, 0), PW_LL(3, 2, 0)},  // w^10: 1+9, 9+1, 3+7, 7+3
+    {0, 0, 0, 0},                                                      // w^11
+};
+#undef PW_LL
+
+template <int N>
+__device__ __forceinline__ void pw_row_scan_step(uint32_t (&acc)[12]) {
+    uint32_t c = 0;
+#pragma unroll
+    for (int j = 0; j < 12; j++) {
+        const uint32_t o = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)acc[j], 0x110 + N, 0xf, 0xf, true);  // row_shr:N
+        acc[j] = addc32(acc[j], o, c, &c);
+    }
+}
+
+// out = A * B (dense).  WITH_L: also outL = l1 * l2, l1 / l2 the five stored coefficients of two line functions
+// (pointer to the w^0 coefficient and to the four others).  All PW_THREADS lanes must call.
+template <bool WITH_L>
+__device__ __attribute__((noinline)) void pb_round(PwShared &S, PB *out, const PB *A, const PB *B, PB *outL, const Fq *l1_0,
+                                                   const Fq *l1_r, const Fq *l2_0, const Fq *l2_r) {
+    constexpr Q6 q6 = pw_make_q6();
+    const int t = threadIdx.x, k = t >> 4, s = t & 15;
+    uint32_t acc[12];
+#pragma unroll
+    for (int j = 0; j < 12; j++) acc[j] = 0;
+    Fq a, b;
+    bool active = false, wrap = false;
+    if (s < 12) {
+        int i = k - s;
+        wrap = i < 0;
+        if (wrap) i += 12;
+        a = lds_load(&A->c[i]);
+        b = lds_load(&B->c[s]);
+        active = true;
+    } else if (WITH_L) {
+        const uint32_t code = PW_LL_TABLE[k][s - 12];
+        if (code & 0x80u) {
+            const uint32_t i = code & 7u, j = (code >> 3) & 7u;
+            a = lds_load(i == 0 ? l1_0 : &l1_r[i - 1]);
+            b = lds_load(j == 0 ? l2_0 : &l2_r[j - 1]);
+            wrap = (code & 0x40u) != 0;
+            active = true;
+        }
+    }
+    if (active) {
+        const Fq p = mul_nr(a, b);
+#pragma unroll
+        for (int j = 0; j < 12; j++) acc[j] = p.l[j];
+        if (wrap) {  // w^12 = -5: 6q - 5p, in (0.9 q, 6 q]
+            uint32_t t5[12], c = 0, bw = 0;
+#pragma unroll
+            for (int j = 0; j < 12; j++) t5[j] = addc32((p.l[j] << 2) | (j ? (p.l[j - 1] >> 30) : 0u), p.l[j], c, &c);
+#pragma unroll
+            for (int j = 0; j < 12; j++) acc[j] = subc32(q6.l[j], t5[j], bw, &bw);
+        }
+    }
+    pw_row_scan_step<1>(acc);
+    pw_row_scan_step<2>(acc);
+    uint32_t v[12];
+    if (WITH_L) {
+#pragma unroll
+        for (int j = 0; j < 12; j++) v[j] = acc[j];  // lane 15: lanes 12..15 summed = the line product's row
+    }
+    pw_row_scan_step<4>(acc);
+    pw_row_scan_step<8>(acc);
+    if (WITH_L) {
+#pragma unroll
+        for (int j = 0; j < 12; j++) v[j] = s == 15 ? v[j] : acc[j];
+    } else {
+#pragma unroll
+        for (int j = 0; j < 12; j++) v[j] = acc[j];
+    }
+    // v < 67 q: k = floor(v11 * floor(2^40 / (q11 + 1)) / 2^40) <= v / q < k + 2
+    {
+        const uint32_t kq = __umulhi(v[11], 38996u) >> 8;
+        uint32_t carry = 0, borrow = 0;
+#pragma unroll
+        for (int j = 0; j < 12; j++) {
+            const uint64_t pr = (uint64_t)kq * FqP::MOD[j] + carry;
+            carry = (uint32_t)(pr >> 32);
+            v[j] = subc32(v[j], (uint32_t)pr, borrow, &borrow);
+        }
+        uint32_t d[12];
+        borrow = 0;
+#pragma unroll
+        for (int j = 0; j < 12; j++) d[j] = subc32(v[j], FqP::MOD[j], borrow, &borrow);
+#pragma unroll
+        for (int j = 0; j < 12; j++) v[j] = borrow ? v[j] : d[j];
+    }
+    __syncthreads();
+    if (s == 11 || (WITH_L && s == 15)) {
+        Fq r;
+#pragma unroll
+        for (int j = 0; j < 12; j++) r.l[j] = v[j];
+        lds_store(s == 11 ? &out->c[k] : &outL->c[k], r);
+    }
+    __syncthreads();
+}
+__device__ __forceinline__ void pb_mul(PwShared &S, PB *out, const PB *A, const PB *B) {
+    pb_round<false>(S, out, A, B, nullptr, nullptr, nullptr, nullptr, nullptr);
+}
+
 __device__ __forceinline__ void pb_mul_line(PwShared &S, PB *out, const PB *A, const Fq *line5) { pb_mul_t<5>(S, out, A, line5); }
 // out = frobenius^e(A): c_k *= gamma_e^k
 __device__ __forceinline__ void pb_frob(PwShared &S, PB *out, const PB *A, const Fq *gamma /* global, 12 */) {
@@ -202,6 +344,37 @@ __device__ __attribute__((noinline)) void pw_miller(PwShared &S, const G2Prepare
     }
 }
 
+// Two live pairs (every KZG / verifier check): all line coefficients first (552 values, three per lane), then per
+// doubling step TWO rounds -- [f^2 beside l_1 l_2] and [f^2 * (l_1 l_2)] -- instead of three rounds plus a line
+// evaluation; an addition step costs one more round (its line product rides in the second round's spare lanes).
+__device__ __attribute__((noinline)) void pw_miller2(PwShared &S, const G2Prepared *const *qs) {
+    const int t = threadIdx.x;
+    for (int item = t; item < MI_MILLER_LINES * 8; item += PW_THREADS) {
+        const int idx = item >> 3, p = (item >> 2) & 1, role = item & 3;
+        const Line *ln = &qs[p]->lines[idx];
+        Fq v;
+        if (role == 0) v = mul(ln->c1.c0, lds_load(&S.px[p]));       // w^1
+        else if (role == 1) v = ln->c3.c0;                            // w^3
+        else if (role == 2) v = mul(ln->c1.c1, lds_load(&S.px[p]));  // w^7
+        else v = ln->c3.c1;                                           // w^9
+        lds_store(&S.lines2[idx][p][role], v);
+    }
+    if (t < 12) lds_store(&S.f.c[t], t == 0 ? Fq::one() : Fq::zero());
+    __syncthreads();
+    int idx = 0;
+    for (int i = 62; i >= 0; i--) {
+        pb_round<true>(S, &S.f, &S.f, &S.f, &S.t, &S.py[0], S.lines2[idx][0], &S.py[1], S.lines2[idx][1]);
+        idx++;
+        if ((MI_BLS_X >> i) & 1) {
+            pb_round<true>(S, &S.f, &S.f, &S.t, &S.a, &S.py[0], S.lines2[idx][0], &S.py[1], S.lines2[idx][1]);
+            idx++;
+            pb_mul(S, &S.f, &S.f, &S.a);
+        } else {
+            pb_mul(S, &S.f, &S.f, &S.t);
+        }
+    }
+}
+
 // S.f <- S.f ^ (3 (q^12 - 1) / r)
 __device__ __attribute__((noinline)) void pw_final_exp(PwShared &S, const PairingConsts *pc) {
     // easy part
@@ -249,7 +422,8 @@ __device__ __forceinline__ void pw_pairing_product(PwShared &S, const G1Affine *
         live_n = m;
     }
     __syncthreads();
-    pw_miller(S, live_q, live_n);
+    if (live_n == 2) pw_miller2(S, live_q);
+    else pw_miller(S, live_q, live_n);
     pw_final_exp(S, pc);
     if (t < 12) {
         // tower index (i, j, b) holds the coefficient of w^(i + 2j + 6b)

@@ -206,8 +206,6 @@ struct Context {
     size_t pinned_cap = 0;
 
     std::map<std::string, std::pair<void *, size_t>> pins;  // named pinned staging buffers
-    hipStream_t stream2 = nullptr;                         // second library stream (concurrent MSMs)
-    hipEvent_t fork_event = nullptr;
     std::map<std::string, hipEvent_t> events;  // named events (completion of an enqueued job)
     hipEvent_t event_named(const char *name) {
         auto it = events.find(name);

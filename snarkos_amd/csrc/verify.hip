@@ -106,8 +106,8 @@ struct VsConsts {
     uint32_t tag[8];           // big-endian words of the 32-byte domain tag
     G1Affine g;
 };
-#define VS_SLOTS 8
-#define VS_ACC_DEPTH 8  // accumulations (derive + both MSMs) that may be enqueued before the oldest is folded
+#define VS_SLOTS MI_VS_MAX_TICKETS
+#define VS_ACC_DEPTH MI_VS_MAX_OPEN_ACCUMULATIONS  // accumulations (derive + both MSMs) that may be enqueued before the oldest is folded
 struct VsAccFwd;
 struct VsSlot {  // one in-flight pairing product (pipelined finalize)
     uint64_t ticket = 0;
@@ -115,7 +115,6 @@ struct VsSlot {  // one in-flight pairing product (pipelined finalize)
     uint64_t fails = 0;
     hipEvent_t done = nullptr;
     hipStream_t stream = nullptr;  // each slot has its own stream: products of different batches run side by side
-    Fq12 *d_out = nullptr;
     Fq12 *h_out = nullptr;  // pinned
 };
 struct VsCtx {
@@ -137,6 +136,7 @@ struct VsCtx {
     hipStream_t acc_st[VS_ACC_DEPTH] = {};  // one stream per accumulation lane
     hipEvent_t acc_ev[VS_ACC_DEPTH] = {};
     uint64_t next_ticket = 1;
+    int lanes = 12;
 };
 static void vs_ctx_free(VsCtx &v) {
     v.circuits.release();
@@ -146,7 +146,6 @@ static void vs_ctx_free(VsCtx &v) {
     for (auto &sl : v.slots) {
         if (sl.done) (void)hipEventDestroy(sl.done);
         if (sl.stream) (void)hipStreamDestroy(sl.stream);
-        if (sl.d_out) (void)hipFree(sl.d_out);
         if (sl.h_out) (void)hipHostFree(sl.h_out);
         sl = VsSlot();
     }
@@ -202,15 +201,25 @@ int32_t vs_ctx_create(Context &cx, const mi_kzg_vk *vk, const mi_vs_circuit_vk *
     void *dk = v.consts.get(sizeof hc);
     MI_HIP(hipMemcpyAsync(dk, &hc, sizeof hc, hipMemcpyHostToDevice, cx.stream));
     MI_HIP(hipStreamSynchronize(cx.stream));
+    // All streams of the context are created here, lanes first, then product slots.  Measured on the box: HIP spreads
+    // streams over at most 24 hardware queues in creation order; with this order 12 lanes + 8 slots run side by side
+    // (4.3e6 proofs/s), created lazily in order of first use (lane, slot, lane, ...) the same streams reach 2.7e6, and
+    // with more than ~24 streams in the process a 1.6 ms pairing kernel ends up queued in front of other batches' MSMs.
+    // MI_SNARK_VS_LANES (1..14, default 12) trims the lane count when the process needs queues for something else
+    // (RCCL, other libraries).
+    v.lanes = 12;
+    if (const char *e = getenv("MI_SNARK_VS_LANES")) {
+        const int x = atoi(e);
+        if (x >= 1 && x <= VS_ACC_DEPTH) v.lanes = x;
+    }
+    for (int p = 0; p < v.lanes; p++) {
+        MI_HIP(hipStreamCreateWithFlags(&v.acc_st[p], hipStreamNonBlocking));
+        MI_HIP(hipEventCreateWithFlags(&v.acc_ev[p], hipEventDisableTiming));
+    }
     for (auto &sl : v.slots) {
         MI_HIP(hipStreamCreateWithFlags(&sl.stream, hipStreamNonBlocking));
         MI_HIP(hipEventCreateWithFlags(&sl.done, hipEventDisableTiming));
-        MI_HIP(hipMalloc((void **)&sl.d_out, sizeof(Fq12)));
         MI_HIP(hipHostMalloc((void **)&sl.h_out, sizeof(Fq12), hipHostMallocDefault));
-    }
-    for (int p = 0; p < VS_ACC_DEPTH; p++) {
-        MI_HIP(hipStreamCreateWithFlags(&v.acc_st[p], hipStreamNonBlocking));
-        MI_HIP(hipEventCreateWithFlags(&v.acc_ev[p], hipEventDisableTiming));
     }
     (void)pairing_consts(cx, cx.stream);  // upload the Frobenius table before any pipelined launch
     *out = id;
@@ -522,12 +531,12 @@ static int32_t vs_accumulate_begin_impl(Context &cx, VsCtx &v, const void *d_pro
                                         hipStream_t st, uint64_t *handle, VsWork *work_out) {
     // any free lane (ends may complete out of order when several host threads fold); the handle names its lane
     int par = -1;
-    for (int p = 0; p < VS_ACC_DEPTH; p++)
+    for (int p = 0; p < v.lanes; p++)
         if (!v.acc[p].open) {
             par = p;
             break;
         }
-    if (par < 0) return MI_ERR_BAD_ARGS;  // at most VS_ACC_DEPTH accumulations in flight
+    if (par < 0) return MI_ERR_BAD_ARGS;  // every lane is taken
     const uint64_t hd = (v.next_acc++ << 8) | (uint64_t)par;
     VsCtx::VsAcc &a = v.acc[par];
     // Each lane has its own stream, so the next batches' derive and MSMs run beside this one's.  The inputs were
@@ -656,9 +665,15 @@ int32_t vs_finalize_async(Context &cx, uint64_t id, const mi_vs_partial *parts, 
     auto it = vs_ctxs().find(id);
     if (it == vs_ctxs().end()) return MI_ERR_BAD_ARGS;
     VsCtx &v = it->second;
-    const uint64_t tk = v.next_ticket++;
-    VsSlot &sl = v.slots[tk % VS_SLOTS];
-    if (sl.busy) return MI_ERR_BAD_ARGS;  // more than VS_SLOTS products in flight: wait for a ticket first
+    int slot = -1;
+    for (int i = 0; i < VS_SLOTS; i++)
+        if (!v.slots[i].busy) {
+            slot = i;
+            break;
+        }
+    if (slot < 0) return MI_ERR_BAD_ARGS;  // VS_SLOTS products in flight: wait for a ticket first
+    const uint64_t tk = (v.next_ticket++ << 8) | (uint64_t)slot;  // the ticket names its slot
+    VsSlot &sl = v.slots[slot];
     HostSpan hs("finalize_async");
     G1Xyzz tc = G1Xyzz::inf(), tw = G1Xyzz::inf();
     uint64_t fails = 0;
@@ -669,8 +684,7 @@ int32_t vs_finalize_async(Context &cx, uint64_t id, const mi_vs_partial *parts, 
     }
     G1Affine ps[2] = {to_affine(tc), neg(to_affine(tw))};
     const G2Prepared *qs[2] = {(const G2Prepared *)v.h_prep.p, (const G2Prepared *)v.tauh_prep.p};
-    pairing_launch(cx, ps, qs, 2, sl.d_out, sl.stream);
-    MI_HIP(hipMemcpyAsync(sl.h_out, sl.d_out, sizeof(Fq12), hipMemcpyDeviceToHost, sl.stream));
+    pairing_launch(cx, ps, qs, 2, sl.h_out, sl.stream);  // the kernel stores its result in pinned host memory
     MI_HIP(hipEventRecord(sl.done, sl.stream));
     sl.ticket = tk;
     sl.busy = true;
@@ -682,7 +696,8 @@ int32_t vs_finalize_wait(Context &cx, uint64_t id, uint64_t ticket, uint8_t *all
     (void)cx;
     auto it = vs_ctxs().find(id);
     if (it == vs_ctxs().end()) return MI_ERR_BAD_ARGS;
-    VsSlot &sl = it->second.slots[ticket % VS_SLOTS];
+    if ((ticket & 0xff) >= VS_SLOTS) return MI_ERR_BAD_ARGS;
+    VsSlot &sl = it->second.slots[ticket & 0xff];
     if (!sl.busy || sl.ticket != ticket) return MI_ERR_BAD_ARGS;
     return vs_slot_wait(sl, all_ok);
 }

@@ -21,6 +21,9 @@ KZG_VK_BYTES = 480
 VS_PROOF_BYTES = 2256
 VS_CIRCUIT_VK_BYTES = 1184
 VS_PARTIAL_BYTES = 304
+VS_MAX_OPEN_ACCUMULATIONS = 14  # compile-time cap; a context has MI_SNARK_VS_LANES (default 12) lanes
+VS_DEFAULT_LANES = 12
+VS_MAX_TICKETS = 8
 
 # every symbol include/mi355x_snark.h declares
 EXPORTS = [

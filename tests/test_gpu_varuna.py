@@ -103,8 +103,8 @@ def test_pipelined_stream_matches_batchwise(orc, mi):
 
 
 def test_pipeline_lanes_out_of_order_and_threads(orc, mi):
-    """the split API under the conditions verify_stream creates: eight accumulations open at once (a ninth is
-    refused), ended out of order and from several host threads; partials bit-exact with the oracle's; a long
+    """the split API under the conditions verify_stream creates: every lane open at once (one more is refused),
+    some ended out of order and from several host threads; partials bit-exact with the oracle's; a long
     stream (more batches than lanes and product slots) through every thread count"""
     import threading
     import torch
@@ -118,9 +118,12 @@ def test_pipeline_lanes_out_of_order_and_threads(orc, mi):
         as_bytes = lambda a: np.frombuffer(np.ascontiguousarray(a).tobytes(), dtype=np.uint8)
         want_good = as_bytes(orc.vs_partial_from_oracle(good, threads=8))
         want_bad = as_bytes(orc.vs_partial_from_oracle(orc.VSArrays(good.vk, good.circuits, bad_np, good.randomizers), threads=8))
-        hs = [v.accumulate_begin(bp if k == 5 else gp, gr) for k in range(8)]
+        from snarkos_amd.lib import VS_DEFAULT_LANES
+        hs = [v.accumulate_begin(bp if k == 5 else gp, gr) for k in range(VS_DEFAULT_LANES)]
         with pytest.raises(MiError):
             v.accumulate_begin(gp, gr)  # all lanes taken
+        for h in hs[8:]:
+            assert (v.accumulate_end(h) == want_good).all()
         got = {}
 
         def end(ks):
