@@ -27,6 +27,7 @@ void msm_enqueue(Context &cx, const G1Affine *d_points, const uint32_t *d_scalar
 // out_b: the second problem's result when the job was enqueued with a split
 void msm_finish(Context &cx, MsmJob *job, hipStream_t st, mi_g1_jac *out, mi_g1_jac *out_b = nullptr);
 void msm_release_graphs();
+size_t msm_small_limit();  // largest n on the latency-bound small path (the only one that takes a split)
 void msm_device(Context &cx, const G1Affine *d_points, const uint32_t *d_scalars, size_t n, mi_g1_jac *out,
                 hipStream_t st, int scalar_bits = 254, int force_c = 0);
 

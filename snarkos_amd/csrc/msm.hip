@@ -31,6 +31,19 @@ struct MsmPlan {
     uint32_t B;  // buckets per window = 2^(c-1)
 };
 
+// largest n that takes the small (latency-bound) path; MI_SNARK_MSM_SMALL_LOG overrides for experiments
+size_t msm_small_limit() {
+    static size_t lim = 0;
+    if (!lim) {
+        int lg = 16;
+        if (const char *e = getenv("MI_SNARK_MSM_SMALL_LOG")) {
+            const int x = atoi(e);
+            if (x >= 6 && x <= 16) lg = x;
+        }
+        lim = (size_t)1 << lg;
+    }
+    return lim;
+}
 static MsmPlan msm_plan(size_t n, int scalar_bits, int force_c) {
     int lg = 0;
     while (((size_t)1 << (lg + 1)) <= n) lg++;
@@ -512,7 +525,7 @@ static void msm_enqueue_eager(Context &cx, const G1Affine *d_points, const uint3
     job->nwin = pl.nwin;
     // A small MSM is latency bound (one mixed addition is ~10k instructions; its ~17 dependent launches cost more
     // than their work): it takes short chunks, one fused planning kernel and the log-depth reduction below.
-    const bool small = n <= ((size_t)1 << 16);
+    const bool small = n <= msm_small_limit();
     const int problems = (split > 0 && split < n) ? 2 : 1;
     if (problems == 2 && !small) throw HipError{hipErrorInvalidValue, "msm split needs n <= 2^16", __LINE__};
     if (problems == 1) split = n;

@@ -562,7 +562,7 @@ static int32_t vs_accumulate_begin_impl(Context &cx, VsCtx &v, const void *d_pro
     HostSpan hs_msm("begin.msm_enqueue");
     // both MSMs (H side: 11n + 12 circuits + 1 points; tau-H side: 2n points, 128-bit scalars) share one launch
     // sequence: the second is the first's extra set of windows (msm_enqueue's split)
-    if (w.n1 + w.n2 <= ((size_t)1 << 16)) {
+    if (w.n1 + w.n2 <= msm_small_limit()) {
         msm_enqueue(cx, w.pts1, w.sc1, w.n1 + w.n2, sa, 254, 4 + 2 * par, &a.j1, 0, par, w.n1);
         a.fused = true;
     } else {
