@@ -270,6 +270,18 @@ def extras(dev, verifier, proofs, rnd):
     ex["msm_2^20"] = {"points_per_s": n / dt, "ms": 1e3 * dt, "accumulate_kernel_ms": ms / launches,
                       "gpu_pipeline_ms": ms_t / l_t,
                       "roofline_frac_hbm": 128.0 * n / dt / 1e9 / HBM_PEAK_GBPS, "result_is_infinity": bool(not res[12:].any())}
+    # --- 8f row 3: KZG10::commit of a 2^20-coefficient polynomial (Montgomery coefficients resident, powers resident):
+    # coefficient conversion + the same MSM
+    rb = A.ResidentBases(pts.cpu().numpy().view(np.uint64).reshape(n, 12))
+    rb.commit(sc)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        rb.commit(sc)
+    torch.cuda.synchronize()
+    dtc = (time.perf_counter() - t0) / reps
+    ex["kzg_commit_2^20"] = {"ms": 1e3 * dtc, "coefficients_per_s": n / dtc}
+    rb.release()
     del pts, sc
     # --- configs[2]: NTT 2^22 forward + inverse round trip, in place in HBM
     log_n = 22

@@ -74,6 +74,17 @@ int32_t mi_msm_g1_h(uint64_t bases_handle, size_t offset, const mi_bigint256 *sc
 int32_t mi_ntt_fr(mi_fr *data, uint32_t log_n, int32_t inverse, int32_t coset);
 int32_t mi_ntt_fr_device(void *d_data, uint32_t log_n, int32_t inverse, int32_t coset, void *stream);
 
+/* ---- prover-side reuse of the same kernels ----
+ * polycommit::kzg10::KZG10::commit without hiding: sum_i coeffs[i] * powers[offset + i], coefficients in Montgomery
+ * form as DensePolynomial holds them (converted to canonical integers on the device, like `to_bigint()` before the
+ * reference's msm call); `powers_handle` = mi_bases_register(powers_of_beta_g).  n may be 0 (commitment to zero). */
+int32_t mi_kzg_commit_h(uint64_t powers_handle, size_t offset, const mi_fr *coeffs, size_t n, mi_g1_jac *out);
+int32_t mi_kzg_commit_h_device(uint64_t powers_handle, size_t offset, const void *d_coeffs, size_t n, mi_g1_jac *out,
+                               void *stream);
+/* fft::DensePolynomial multiplication through the evaluation domain of size >= na + nb - 1 (two forward NTTs, a
+ * pointwise product, one inverse NTT): out[0 .. na + nb - 1).  na, nb >= 1. */
+int32_t mi_poly_mul_fr(const mi_fr *a, size_t na, const mi_fr *b, size_t nb, mi_fr *out);
+
 /* ---- pairing (Bls12_377::{miller_loop, final_exponentiation, product_of_pairings}) ---- */
 int32_t mi_pairing_product_is_one(const mi_g1_affine *ps, const mi_g2_affine *qs, size_t n, uint8_t *is_one);
 int32_t mi_pairing(const mi_g1_affine *p, const mi_g2_affine *q, mi_fq12 *out); /* f^(3(q^12-1)/r) */

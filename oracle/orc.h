@@ -99,6 +99,14 @@ int orc_kzg_batch_check(const orc_kzg_vk *vk, const orc_g1_affine *comms, const 
                         const orc_fr *values, const orc_g1_affine *witnesses, size_t n,
                         const uint8_t *randomizers128);
 
+/* prover side: KZG10::commit without hiding (coefficients Montgomery, converted with
+ * to_bigint() as the reference does before its msm call); schoolbook polynomial product; Horner evaluation;
+ * witness polynomial (p(x) - p(z)) / (x - z) by synthetic division, returns p(z) */
+void orc_kzg_commit(orc_g1_jac *out, const orc_g1_affine *powers, const orc_fr *coeffs, size_t n, int threads);
+void orc_poly_mul_schoolbook(orc_fr *out, const orc_fr *a, size_t na, const orc_fr *b, size_t nb);
+void orc_poly_eval(orc_fr *out, const orc_fr *coeffs, size_t n, const orc_fr *z);
+void orc_poly_witness(orc_fr *q, orc_fr *value, const orc_fr *coeffs, size_t n, const orc_fr *z);
+
 /* ---- Poseidon sponge over Fq (crypto_hash::PoseidonSponge<Fq,2,1>) ----
  * width 3, S-box x^17, 4 + 31 + 4 rounds; constants generated by tools/gen_constants.py (snarkVM's are not
  * available offline: parity unpinned).  inputs: n x m Montgomery Fq, outputs: n x k. */

@@ -172,6 +172,43 @@ static void g1_mul_fr(orc_g1_jac *r, const orc_g1_affine *p, const fr_t *k_mont)
     fr_to_canonical(k.l, k_mont);
     orc_g1_mul(r, p, &k);
 }
+void orc_kzg_commit(orc_g1_jac *out, const orc_g1_affine *powers, const orc_fr *coeffs, size_t n, int threads) {
+    orc_bigint256 *plain = (orc_bigint256 *)malloc(sizeof(orc_bigint256) * (n ? n : 1));
+    for (size_t i = 0; i < n; i++) orc_fr_to_canonical(&plain[i], &coeffs[i]);
+    orc_msm_pippenger(out, powers, plain, n, threads);
+    free(plain);
+}
+void orc_poly_mul_schoolbook(orc_fr *out, const orc_fr *a, size_t na, const orc_fr *b, size_t nb) {
+    fr_t t;
+    for (size_t k = 0; k < na + nb - 1; k++) fr_zero((fr_t *)&out[k]);
+    for (size_t i = 0; i < na; i++)
+        for (size_t j = 0; j < nb; j++) {
+            fr_mul(&t, S(&a[i]), S(&b[j]));
+            fr_add((fr_t *)&out[i + j], (fr_t *)&out[i + j], &t);
+        }
+}
+void orc_poly_eval(orc_fr *out, const orc_fr *coeffs, size_t n, const orc_fr *z) {
+    fr_t acc;
+    fr_zero(&acc);
+    for (size_t i = n; i-- > 0;) {
+        fr_mul(&acc, &acc, S(z));
+        fr_add(&acc, &acc, S(&coeffs[i]));
+    }
+    *(fr_t *)out = acc;
+}
+void orc_poly_witness(orc_fr *q, orc_fr *value, const orc_fr *coeffs, size_t n, const orc_fr *z) {
+    /* p(x) = (x - z) q(x) + p(z):  q_{n-2} = c_{n-1},  q_{i-1} = c_i + z q_i,  p(z) = c_0 + z q_0 */
+    fr_t carry;
+    fr_zero(&carry);
+    for (size_t i = n; i-- > 0;) {
+        fr_t t;
+        fr_mul(&t, &carry, S(z));
+        fr_add(&t, &t, S(&coeffs[i]));
+        if (i > 0) *(fr_t *)&q[i - 1] = t;
+        else *(fr_t *)value = t;
+        carry = t;
+    }
+}
 int orc_kzg_check(const orc_kzg_vk *vk, const orc_g1_affine *comm, const orc_fr *point, const orc_fr *value,
                   const orc_g1_affine *witness) {
     uint8_t one[16] = {1};

@@ -223,6 +223,37 @@ def kzg_batch_check(vk, comms, points, values, witnesses, randomizers):
                                           C.c_size_t(n), _p(rnd)))
 
 
+def kzg_commit(powers, coeffs, threads=1):
+    """sum_i coeffs[i] * powers[i] (coefficients Montgomery) -> (12,) affine"""
+    coeffs = np.ascontiguousarray(coeffs, dtype=np.uint64).reshape(-1, 4)
+    out = u64(18)
+    lib().orc_kzg_commit(_p(out), _p(np.ascontiguousarray(powers, dtype=np.uint64)), _p(coeffs), C.c_size_t(len(coeffs)), C.c_int(threads))
+    return jac_to_affine(out)
+
+
+def poly_mul_schoolbook(a, b):
+    a = np.ascontiguousarray(a, dtype=np.uint64).reshape(-1, 4)
+    b = np.ascontiguousarray(b, dtype=np.uint64).reshape(-1, 4)
+    out = u64((len(a) + len(b) - 1, 4))
+    lib().orc_poly_mul_schoolbook(_p(out), _p(a), C.c_size_t(len(a)), _p(b), C.c_size_t(len(b)))
+    return out
+
+
+def poly_eval(coeffs, z):
+    coeffs = np.ascontiguousarray(coeffs, dtype=np.uint64).reshape(-1, 4)
+    out = u64(4)
+    lib().orc_poly_eval(_p(out), _p(coeffs), C.c_size_t(len(coeffs)), _p(np.ascontiguousarray(z, dtype=np.uint64)))
+    return out
+
+
+def poly_witness(coeffs, z):
+    """(q, p(z)) with p(x) - p(z) = (x - z) q(x)"""
+    coeffs = np.ascontiguousarray(coeffs, dtype=np.uint64).reshape(-1, 4)
+    q, v = u64((max(len(coeffs) - 1, 1), 4)), u64(4)
+    lib().orc_poly_witness(_p(q), _p(v), _p(coeffs), C.c_size_t(len(coeffs)), _p(np.ascontiguousarray(z, dtype=np.uint64)))
+    return q[:len(coeffs) - 1], v
+
+
 def poseidon_hash_many(inputs, k, threads=1):
     """inputs: (n, m, 6) Montgomery Fq -> (n, k, 6)"""
     a = np.ascontiguousarray(inputs, dtype=np.uint64)

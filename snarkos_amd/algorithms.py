@@ -72,6 +72,20 @@ class ResidentBases:
                                     C.c_size_t(len(scalars)), L.ptr(out)), "mi_msm_g1_h")
         return out
 
+    def commit(self, coeffs, offset=0, stream=None):
+        """kzg10::KZG10::commit (no hiding) with these bases as powers_of_beta_g: sum_i coeffs[i] * powers[offset+i].
+        coeffs: (n, 4) uint64 Montgomery Fr (numpy, or a CUDA tensor to stay on the device)."""
+        out = np.zeros(L.G1_JAC_U64, dtype=np.uint64)
+        if _is_torch_cuda(coeffs):
+            n = coeffs.numel() * coeffs.element_size() // 32
+            L.check(L.lib().mi_kzg_commit_h_device(C.c_uint64(self.handle), C.c_size_t(offset), L.dptr(coeffs), C.c_size_t(n),
+                                                   L.ptr(out), L.stream_ptr(stream)), "mi_kzg_commit_h_device")
+            return out
+        coeffs = np.ascontiguousarray(coeffs, dtype=np.uint64).reshape(-1, 4)
+        L.check(L.lib().mi_kzg_commit_h(C.c_uint64(self.handle), C.c_size_t(offset), L.ptr(coeffs), C.c_size_t(len(coeffs)),
+                                        L.ptr(out)), "mi_kzg_commit_h")
+        return out
+
     def release(self):
         if self.handle:
             L.check(L.lib().mi_bases_release(C.c_uint64(self.handle)), "mi_bases_release")
@@ -120,6 +134,19 @@ class EvaluationDomain:
 
     def coset_ifft(self, evals, stream=None):
         return self._run(evals, 1, 1, stream)
+
+
+class DensePolynomial:
+    """snarkvm_algorithms::fft::DensePolynomial (the product only)"""
+
+    @staticmethod
+    def mul(a, b):
+        """Coefficients of a * b, (len(a) + len(b) - 1, 4) uint64 Montgomery, through the evaluation domain."""
+        a = np.ascontiguousarray(a, dtype=np.uint64).reshape(-1, 4)
+        b = np.ascontiguousarray(b, dtype=np.uint64).reshape(-1, 4)
+        out = np.zeros((len(a) + len(b) - 1, 4), dtype=np.uint64)
+        L.check(L.lib().mi_poly_mul_fr(L.ptr(a), C.c_size_t(len(a)), L.ptr(b), C.c_size_t(len(b)), L.ptr(out)), "mi_poly_mul_fr")
+        return out
 
 
 class Bls12_377:

@@ -314,6 +314,67 @@ int32_t mi_ntt_fr_device(void *d_data, uint32_t log_n, int32_t inverse, int32_t 
     });
 }
 
+// ------------------------------------------------------------ prover-side reuse (KZG10::commit, polynomial product)
+__global__ void __launch_bounds__(256) fr_to_canonical_kernel(const Fr *__restrict__ in, size_t n, uint32_t *__restrict__ out) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    Fr v = from_mont(in[i]);
+#pragma unroll
+    for (int k = 0; k < 8; k++) out[i * 8 + k] = v.l[k];
+}
+// a[i] *= b[i]
+__global__ void __launch_bounds__(256) fr_pointwise_mul_kernel(Fr *__restrict__ a, const Fr *__restrict__ b, size_t n) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) a[i] = mul(a[i], b[i]);
+}
+static int32_t kzg_commit_impl(Context &cx, uint64_t handle, size_t offset, const Fr *d_coeffs, size_t n, mi_g1_jac *out,
+                               hipStream_t st) {
+    auto it = cx.handles.find(handle);
+    if (it == cx.handles.end() || offset + n > cx.handle_len[handle]) return MI_ERR_BAD_ARGS;
+    uint32_t *ds = (uint32_t *)cx.buf("kzg.commit_scalars", 32 * (n ? n : 1));
+    if (n) hipLaunchKernelGGL(fr_to_canonical_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, d_coeffs, n, ds);
+    msm_device(cx, (const G1Affine *)it->second.p + offset, ds, n, out, st);
+    return MI_OK;
+}
+int32_t mi_kzg_commit_h(uint64_t handle, size_t offset, const mi_fr *coeffs, size_t n, mi_g1_jac *out) {
+    if (!out || (n && !coeffs) || n > MI_MSM_MAX_N) return MI_ERR_BAD_ARGS;
+    return guarded([&]() -> int32_t {
+        Context &cx = ctx();
+        Fr *d = (Fr *)cx.buf("kzg.commit_coeffs", 32 * (n ? n : 1));
+        if (n) MI_HIP(hipMemcpyAsync(d, coeffs, 32 * n, hipMemcpyHostToDevice, cx.stream));
+        return kzg_commit_impl(cx, handle, offset, d, n, out, cx.stream);
+    });
+}
+int32_t mi_kzg_commit_h_device(uint64_t handle, size_t offset, const void *d_coeffs, size_t n, mi_g1_jac *out, void *stream) {
+    if (!out || (n && !d_coeffs) || n > MI_MSM_MAX_N) return MI_ERR_BAD_ARGS;
+    return guarded([&]() -> int32_t {
+        return kzg_commit_impl(ctx(), handle, offset, (const Fr *)d_coeffs, n, out, (hipStream_t)stream);
+    });
+}
+int32_t mi_poly_mul_fr(const mi_fr *a, size_t na, const mi_fr *b, size_t nb, mi_fr *out) {
+    if (!a || !b || !out || !na || !nb || na + nb - 1 > ((size_t)1 << 30)) return MI_ERR_BAD_ARGS;
+    return guarded([&]() -> int32_t {
+        Context &cx = ctx();
+        const size_t nout = na + nb - 1;
+        uint32_t log_n = 0;
+        while (((size_t)1 << log_n) < nout) log_n++;
+        const size_t N = (size_t)1 << log_n;
+        Fr *da = (Fr *)cx.buf("poly.a", sizeof(Fr) * N), *db = (Fr *)cx.buf("poly.b", sizeof(Fr) * N);
+        MI_HIP(hipMemsetAsync(da, 0, sizeof(Fr) * N, cx.stream));  // zero is zero in Montgomery form too
+        MI_HIP(hipMemsetAsync(db, 0, sizeof(Fr) * N, cx.stream));
+        MI_HIP(hipMemcpyAsync(da, a, sizeof(Fr) * na, hipMemcpyHostToDevice, cx.stream));
+        MI_HIP(hipMemcpyAsync(db, b, sizeof(Fr) * nb, hipMemcpyHostToDevice, cx.stream));
+        ntt_device(cx, da, log_n, false, false, cx.stream);
+        ntt_device(cx, db, log_n, false, false, cx.stream);
+        hipLaunchKernelGGL(fr_pointwise_mul_kernel, dim3(cdiv(N, 256)), dim3(256), 0, cx.stream, da, db, N);
+        ntt_device(cx, da, log_n, true, false, cx.stream);
+        MI_HIP(hipGetLastError());
+        MI_HIP(hipMemcpyAsync(out, da, sizeof(Fr) * nout, hipMemcpyDeviceToHost, cx.stream));
+        MI_HIP(hipStreamSynchronize(cx.stream));
+        return MI_OK;
+    });
+}
+
 // ------------------------------------------------------------ pairing / KZG
 int32_t mi_pairing_product_is_one(const mi_g1_affine *ps, const mi_g2_affine *qs, size_t n, uint8_t *is_one) {
     if (!ps || !qs || !is_one || n == 0 || n > MI_MAX_PAIRS) return MI_ERR_BAD_ARGS;

@@ -39,3 +39,12 @@ def jac_affine(j):
     one = np.array([int(x) for x in O.int_to_limbs(P.FQ_MONT_R, 6)], dtype=np.uint64)
     assert (j[12:] == one).all(), "library outputs must be normalised (z = 1)"
     return j[:12].copy()
+
+
+def toy_srs(n, tau):
+    """powers_of_beta_g[i] = tau^i * G for i < n ((n, 12) Montgomery affine) and the matching kzg vk (toy setup: tau known)"""
+    pw, acc = [], 1
+    for _ in range(n):
+        pw.append(acc)
+        acc = acc * tau % P.R
+    return O.fixed_base_batch(O.fr_from_ints(pw)), O.kzg_vk(tau)

@@ -1,0 +1,102 @@
+"""-m gpu: prover-side reuse of the MSM / NTT kernels: KZG10::commit and the polynomial product,
+bit-exact against the CPU oracle, tied to the verifier side by an end-to-end commit -> open -> check."""
+import numpy as np
+import pytest
+
+import pyref as P
+from helpers import jac_affine, rng_fr_mont, toy_srs
+
+pytestmark = pytest.mark.gpu
+
+TAU = 0x1234567890ABCDEF1122334455667788 % P.R
+
+
+@pytest.fixture(scope="module")
+def srs(orc, mi):
+    powers, vk = toy_srs(5200, TAU)
+    rb = mi.ResidentBases(powers)
+    yield powers, vk, rb
+    rb.release()
+
+
+@pytest.mark.parametrize("n", [1, 2, 100, 5000])
+def test_commit_matches_oracle_and_p_of_tau(orc, mi, srs, n):
+    powers, _, rb = srs
+    coeffs = rng_fr_mont(900 + n, n)
+    got = jac_affine(rb.commit(coeffs))
+    assert (got == orc.kzg_commit(powers[:n], coeffs, threads=8)).all()
+    # commitment to p is p(tau) * G: an identity neither implementation's MSM knows about
+    p_tau = orc.fr_to_ints(orc.poly_eval(coeffs, orc.fr_from_ints([TAU])[0]))[0]
+    assert (got == orc.g1_mul(orc.g1_generator(), p_tau)).all()
+
+
+def test_commit_edge_cases(orc, mi, srs):
+    import torch
+    powers, _, rb = srs
+    assert not jac_affine(rb.commit(np.zeros((0, 4), dtype=np.uint64))).any()          # empty polynomial
+    assert not jac_affine(rb.commit(np.zeros((17, 4), dtype=np.uint64))).any()         # zero polynomial
+    coeffs = rng_fr_mont(77, 300)
+    coeffs[5] = 0
+    coeffs[9] = orc.fr_from_ints([P.R - 1])[0]
+    want = orc.kzg_commit(powers[40:340], coeffs, threads=8)
+    assert (jac_affine(rb.commit(coeffs, offset=40)) == want).all()                    # shifted powers
+    dev = torch.from_numpy(coeffs.view(np.int64)).cuda()
+    assert (jac_affine(rb.commit(dev, offset=40)) == want).all()                       # coefficients already in HBM
+    from snarkos_amd.lib import MiError
+    with pytest.raises(MiError):
+        rb.commit(rng_fr_mont(1, 10), offset=5195)                                     # runs past the powers
+
+
+def test_commit_is_linear_at_2_16(orc, mi):
+    n = 1 << 16
+    powers, _ = toy_srs(n, TAU)
+    rb = mi.ResidentBases(powers)
+    try:
+        a, b = rng_fr_mont(11, n), rng_fr_mont(12, n)
+        ai, bi = orc.fr_to_ints(a), orc.fr_to_ints(b)
+        s = orc.fr_from_ints([(x + y) % P.R for x, y in zip(ai, bi)])
+        ca, cb, cs = (jac_affine(rb.commit(x)) for x in (a, b, s))
+        assert (orc.g1_add_affine(ca, cb) == cs).all()
+        assert (ca == orc.kzg_commit(powers, a, threads=8)).all()
+    finally:
+        rb.release()
+
+
+@pytest.mark.parametrize("na,nb", [(1, 1), (7, 5), (1000, 1), (300, 257), (1024, 1025)])
+def test_poly_mul_matches_schoolbook(orc, mi, na, nb):
+    a, b = rng_fr_mont(3000 + na, na), rng_fr_mont(4000 + nb, nb)
+    got = mi.DensePolynomial.mul(a, b)
+    assert got.shape == (na + nb - 1, 4)
+    assert (got == orc.poly_mul_schoolbook(a, b)).all()
+
+
+def test_poly_mul_large_by_evaluation(orc, mi):
+    """2^17-coefficient operands: (a b)(z) = a(z) b(z) at a random z, and the top coefficient is the product of the tops"""
+    n = 1 << 17
+    a, b = rng_fr_mont(51, n), rng_fr_mont(52, n - 3)
+    got = mi.DensePolynomial.mul(a, b)
+    z = orc.fr_from_ints([0x5EED5EED5EED5EED5EED5EED5EED % P.R])[0]
+    ev = lambda c: orc.fr_to_ints(orc.poly_eval(c, z))[0]
+    assert ev(got) == ev(a) * ev(b) % P.R
+    assert orc.fr_to_ints(got[-1:])[0] == orc.fr_to_ints(a[-1:])[0] * orc.fr_to_ints(b[-1:])[0] % P.R
+
+
+def test_commit_open_check_end_to_end(orc, mi, srs):
+    """prover side on the GPU (commit p, commit the witness polynomial), verifier side on the GPU (KZG10 check):
+    the pairing equation only holds if MSM, the conversion of coefficients and the check agree with the algebra"""
+    powers, vk, rb = srs
+    p = rng_fr_mont(7001, 4096)
+    z = orc.fr_from_ints([0xC0FFEE1234567 % P.R])[0]
+    q, value = orc.poly_witness(p, z)
+    assert (value == orc.poly_eval(p, z)).all()
+    comm, wit = jac_affine(rb.commit(p)), jac_affine(rb.commit(q))
+    assert mi.KZG10.check(vk, comm, z, value, wit)
+    assert orc.kzg_batch_check(vk, comm[None], z[None], value[None], wit[None], np.frombuffer((1).to_bytes(16, "little"), dtype=np.uint8))
+    bad = orc.fr_from_ints([(orc.fr_to_ints(value)[0] + 1) % P.R])[0]
+    assert not mi.KZG10.check(vk, comm, z, bad, wit)
+    # a product polynomial commits to the product of evaluations at tau
+    f, g = rng_fr_mont(7002, 1500), rng_fr_mont(7003, 2000)
+    fg = mi.DensePolynomial.mul(f, g)
+    t = orc.fr_from_ints([TAU])[0]
+    want = orc.fr_to_ints(orc.poly_eval(f, t))[0] * orc.fr_to_ints(orc.poly_eval(g, t))[0] % P.R
+    assert (jac_affine(rb.commit(fg)) == orc.g1_mul(orc.g1_generator(), want)).all()
