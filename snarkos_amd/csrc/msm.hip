@@ -340,19 +340,6 @@ __global__ void __launch_bounds__(128) msm_accumulate_kernel(const G1Affine *__r
     }
     store_xyzz(&chunk_partial[t], acc);
 }
-// lane per bucket: bucket = sum of its (few) chunk partials; heavy buckets are left to the block kernel
-__global__ void __launch_bounds__(128) msm_combine_kernel(const G1Xyzz *__restrict__ chunk_partial,
-                                                          const uint32_t *__restrict__ chunk_off, size_t nb, uint32_t heavy,
-                                                          G1Xyzz *__restrict__ buckets) {
-    size_t b = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= nb) return;
-    uint32_t lo = chunk_off[b], hi = chunk_off[b + 1];
-    if (hi - lo > heavy) return;
-    G1Xyzz acc = G1Xyzz::inf();
-    if (lo < hi) acc = load_xyzz(&chunk_partial[lo]);
-    for (uint32_t t = lo + 1; t < hi; t++) acc = xyzz_add_ni(acc, load_xyzz(&chunk_partial[t]));
-    store_xyzz(&buckets[b], acc);
-}
 // block per heavy bucket: strided partial sums, then an LDS tree
 __global__ void __launch_bounds__(256) msm_combine_heavy_kernel(const G1Xyzz *__restrict__ chunk_partial,
                                                                 const uint32_t *__restrict__ chunk_off,
@@ -379,17 +366,29 @@ __global__ void __launch_bounds__(256) msm_combine_heavy_kernel(const G1Xyzz *__
 
 // ---------------------------------------------------------------- K5: segment partials
 // thread (w, g): part = sum_{j=0}^{L-1} (g*L + j + 1) * bucket[w][g*L + j]
-__global__ void __launch_bounds__(128) msm_segments_kernel(const G1Xyzz *__restrict__ buckets, uint32_t B, uint32_t L,
+__global__ void __launch_bounds__(128) msm_segments_kernel(const G1Xyzz *__restrict__ chunk_partial,
+                                                           const uint32_t *__restrict__ chunk_off, uint32_t heavy,
+                                                           const G1Xyzz *__restrict__ heavy_buckets, uint32_t B, uint32_t L,
                                                            size_t n_segments_total, G1Xyzz *__restrict__ partials) {
     size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= n_segments_total) return;
     uint32_t G = B / L;
     size_t w = t / G;
     uint32_t g = (uint32_t)(t - w * G);
-    const G1Xyzz *seg = buckets + w * B + (size_t)g * L;
+    const size_t b0 = w * B + (size_t)g * L;
     G1Xyzz run = G1Xyzz::inf(), wsum = G1Xyzz::inf();
     for (int j = (int)L - 1; j >= 0; j--) {
-        run = add(run, load_xyzz(&seg[j]));
+        // the bucket's value straight from its chunk partials (nearly always exactly one: no separate combine pass);
+        // only buckets cut into more than `heavy` chunks were summed by the block kernel
+        const uint32_t lo = chunk_off[b0 + j], hi = chunk_off[b0 + j + 1];
+        G1Xyzz v = G1Xyzz::inf();
+        if (hi - lo > heavy) {
+            v = load_xyzz(&heavy_buckets[b0 + j]);
+        } else if (lo < hi) {
+            v = load_xyzz(&chunk_partial[lo]);
+            for (uint32_t e = lo + 1; e < hi; e++) v = add(v, load_xyzz(&chunk_partial[e]));
+        }
+        run = add(run, v);
         wsum = add(wsum, run);
     }
     // + (g*L) * run  (double-and-add on the XYZZ point)
@@ -630,14 +629,14 @@ static void msm_enqueue_eager(Context &cx, const G1Affine *d_points, const uint3
     } else {
         G1Xyzz *buckets = (G1Xyzz *)cx.buf(W("buckets"), sizeof(G1Xyzz) * nb);
         cx.prof.begin("msm_combine", st, n);
-        hipLaunchKernelGGL(msm_combine_kernel, dim3(cdiv(nb, 128)), dim3(128), 0, st, chunk_partial, chunk_off, nb, HEAVY, buckets);
         hipLaunchKernelGGL(msm_combine_heavy_kernel, dim3(1024), dim3(256), 0, st, chunk_partial, chunk_off, heavy_list, heavy_count, buckets);
         cx.prof.end("msm_combine", st);
         uint32_t L = pl.B >= 4096 ? 8 : 4;
         const size_t nseg = nb / L;
         G1Xyzz *partials = (G1Xyzz *)cx.buf(W("partials"), sizeof(G1Xyzz) * nseg);
         cx.prof.begin("msm_segments", st, n);
-        hipLaunchKernelGGL(msm_segments_kernel, dim3(cdiv(nseg, 128)), dim3(128), 0, st, buckets, pl.B, L, nseg, partials);
+        hipLaunchKernelGGL(msm_segments_kernel, dim3(cdiv(nseg, 128)), dim3(128), 0, st, chunk_partial, chunk_off, HEAVY, buckets, pl.B,
+                           L, nseg, partials);
         cx.prof.end("msm_segments", st);
         cx.prof.begin("msm_tree", st, n);
         result = device_group_sum(cx, partials, pl.nwin, pl.B / L, st, ta, tb);
