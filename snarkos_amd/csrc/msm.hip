@@ -32,6 +32,19 @@ struct MsmPlan {
 };
 
 // largest n that takes the small (latency-bound) path; MI_SNARK_MSM_SMALL_LOG overrides for experiments
+// chunk length on the small path: longer chunks = fewer partials for the bit-sum reduction (less GPU work per MSM),
+// shorter = shorter accumulation chains (latency); MI_SNARK_MSM_SMALL_T overrides for experiments
+static uint32_t msm_small_chunk() {
+    static uint32_t t = 0;
+    if (!t) {
+        t = 16;
+        if (const char *e = getenv("MI_SNARK_MSM_SMALL_T")) {
+            const int x = atoi(e);
+            if (x >= 4 && x <= 256) t = (uint32_t)x;
+        }
+    }
+    return t;
+}
 size_t msm_small_limit() {
     static size_t lim = 0;
     if (!lim) {
@@ -558,7 +571,7 @@ static void msm_enqueue_eager(Context &cx, const G1Affine *d_points, const uint3
     // chunking: T = twice the mean bucket load of a full window, so only over-full buckets are split
     uint32_t T = (uint32_t)(2 * ((n + pl.B - 1) / pl.B));
     if (T < 16) T = 16;
-    if (small) T = 16;
+    if (small) T = msm_small_chunk();
     const uint32_t HEAVY = 8;
     const size_t max_chunks = nb + (n * (size_t)pl.nwin) / T + 1;
     uint32_t *chunk_off = (uint32_t *)cx.buf(W("chunk_off"), sizeof(uint32_t) * (nb + 1));
