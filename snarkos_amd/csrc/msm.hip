@@ -456,29 +456,32 @@ __device__ __forceinline__ G1Xyzz xyzz_shfl_down(const G1Xyzz &a, int delta) {
         for (int k = 0; k < 12; k++) dst[q]->l[k] = __shfl_down(src[q]->l[k], delta, 64);
     return r;
 }
+template <int LPG>  // lanes per group: 64 (one group per wave) or 32 (two: half the tree work, twice the walk)
 __global__ void __launch_bounds__(64) msm_bit_sums_wave_kernel(const G1Xyzz *__restrict__ chunk_partial,
                                                                const uint32_t *__restrict__ chunk_off,
                                                                const uint32_t *__restrict__ chunk_bucket, uint32_t B, int c,
-                                                               G1Xyzz *__restrict__ out) {
-    const uint32_t g = blockIdx.x, w = g / (uint32_t)c, bit = g - w * (uint32_t)c;
-    const uint32_t lo = chunk_off[(size_t)w * B], hi = chunk_off[(size_t)(w + 1) * B];
-    const int lane = threadIdx.x;
+                                                               uint32_t n_groups, G1Xyzz *__restrict__ out) {
+    const int lane = threadIdx.x % LPG;
+    const uint32_t g = blockIdx.x * (64 / LPG) + threadIdx.x / LPG;
+    const bool valid = g < n_groups;
+    const uint32_t gg = valid ? g : 0, w = gg / (uint32_t)c, bit = gg - w * (uint32_t)c;
+    const uint32_t lo = chunk_off[(size_t)w * B], hi = valid ? chunk_off[(size_t)(w + 1) * B] : lo;
     G1Xyzz acc = G1Xyzz::inf();
     uint32_t e = lo + lane;
     for (;;) {
-        while (e < hi && !(((chunk_bucket[e] - w * B + 1) >> bit) & 1u)) e += 64;
+        while (e < hi && !(((chunk_bucket[e] - w * B + 1) >> bit) & 1u)) e += LPG;
         if (__ballot(e < hi) == 0ull) break;
         if (e < hi) {
             acc = add<true>(acc, load_xyzz(&chunk_partial[e]));  // products inlined: the call overhead of the shared copy doubles an addition
-            e += 64;
+            e += LPG;
         }
     }
 #pragma unroll 1
-    for (int stride = 32; stride >= 1; stride >>= 1) {
+    for (int stride = LPG / 2; stride >= 1; stride >>= 1) {
         G1Xyzz other = xyzz_shfl_down(acc, stride);
         if (lane < stride) acc = add<true>(acc, other);
     }
-    if (lane == 0) store_xyzz(&out[g], acc);
+    if (lane == 0 && valid) store_xyzz(&out[g], acc);
 }
 
 // ---------------------------------------------------------------- host driver
@@ -635,8 +638,13 @@ static void msm_enqueue_eager(Context &cx, const G1Affine *d_points, const uint3
         snprintf(pn, sizeof pn, "msm%d.pin%d", slot, pin_parity);
         job->h = (G1Xyzz *)cx.pin_named(pn, sizeof(G1Xyzz) * all_groups);
         cx.prof.begin("msm_bitsums", st, n);
-        hipLaunchKernelGGL(msm_bit_sums_wave_kernel, dim3((unsigned)all_groups), dim3(64), 0, st, chunk_partial, chunk_off,
-                           chunk_bucket, pl.B, pl.c, job->h);  // straight into pinned host memory
+        static const int lpg = getenv("MI_SNARK_BITSUM_LPG") ? atoi(getenv("MI_SNARK_BITSUM_LPG")) : 64;
+        if (lpg == 32)
+            hipLaunchKernelGGL(msm_bit_sums_wave_kernel<32>, dim3((unsigned)((all_groups + 1) / 2)), dim3(64), 0, st, chunk_partial,
+                               chunk_off, chunk_bucket, pl.B, pl.c, (uint32_t)all_groups, job->h);
+        else
+            hipLaunchKernelGGL(msm_bit_sums_wave_kernel<64>, dim3((unsigned)all_groups), dim3(64), 0, st, chunk_partial, chunk_off,
+                               chunk_bucket, pl.B, pl.c, (uint32_t)all_groups, job->h);  // straight into pinned host memory
         cx.prof.end("msm_bitsums", st);
         result = nullptr;
     } else {
