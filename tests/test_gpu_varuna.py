@@ -208,3 +208,26 @@ def test_block_of_8192_proofs_as_eight_shards(orc, mi):
         assert not v.finalize(parts)
     finally:
         v.close()
+
+
+def test_batch_too_large_for_the_fused_msm_pair(orc, mi):
+    """5 100 proofs: 13 n + 97 operand points exceed the small-MSM limit (2^16), so the two accumulators run as two
+    separate MSMs (the H side on the large-MSM path); partial bit-exact with the oracle, verdicts with one bad proof"""
+    import torch
+    n = 5100
+    b = orc.VSBatch(0xB16B, n, 4, 0)
+    v = _ctx(mi, b)
+    try:
+        p = torch.from_numpy(b.proofs).cuda(); r = torch.from_numpy(b.randomizers).cuda()
+        part = v.accumulate(p, r)
+        want = np.frombuffer(np.ascontiguousarray(orc.vs_partial_from_oracle(b, threads=8)).tobytes(), dtype=np.uint8)
+        assert (part == want).all()
+        assert v.finalize([part])
+        ok, verdicts = v.verify_batch(p, r)
+        assert ok and verdicts.all()
+        bad = b.proofs.copy(); bad[4321 * 2256 + 16 + 512 + 864 + 32 * 2] ^= 8
+        ok, verdicts = v.verify_batch(bad, b.randomizers)
+        assert not ok and verdicts.sum() == n - 1 and verdicts[4321] == 0
+        assert list(v.verify_stream(iter([(p, r), (torch.from_numpy(bad).cuda(), r), (p, r)]))) == [True, False, True]
+    finally:
+        v.close()
