@@ -81,6 +81,11 @@ int32_t mi_ntt_fr_device(void *d_data, uint32_t log_n, int32_t inverse, int32_t 
 int32_t mi_kzg_commit_h(uint64_t powers_handle, size_t offset, const mi_fr *coeffs, size_t n, mi_g1_jac *out);
 int32_t mi_kzg_commit_h_device(uint64_t powers_handle, size_t offset, const void *d_coeffs, size_t n, mi_g1_jac *out,
                                void *stream);
+/* polycommit::kzg10::KZG10::open without hiding: value = p(point) and the commitment to the witness polynomial
+ * (p(X) - p(point)) / (X - point), whose coefficients are the suffix Horner sums of p (a scan on the device), committed
+ * with the same powers.  coeffs / point / value_out in Montgomery form.  n = 0: value 0, witness infinity. */
+int32_t mi_kzg_open_h(uint64_t powers_handle, const mi_fr *coeffs, size_t n, const mi_fr *point, mi_fr *value_out,
+                      mi_g1_jac *witness_out);
 /* fft::DensePolynomial multiplication through the evaluation domain of size >= na + nb - 1 (two forward NTTs, a
  * pointwise product, one inverse NTT): out[0 .. na + nb - 1).  na, nb >= 1. */
 int32_t mi_poly_mul_fr(const mi_fr *a, size_t na, const mi_fr *b, size_t nb, mi_fr *out);

@@ -86,6 +86,16 @@ class ResidentBases:
                                         L.ptr(out)), "mi_kzg_commit_h")
         return out
 
+    def open(self, coeffs, point):
+        """kzg10::KZG10::open (no hiding) with these bases as powers: (p(point) as (4,) uint64 Montgomery, commitment to
+        the witness polynomial (p(X) - p(point)) / (X - point) as a normalised Jacobian point)."""
+        coeffs = np.ascontiguousarray(coeffs, dtype=np.uint64).reshape(-1, 4)
+        point = np.ascontiguousarray(point, dtype=np.uint64).reshape(4)
+        value, wit = np.zeros(4, dtype=np.uint64), np.zeros(L.G1_JAC_U64, dtype=np.uint64)
+        L.check(L.lib().mi_kzg_open_h(C.c_uint64(self.handle), L.ptr(coeffs), C.c_size_t(len(coeffs)), L.ptr(point),
+                                      L.ptr(value), L.ptr(wit)), "mi_kzg_open_h")
+        return value, wit
+
     def release(self):
         if self.handle:
             L.check(L.lib().mi_bases_release(C.c_uint64(self.handle)), "mi_bases_release")

@@ -351,6 +351,129 @@ int32_t mi_kzg_commit_h_device(uint64_t handle, size_t offset, const void *d_coe
         return kzg_commit_impl(ctx(), handle, offset, (const Fr *)d_coeffs, n, out, (hipStream_t)stream);
     });
 }
+// ---- witness polynomial q(X) = (p(X) - p(z)) / (X - z): q_{i-1} = S_i, p(z) = S_0 with the suffix Horner sums
+// S_i = c_i + z S_{i+1}.  Three kernels: (1) every thread folds OPEN_R consecutive coefficients into (L, z^R) and the
+// block scans these affine maps from the top (suffix scan, Hillis-Steele over 256 threads); (2) one workgroup carries
+// the block totals across blocks; (3) every thread re-walks its coefficients from the value entering its range.
+#define OPEN_R 8
+#define OPEN_BLOCK 256
+struct OpenMap {  // x -> l + w x
+    Fr l, w;
+};
+__device__ __forceinline__ OpenMap open_compose(const OpenMap &lo, const OpenMap &hi) {  // lo after hi (hi is nearer the top)
+    return OpenMap{add(lo.l, mul(lo.w, hi.l)), mul(lo.w, hi.w)};
+}
+__global__ void __launch_bounds__(OPEN_BLOCK) open_local_kernel(const Fr *__restrict__ c, size_t n, Fr z, OpenMap *__restrict__ thread_maps,
+                                                                OpenMap *__restrict__ block_maps) {
+    __shared__ OpenMap sh[OPEN_BLOCK];
+    const int t = threadIdx.x;
+    const size_t base = ((size_t)blockIdx.x * OPEN_BLOCK + t) * OPEN_R;
+    OpenMap m{Fr::zero(), Fr::one()};
+    for (int k = OPEN_R - 1; k >= 0; k--) {  // x -> c_base + z (c_{base+1} + z (... + z x)); past the end: identity
+        if (base + k < n) {
+            m.l = add(c[base + k], mul(z, m.l));
+            m.w = mul(z, m.w);
+        }
+    }
+    // suffix scan: after the loop sh[t] maps the value entering the block's top to S at this thread's first index
+    sh[t] = m;
+    __syncthreads();
+    for (int d = 1; d < OPEN_BLOCK; d <<= 1) {
+        OpenMap other;
+        const bool has = t + d < OPEN_BLOCK;
+        if (has) other = sh[t + d];
+        __syncthreads();
+        if (has) {
+            m = open_compose(m, other);
+            sh[t] = m;
+        }
+        __syncthreads();
+    }
+    thread_maps[(size_t)blockIdx.x * OPEN_BLOCK + t] = m;
+    if (t == 0) block_maps[blockIdx.x] = m;
+}
+// carry[b] = S at the first index of block b + 1 (0 for the last block); single workgroup, serial over the blocks in
+// chunks: thread t owns blocks [t * per, (t + 1) * per)
+__global__ void __launch_bounds__(1024) open_carry_kernel(const OpenMap *__restrict__ block_maps, size_t nblocks, Fr *__restrict__ carry) {
+    __shared__ OpenMap sh[1024];
+    const int t = threadIdx.x;
+    const size_t per = (nblocks + 1023) / 1024;
+    const size_t lo = (size_t)t * per, hi = lo + per < nblocks ? lo + per : nblocks;
+    OpenMap m{Fr::zero(), Fr::one()};
+    for (size_t b = hi; b-- > lo;) m = open_compose(block_maps[b], m);  // map over this thread's blocks
+    sh[t] = m;
+    __syncthreads();
+    for (int d = 1; d < 1024; d <<= 1) {
+        OpenMap other;
+        const bool has = t + d < 1024;
+        if (has) other = sh[t + d];
+        __syncthreads();
+        if (has) {
+            m = open_compose(m, other);
+            sh[t] = m;
+        }
+        __syncthreads();
+    }
+    // value entering this thread's topmost block = S just above it = (suffix map of the threads above)(0)
+    Fr x = t + 1 < 1024 ? sh[t + 1].l : Fr::zero();
+    for (size_t b = hi; b-- > lo;) {
+        carry[b] = x;
+        x = add(block_maps[b].l, mul(block_maps[b].w, x));
+    }
+}
+__global__ void __launch_bounds__(OPEN_BLOCK) open_apply_kernel(const Fr *__restrict__ c, size_t n, Fr z,
+                                                                const OpenMap *__restrict__ thread_maps, const Fr *__restrict__ carry,
+                                                                Fr *__restrict__ q, Fr *__restrict__ value) {
+    const int t = threadIdx.x;
+    const size_t tid = (size_t)blockIdx.x * OPEN_BLOCK + t, base = tid * OPEN_R;
+    if (base >= n) return;
+    const Fr cb = carry[blockIdx.x];
+    Fr x = cb;
+    if (t + 1 < OPEN_BLOCK) {
+        const OpenMap m = thread_maps[tid + 1];
+        x = add(m.l, mul(m.w, cb));
+    }
+    for (int k = OPEN_R - 1; k >= 0; k--) {
+        const size_t i = base + k;
+        if (i < n) {
+            x = add(c[i], mul(z, x));  // S_i
+            if (i > 0) q[i - 1] = x;
+            else *value = x;
+        }
+    }
+}
+int32_t mi_kzg_open_h(uint64_t handle, const mi_fr *coeffs, size_t n, const mi_fr *point, mi_fr *value_out, mi_g1_jac *witness_out) {
+    if (!point || !value_out || !witness_out || (n && !coeffs) || n > MI_MSM_MAX_N) return MI_ERR_BAD_ARGS;
+    return guarded([&]() -> int32_t {
+        Context &cx = ctx();
+        hipStream_t st = cx.stream;
+        if (n == 0) {
+            memset(value_out, 0, sizeof *value_out);
+            return kzg_commit_impl(cx, handle, 0, nullptr, 0, witness_out, st);
+        }
+        if (cx.handles.find(handle) == cx.handles.end() || n - 1 > cx.handle_len[handle]) return MI_ERR_BAD_ARGS;
+        Fr z;
+        memcpy(&z, point, sizeof z);
+        const size_t nthreads = (n + OPEN_R - 1) / OPEN_R, nblocks = (nthreads + OPEN_BLOCK - 1) / OPEN_BLOCK;
+        Fr *dc = (Fr *)cx.buf("open.coeffs", sizeof(Fr) * n);
+        Fr *dq = (Fr *)cx.buf("open.q", sizeof(Fr) * n);  // q (n - 1 coefficients) followed by the value
+        OpenMap *tm = (OpenMap *)cx.buf("open.thread_maps", sizeof(OpenMap) * nblocks * OPEN_BLOCK);
+        OpenMap *bm = (OpenMap *)cx.buf("open.block_maps", sizeof(OpenMap) * nblocks);
+        Fr *carry = (Fr *)cx.buf("open.carry", sizeof(Fr) * nblocks);
+        MI_HIP(hipMemcpyAsync(dc, coeffs, sizeof(Fr) * n, hipMemcpyHostToDevice, st));
+        hipLaunchKernelGGL(open_local_kernel, dim3((unsigned)nblocks), dim3(OPEN_BLOCK), 0, st, dc, n, z, tm, bm);
+        hipLaunchKernelGGL(open_carry_kernel, dim3(1), dim3(1024), 0, st, bm, nblocks, carry);
+        hipLaunchKernelGGL(open_apply_kernel, dim3((unsigned)nblocks), dim3(OPEN_BLOCK), 0, st, dc, n, z, tm, carry, dq, dq + (n - 1));
+        MI_HIP(hipGetLastError());
+        Fr *hv = (Fr *)cx.pin(sizeof(Fr));
+        MI_HIP(hipMemcpyAsync(hv, dq + (n - 1), sizeof(Fr), hipMemcpyDeviceToHost, st));
+        int32_t s = kzg_commit_impl(cx, handle, 0, dq, n - 1, witness_out, st);  // msm_device waits for the stream's work
+        if (s != MI_OK) return s;
+        MI_HIP(hipStreamSynchronize(st));
+        memcpy(value_out, hv, sizeof(Fr));
+        return MI_OK;
+    });
+}
 int32_t mi_poly_mul_fr(const mi_fr *a, size_t na, const mi_fr *b, size_t nb, mi_fr *out) {
     if (!a || !b || !out || !na || !nb || na + nb - 1 > ((size_t)1 << 30)) return MI_ERR_BAD_ARGS;
     return guarded([&]() -> int32_t {

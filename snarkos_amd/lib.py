@@ -29,7 +29,7 @@ VS_MAX_TICKETS = 8
 EXPORTS = [
     "mi_init", "mi_shutdown", "mi_error_string", "mi_abi_version",
     "mi_msm_g1", "mi_msm_g1_device", "mi_g1_sum", "mi_bases_register", "mi_bases_release", "mi_msm_g1_h",
-    "mi_ntt_fr", "mi_ntt_fr_device", "mi_kzg_commit_h", "mi_kzg_commit_h_device", "mi_poly_mul_fr",
+    "mi_ntt_fr", "mi_ntt_fr_device", "mi_kzg_commit_h", "mi_kzg_commit_h_device", "mi_kzg_open_h", "mi_poly_mul_fr",
     "mi_pairing_product_is_one", "mi_pairing", "mi_kzg_batch_check",
     "mi_poseidon_fq_hash_many", "mi_poseidon_fq_hash_many_device",
     "mi_vs_ctx_create", "mi_vs_ctx_destroy", "mi_vs_verify_batch", "mi_vs_verify_batch_device",

@@ -100,3 +100,38 @@ def test_commit_open_check_end_to_end(orc, mi, srs):
     t = orc.fr_from_ints([TAU])[0]
     want = orc.fr_to_ints(orc.poly_eval(f, t))[0] * orc.fr_to_ints(orc.poly_eval(g, t))[0] % P.R
     assert (jac_affine(rb.commit(fg)) == orc.g1_mul(orc.g1_generator(), want)).all()
+
+
+@pytest.mark.parametrize("n", [1, 2, 9, 2048, 2049, 5000])
+def test_open_matches_oracle(orc, mi, srs, n):
+    """KZG10::open: value and witness commitment against the oracle's synthetic division + Pippenger"""
+    powers, vk, rb = srs
+    p = rng_fr_mont(8100 + n, n)
+    z = orc.fr_from_ints([(0xDEADBEEF00 + n) % P.R])[0]
+    value, wit = rb.open(p, z)
+    q, want_v = orc.poly_witness(p, z)
+    assert (value == want_v).all()
+    want_w = orc.kzg_commit(powers[:max(n - 1, 1)], q, threads=8) if n > 1 else np.zeros(12, dtype=np.uint64)
+    assert (jac_affine(wit) == want_w).all()
+    if n > 1:
+        assert mi.KZG10.check(vk, jac_affine(rb.commit(p)), z, value, jac_affine(wit))
+
+
+def test_open_edge_cases_and_large(orc, mi):
+    n = (1 << 16) + 7   # several scan blocks, ragged tail
+    powers, vk = toy_srs(n, TAU)
+    rb = mi.ResidentBases(powers)
+    try:
+        p = rng_fr_mont(8200, n)
+        p[n - 1] = 0                                     # leading zero coefficient
+        for zi in (0, 1, 0x1234567 % P.R):               # z = 0: value = c_0, q = shift; z = 1: value = sum
+            z = orc.fr_from_ints([zi])[0]
+            value, wit = rb.open(p, z)
+            q, want_v = orc.poly_witness(p, z)
+            assert (value == want_v).all()
+            assert (jac_affine(wit) == orc.kzg_commit(powers[:n - 1], q, threads=8)).all()
+        assert mi.KZG10.check(vk, jac_affine(rb.commit(p)), z, value, jac_affine(wit))
+        value, wit = rb.open(np.zeros((0, 4), dtype=np.uint64), z)
+        assert not value.any() and not jac_affine(wit).any()
+    finally:
+        rb.release()
