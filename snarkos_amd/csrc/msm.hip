@@ -57,6 +57,20 @@ size_t msm_small_limit() {
     }
     return lim;
 }
+// Window width of the large path relative to floor(log2 n) - 4.  Measured (252-bit scalars): one bit wider pays up to
+// 2^18 (2^17: 3.16 -> 2.70 ms, 2^18: 3.50 -> 2.87 ms: fewer windows to accumulate), not at 2^19 (4.16 vs 4.35 ms: the
+// bucket reduction grows).  MI_SNARK_MSM_C_BIAS overrides for experiments.
+static int msm_large_c_bias(int lg) {
+    static int b = 99;
+    if (b == 99) {
+        b = 98;
+        if (const char *e = getenv("MI_SNARK_MSM_C_BIAS")) {
+            const int x = atoi(e);
+            if (x >= -4 && x <= 2) b = x;
+        }
+    }
+    return b == 98 ? (lg <= 18 ? 1 : 0) : b;
+}
 static MsmPlan msm_plan(size_t n, int scalar_bits, int force_c) {
     int lg = 0;
     while (((size_t)1 << (lg + 1)) <= n) lg++;
@@ -64,6 +78,11 @@ static MsmPlan msm_plan(size_t n, int scalar_bits, int force_c) {
     if (c < 6) c = 6;
     if (c > 16) c = 16;
     if (force_c >= 6 && force_c <= 16) c = force_c;
+    else if (n > msm_small_limit()) {
+        c += msm_large_c_bias(lg);
+        if (c < 6) c = 6;
+        if (c > 16) c = 16;
+    }
     MsmPlan p;
     p.c = c;
     const int bits = scalar_bits > 128 ? 254 : 129;  // one spare bit so the top signed digit never overflows
@@ -82,7 +101,8 @@ __global__ void __launch_bounds__(256) msm_digits_kernel(const uint32_t *__restr
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     // two problems in one launch: points [split, n) use a second set of NWIN windows (buckets NWIN*B ...)
-    uint32_t *__restrict__ counts = counts_all + (i >= split ? (size_t)NWIN * B : 0);
+    const uint32_t pbase = i >= split ? (uint32_t)NWIN * B : 0u;
+    const int lane = threadIdx.x & 63;
     const uint4 *sp = reinterpret_cast<const uint4 *>(scalars + i * 8);
     uint4 lo = sp[0], hi = sp[1];
     uint32_t s[9] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w, 0u};
@@ -102,11 +122,34 @@ __global__ void __launch_bounds__(256) msm_digits_kernel(const uint32_t *__restr
             carry = 0;
         }
         digits[(size_t)w * n + i] = d;
-        if (d != 0) {
-            uint32_t mag = d < 0 ? (uint32_t)(-d) : (uint32_t)d;
-            // the histogram atomic also hands this entry its rank inside the bucket, so the scatter needs no atomics
-            ranks[(size_t)w * n + i] = atomicAdd(&counts[(size_t)w * B + (mag - 1)], 1u);
+        // The histogram atomic also hands this entry its rank inside the bucket, so the scatter needs no atomics.
+        // Windows with few live buckets (the top window of a 253-bit scalar holds one or two digits; skewed scalars
+        // anywhere) would serialise thousands of atomics on one address (measured: 1.7 ms of a 4.9 ms MSM at 2^18):
+        // while the first live lane's bucket is shared by 8+ lanes of the wave, those lanes take ONE atomic and number
+        // themselves by their position in the match mask.
+        bool live = d != 0;
+        const uint32_t mag = d < 0 ? (uint32_t)(-d) : (uint32_t)d;
+        const uint32_t bkt = pbase + (uint32_t)w * B + (mag - 1);
+        uint32_t rank = 0;
+#pragma unroll 1
+        for (int it = 0; it < 4; it++) {
+            const uint64_t am = __ballot(live);
+            if (!am) break;
+            const int leader = __ffsll((long long)am) - 1;
+            const uint32_t fb = (uint32_t)__shfl((int)bkt, leader, 64);
+            const bool mine = live && bkt == fb;
+            const uint64_t mm = __ballot(mine);
+            if (__popcll(mm) < 8) break;
+            uint32_t base = 0;
+            if (lane == leader) base = atomicAdd(&counts_all[fb], (uint32_t)__popcll(mm));
+            base = (uint32_t)__shfl((int)base, leader, 64);
+            if (mine) {
+                rank = base + (uint32_t)__popcll(mm & ((1ull << lane) - 1ull));
+                live = false;
+            }
         }
+        if (live) rank = atomicAdd(&counts_all[bkt], 1u);
+        if (d != 0) ranks[(size_t)w * n + i] = rank;
     }
 }
 

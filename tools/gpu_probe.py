@@ -19,12 +19,12 @@ for nt in (256 * 256, 256 * 1024):
     L.check(L.lib().mi_dbg_fq_mul_throughput(C.c_size_t(nt), C.c_uint32(200), C.byref(r)), "tp")
     print("fq mul throughput threads=%d: %.2f Gmul/s" % (nt, r.value), flush=True)
 names = ["msm_total", "msm_accumulate", "msm_digits", "msm_scan", "msm_scatter", "msm_chunks", "msm_combine", "msm_segments", "msm_tree", "msm_bitsums"]
-for lg in (10, 12, 13, 14, 16, 18, 20):
+for lg in [int(x) for x in os.environ.get("PROBE_LGS", "10,12,13,14,16,18,20").split(",")]:
     n = 1 << lg
     pts = torch.empty(n * 96, dtype=torch.uint8, device=dev)
     L.check(L.lib().mi_dbg_gen_points_device(C.c_uint64(7), C.c_size_t(n), L.dptr(pts), L.stream_ptr()), "gen")
     sc = torch.randint(0, 1 << 62, (n, 4), dtype=torch.int64, generator=g)
-    sc[:, 3] &= (1 << 58) - 1
+    sc[:, 3] &= (1 << 60) - 1  # uniform below 2^252 < r
     sc = sc.to(dev)
     torch.cuda.synchronize()
     A.VariableBase.msm(pts, sc)
