@@ -245,6 +245,16 @@ __global__ void __launch_bounds__(256) msm_scatter_kernel(const int32_t *__restr
 // out-of-line group addition for the cold reduction kernels
 // (group law inlined, field products out of line and register-passed: curve.hpp fm<false>)
 __device__ __forceinline__ G1Xyzz xyzz_add_ni(const G1Xyzz &a, const G1Xyzz &b) { return add<false>(a, b); }
+__device__ __forceinline__ G1Xyzz xyzz_shfl_down(const G1Xyzz &a, int delta) {
+    G1Xyzz r;
+    const Fq *src[4] = {&a.x, &a.y, &a.zz, &a.zzz};
+    Fq *dst[4] = {&r.x, &r.y, &r.zz, &r.zzz};
+#pragma unroll
+    for (int q = 0; q < 4; q++)
+#pragma unroll
+        for (int k = 0; k < 12; k++) dst[q]->l[k] = __shfl_down(src[q]->l[k], delta, 64);
+    return r;
+}
 
 // ---------------------------------------------------------------- K4: bucket accumulation, load-balanced
 // A bucket with more than T entries is cut into ceil(count / T) chunks, one lane each; the top window of a
@@ -396,7 +406,25 @@ __global__ void __launch_bounds__(128) msm_accumulate_kernel(const G1Affine *__r
     }
     store_xyzz(&chunk_partial[t], acc);
 }
-// block per heavy bucket: strided partial sums, then an LDS tree
+// Buckets cut into more than one chunk ("heavy": the top window, skewed scalars): sum their chunk partials into
+// buckets[b].  Up to SERIAL_MAX chunks one LANE walks them (a realistic top window is cut into 4-8 chunks per bucket);
+// beyond that a whole block does (strided partial sums, LDS tree).
+constexpr uint32_t MSM_HEAVY_SERIAL_MAX = 16;
+__global__ void __launch_bounds__(64) msm_combine_serial_kernel(const G1Xyzz *__restrict__ chunk_partial,
+                                                                const uint32_t *__restrict__ chunk_off,
+                                                                const uint32_t *__restrict__ heavy_list,
+                                                                const uint32_t *__restrict__ heavy_count,
+                                                                G1Xyzz *__restrict__ buckets) {
+    const uint32_t nheavy = *heavy_count;
+    for (uint32_t h = blockIdx.x * 64 + threadIdx.x; h < nheavy; h += gridDim.x * 64) {
+        const uint32_t b = heavy_list[h];
+        const uint32_t lo = chunk_off[b], hi = chunk_off[b + 1];
+        if (hi - lo > MSM_HEAVY_SERIAL_MAX) continue;
+        G1Xyzz acc = load_xyzz(&chunk_partial[lo]);
+        for (uint32_t e = lo + 1; e < hi; e++) acc = xyzz_add_ni(acc, load_xyzz(&chunk_partial[e]));
+        store_xyzz(&buckets[b], acc);
+    }
+}
 __global__ void __launch_bounds__(256) msm_combine_heavy_kernel(const G1Xyzz *__restrict__ chunk_partial,
                                                                 const uint32_t *__restrict__ chunk_off,
                                                                 const uint32_t *__restrict__ heavy_list,
@@ -408,6 +436,7 @@ __global__ void __launch_bounds__(256) msm_combine_heavy_kernel(const G1Xyzz *__
     for (uint32_t h = blockIdx.x; h < nheavy; h += gridDim.x) {
         const uint32_t b = heavy_list[h];
         const uint32_t lo = chunk_off[b], hi = chunk_off[b + 1];
+        if (hi - lo <= MSM_HEAVY_SERIAL_MAX) continue;  // block-uniform
         G1Xyzz acc = G1Xyzz::inf();
         for (uint32_t i = lo + t; i < hi; i += 256) acc = xyzz_add_ni(acc, load_xyzz(&chunk_partial[i]));
         for (int stride = 128; stride >= 1; stride >>= 1) {
@@ -434,16 +463,12 @@ __global__ void __launch_bounds__(128) msm_segments_kernel(const G1Xyzz *__restr
     const size_t b0 = w * B + (size_t)g * L;
     G1Xyzz run = G1Xyzz::inf(), wsum = G1Xyzz::inf();
     for (int j = (int)L - 1; j >= 0; j--) {
-        // the bucket's value straight from its chunk partials (nearly always exactly one: no separate combine pass);
-        // only buckets cut into more than `heavy` chunks were summed by the block kernel
+        // the bucket's value is its single chunk partial (no separate combine pass); buckets cut into more chunks
+        // (heavy = 1) were summed by the heavy kernel
         const uint32_t lo = chunk_off[b0 + j], hi = chunk_off[b0 + j + 1];
         G1Xyzz v = G1Xyzz::inf();
-        if (hi - lo > heavy) {
-            v = load_xyzz(&heavy_buckets[b0 + j]);
-        } else if (lo < hi) {
-            v = load_xyzz(&chunk_partial[lo]);
-            for (uint32_t e = lo + 1; e < hi; e++) v = add(v, load_xyzz(&chunk_partial[e]));
-        }
+        if (hi - lo > heavy) v = load_xyzz(&heavy_buckets[b0 + j]);
+        else if (lo < hi) v = load_xyzz(&chunk_partial[lo]);
         run = add(run, v);
         wsum = add(wsum, run);
     }
@@ -489,16 +514,6 @@ __global__ void __launch_bounds__(256) point_tree_sum_kernel(const G1Xyzz *__res
 // then 6 shuffle levels.  A quarter of the waves of the 256-lane version and no barrier: the whole verifier is bound
 // by wave-slots x time of this reduction, not by its latency.  `out` may be pinned host memory (results go straight
 // to the folding thread, no copy kernel).
-__device__ __forceinline__ G1Xyzz xyzz_shfl_down(const G1Xyzz &a, int delta) {
-    G1Xyzz r;
-    const Fq *src[4] = {&a.x, &a.y, &a.zz, &a.zzz};
-    Fq *dst[4] = {&r.x, &r.y, &r.zz, &r.zzz};
-#pragma unroll
-    for (int q = 0; q < 4; q++)
-#pragma unroll
-        for (int k = 0; k < 12; k++) dst[q]->l[k] = __shfl_down(src[q]->l[k], delta, 64);
-    return r;
-}
 template <int LPG>  // lanes per group: 64 (one group per wave) or 32 (two: half the tree work, twice the walk)
 __global__ void __launch_bounds__(64) msm_bit_sums_wave_kernel(const G1Xyzz *__restrict__ chunk_partial,
                                                                const uint32_t *__restrict__ chunk_off,
@@ -618,7 +633,7 @@ static void msm_enqueue_eager(Context &cx, const G1Affine *d_points, const uint3
     uint32_t T = (uint32_t)(2 * ((n + pl.B - 1) / pl.B));
     if (T < 16) T = 16;
     if (small) T = msm_small_chunk();
-    const uint32_t HEAVY = 8;
+    const uint32_t HEAVY = 1;  // every bucket with more than one chunk is summed by the heavy kernel (a wave each)
     const size_t max_chunks = nb + (n * (size_t)pl.nwin) / T + 1;
     uint32_t *chunk_off = (uint32_t *)cx.buf(W("chunk_off"), sizeof(uint32_t) * (nb + 1));
     uint32_t *chunk_bucket = (uint32_t *)cx.buf(W("chunk_bucket"), sizeof(uint32_t) * max_chunks);
@@ -693,6 +708,7 @@ static void msm_enqueue_eager(Context &cx, const G1Affine *d_points, const uint3
     } else {
         G1Xyzz *buckets = (G1Xyzz *)cx.buf(W("buckets"), sizeof(G1Xyzz) * nb);
         cx.prof.begin("msm_combine", st, n);
+        hipLaunchKernelGGL(msm_combine_serial_kernel, dim3(256), dim3(64), 0, st, chunk_partial, chunk_off, heavy_list, heavy_count, buckets);
         hipLaunchKernelGGL(msm_combine_heavy_kernel, dim3(1024), dim3(256), 0, st, chunk_partial, chunk_off, heavy_list, heavy_count, buckets);
         cx.prof.end("msm_combine", st);
         uint32_t L = pl.B >= 4096 ? 8 : 4;
