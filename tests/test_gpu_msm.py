@@ -133,3 +133,16 @@ def test_msm_points_split_across_ranks(orc, mi):
     # the protocol object, world = 1
     whole = sharding.msm_sharded(bases, scalars, mi.VariableBase.msm, mi.VariableBase.sum_partials)
     assert (jac_affine(whole) == got).all()
+
+
+@pytest.mark.parametrize("n", [(1 << 16) - 1, 1 << 16, (1 << 16) + 1])
+def test_msm_around_the_small_path_limit(orc, mi, n):
+    """the last sizes of the latency-bound path (fused planning kernel, bit sums) and the first of the general one,
+    with a block of zero scalars, repeated points and a run of equal scalars (one bucket shared by a whole wave:
+    the aggregated histogram atomics)"""
+    bases, scalars = rng_points(7000 + n % 7, 4096), rng_scalars(7100 + n % 7, n)
+    bases = np.ascontiguousarray(np.tile(bases, (n // 4096 + 1, 1))[:n])   # repeated points
+    scalars[100:400] = 0
+    scalars[1000:1200] = scalars[1000]                                      # 200 equal scalars in a row
+    got = jac_affine(mi.VariableBase.msm(bases, scalars))
+    assert (got == orc.msm_pippenger(bases, scalars, threads=8)).all()
