@@ -10,6 +10,7 @@
 // The same header compiles for the host (plain C++), which the library uses for the short serial
 // tails (window fold of an MSM, G2 line precomputation at key registration).
 #pragma once
+#include <string.h>
 #include <stdint.h>
 #include "constants.hpp"
 
@@ -171,9 +172,9 @@ template <class P>
 inline Fp<P> mul_host64(const Fp<P> &a, const Fp<P> &b) {
     constexpr int M = P::N / 2;
     uint64_t A[M], B[M], Q[M], t[M + 1];
+    memcpy(A, a.l, sizeof A);  // the same little-endian bytes, as 64-bit limbs
+    memcpy(B, b.l, sizeof B);
     for (int i = 0; i < M; i++) {
-        A[i] = ((uint64_t)a.l[2 * i + 1] << 32) | a.l[2 * i];
-        B[i] = ((uint64_t)b.l[2 * i + 1] << 32) | b.l[2 * i];
         Q[i] = ((uint64_t)P::MOD[2 * i + 1] << 32) | P::MOD[2 * i];
         t[i] = 0;
     }
@@ -197,9 +198,16 @@ inline Fp<P> mul_host64(const Fp<P> &a, const Fp<P> &b) {
         }
         t[M - 1] = t[M] + carry;
     }
+    // one conditional subtraction, in 64-bit limbs
+    uint64_t d[M];
+    unsigned __int128 bw = 0;
+    for (int i = 0; i < M; i++) {
+        unsigned __int128 x = (unsigned __int128)t[i] - Q[i] - (uint64_t)bw;
+        d[i] = (uint64_t)x;
+        bw = (x >> 64) & 1;
+    }
     Fp<P> r;
-    for (int i = 0; i < M; i++) { r.l[2 * i] = (uint32_t)t[i]; r.l[2 * i + 1] = (uint32_t)(t[i] >> 32); }
-    reduce_once(r);
+    memcpy(r.l, bw ? t : d, sizeof A);
     return r;
 }
 #endif
