@@ -128,7 +128,9 @@ int32_t mi_vs_accumulate_device(uint64_t ctx, const void *d_proofs, size_t n, co
                                 mi_vs_partial *partial_out, void *stream);
 int32_t mi_vs_finalize(uint64_t ctx, const mi_vs_partial *partials, size_t n_partials, uint8_t *all_ok);
 #define MI_VS_MAX_OPEN_ACCUMULATIONS 14 /* mi_vs_accumulate_begin without a matching _end: 12 by default, env
-                                           MI_SNARK_VS_LANES = 1..14 when the context is created */
+                                           MI_SNARK_VS_LANES = 1..14, read when the first context is created.  Lanes
+                                           and product slots (streams, workspaces) belong to the process and are
+                                           shared by all contexts: the limits hold across contexts. */
 #define MI_VS_MAX_TICKETS 8             /* mi_vs_finalize_async without a matching _wait */
 /* pipelined form: the pairing product of batch i runs on the context's own stream while the caller accumulates
  * batch i+1 (VM::check_transactions walks a block in chunks of <= 1000 executions; mempool admission streams).

@@ -117,44 +117,88 @@ struct VsSlot {  // one in-flight pairing product (pipelined finalize)
     hipStream_t stream = nullptr;  // each slot has its own stream: products of different batches run side by side
     Fq12 *h_out = nullptr;  // pinned
 };
-struct VsCtx {
+struct VsCtx {  // the keys of one verifier: circuit commitments, G, the two prepared G2 line tables
     size_t n_circuits = 0;
     DevBuf circuits, h_prep, tauh_prep, consts;
     mi_kzg_vk vk;
-    VsSlot slots[VS_SLOTS];  // pairing products run on the slots' streams, beside the next batches' accumulation
-    struct VsAcc {           // an accumulation whose kernels are enqueued but whose host fold is still to come
-        bool open = false;
-        uint64_t handle = 0;
-        size_t n = 0;
-        hipStream_t st = nullptr;
-        MsmJob j1, j2;
-        bool fused = false;  // j1 carries both MSMs
-        bool closing = false;
-        uint8_t *h_alg = nullptr;
-    } acc[VS_ACC_DEPTH];
-    uint64_t next_acc = 2;
+};
+struct VsAcc {  // an accumulation whose kernels are enqueued but whose host fold is still to come
+    bool open = false;
+    uint64_t handle = 0, ctx = 0;
+    size_t n = 0;
+    hipStream_t st = nullptr;
+    MsmJob j1, j2;
+    bool fused = false;  // j1 carries both MSMs
+    bool closing = false;
+    uint8_t *h_alg = nullptr;
+};
+// The pipeline -- accumulation lanes and product slots, each with its stream, workspaces (named per lane in the
+// Context) and pinned result buffer -- belongs to the PROCESS, not to a verifier context: lanes index shared
+// workspaces, so two contexts must never hold the same lane, and HIP keeps a destroyed stream's queue and scratch
+// (measured: 45 MB of device memory per create/destroy cycle when every context made its own 20 streams).
+struct VsPipe {
+    bool ready = false;
+    int lanes = 12;
+    VsAcc acc[VS_ACC_DEPTH];
     hipStream_t acc_st[VS_ACC_DEPTH] = {};  // one stream per accumulation lane
     hipEvent_t acc_ev[VS_ACC_DEPTH] = {};
-    uint64_t next_ticket = 1;
-    int lanes = 12;
+    VsSlot slots[VS_SLOTS];  // pairing products run on the slots' streams, beside the next batches' accumulation
+    uint64_t next_acc = 2, next_ticket = 1;
 };
+static VsPipe &vs_pipe() {
+    static VsPipe p;
+    return p;
+}
+// All streams are created at once, lanes first, then product slots.  Measured on the box: HIP spreads streams over
+// at most 24 hardware queues in creation order; with this order 12 lanes + 8 slots run side by side (4.3e6 proofs/s),
+// created lazily in order of first use (lane, slot, lane, ...) the same streams reach 2.7e6, and with more than ~24
+// streams in the process a 1.6 ms pairing kernel ends up queued in front of other batches' MSMs.
+// MI_SNARK_VS_LANES (1..14, default 12; read once) trims the lane count when the process needs queues for something
+// else (RCCL, other libraries).
+static void vs_pipe_init() {
+    VsPipe &pp = vs_pipe();
+    if (pp.ready) return;
+    pp.lanes = 12;
+    if (const char *e = getenv("MI_SNARK_VS_LANES")) {
+        const int x = atoi(e);
+        if (x >= 1 && x <= VS_ACC_DEPTH) pp.lanes = x;
+    }
+    for (int p = 0; p < pp.lanes; p++) {
+        MI_HIP(hipStreamCreateWithFlags(&pp.acc_st[p], hipStreamNonBlocking));
+        MI_HIP(hipEventCreateWithFlags(&pp.acc_ev[p], hipEventDisableTiming));
+    }
+    for (auto &sl : pp.slots) {
+        MI_HIP(hipStreamCreateWithFlags(&sl.stream, hipStreamNonBlocking));
+        MI_HIP(hipEventCreateWithFlags(&sl.done, hipEventDisableTiming));
+        MI_HIP(hipHostMalloc((void **)&sl.h_out, sizeof(Fq12), hipHostMallocDefault));
+    }
+    pp.ready = true;
+}
+static void vs_pipe_sync() {
+    VsPipe &pp = vs_pipe();
+    for (auto &sl : pp.slots)
+        if (sl.stream) MI_HIP(hipStreamSynchronize(sl.stream));
+    for (int p = 0; p < VS_ACC_DEPTH; p++)
+        if (pp.acc_st[p]) MI_HIP(hipStreamSynchronize(pp.acc_st[p]));
+}
+static void vs_pipe_free() {
+    VsPipe &pp = vs_pipe();
+    for (auto &sl : pp.slots) {
+        if (sl.done) (void)hipEventDestroy(sl.done);
+        if (sl.stream) (void)hipStreamDestroy(sl.stream);
+        if (sl.h_out) (void)hipHostFree(sl.h_out);
+    }
+    for (int p = 0; p < VS_ACC_DEPTH; p++) {
+        if (pp.acc_st[p]) (void)hipStreamDestroy(pp.acc_st[p]);
+        if (pp.acc_ev[p]) (void)hipEventDestroy(pp.acc_ev[p]);
+    }
+    pp = VsPipe();
+}
 static void vs_ctx_free(VsCtx &v) {
     v.circuits.release();
     v.h_prep.release();
     v.tauh_prep.release();
     v.consts.release();
-    for (auto &sl : v.slots) {
-        if (sl.done) (void)hipEventDestroy(sl.done);
-        if (sl.stream) (void)hipStreamDestroy(sl.stream);
-        if (sl.h_out) (void)hipHostFree(sl.h_out);
-        sl = VsSlot();
-    }
-    for (int p = 0; p < VS_ACC_DEPTH; p++) {
-        if (v.acc_st[p]) (void)hipStreamDestroy(v.acc_st[p]);
-        if (v.acc_ev[p]) (void)hipEventDestroy(v.acc_ev[p]);
-        v.acc_st[p] = nullptr;
-        v.acc_ev[p] = nullptr;
-    }
 }
 static std::map<uint64_t, VsCtx> &vs_ctxs() {
     static std::map<uint64_t, VsCtx> m;
@@ -164,6 +208,7 @@ static uint64_t g_vs_next = 1;
 void verify_release_all() {
     for (auto &kv : vs_ctxs()) vs_ctx_free(kv.second);
     vs_ctxs().clear();
+    vs_pipe_free();
     ntt_release_tables();
     pairing_release();
 }
@@ -201,26 +246,7 @@ int32_t vs_ctx_create(Context &cx, const mi_kzg_vk *vk, const mi_vs_circuit_vk *
     void *dk = v.consts.get(sizeof hc);
     MI_HIP(hipMemcpyAsync(dk, &hc, sizeof hc, hipMemcpyHostToDevice, cx.stream));
     MI_HIP(hipStreamSynchronize(cx.stream));
-    // All streams of the context are created here, lanes first, then product slots.  Measured on the box: HIP spreads
-    // streams over at most 24 hardware queues in creation order; with this order 12 lanes + 8 slots run side by side
-    // (4.3e6 proofs/s), created lazily in order of first use (lane, slot, lane, ...) the same streams reach 2.7e6, and
-    // with more than ~24 streams in the process a 1.6 ms pairing kernel ends up queued in front of other batches' MSMs.
-    // MI_SNARK_VS_LANES (1..14, default 12) trims the lane count when the process needs queues for something else
-    // (RCCL, other libraries).
-    v.lanes = 12;
-    if (const char *e = getenv("MI_SNARK_VS_LANES")) {
-        const int x = atoi(e);
-        if (x >= 1 && x <= VS_ACC_DEPTH) v.lanes = x;
-    }
-    for (int p = 0; p < v.lanes; p++) {
-        MI_HIP(hipStreamCreateWithFlags(&v.acc_st[p], hipStreamNonBlocking));
-        MI_HIP(hipEventCreateWithFlags(&v.acc_ev[p], hipEventDisableTiming));
-    }
-    for (auto &sl : v.slots) {
-        MI_HIP(hipStreamCreateWithFlags(&sl.stream, hipStreamNonBlocking));
-        MI_HIP(hipEventCreateWithFlags(&sl.done, hipEventDisableTiming));
-        MI_HIP(hipHostMalloc((void **)&sl.h_out, sizeof(Fq12), hipHostMallocDefault));
-    }
+    vs_pipe_init();
     (void)pairing_consts(cx, cx.stream);  // upload the Frobenius table before any pipelined launch
     *out = id;
     return MI_OK;
@@ -229,10 +255,10 @@ int32_t vs_ctx_destroy(Context &cx, uint64_t id) {
     auto it = vs_ctxs().find(id);
     if (it == vs_ctxs().end()) return MI_ERR_BAD_ARGS;
     MI_HIP(hipStreamSynchronize(cx.stream));
-    for (auto &sl : it->second.slots)
-        if (sl.stream) MI_HIP(hipStreamSynchronize(sl.stream));
-    for (int p = 0; p < VS_ACC_DEPTH; p++)
-        if (it->second.acc_st[p]) MI_HIP(hipStreamSynchronize(it->second.acc_st[p]));
+    vs_pipe_sync();  // nothing of this context's may still be running
+    VsPipe &pp = vs_pipe();
+    for (auto &a : pp.acc)
+        if (a.open && a.ctx == id && !a.closing) a.open = false;  // abandoned accumulations give their lanes back
     vs_ctx_free(it->second);
     vs_ctxs().erase(it);
     return MI_OK;
@@ -527,25 +553,26 @@ static G1Affine host_jac_to_affine_normalised(const mi_g1_jac &j) {
 // accumulate = begin (enqueue derive + both MSMs, no host synchronisation) + end (wait, fold on the host).
 // VS_ACC_DEPTH begin/end pairs may be open at once (lane p = handle & 0xff): every lane has its own stream
 // pair, device workspaces and pinned result buffers, so the next batches' kernels run while batch k is folded.
-static int32_t vs_accumulate_begin_impl(Context &cx, VsCtx &v, const void *d_proofs, size_t n, const void *d_rand,
-                                        hipStream_t st, uint64_t *handle, VsWork *work_out) {
+static int32_t vs_accumulate_begin_impl(Context &cx, uint64_t ctx_id, VsCtx &v, const void *d_proofs, size_t n,
+                                        const void *d_rand, hipStream_t st, uint64_t *handle, VsWork *work_out) {
     // any free lane (ends may complete out of order when several host threads fold); the handle names its lane
     int par = -1;
-    for (int p = 0; p < v.lanes; p++)
-        if (!v.acc[p].open) {
+    VsPipe &pp = vs_pipe();
+    for (int p = 0; p < pp.lanes; p++)
+        if (!pp.acc[p].open) {
             par = p;
             break;
         }
     if (par < 0) return MI_ERR_BAD_ARGS;  // every lane is taken
-    const uint64_t hd = (v.next_acc++ << 8) | (uint64_t)par;
-    VsCtx::VsAcc &a = v.acc[par];
+    const uint64_t hd = (pp.next_acc++ << 8) | (uint64_t)par;
+    VsAcc &a = pp.acc[par];
     // Each lane has its own stream, so the next batches' derive and MSMs run beside this one's.  The inputs were
     // produced on the caller's stream: order ours behind it.
-    hipStream_t sa = v.acc_st[par];
+    hipStream_t sa = pp.acc_st[par];
     {
         HostSpan hs("begin.order");
-        MI_HIP(hipEventRecord(v.acc_ev[par], st));
-        MI_HIP(hipStreamWaitEvent(sa, v.acc_ev[par], 0));
+        MI_HIP(hipEventRecord(pp.acc_ev[par], st));
+        MI_HIP(hipStreamWaitEvent(sa, pp.acc_ev[par], 0));
     }
     VsWork w;
     {
@@ -574,6 +601,7 @@ static int32_t vs_accumulate_begin_impl(Context &cx, VsCtx &v, const void *d_pro
     a.n = n;
     a.st = st;
     a.handle = hd;
+    a.ctx = ctx_id;
     a.open = true;
     if (work_out) *work_out = w;
     *handle = hd;
@@ -581,7 +609,7 @@ static int32_t vs_accumulate_begin_impl(Context &cx, VsCtx &v, const void *d_pro
 }
 static int32_t vs_accumulate_end_impl(Context &cx, VsCtx &v, uint64_t handle, mi_vs_partial *out) {
     if ((handle & 0xff) >= VS_ACC_DEPTH) return MI_ERR_BAD_ARGS;
-    VsCtx::VsAcc &a = v.acc[handle & 0xff];
+    VsAcc &a = vs_pipe().acc[handle & 0xff];
     if (!a.open || a.handle != handle || a.closing) return MI_ERR_BAD_ARGS;
     a.closing = true;  // the lane stays taken until the fold is done; the context lock is not held meanwhile
     // host folds (~250 doublings + ~250 additions for 254-bit scalars, half that for the randomizer side), each
@@ -610,7 +638,7 @@ static int32_t vs_accumulate_impl(Context &cx, uint64_t id, const void *d_proofs
     auto it = vs_ctxs().find(id);
     if (it == vs_ctxs().end()) return MI_ERR_BAD_ARGS;
     uint64_t hd;
-    int32_t s = vs_accumulate_begin_impl(cx, it->second, d_proofs, n, d_rand, st, &hd, work_out);
+    int32_t s = vs_accumulate_begin_impl(cx, id, it->second, d_proofs, n, d_rand, st, &hd, work_out);
     if (s != MI_OK) return s;
     return vs_accumulate_end_impl(cx, it->second, hd, out);
 }
@@ -618,7 +646,7 @@ int32_t vs_accumulate_begin(Context &cx, uint64_t id, const void *d_proofs, size
                             uint64_t *handle) {
     auto it = vs_ctxs().find(id);
     if (it == vs_ctxs().end()) return MI_ERR_BAD_ARGS;
-    return vs_accumulate_begin_impl(cx, it->second, d_proofs, n, d_rand, st, handle, nullptr);
+    return vs_accumulate_begin_impl(cx, id, it->second, d_proofs, n, d_rand, st, handle, nullptr);
 }
 int32_t vs_accumulate_end(Context &cx, uint64_t id, uint64_t handle, mi_vs_partial *out) {
     auto it = vs_ctxs().find(id);
@@ -667,13 +695,13 @@ int32_t vs_finalize_async(Context &cx, uint64_t id, const mi_vs_partial *parts, 
     VsCtx &v = it->second;
     int slot = -1;
     for (int i = 0; i < VS_SLOTS; i++)
-        if (!v.slots[i].busy) {
+        if (!vs_pipe().slots[i].busy) {
             slot = i;
             break;
         }
     if (slot < 0) return MI_ERR_BAD_ARGS;  // VS_SLOTS products in flight: wait for a ticket first
-    const uint64_t tk = (v.next_ticket++ << 8) | (uint64_t)slot;  // the ticket names its slot
-    VsSlot &sl = v.slots[slot];
+    const uint64_t tk = (vs_pipe().next_ticket++ << 8) | (uint64_t)slot;  // the ticket names its slot
+    VsSlot &sl = vs_pipe().slots[slot];
     HostSpan hs("finalize_async");
     G1Xyzz tc = G1Xyzz::inf(), tw = G1Xyzz::inf();
     uint64_t fails = 0;
@@ -697,7 +725,7 @@ int32_t vs_finalize_wait(Context &cx, uint64_t id, uint64_t ticket, uint8_t *all
     auto it = vs_ctxs().find(id);
     if (it == vs_ctxs().end()) return MI_ERR_BAD_ARGS;
     if ((ticket & 0xff) >= VS_SLOTS) return MI_ERR_BAD_ARGS;
-    VsSlot &sl = it->second.slots[ticket & 0xff];
+    VsSlot &sl = vs_pipe().slots[ticket & 0xff];
     if (!sl.busy || sl.ticket != ticket) return MI_ERR_BAD_ARGS;
     return vs_slot_wait(sl, all_ok);
 }

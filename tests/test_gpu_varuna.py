@@ -231,3 +231,33 @@ def test_batch_too_large_for_the_fused_msm_pair(orc, mi):
         assert list(v.verify_stream(iter([(p, r), (torch.from_numpy(bad).cuda(), r), (p, r)]))) == [True, False, True]
     finally:
         v.close()
+
+
+def test_two_contexts_share_the_pipeline(orc, mi):
+    """two verifier contexts (different SRS and circuits) with accumulations open at the same time: lanes, streams and
+    workspaces belong to the process, so their batches must never meet in one lane; partials bit-exact per context,
+    and destroying one context leaves the other's open work intact"""
+    import torch
+    b1, b2 = orc.VSBatch(0xC0A, 30, 2, 0), orc.VSBatch(0xC0B, 45, 3, 0)
+    v1, v2 = _ctx(mi, b1), _ctx(mi, b2)
+    as_bytes = lambda a: np.frombuffer(np.ascontiguousarray(a).tobytes(), dtype=np.uint8)
+    w1, w2 = as_bytes(orc.vs_partial_from_oracle(b1, threads=8)), as_bytes(orc.vs_partial_from_oracle(b2, threads=8))
+    try:
+        p1, r1 = torch.from_numpy(b1.proofs).cuda(), torch.from_numpy(b1.randomizers).cuda()
+        p2, r2 = torch.from_numpy(b2.proofs).cuda(), torch.from_numpy(b2.randomizers).cuda()
+        hs = []
+        for k in range(10):
+            hs.append((1, v1.accumulate_begin(p1, r1)) if k % 2 == 0 else (2, v2.accumulate_begin(p2, r2)))
+        for which, h in reversed(hs):
+            got = (v1 if which == 1 else v2).accumulate_end(h)
+            assert (got == (w1 if which == 1 else w2)).all()
+        assert list(v1.verify_stream(iter([(p1, r1)] * 5))) == [True] * 5
+        h2 = v2.accumulate_begin(p2, r2)
+        v1.close()                                   # the other context's open accumulation survives
+        assert (v2.accumulate_end(h2) == w2).all()
+        assert v2.verify_batch(p2, r2)[0]
+        v1 = _ctx(mi, b1)                            # and a new context works on the same pipeline
+        assert v1.verify_batch(p1, r1)[0] and (v1.accumulate(p1, r1) == w1).all()
+    finally:
+        v1.close()
+        v2.close()
