@@ -590,7 +590,8 @@ static int32_t vs_accumulate_begin_impl(Context &cx, uint64_t ctx_id, VsCtx &v, 
     // both MSMs (H side: 11n + 12 circuits + 1 points; tau-H side: 2n points, 128-bit scalars) share one launch
     // sequence: the second is the first's extra set of windows (msm_enqueue's split)
     if (w.n1 + w.n2 <= msm_small_limit()) {
-        msm_enqueue(cx, w.pts1, w.sc1, w.n1 + w.n2, sa, 254, 4 + 2 * par, &a.j1, 0, par, w.n1);
+        static const int vs_c = getenv("MI_SNARK_VS_C") ? atoi(getenv("MI_SNARK_VS_C")) : 0;  // window width override (experiments)
+        msm_enqueue(cx, w.pts1, w.sc1, w.n1 + w.n2, sa, 254, 4 + 2 * par, &a.j1, vs_c, par, w.n1);
         a.fused = true;
     } else {
         msm_enqueue(cx, w.pts2, w.sc2, w.n2, sa, 128, 4 + 2 * par + 1, &a.j2, 0, par);
