@@ -108,7 +108,6 @@ struct VsConsts {
 };
 #define VS_SLOTS MI_VS_MAX_TICKETS
 #define VS_ACC_DEPTH MI_VS_MAX_OPEN_ACCUMULATIONS  // accumulations (derive + both MSMs) that may be enqueued before the oldest is folded
-struct VsAccFwd;
 struct VsSlot {  // one in-flight pairing product (pipelined finalize)
     uint64_t ticket = 0;
     bool busy = false;
