@@ -521,6 +521,43 @@ __global__ void __launch_bounds__(256) point_tree_sum_kernel(const G1Xyzz *__res
 // then 6 shuffle levels.  A quarter of the waves of the 256-lane version and no barrier: the whole verifier is bound
 // by wave-slots x time of this reduction, not by its latency.  `out` may be pinned host memory (results go straight
 // to the folding thread, no copy kernel).
+// One WAVE per group, balanced: the wave reads the window's chunk list 64 entries at a time, the lanes whose entry has
+// the bit set append it to a small LDS queue (ballot + prefix count), and whenever 64 entries are queued every lane
+// takes one and adds it.  ceil(matches / 64) additions per lane instead of the longest lane's share of a strided walk
+// (~7 instead of ~10 for the verifier's windows), then the 6 shuffle levels.
+__global__ void __launch_bounds__(64) msm_bit_sums_queue_kernel(const G1Xyzz *__restrict__ chunk_partial,
+                                                                const uint32_t *__restrict__ chunk_off,
+                                                                const uint32_t *__restrict__ chunk_bucket, uint32_t B, int c,
+                                                                G1Xyzz *__restrict__ out) {
+    __shared__ uint32_t queue[128];
+    const int lane = threadIdx.x;
+    const uint32_t g = blockIdx.x, w = g / (uint32_t)c, bit = g - w * (uint32_t)c;
+    const uint32_t lo = chunk_off[(size_t)w * B], hi = chunk_off[(size_t)(w + 1) * B];
+    G1Xyzz acc = G1Xyzz::inf();
+    uint32_t head = 0, tail = 0;  // wave-uniform
+    for (uint32_t base = lo; base < hi; base += 64) {
+        const uint32_t e = base + lane;
+        const bool match = e < hi && (((chunk_bucket[e] - w * B + 1) >> bit) & 1u);
+        const uint64_t mm = __ballot(match);
+        if (match) queue[(tail + (uint32_t)__popcll(mm & ((1ull << lane) - 1ull))) & 127u] = e;
+        tail += (uint32_t)__popcll(mm);
+        __syncthreads();  // one wave: orders the queue writes before the reads below
+        if (tail - head >= 64) {
+            const uint32_t q = queue[(head + lane) & 127u];
+            head += 64;
+            acc = add<true>(acc, load_xyzz(&chunk_partial[q]));
+        }
+        __syncthreads();
+    }
+    if ((uint32_t)lane < tail - head) acc = add<true>(acc, load_xyzz(&chunk_partial[queue[(head + lane) & 127u]]));
+#pragma unroll 1
+    for (int stride = 32; stride >= 1; stride >>= 1) {
+        G1Xyzz other = xyzz_shfl_down(acc, stride);
+        if (lane < stride) acc = add<true>(acc, other);
+    }
+    if (lane == 0) store_xyzz(&out[g], acc);
+}
+
 template <int LPG>  // lanes per group: 64 (one group per wave) or 32 (two: half the tree work, twice the walk)
 __global__ void __launch_bounds__(64) msm_bit_sums_wave_kernel(const G1Xyzz *__restrict__ chunk_partial,
                                                                const uint32_t *__restrict__ chunk_off,
@@ -703,8 +740,11 @@ static void msm_enqueue_eager(Context &cx, const G1Affine *d_points, const uint3
         snprintf(pn, sizeof pn, "msm%d.pin%d", slot, pin_parity);
         job->h = (G1Xyzz *)cx.pin_named(pn, sizeof(G1Xyzz) * all_groups);
         cx.prof.begin("msm_bitsums", st, n);
-        static const int lpg = getenv("MI_SNARK_BITSUM_LPG") ? atoi(getenv("MI_SNARK_BITSUM_LPG")) : 64;
-        if (lpg == 32)
+        static const int lpg = getenv("MI_SNARK_BITSUM_LPG") ? atoi(getenv("MI_SNARK_BITSUM_LPG")) : 0;  // 0: queue-balanced (default)
+        if (lpg == 0)
+            hipLaunchKernelGGL(msm_bit_sums_queue_kernel, dim3((unsigned)all_groups), dim3(64), 0, st, chunk_partial, chunk_off,
+                               chunk_bucket, pl.B, pl.c, job->h);
+        else if (lpg == 32)
             hipLaunchKernelGGL(msm_bit_sums_wave_kernel<32>, dim3((unsigned)((all_groups + 1) / 2)), dim3(64), 0, st, chunk_partial,
                                chunk_off, chunk_bucket, pl.B, pl.c, (uint32_t)all_groups, job->h);
         else
