@@ -291,83 +291,104 @@ __host__ __device__ __forceinline__ int vs_query_of(int p) {
 //   pts2[i*2 + q]    = W_q                                    sc2[i*2 + q]  = r_q                  (canonical)
 //   vk_scal[i*12+k]  = r_q xi^(9+k)  (Montgomery)             g_scal[i] = -(sum_q r_q val_q)       (Montgomery)
 //   alg_ok[i]        = public-input consistency v_0 == x_hat(z_beta) + (z_beta^16 - 1) v_1
-__global__ void __launch_bounds__(64) vs_derive_kernel(const mi_vs_proof *__restrict__ proofs, size_t n,
-                                                       const uint8_t *__restrict__ rand128,
-                                                       const mi_vs_circuit_vk *__restrict__ circuits, size_t n_circuits,
-                                                       const VsConsts *__restrict__ kc, G1Affine *__restrict__ pts1,
-                                                       uint32_t *__restrict__ sc1, G1Affine *__restrict__ pts2,
-                                                       uint32_t *__restrict__ sc2, Fr *__restrict__ vk_scal,
-                                                       Fr *__restrict__ g_scal, uint8_t *__restrict__ alg_ok,
-                                                       uint32_t *__restrict__ circuit_of) {
-    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const mi_vs_proof *p = proofs + i;
+// Two waves per 64 proofs.  Wave 0 walks the transcript (four chained SHA-256, ~140 us: the serial spine) and then the
+// opening-challenge loop that needs xi; wave 1 meanwhile copies the points into MSM order and, as soon as z_beta is
+// known (after the second hash), runs the public-input check.  z_beta crosses through LDS at the one barrier.
+__global__ void __launch_bounds__(128) vs_derive_kernel(const mi_vs_proof *__restrict__ proofs, size_t n,
+                                                        const uint8_t *__restrict__ rand128,
+                                                        const mi_vs_circuit_vk *__restrict__ circuits, size_t n_circuits,
+                                                        const VsConsts *__restrict__ kc, G1Affine *__restrict__ pts1,
+                                                        uint32_t *__restrict__ sc1, G1Affine *__restrict__ pts2,
+                                                        uint32_t *__restrict__ sc2, Fr *__restrict__ vk_scal,
+                                                        Fr *__restrict__ g_scal, uint8_t *__restrict__ alg_ok,
+                                                        uint32_t *__restrict__ circuit_of) {
+    __shared__ uint32_t zb_lds[64][4];
+    const int lane = threadIdx.x & 63, role = threadIdx.x >> 6;  // role 0: transcript + scalars, role 1: points + check
+    const size_t i = (size_t)blockIdx.x * 64 + lane;
+    const bool live = i < n;
+    const mi_vs_proof *p = proofs + (live ? i : 0);
     const uint32_t *pw = reinterpret_cast<const uint32_t *>(p);
     uint32_t circuit = pw[0];
     if (circuit >= n_circuits) circuit = 0;  // malformed index: still well-defined, proof is rejected below
     const bool bad_circuit = pw[0] >= n_circuits;
-    circuit_of[i] = circuit;
     const uint32_t *digest = reinterpret_cast<const uint32_t *>(circuits[circuit].digest);
     const uint32_t *inputs = pw + 4;                 // 16 x 8 words
     const uint32_t *comms = inputs + 128;            // 9 x 24 words
     const uint32_t *evals = comms + 216;             // 21 x 8 words
-    // ---- transcript
-    uint32_t tag[8], h[8], zw[2][4], xw[4];
+    uint32_t h[8], zw[2][4], xw[4];
+    if (role == 0) {
+        if (live) {
+            uint32_t tag[8];
 #pragma unroll
-    for (int k = 0; k < 8; k++) tag[k] = kc->tag[k];
-    sha256_prefixed(h, tag, digest, 8, inputs, 128 + 48);
-    sha256_prefixed(h, h, comms + 48, 72, nullptr, 0);
+            for (int k = 0; k < 8; k++) tag[k] = kc->tag[k];
+            sha256_prefixed(h, tag, digest, 8, inputs, 128 + 48);
+            sha256_prefixed(h, h, comms + 48, 72, nullptr, 0);
 #pragma unroll
-    for (int k = 0; k < 4; k++) zw[0][k] = __builtin_bswap32(h[k]);
-    sha256_prefixed(h, h, comms + 120, 96, nullptr, 0);
+            for (int k = 0; k < 4; k++) {
+                zw[0][k] = __builtin_bswap32(h[k]);
+                zb_lds[lane][k] = zw[0][k];
+            }
+        }
+    } else if (live) {
+        circuit_of[i] = circuit;
+        // ---- points into MSM order, randomizers as the tau-H side's scalars
+        const G1Affine *pc = reinterpret_cast<const G1Affine *>(comms);
+        for (int k = 0; k < MI_VS_PROOF_COMMS; k++) copy_g1(pts1 + i * VS_PER_PROOF_POINTS + k, pc + k);
+        const G1Affine *wpt = reinterpret_cast<const G1Affine *>(evals + 168);
 #pragma unroll
-    for (int k = 0; k < 4; k++) zw[1][k] = __builtin_bswap32(h[k]);
-    sha256_prefixed(h, h, evals, 168, nullptr, 0);
-#pragma unroll
-    for (int k = 0; k < 4; k++) xw[k] = __builtin_bswap32(h[k]);
-    Fr z[2] = {fr_from_u128(zw[0]), fr_from_u128(zw[1])};
-    Fr xi = fr_from_u128(xw);
-    // ---- randomizers
-    const uint32_t *rw = reinterpret_cast<const uint32_t *>(rand128 + 32 * i);
-    uint32_t r0[4] = {rw[0], rw[1], rw[2], rw[3]}, r1[4] = {rw[4], rw[5], rw[6], rw[7]};
-    Fr r[2] = {fr_from_u128(r0), fr_from_u128(r1)};
-    // ---- opening-challenge powers, combined values, MSM scalars
-    Fr xip = Fr::one(), val[2] = {Fr::zero(), Fr::zero()};
-    for (int k = 0; k < MI_VS_EVALS; k++) {
-        int q = vs_query_of(k);
-        Fr s = mul(r[q], xip);
-        if (k < MI_VS_PROOF_COMMS) fr_store(sc1 + (i * VS_PER_PROOF_POINTS + k) * 8, from_mont(s));
-        else fr_store(vk_scal + i * MI_VS_VK_COMMS + (k - MI_VS_PROOF_COMMS), s);
-        val[q] = add(val[q], mul(xip, fr_load(evals + 8 * k)));
-        xip = mul(xip, xi);
-    }
-    Fr gs = Fr::zero();
-#pragma unroll
-    for (int q = 0; q < 2; q++) {
-        fr_store(sc1 + (i * VS_PER_PROOF_POINTS + MI_VS_PROOF_COMMS + q) * 8, from_mont(mul(r[q], z[q])));
-        gs = sub(gs, mul(r[q], val[q]));
-    }
-    {
+        for (int q = 0; q < 2; q++) {
+            copy_g1(pts1 + i * VS_PER_PROOF_POINTS + MI_VS_PROOF_COMMS + q, wpt + q);
+            copy_g1(pts2 + i * 2 + q, wpt + q);
+        }
+        const uint32_t *rw = reinterpret_cast<const uint32_t *>(rand128 + 32 * i);
         uint32_t *o = sc2 + i * 16;
 #pragma unroll
-        for (int k = 0; k < 4; k++) { o[k] = r0[k]; o[4 + k] = 0; o[8 + k] = r1[k]; o[12 + k] = 0; }
+        for (int k = 0; k < 4; k++) { o[k] = rw[k]; o[4 + k] = 0; o[8 + k] = rw[4 + k]; o[12 + k] = 0; }
     }
-    fr_store(g_scal + i, gs);
-    // ---- points into MSM order
-    const G1Affine *pc = reinterpret_cast<const G1Affine *>(comms);
-    for (int k = 0; k < MI_VS_PROOF_COMMS; k++) copy_g1(pts1 + i * VS_PER_PROOF_POINTS + k, pc + k);
-    const G1Affine *wpt = reinterpret_cast<const G1Affine *>(evals + 168);
+    __syncthreads();
+    if (!live) return;
+    if (role == 0) {
+        sha256_prefixed(h, h, comms + 120, 96, nullptr, 0);
 #pragma unroll
-    for (int q = 0; q < 2; q++) {
-        copy_g1(pts1 + i * VS_PER_PROOF_POINTS + MI_VS_PROOF_COMMS + q, wpt + q);
-        copy_g1(pts2 + i * 2 + q, wpt + q);
+        for (int k = 0; k < 4; k++) zw[1][k] = __builtin_bswap32(h[k]);
+        sha256_prefixed(h, h, evals, 168, nullptr, 0);
+#pragma unroll
+        for (int k = 0; k < 4; k++) xw[k] = __builtin_bswap32(h[k]);
+        Fr z[2] = {fr_from_u128(zw[0]), fr_from_u128(zw[1])};
+        Fr xi = fr_from_u128(xw);
+        // ---- randomizers
+        const uint32_t *rw = reinterpret_cast<const uint32_t *>(rand128 + 32 * i);
+        uint32_t r0[4] = {rw[0], rw[1], rw[2], rw[3]}, r1[4] = {rw[4], rw[5], rw[6], rw[7]};
+        Fr r[2] = {fr_from_u128(r0), fr_from_u128(r1)};
+        // ---- opening-challenge powers, combined values, MSM scalars
+        Fr xip = Fr::one(), val[2] = {Fr::zero(), Fr::zero()};
+        for (int k = 0; k < MI_VS_EVALS; k++) {
+            int q = vs_query_of(k);
+            Fr s = mul(r[q], xip);
+            if (k < MI_VS_PROOF_COMMS) fr_store(sc1 + (i * VS_PER_PROOF_POINTS + k) * 8, from_mont(s));
+            else fr_store(vk_scal + i * MI_VS_VK_COMMS + (k - MI_VS_PROOF_COMMS), s);
+            val[q] = add(val[q], mul(xip, fr_load(evals + 8 * k)));
+            xip = mul(xip, xi);
+        }
+        Fr gs = Fr::zero();
+#pragma unroll
+        for (int q = 0; q < 2; q++) {
+            fr_store(sc1 + (i * VS_PER_PROOF_POINTS + MI_VS_PROOF_COMMS + q) * 8, from_mont(mul(r[q], z[q])));
+            gs = sub(gs, mul(r[q], val[q]));
+        }
+        fr_store(g_scal + i, gs);
+        return;
     }
-    // ---- public-input consistency, inversion-free.  With d_k = z - w^k and prod_k d_k = z^16 - 1:
+    // ---- role 1: public-input consistency, inversion-free.  With d_k = z - w^k and prod_k d_k = z^16 - 1:
     //   v_0 = x_hat(z) + (z^16-1) v_1,  x_hat(z) = (z^16-1)/16 * sum_k in_k w^k / d_k
     //   <=>  16 (v_0 - (z^16-1) v_1) = sum_k in_k w^k prod_{j != k} d_j          (for z^16 != 1)
     // The right-hand side takes prefix/suffix products: 4 * 16 multiplications instead of a field inversion
-    // (which is ~380 sequential multiplications per lane and dominated this kernel).
-    Fr zn = z[0];
+    // (which is ~380 sequential multiplications per lane).
+    uint32_t zbw[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) zbw[k] = zb_lds[lane][k];
+    const Fr zb = fr_from_u128(zbw);
+    Fr zn = zb;
 #pragma unroll
     for (int k = 0; k < 4; k++) zn = sqr(zn);
     Fr znm1 = sub(zn, Fr::one());
@@ -375,13 +396,13 @@ __global__ void __launch_bounds__(64) vs_derive_kernel(const mi_vs_proof *__rest
     Fr pre[MI_VS_INPUTS], acc = Fr::one();
     for (int k = 0; k < MI_VS_INPUTS; k++) {  // pre[k] = prod_{j < k} d_j
         pre[k] = acc;
-        acc = mul(acc, sub(z[0], fr_load(&kc->omega16[k])));
+        acc = mul(acc, sub(zb, fr_load(&kc->omega16[k])));
     }
     Fr rhs = Fr::zero(), suf = Fr::one();
     for (int k = MI_VS_INPUTS - 1; k >= 0; k--) {  // suf = prod_{j > k} d_j
         Fr wk = fr_load(&kc->omega16[k]);
         rhs = add(rhs, mul(mul(fr_load(inputs + 8 * k), wk), mul(pre[k], suf)));
-        suf = mul(suf, sub(z[0], wk));
+        suf = mul(suf, sub(zb, wk));
     }
     Fr lhs = sub(fr_load(evals), mul(znm1, fr_load(evals + 8)));
 #pragma unroll
@@ -540,7 +561,7 @@ static VsWork vs_run_derive(Context &cx, VsCtx &v, const void *d_proofs, size_t 
     w.alg_ok = (uint8_t *)cx.buf(W("alg_ok"), n);
     w.circuit_of = (uint32_t *)cx.buf(W("circuit_of"), 4 * n);
     cx.prof.begin("vs_derive", st, n);
-    hipLaunchKernelGGL(vs_derive_kernel, dim3(cdiv(n, 64)), dim3(64), 0, st, (const mi_vs_proof *)d_proofs, n,
+    hipLaunchKernelGGL(vs_derive_kernel, dim3(cdiv(n, 64)), dim3(128), 0, st, (const mi_vs_proof *)d_proofs, n,
                        (const uint8_t *)d_rand, (const mi_vs_circuit_vk *)v.circuits.p, v.n_circuits,
                        (const VsConsts *)v.consts.p, w.pts1, w.sc1, w.pts2, w.sc2, w.vk_scal, w.g_scal, w.alg_ok, w.circuit_of);
     cx.prof.end("vs_derive", st);
