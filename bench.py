@@ -170,6 +170,14 @@ def main():
                 "unit": "GB/s", "frac": kernels[dom]["achieved_GBps"] / HBM_PEAK_GBPS,
                 "avg_launch_us": kernels[dom]["avg_us"],
                 "algorithmic_bytes_per_launch": ALG_BYTES[dom] * kernels[dom]["units_per_launch"], "traffic": traffic}
+    if "msm_accumulate" in kernels:
+        # SURVEY.md 8d's per-proof figure for the verifier (128 B x the proof's (point, scalar) pairs after vk merging):
+        # the MSM accumulation kernel's view, beside the dominant-by-time kernel above
+        ka = kernels["msm_accumulate"]
+        roofline["msm_accumulate_view"] = {
+            "points_per_proof": ka["units_per_launch"] / PROOFS_PER_GPU, "algorithmic_bytes_per_launch": 128.0 * ka["units_per_launch"],
+            "avg_launch_us": ka["avg_us"], "achieved": ka["achieved_GBps"], "frac": ka["achieved_GBps"] / HBM_PEAK_GBPS,
+            "note": "integer-ALU bound: see extra.msm_2^20.accumulate_frac_of_measured_alu_peak for the same kernel at full occupancy"}
 
     out = {
         "metric": "varuna_proofs_verified_per_sec", "value": world * PROOFS_PER_GPU * args.steps / dt,
