@@ -4,8 +4,9 @@
 // Miller loop, ~350 more Fq12 operations in the final exponentiation), so one lane per pairing is purely
 // latency bound (~90 ms).  Here every Fq12 operation is one "round": Fq12 is held in the power basis
 // Fq[w]/(w^12 + 5) (the tower basis element u^b v^j w^i IS w^(6b+2j+i), so this is a relabelling), the
-// 144 (dense) or 60 (sparse line) coefficient products a_i * b_j go one per lane, and 12 lanes then fold
-// them: c_k = sum_{i+j=k} - 5 sum_{i+j=k+12}, with lazy 384-bit sums and a single reduction.
+// 144 coefficient products a_i * b_j go one per lane, and each 16-lane row folds its twelve:
+// c_k = sum_{i+j=k} - 5 sum_{i+j=k+12}, with lazy 384-bit sums and a single reduction; the rows' four spare lanes
+// can carry the product of two sparse line functions in the same round (pb_round).
 // Frobenius is diagonal in this basis (c_k *= gamma_e^k), conjugation negates the odd coefficients.
 // Replaces Bls12_377::{miller_loop, final_exponentiation, product_of_pairings}.
 #pragma once
@@ -21,9 +22,9 @@ struct alignas(16) PB {
 
 struct alignas(16) PwShared {
     PB f, t, a, b, c, d, x, y;
-    alignas(16) Fq line[MI_MAX_PAIRS][8];  // per pair: coefficients at w^0, w^1, w^3, w^7, w^9 (+ padding)
+    alignas(16) Fq one;  // the constant line of a couple's missing second pair
     alignas(16) Fq px[MI_MAX_PAIRS], py[MI_MAX_PAIRS];
-    // two-pair fast path: every line of the Miller loop evaluated at its P up front, [step][pair][w^1, w^3, w^7, w^9]
+    // every line of the current couple's Miller loop evaluated at its P up front, [step][pair][w^1, w^3, w^7, w^9]
     // (the w^0 coefficient is py[pair]); 26 KB
     alignas(16) Fq lines2[MI_MILLER_LINES][2][4];
 };
@@ -45,71 +46,9 @@ __device__ __forceinline__ void lds_store(Fq *p, const Fq &v) {
     q[2] = make_uint4(v.l[8], v.l[9], v.l[10], v.l[11]);
 }
 
-// position (power of w) of the s-th stored coefficient of the right operand: dense 0..11, line {0,1,3,7,9}
-template <int M>
-__device__ __forceinline__ int pb_pos(int s) {
-    if (M == 12) return s;
-    return s == 0 ? 0 : s == 1 ? 1 : s == 2 ? 3 : s == 3 ? 7 : 9;
-}
-
-// out = A * B, B given compactly as its M stored coefficients bc[0..M).  All PW_THREADS lanes must call.
-// Lane (k = t / 16, s = t % 16): the 16-lane row k produces coefficient k.  Lane s < M multiplies
-// a_((k - pos(s)) mod 12) by bc[s], turns a wrapped product p (degree >= 12) into 8q - 5p, and the row sums its
-// <= 12 values with a 4-step xor-shuffle tree of lazy 384-bit additions (< 100 q < 2^384); one binary
-// reduction (conditional subtraction of 64q .. q) per coefficient.  out may alias A or bc (reads finish before the barrier).
-template <int M>
-__device__ __attribute__((noinline)) void pb_mul_t(PwShared &S, PB *out, const PB *A, const Fq *bc) {
-    const int t = threadIdx.x, k = t >> 4, s = t & 15;
-    uint32_t acc[12];
-#pragma unroll
-    for (int i = 0; i < 12; i++) acc[i] = 0;
-    if (s < M) {
-        int i = k - pb_pos<M>(s);
-        const bool wrap = i < 0;
-        if (wrap) i += 12;
-        Fq p = mul(lds_load(&A->c[i]), lds_load(&bc[s]));
-#pragma unroll
-        for (int j = 0; j < 12; j++) acc[j] = p.l[j];
-        if (wrap) {  // w^12 = -5: contribute 8q - 5p (in (3q, 8q]) instead of a reduced -5p; the row sum stays < 2^384
-            uint32_t t5[12], c = 0, bw = 0;
-#pragma unroll
-            for (int j = 0; j < 12; j++) t5[j] = addc32((p.l[j] << 2) | (j ? (p.l[j - 1] >> 30) : 0u), p.l[j], c, &c);
-#pragma unroll
-            for (int j = 0; j < 12; j++) {
-                const uint32_t q8 = (FqP::MOD[j] << 3) | (j ? (FqP::MOD[j - 1] >> 29) : 0u);
-                acc[j] = subc32(q8, t5[j], bw, &bw);
-            }
-        }
-    }
-#pragma unroll
-    for (int d = 8; d >= 1; d >>= 1) {
-        uint32_t c = 0;
-#pragma unroll
-        for (int j = 0; j < 12; j++) acc[j] = addc32(acc[j], (uint32_t)__shfl_xor((int)acc[j], d, 16), c, &c);
-    }
-    // acc < 100 q < 2^384: subtract 64q, 32q, ..., q where possible
-#pragma unroll
-    for (int sh = 6; sh >= 0; sh--) {
-        uint32_t d[12], borrow = 0;
-#pragma unroll
-        for (int j = 0; j < 12; j++) {
-            const uint32_t qs = sh ? ((FqP::MOD[j] << sh) | (j ? (FqP::MOD[j - 1] >> (32 - sh)) : 0u)) : FqP::MOD[j];
-            d[j] = subc32(acc[j], qs, borrow, &borrow);
-        }
-#pragma unroll
-        for (int j = 0; j < 12; j++) acc[j] = borrow ? acc[j] : d[j];
-    }
-    __syncthreads();
-    if (s == 0) {
-        Fq r;
-#pragma unroll
-        for (int j = 0; j < 12; j++) r.l[j] = acc[j];
-        lds_store(&out->c[k], r);
-    }
-    __syncthreads();
-}
 // ---------------------------------------------------------------------------------------------------------------
-// The dense round, second version (every round of the final exponentiation and of the two-pair Miller loop).
+// The round (every Fq12 operation of the Miller loop and of the final exponentiation).  out = A * B: lane (k = t / 16,
+// s = t % 16 < 12) of the 16-lane row k multiplies a_((k - s) mod 12) by b_s; the row's sum is coefficient k.
 //   * products are taken without their final conditional subtraction (< 1.007 q); a wrapped product p contributes
 //     6q - 5p; a row's lazy sum stays < 67 q < 2^384;
 //   * the row sum is an inclusive scan over the 16-lane row with DPP row_shr:1/2/4/8 -- no LDS traffic; lane 11 ends
@@ -248,7 +187,6 @@ __device__ __forceinline__ void pb_mul(PwShared &S, PB *out, const PB *A, const 
     pb_round<false>(S, out, A, B, nullptr, nullptr, nullptr, nullptr, nullptr);
 }
 
-__device__ __forceinline__ void pb_mul_line(PwShared &S, PB *out, const PB *A, const Fq *line5) { pb_mul_t<5>(S, out, A, line5); }
 // out = frobenius^e(A): c_k *= gamma_e^k
 __device__ __forceinline__ void pb_frob(PwShared &S, PB *out, const PB *A, const Fq *gamma /* global, 12 */) {
     const int t = threadIdx.x;
@@ -316,57 +254,35 @@ __device__ __attribute__((noinline)) void pb_inv(PwShared &S, PB *out, const PB 
     __syncthreads();
 }
 
-// Miller loop over n pairs (none at infinity); P coordinates in S.px / S.py; result in S.f
-__device__ __attribute__((noinline)) void pw_miller(PwShared &S, const G2Prepared *const *qs, int n) {
-    const int t = threadIdx.x;
-    if (t < 12) lds_store(&S.f.c[t], t == 0 ? Fq::one() : Fq::zero());
-    __syncthreads();
-    int idx = 0;
-    for (int i = 62; i >= 0; i--) {
-        const int steps = 1 + (int)((MI_BLS_X >> i) & 1);
-        pb_mul(S, &S.f, &S.f, &S.f);
-        for (int s = 0; s < steps; s++, idx++) {
-            // line coefficients for all pairs: lane (p, role)
-            if (t < 5 * n) {
-                const int p = t / 5, role = t - p * 5;
-                const Line *ln = &qs[p]->lines[idx];
-                Fq v;
-                if (role == 0) v = lds_load(&S.py[p]);
-                else if (role == 1) v = mul(ln->c1.c0, lds_load(&S.px[p]));
-                else if (role == 2) v = ln->c3.c0;
-                else if (role == 3) v = mul(ln->c1.c1, lds_load(&S.px[p]));
-                else v = ln->c3.c1;
-                lds_store(&S.line[p][role], v);
-            }
-            __syncthreads();
-            for (int p = 0; p < n; p++) pb_mul_line(S, &S.f, &S.f, S.line[p]);
-        }
-    }
-}
-
-// Two live pairs (every KZG / verifier check): all line coefficients first (552 values, three per lane), then per
-// doubling step TWO rounds -- [f^2 beside l_1 l_2] and [f^2 * (l_1 l_2)] -- instead of three rounds plus a line
-// evaluation; an addition step costs one more round (its line product rides in the second round's spare lanes).
-__device__ __attribute__((noinline)) void pw_miller2(PwShared &S, const G2Prepared *const *qs) {
+// Miller loop of one COUPLE of live pairs (p0, p0 + 1) -- every KZG / verifier check is one couple -- into S.f.  All
+// line coefficients first (552 values, three per lane), then per doubling step TWO rounds -- [f^2 beside l_1 l_2] and
+// [f^2 * (l_1 l_2)] -- instead of three rounds plus a line evaluation; an addition step costs one more round (its line
+// product rides in the second round's spare lanes).  A single pair (np = 1) runs as a couple whose second line is the
+// constant 1.  Products over more pairs multiply the couples' values (pw_pairing_product).
+__device__ __attribute__((noinline)) void pw_miller2(PwShared &S, const G2Prepared *const *qs, int p0, int np) {
     const int t = threadIdx.x;
     for (int item = t; item < MI_MILLER_LINES * 8; item += PW_THREADS) {
         const int idx = item >> 3, p = (item >> 2) & 1, role = item & 3;
-        const Line *ln = &qs[p]->lines[idx];
-        Fq v;
-        if (role == 0) v = mul(ln->c1.c0, lds_load(&S.px[p]));       // w^1
-        else if (role == 1) v = ln->c3.c0;                            // w^3
-        else if (role == 2) v = mul(ln->c1.c1, lds_load(&S.px[p]));  // w^7
-        else v = ln->c3.c1;                                           // w^9
+        Fq v = Fq::zero();
+        if (p < np) {
+            const Line *ln = &qs[p0 + p]->lines[idx];
+            if (role == 0) v = mul(ln->c1.c0, lds_load(&S.px[p0 + p]));       // w^1
+            else if (role == 1) v = ln->c3.c0;                                 // w^3
+            else if (role == 2) v = mul(ln->c1.c1, lds_load(&S.px[p0 + p]));  // w^7
+            else v = ln->c3.c1;                                                // w^9
+        }
         lds_store(&S.lines2[idx][p][role], v);
     }
     if (t < 12) lds_store(&S.f.c[t], t == 0 ? Fq::one() : Fq::zero());
+    if (t == 12) lds_store(&S.one, Fq::one());
     __syncthreads();
+    const Fq *y1 = &S.py[p0], *y2 = np == 2 ? &S.py[p0 + 1] : &S.one;
     int idx = 0;
     for (int i = 62; i >= 0; i--) {
-        pb_round<true>(S, &S.f, &S.f, &S.f, &S.t, &S.py[0], S.lines2[idx][0], &S.py[1], S.lines2[idx][1]);
+        pb_round<true>(S, &S.f, &S.f, &S.f, &S.t, y1, S.lines2[idx][0], y2, S.lines2[idx][1]);
         idx++;
         if ((MI_BLS_X >> i) & 1) {
-            pb_round<true>(S, &S.f, &S.f, &S.t, &S.a, &S.py[0], S.lines2[idx][0], &S.py[1], S.lines2[idx][1]);
+            pb_round<true>(S, &S.f, &S.f, &S.t, &S.a, y1, S.lines2[idx][0], y2, S.lines2[idx][1]);
             idx++;
             pb_mul(S, &S.f, &S.f, &S.a);
         } else {
@@ -422,8 +338,15 @@ __device__ __forceinline__ void pw_pairing_product(PwShared &S, const G1Affine *
         live_n = m;
     }
     __syncthreads();
-    if (live_n == 2) pw_miller2(S, live_q);
-    else pw_miller(S, live_q, live_n);
+    if (live_n == 0) {
+        if (t < 12) lds_store(&S.f.c[t], t == 0 ? Fq::one() : Fq::zero());
+        __syncthreads();
+    }
+    for (int c = 0; c < live_n; c += 2) {
+        if (c > 0) pb_copy(S, &S.b, &S.f);  // the couples before this one
+        pw_miller2(S, live_q, c, live_n - c >= 2 ? 2 : 1);
+        if (c > 0) pb_mul(S, &S.f, &S.f, &S.b);
+    }
     pw_final_exp(S, pc);
     if (t < 12) {
         // tower index (i, j, b) holds the coefficient of w^(i + 2j + 6b)

@@ -28,6 +28,27 @@ def test_pairing_product(orc, mi):
     assert mi.Bls12_377.product_of_pairings_is_one(ps3, qs3)
 
 
+@pytest.mark.parametrize("n", [1, 3, 4])
+def test_pairing_product_any_number_of_pairs(orc, mi, n):
+    """prod_i e(a_i G, b_i H) * e(-(sum a_i b_i) G, H) == 1 over n + 1 <= 4 pairs (couples of Miller loops multiplied),
+    the single-pair loop, and the all-infinity product"""
+    g, h = orc.g1_generator(), orc.g2_generator()
+    ab = [(1000003 + 17 * i, 777767 + 31 * i) for i in range(n)]
+    if n < 4:
+        total = sum(a * b for a, b in ab) % P.R
+        ps = np.stack([orc.g1_mul(g, a) for a, _ in ab] + [orc.g1_mul(g, (P.R - total) % P.R)])
+        qs = np.stack([orc.g2_mul(h, b) for _, b in ab] + [h])
+    else:  # four pairs in all: the last one closes the product
+        total = sum(a * b for a, b in ab[:3]) % P.R
+        ps = np.stack([orc.g1_mul(g, a) for a, _ in ab[:3]] + [orc.g1_mul(g, (P.R - total) % P.R)])
+        qs = np.stack([orc.g2_mul(h, b) for _, b in ab[:3]] + [h])
+    assert mi.Bls12_377.product_of_pairings_is_one(ps, qs)
+    qs_bad = qs.copy(); qs_bad[0] = orc.g2_mul(h, ab[0][1] + 1)
+    assert not mi.Bls12_377.product_of_pairings_is_one(ps, qs_bad)
+    zero_p = np.zeros_like(ps)
+    assert mi.Bls12_377.product_of_pairings_is_one(zero_p, qs)      # every pair at infinity: empty product
+
+
 def _kzg_instance(orc, n, seed):
     rng = P.SplitMix64(seed)
     tau = rng.below(P.R, 5)
