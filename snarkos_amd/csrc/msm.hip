@@ -1,21 +1,26 @@
-// Variable-base MSM over BLS12-377 G1 on gfx950: signed-digit Pippenger, sort-by-bucket, one lane per
-// bucket with a register-resident XYZZ accumulator, segmented bucket reduction, LDS tree sums.
+// Variable-base MSM over BLS12-377 G1 on gfx950: signed-digit Pippenger, sort-by-bucket, load-balanced bucket
+// accumulation in register-resident XYZZ accumulators, two reductions (by size), host Horner fold.
 //
 // Replaces snarkvm_algorithms::msm::VariableBase::msm (snarkVM 1.0.0 @ dea322b, un-vendored; SURVEY.md
 // 8a row A3): out = sum_i scalars[i] * bases[i], scalars canonical BigInteger256, bases Montgomery
 // affine.  The CPU reference walks c-bit windows with batched-affine bucket adds on rayon threads; this
 // is a different algorithm with the same (unique) group result.
 //
-// Pipeline (all on one stream, no host sync until the final 192*nwin-byte copy):
-//   K1 msm_digits    one lane per scalar: signed c-bit digits -> digits[w][i], histogram counts[w][b]
-//   K2 scan          exclusive scan of the nwin*B counts (B = 2^(c-1) buckets per window)
-//   K3 msm_scatter   one lane per (w,i): sorted[offset[bucket]++] = (i << 1) | negate
-//   K4 msm_accumulate one lane per bucket: gather its points (96 B each, random), mixed-add into XYZZ
-//   K5 msm_segments  one lane per L-bucket segment: running sums -> sum_j (gL + j) * bucket
-//   K6 point_tree_sum LDS tree: per-window sum of the segment partials
-//   host             Horner fold of the nwin window sums (<= 256 doublings), normalise to z = 1
+// Common front (one stream, no host synchronisation until the result):
+//   msm_digits     lane per scalar: signed c-bit digits -> digits[w][i]; bucket histogram whose atomic also returns
+//                  the entry's rank in its bucket (lanes of a wave sharing a bucket take one atomic together)
+//   scan / plan    bucket offsets; buckets over T entries are cut into chunks (offsets of those too)
+//   msm_scatter    lane per (w, i): sorted[offset[bucket] + rank] = (i << 1) | negate        (no atomics)
+//   msm_accumulate lane per CHUNK: gather its points (96 B each, random), mixed-add into XYZZ
+// Large path (n > 2^16): chunk map + chunks ordered by length; multi-chunk buckets summed (msm_combine_*);
+//   msm_segments (running sums per L-bucket segment + (gL) fix-up); point_tree_sum per window; the host folds the
+//   nwin window sums (<= 256 doublings) and normalises to z = 1.
+// Small path (n <= 2^16, latency bound; takes an optional `split`: two MSMs as one launch sequence, the second as
+//   the first's extra windows): ONE planning workgroup instead of scans / memsets / chunk kernels, accumulate finds its
+//   bucket by bisection, msm_bit_sums_* forms per-(window, bit) subset sums straight from the chunk partials into
+//   pinned host memory, and the host folds over bit positions (halves of each problem on pool threads).
 // HBM traffic per (point, scalar) pair: 32 B scalar read once, 96 B point read once per window from
-// HBM/Infinity Cache (the 100 MB base table of a 2^20 MSM stays cache resident), 4 B digit + 4 B index
+// HBM/Infinity Cache (the 100 MB base table of a 2^20 MSM stays cache resident), 4 B digit + 4 B rank + 4 B index
 // written and read once per window.
 #include <stdio.h>
 #include <stdlib.h>
