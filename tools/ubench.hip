@@ -1,5 +1,5 @@
 // Integer-ALU micro-benchmarks for gfx950: issue rates that bound the 377-bit Montgomery product.
-//   hipcc -O3 --offload-arch=gfx950 -std=c++17 -o tools/ubench tools/ubench.hip && ./tools/ubench
+//   hipcc -O3 --offload-arch=gfx950 -std=c++17 -o build/ubench tools/ubench.hip && ./build/ubench
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <type_traits>
