@@ -188,12 +188,9 @@ __device__ __attribute__((noinline)) void pb_round(PwShared &S, PB *out, const P
             carry = (uint32_t)(pr >> 32);
             v[j] = subc32(v[j], (uint32_t)pr, borrow, &borrow);
         }
-        uint32_t d[12];
-        borrow = 0;
-#pragma unroll
-        for (int j = 0; j < 12; j++) d[j] = subc32(v[j], FqP::MOD[j], borrow, &borrow);
-#pragma unroll
-        for (int j = 0; j < 12; j++) v[j] = borrow ? v[j] : d[j];
+        // no final conditional subtraction: v is left in [0, 2q).  The next round's unreduced products of operands
+        // below 2q stay below 1.03 q (4 q^2 / R + q), so every bound above holds; the few consumers that need the
+        // canonical representative (negation, inversion, the result) reduce once themselves.
     }
     if (!NOALIAS) __syncthreads();
     if (s == 11 || (WITH_L && s == 15)) {
@@ -227,6 +224,7 @@ __device__ __forceinline__ void pb_conj(PwShared &S, PB *out, const PB *A) {
     Fq v;
     if (t < 12) {
         v = lds_load(&A->c[t]);
+        reduce_once(v);  // rounds leave values in [0, 2q)
         if (t & 1) v = neg(v);
     }
     __syncthreads();
@@ -276,7 +274,11 @@ __device__ __attribute__((noinline)) void pb_inv(PwShared &S, PB *out, const PB 
     pb_frob(S, &S.x, &S.y, pc->frob[0]);      // x = Abar
     pb_mul(S, &S.y, A, &S.x);                 // y = N (coefficient 0; the others vanish)
     const int t = threadIdx.x;
-    if (t == 0) lds_store(&S.y.c[1], invq(lds_load(&S.y.c[0])));  // 1/N parked in y.c[1]
+    if (t == 0) {
+        Fq nrm = lds_load(&S.y.c[0]);
+        reduce_once(nrm);  // rounds leave values in [0, 2q)
+        lds_store(&S.y.c[1], invq(nrm));  // 1/N parked in y.c[1]
+    }
     __syncthreads();
     Fq v;
     if (t < 12) v = mul(lds_load(&S.x.c[t]), lds_load(&S.y.c[1]));
@@ -386,7 +388,9 @@ __device__ __forceinline__ void pw_pairing_product(PwShared &S, const G1Affine *
         // tower index (i, j, b) holds the coefficient of w^(i + 2j + 6b)
         const int b = t / 6, rem = t - 6 * b, j = rem >> 1, i = rem & 1;
         Fq *o = &out->c0.c0.c0;
-        o[(i * 3 + j) * 2 + b] = lds_load(&S.f.c[t]);
+        Fq res = lds_load(&S.f.c[t]);
+        reduce_once(res);  // rounds leave values in [0, 2q)
+        o[(i * 3 + j) * 2 + b] = res;
     }
     __syncthreads();
 }
