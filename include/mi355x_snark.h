@@ -42,6 +42,8 @@ extern "C" {
 #define MI_ERR_OOM (-3)
 #define MI_ERR_KERNEL (-4)
 #define MI_ERR_NOT_INIT (-5)
+#define MI_ERR_AGAIN (-6) /* mi_vs_stream_next: the next verdict is not ready */
+#define MI_ERR_DONE (-7)  /* mi_vs_stream_next: the stream is finished and drained */
 
 typedef struct { uint64_t l[4]; } mi_fr;        /* Fr, Montgomery */
 typedef struct { uint64_t l[4]; } mi_bigint256; /* canonical integer < r */
@@ -147,6 +149,24 @@ int32_t mi_vs_accumulate_begin(uint64_t ctx, const void *d_proofs, size_t n, con
 int32_t mi_vs_accumulate_end(uint64_t ctx, uint64_t handle, mi_vs_partial *partial_out);
 int32_t mi_vs_finalize_async(uint64_t ctx, const mi_vs_partial *partials, size_t n_partials, uint64_t *ticket_out);
 int32_t mi_vs_finalize_wait(uint64_t ctx, uint64_t ticket, uint8_t *all_ok);
+
+/* ---- native streaming driver over the split entry points above (what rayon workers would otherwise hand-roll) ----
+ * One driver owns host threads: `fold_threads` wait for accumulations and fold them, one finisher turns partials into
+ * pairing products (up to `products` in flight) and hands verdicts back in submission order.  The caller's thread only
+ * enqueues.  `exchange` (may be NULL) runs on the finisher thread once per batch, in batch order: it receives this
+ * rank's partial and must return all ranks' partials (multi-GPU: one all-gather of 304 bytes per rank); it returns the
+ * number of partials written (<= max_partials) or a negative value on failure. */
+typedef int32_t (*mi_vs_exchange_fn)(void *user, const mi_vs_partial *mine, mi_vs_partial *all, size_t max_partials);
+int32_t mi_vs_stream_open(uint64_t ctx, int32_t fold_threads, int32_t products, int32_t lanes, mi_vs_exchange_fn exchange,
+                          void *user, uint64_t *stream_out);
+/* enqueue one batch (device pointers; blocks while every lane is taken); batches are numbered 0, 1, 2, ... */
+int32_t mi_vs_stream_submit(uint64_t stream, const void *d_proofs, size_t n, const void *d_randomizers128, void *hip_stream);
+/* no more batches will be submitted: lets mi_vs_stream_next drain */
+int32_t mi_vs_stream_finish(uint64_t stream);
+/* next verdict in submission order.  block = 0: MI_ERR_AGAIN if it is not ready yet; after the last verdict of a
+ * finished stream: MI_ERR_DONE.  A failure inside the pipeline is reported here (status of the failing call). */
+int32_t mi_vs_stream_next(uint64_t stream, int32_t block, uint8_t *all_ok);
+int32_t mi_vs_stream_close(uint64_t stream); /* finishes, drains and joins the threads */
 
 /* ---- crypto_hash::PoseidonSponge<Fq, 2, 1>, many independent sponges at once ----
  * Structure as snarkVM's (width 3, S-box x^17, 8 full + 31 partial rounds); the round constants and MDS matrix

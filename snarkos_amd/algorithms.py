@@ -313,113 +313,59 @@ class VarunaShaped:
         """Pipelined verification of a stream of batches (chunks of a block, or mempool traffic): yields all_ok per
         batch, in order.
 
-        Three host stages drive the GPU.  The caller's thread enqueues batch k (derive + both MSMs on one of
-        `acc_depth` <= 14 stream lanes); `fold_threads` threads wait for accumulations and fold them on the host
-        (accumulate_end); one finisher thread takes the partials in batch order, exchanges them (`gather`,
-        optional: maps this rank's partial to the list of all ranks' partials -- every collective is issued from
-        that one thread) and starts the pairing product; up to `depth` (<= 8) products are in flight, each on its own
-        stream.  `batches` yields (proofs_cuda, randomizers_cuda).  The library's entry points drop the context lock
-        around their host-side waits and folds, so the stages overlap.
+        A thin wrapper over the library's native driver (mi_vs_stream_*: csrc/stream.hip).  The caller's thread
+        enqueues batch k (derive + both MSMs on one of `acc_depth` stream lanes); `fold_threads` native threads wait
+        for accumulations and fold them on the host; one finisher thread takes the partials in batch order,
+        exchanges them (`gather`, optional: maps this rank's partial to all ranks' partials -- every collective is
+        issued from that one thread) and starts the pairing product; up to `depth` (<= 8) products are in flight,
+        each on its own stream.  `batches` yields (proofs_cuda, randomizers_cuda).
         """
-        import queue
-        import threading
+        lib = L.lib()
+        keep = {}
 
-        depth = max(1, min(depth, 8))
-        acc_depth = max(1, min(acc_depth, self.lanes))
-        fold_threads = max(1, min(fold_threads, 4))
-        lanes = threading.Semaphore(acc_depth)
-        handles, results = queue.Queue(), queue.Queue()
-        parts_ready, parts_cv = {}, threading.Condition()
-        END = object()
-        state = {"n": None, "err": None}
-
-        def fail(e):
-            with parts_cv:
-                if state["err"] is None:
-                    state["err"] = e
-                parts_cv.notify_all()
-            lanes.release()
-            results.put(e)
-
-        def folder():
+        def exchange(_user, mine, out, max_parts):  # runs on the finisher thread (ctypes takes the GIL)
             try:
-                while True:
-                    item = handles.get()
-                    if item is END:
-                        handles.put(END)  # for the other folders
-                        return
-                    seq, h = item
-                    part = self.accumulate_end(h)  # wait for the GPU, fold on the host
-                    lanes.release()
-                    with parts_cv:
-                        parts_ready[seq] = part
-                        parts_cv.notify_all()
-            except BaseException as e:
-                fail(e)
+                part = np.ctypeslib.as_array(mine, shape=(L.VS_PARTIAL_BYTES,)).copy()
+                parts = np.ascontiguousarray(gather(part), dtype=np.uint8).reshape(-1, L.VS_PARTIAL_BYTES)
+                if len(parts) == 0 or len(parts) > max_parts:
+                    return -1
+                np.ctypeslib.as_array(out, shape=(len(parts) * L.VS_PARTIAL_BYTES,))[:] = parts.reshape(-1)
+                return len(parts)
+            except BaseException as e:  # surfaced by the generator below
+                keep["error"] = e
+                return L.MI_ERR_KERNEL
 
-        def finisher():
-            pending, seq = [], 0
-            try:
-                while True:
-                    with parts_cv:
-                        while seq not in parts_ready and state["err"] is None and state["n"] != seq:
-                            parts_cv.wait()
-                        if state["err"] is not None:
-                            return
-                        if seq not in parts_ready:
-                            break  # all batches taken
-                        part = parts_ready.pop(seq)
-                    seq += 1
-                    parts = gather(part) if gather is not None else [part]
-                    if len(pending) >= depth:
-                        results.put(self.finalize_wait(pending.pop(0)))
-                    pending.append(self.finalize_async(parts))
-                while pending:
-                    results.put(self.finalize_wait(pending.pop(0)))
-                results.put(END)
-            except BaseException as e:
-                fail(e)
+        cb = L.VS_EXCHANGE_FN(exchange) if gather is not None else C.cast(None, L.VS_EXCHANGE_FN)
+        sid = C.c_uint64(0)
+        L.check(lib.mi_vs_stream_open(C.c_uint64(self.ctx), C.c_int32(fold_threads), C.c_int32(depth),
+                                      C.c_int32(max(1, min(acc_depth, self.lanes))), cb, None, C.byref(sid)), "mi_vs_stream_open")
+        ok = C.c_uint8(0)
 
-        threads = [threading.Thread(target=folder, name="mi-snark-fold%d" % i, daemon=True) for i in range(fold_threads)]
-        threads.append(threading.Thread(target=finisher, name="mi-snark-finish", daemon=True))
-        for th in threads:
-            th.start()
+        def drain(block):
+            while True:
+                st = lib.mi_vs_stream_next(sid, 1 if block else 0, C.byref(ok))
+                if st == L.MI_OK:
+                    yield bool(ok.value)
+                elif st == L.MI_ERR_AGAIN or st == L.MI_ERR_DONE:
+                    return
+                else:
+                    if "error" in keep:
+                        raise keep["error"]
+                    raise L.MiError(st, "mi_vs_stream_next")
 
-        def close_input(n):
-            with parts_cv:
-                if state["n"] is None:
-                    state["n"] = n
-                parts_cv.notify_all()
-            handles.put(END)
-
-        n = 0
         try:
             for proofs, rnd in batches:
-                lanes.acquire()
-                if state["err"] is not None:
-                    raise state["err"]
-                handles.put((n, self.accumulate_begin(proofs, rnd)))
-                n += 1
-                while True:
-                    try:
-                        r = results.get_nowait()
-                    except queue.Empty:
-                        break
-                    if isinstance(r, BaseException):
-                        raise r
-                    yield r
-            close_input(n)
-            while True:
-                r = results.get()
-                if r is END:
-                    break
-                if isinstance(r, BaseException):
-                    raise r
-                yield r
+                n = proofs.numel() * proofs.element_size() // L.VS_PROOF_BYTES
+                st = lib.mi_vs_stream_submit(sid, L.dptr(proofs), C.c_size_t(n), L.dptr(rnd), L.stream_ptr(None))
+                if st != L.MI_OK:
+                    if "error" in keep:
+                        raise keep["error"]
+                    raise L.MiError(st, "mi_vs_stream_submit")
+                yield from drain(False)
+            L.check(lib.mi_vs_stream_finish(sid), "mi_vs_stream_finish")
+            yield from drain(True)
         finally:
-            close_input(n)
-            for th in threads:
-                th.join(timeout=60)
+            lib.mi_vs_stream_close(sid)
 
     def finalize(self, partials):
         parts = np.ascontiguousarray(partials, dtype=np.uint8).reshape(-1, L.VS_PARTIAL_BYTES)

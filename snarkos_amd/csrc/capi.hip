@@ -208,6 +208,8 @@ const char *mi_error_string(int32_t s) {
     case MI_ERR_OOM: return "out of device memory";
     case MI_ERR_KERNEL: return "HIP runtime or kernel failure";
     case MI_ERR_NOT_INIT: return "not initialised";
+    case MI_ERR_AGAIN: return "not ready yet";
+    case MI_ERR_DONE: return "stream finished";
     default: return "unknown status";
     }
 }

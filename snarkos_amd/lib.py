@@ -13,6 +13,11 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmi355x_snark.so")
 
 MI_OK = 0
+MI_ERR_KERNEL = -4
+MI_ERR_AGAIN = -6
+MI_ERR_DONE = -7
+# int32_t (*mi_vs_exchange_fn)(void *user, const mi_vs_partial *mine, mi_vs_partial *all, size_t max_partials)
+VS_EXCHANGE_FN = C.CFUNCTYPE(C.c_int32, C.c_void_p, C.POINTER(C.c_uint8), C.POINTER(C.c_uint8), C.c_size_t)
 G1_AFFINE_U64 = 12
 G1_JAC_U64 = 18
 G2_AFFINE_U64 = 24
@@ -34,6 +39,7 @@ EXPORTS = [
     "mi_poseidon_fq_hash_many", "mi_poseidon_fq_hash_many_device",
     "mi_vs_ctx_create", "mi_vs_ctx_destroy", "mi_vs_verify_batch", "mi_vs_verify_batch_device",
     "mi_vs_accumulate_device", "mi_vs_accumulate_begin", "mi_vs_accumulate_end", "mi_vs_finalize", "mi_vs_finalize_async", "mi_vs_finalize_wait",
+    "mi_vs_stream_open", "mi_vs_stream_submit", "mi_vs_stream_finish", "mi_vs_stream_next", "mi_vs_stream_close",
     "mi_dbg_fq_mul", "mi_dbg_fr_mul", "mi_dbg_g1_add", "mi_dbg_fq_mul_throughput", "mi_dbg_gen_points_device",
     "mi_prof_enable", "mi_prof_read",
 ]
@@ -72,6 +78,11 @@ def lib():
         for name in EXPORTS:
             getattr(l, name).restype = C.c_int32
         l.mi_error_string.restype = C.c_char_p
+        l.mi_vs_stream_open.argtypes = [C.c_uint64, C.c_int32, C.c_int32, C.c_int32, VS_EXCHANGE_FN, C.c_void_p, C.POINTER(C.c_uint64)]
+        l.mi_vs_stream_submit.argtypes = [C.c_uint64, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
+        l.mi_vs_stream_next.argtypes = [C.c_uint64, C.c_int32, C.POINTER(C.c_uint8)]
+        l.mi_vs_stream_finish.argtypes = [C.c_uint64]
+        l.mi_vs_stream_close.argtypes = [C.c_uint64]
         l.mi_error_string.argtypes = [C.c_int32]
         _LIB = l
     return _LIB
