@@ -261,3 +261,73 @@ def test_two_contexts_share_the_pipeline(orc, mi):
     finally:
         v1.close()
         v2.close()
+
+
+def test_native_stream_driver_api(orc, mi):
+    """mi_vs_stream_*: polling, draining, the exchange callback (identity, two shards, failure), misuse"""
+    import ctypes as C
+    import torch
+    from snarkos_amd import lib as L
+    b = orc.VSBatch(0x57EC, 24, 2, 0)
+    v = _ctx(mi, b)
+    lib = L.lib()
+    p, r = torch.from_numpy(b.proofs).cuda(), torch.from_numpy(b.randomizers).cuda()
+    half = 12 * 2256
+    pa, ra = p[:half].contiguous(), r[:12 * 32].contiguous()
+    pb, rb = p[half:].contiguous(), r[12 * 32:].contiguous()
+    other = v.accumulate(pb, rb)  # the second shard's partial, as another rank would hold it
+    ok = C.c_uint8(9)
+
+    def run(cb, batches, n_each=24):
+        sid = C.c_uint64(0)
+        L.check(lib.mi_vs_stream_open(C.c_uint64(v.ctx), 2, 4, 6, cb, None, C.byref(sid)), "open")
+        out = []
+        try:
+            for (pp, rr) in batches:
+                n = pp.numel() // 2256
+                st = lib.mi_vs_stream_submit(sid, L.dptr(pp), C.c_size_t(n), L.dptr(rr), L.stream_ptr(None))
+                if st != L.MI_OK:
+                    out.append(("submit", st))
+                    break
+            assert lib.mi_vs_stream_finish(sid) == L.MI_OK
+            assert lib.mi_vs_stream_submit(sid, L.dptr(p), C.c_size_t(24), L.dptr(r), L.stream_ptr(None)) == -1  # finished
+            while True:
+                st = lib.mi_vs_stream_next(sid, 1, C.byref(ok))
+                if st == L.MI_ERR_DONE:
+                    break
+                out.append(bool(ok.value) if st == L.MI_OK else ("next", st))
+                if st != L.MI_OK:
+                    break
+        finally:
+            assert lib.mi_vs_stream_close(sid) == L.MI_OK
+        return out
+
+    none = C.cast(None, L.VS_EXCHANGE_FN)
+    try:
+        assert run(none, [(p, r)] * 9) == [True] * 9
+        # polling an empty, unfinished stream: not ready
+        sid = C.c_uint64(0)
+        L.check(lib.mi_vs_stream_open(C.c_uint64(v.ctx), 1, 1, 1, none, None, C.byref(sid)), "open")
+        assert lib.mi_vs_stream_next(sid, 0, C.byref(ok)) == L.MI_ERR_AGAIN
+        assert lib.mi_vs_stream_close(sid) == L.MI_OK
+        assert lib.mi_vs_stream_next(sid, 0, C.byref(ok)) == -1  # closed
+        # two shards: this rank submits the first half, the callback supplies the other rank's partial
+        calls = []
+
+        def two(_u, mine, out, cap):
+            calls.append(cap)
+            np.ctypeslib.as_array(out, shape=(608,))[:304] = np.ctypeslib.as_array(mine, shape=(304,))
+            np.ctypeslib.as_array(out, shape=(608,))[304:] = other
+            return 2
+        assert run(L.VS_EXCHANGE_FN(two), [(pa, ra)] * 5) == [True] * 5 and len(calls) == 5
+        # without the other shard's partial the first half alone still verifies; with a corrupted shard it does not
+        assert run(none, [(pa, ra)]) == [True]
+        bad = b.proofs.copy(); bad[3 * 2256 + 16 + 512 + 864 + 32 * 2] ^= 1
+        assert run(L.VS_EXCHANGE_FN(two), [(torch.from_numpy(bad[:half]).cuda(), ra)]) == [False]
+        # a failing exchange surfaces as an error status from next (after the verdicts that were already under way)
+        boom = L.VS_EXCHANGE_FN(lambda _u, mine, out, cap: -4)
+        res = run(boom, [(pa, ra)] * 3)
+        assert res and res[-1] == ("next", -4) and all(x is True for x in res[:-1])
+        assert v.verify_batch(p, r)[0]  # the context is still usable
+    finally:
+        v.close()
