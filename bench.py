@@ -69,6 +69,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--acc-depth", type=int, default=0,
                     help="accumulation lanes (batches on the GPU before the oldest is folded, <= 14); default 12, or 8 when RCCL needs queues too")
+    ap.add_argument("--exchange-group", type=int, default=0,
+                    help="batches per partial exchange when sharded (fewer, larger all-gathers); default 4 with a process group")
     ap.add_argument("--fold-threads", type=int, default=3, help="host threads folding finished accumulations")
     ap.add_argument("--products", type=int, default=8, help="pairing products in flight (<= 8)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for rehearsals on one GPU)")
@@ -80,6 +82,11 @@ def main():
         # process group RCCL's own streams must fit too
         args.acc_depth = 12 if world == 1 else 8  # measured with an RCCL group up: 12 -> 0.64, 10 -> 0.29, 8 -> 0.31 ms/batch
     os.environ["MI_SNARK_VS_LANES"] = str(args.acc_depth)  # read when the verifier context is created
+    if world > 1 and args.products == 8:
+        args.products = 6  # 8 lanes + 6 product streams: room for RCCL's own queues below the 24-queue cliff
+    os.environ["MI_SNARK_VS_SLOTS"] = str(args.products)
+    if args.exchange_group <= 0:
+        args.exchange_group = 4 if world > 1 else 1
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     dist_on = world > 1
@@ -109,13 +116,14 @@ def main():
     # its own, unpipelined.
     def gather_all(part):  # runs on verify_stream's finisher thread: every collective comes from that one thread
         torch.cuda.set_device(dev_index)
-        return sharding.gather_partials(part, torch.distributed, gather_dev)
+        part = np.ascontiguousarray(part, dtype=np.uint8)  # (count, 304): one collective per group of batches
+        return sharding.gather_bytes(part, part.size, torch.distributed, gather_dev).reshape(world, -1, L.VS_PARTIAL_BYTES)
 
     gather = gather_all if dist_on else None
 
     def run(k):
         oks = list(verifier.verify_stream(((d_proofs, d_rnd) for _ in range(k)), gather, depth=args.products, acc_depth=args.acc_depth,
-                                          fold_threads=args.fold_threads))
+                                          fold_threads=args.fold_threads, exchange_group=args.exchange_group))
         assert len(oks) == k and all(oks), "synthetic batch must verify"
 
     if args.warmup:

@@ -153,12 +153,14 @@ int32_t mi_vs_finalize_wait(uint64_t ctx, uint64_t ticket, uint8_t *all_ok);
 /* ---- native streaming driver over the split entry points above (what rayon workers would otherwise hand-roll) ----
  * One driver owns host threads: `fold_threads` wait for accumulations and fold them, one finisher turns partials into
  * pairing products (up to `products` in flight) and hands verdicts back in submission order.  The caller's thread only
- * enqueues.  `exchange` (may be NULL) runs on the finisher thread once per batch, in batch order: it receives this
- * rank's partial and must return all ranks' partials (multi-GPU: one all-gather of 304 bytes per rank); it returns the
- * number of partials written (<= max_partials) or a negative value on failure. */
-typedef int32_t (*mi_vs_exchange_fn)(void *user, const mi_vs_partial *mine, mi_vs_partial *all, size_t max_partials);
+ * enqueues.  `exchange` (may be NULL) runs on the finisher thread, in batch order, once per GROUP of `exchange_group`
+ * consecutive batches (1..8; the last group of a finished stream may be shorter; larger groups mean fewer collectives
+ * and later verdicts): it receives this rank's `count` partials and must write all ranks' partials rank-major
+ * (all[rank * count + k] = rank's partial of the group's k-th batch; multi-GPU: one all-gather of count * 304 bytes per
+ * rank) and return the number of RANKS (world * count <= max_partials), or a negative value on failure. */
+typedef int32_t (*mi_vs_exchange_fn)(void *user, const mi_vs_partial *mine, size_t count, mi_vs_partial *all, size_t max_partials);
 int32_t mi_vs_stream_open(uint64_t ctx, int32_t fold_threads, int32_t products, int32_t lanes, mi_vs_exchange_fn exchange,
-                          void *user, uint64_t *stream_out);
+                          void *user, int32_t exchange_group, uint64_t *stream_out);
 /* enqueue one batch (device pointers; blocks while every lane is taken); batches are numbered 0, 1, 2, ... */
 int32_t mi_vs_stream_submit(uint64_t stream, const void *d_proofs, size_t n, const void *d_randomizers128, void *hip_stream);
 /* no more batches will be submitted: lets mi_vs_stream_next drain */

@@ -309,28 +309,30 @@ class VarunaShaped:
         L.check(L.lib().mi_vs_finalize_wait(C.c_uint64(self.ctx), C.c_uint64(ticket), L.ptr(ok)), "mi_vs_finalize_wait")
         return bool(ok[0])
 
-    def verify_stream(self, batches, gather=None, depth=8, acc_depth=12, fold_threads=3):
+    def verify_stream(self, batches, gather=None, depth=8, acc_depth=12, fold_threads=3, exchange_group=1):
         """Pipelined verification of a stream of batches (chunks of a block, or mempool traffic): yields all_ok per
         batch, in order.
 
         A thin wrapper over the library's native driver (mi_vs_stream_*: csrc/stream.hip).  The caller's thread
         enqueues batch k (derive + both MSMs on one of `acc_depth` stream lanes); `fold_threads` native threads wait
         for accumulations and fold them on the host; one finisher thread takes the partials in batch order,
-        exchanges them (`gather`, optional: maps this rank's partial to all ranks' partials -- every collective is
-        issued from that one thread) and starts the pairing product; up to `depth` (<= 8) products are in flight,
-        each on its own stream.  `batches` yields (proofs_cuda, randomizers_cuda).
+        exchanges them (`gather`, optional: maps this rank's (count, 304) partials of `exchange_group` consecutive
+        batches to all ranks' (world, count, 304) -- one collective per group, issued from that one thread) and starts
+        the pairing products; up to `depth` (<= 8) products are in flight, each on its own stream.  `batches` yields
+        (proofs_cuda, randomizers_cuda).
         """
         lib = L.lib()
         keep = {}
 
-        def exchange(_user, mine, out, max_parts):  # runs on the finisher thread (ctypes takes the GIL)
+        def exchange(_user, mine, count, out, max_parts):  # runs on the finisher thread (ctypes takes the GIL)
             try:
-                part = np.ctypeslib.as_array(mine, shape=(L.VS_PARTIAL_BYTES,)).copy()
-                parts = np.ascontiguousarray(gather(part), dtype=np.uint8).reshape(-1, L.VS_PARTIAL_BYTES)
-                if len(parts) == 0 or len(parts) > max_parts:
+                part = np.ctypeslib.as_array(mine, shape=(count, L.VS_PARTIAL_BYTES)).copy()
+                parts = np.ascontiguousarray(gather(part), dtype=np.uint8).reshape(-1, count, L.VS_PARTIAL_BYTES)
+                world = len(parts)
+                if world == 0 or world * count > max_parts:
                     return -1
-                np.ctypeslib.as_array(out, shape=(len(parts) * L.VS_PARTIAL_BYTES,))[:] = parts.reshape(-1)
-                return len(parts)
+                np.ctypeslib.as_array(out, shape=(world * count * L.VS_PARTIAL_BYTES,))[:] = parts.reshape(-1)
+                return world
             except BaseException as e:  # surfaced by the generator below
                 keep["error"] = e
                 return L.MI_ERR_KERNEL
@@ -338,7 +340,8 @@ class VarunaShaped:
         cb = L.VS_EXCHANGE_FN(exchange) if gather is not None else C.cast(None, L.VS_EXCHANGE_FN)
         sid = C.c_uint64(0)
         L.check(lib.mi_vs_stream_open(C.c_uint64(self.ctx), C.c_int32(fold_threads), C.c_int32(depth),
-                                      C.c_int32(max(1, min(acc_depth, self.lanes))), cb, None, C.byref(sid)), "mi_vs_stream_open")
+                                      C.c_int32(max(1, min(acc_depth, self.lanes))), cb, None, C.c_int32(exchange_group), C.byref(sid)),
+                "mi_vs_stream_open")
         ok = C.c_uint8(0)
 
         def drain(block):

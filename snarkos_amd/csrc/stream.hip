@@ -19,7 +19,7 @@ namespace {
 
 struct Stream {
     uint64_t ctx = 0;
-    int products = 8, lanes = 12;
+    int products = 8, lanes = 12, group = 1;
     mi_vs_exchange_fn exchange = nullptr;
     void *user = nullptr;
 
@@ -63,7 +63,7 @@ struct Stream {
 
     void finisher_main() {
         std::deque<uint64_t> tickets;
-        std::vector<mi_vs_partial> all(64);
+        std::vector<mi_vs_partial> mine(8), all(8 * 64), one(64);
         uint64_t seq = 0;
         auto publish = [&](int32_t v) {
             std::lock_guard<std::mutex> lk(mu);
@@ -76,37 +76,59 @@ struct Stream {
             tickets.pop_front();
             publish(st == MI_OK ? (int32_t)ok : st);
         };
-        for (;;) {
-            mi_vs_partial mine;
+        bool failed = false;
+        while (!failed) {
+            // the next group: batches [seq, seq + count), count = group, or what is left of a finished stream
+            size_t count = 0;
             {
                 std::unique_lock<std::mutex> lk(mu);
-                cv.wait(lk, [&] { return folded.count(seq) || error != MI_OK || (finished && seq == submitted); });
-                if (error != MI_OK || !folded.count(seq)) break;
-                mine = folded[seq];
-                folded.erase(seq);
+                auto ready = [&]() -> bool {
+                    if (error != MI_OK) return true;
+                    const uint64_t want = finished && submitted - seq < (uint64_t)group ? submitted - seq : (uint64_t)group;
+                    if (want == 0) return finished;
+                    for (uint64_t k = 0; k < want; k++)
+                        if (!folded.count(seq + k)) return false;
+                    return finished || want == (uint64_t)group;
+                };
+                cv.wait(lk, ready);
+                if (error != MI_OK) break;
+                count = (size_t)(finished && submitted - seq < (uint64_t)group ? submitted - seq : (uint64_t)group);
+                if (count == 0) break;  // finished and drained
+                for (size_t k = 0; k < count; k++) {
+                    mine[k] = folded[seq + k];
+                    folded.erase(seq + k);
+                }
             }
-            seq++;
-            size_t np = 1;
-            const mi_vs_partial *parts = &mine;
+            seq += count;
+            size_t world = 1;
+            const mi_vs_partial *src = mine.data();
             if (exchange) {
-                const int32_t got = exchange(user, &mine, all.data(), all.size());
-                if (got <= 0) {
+                const int32_t got = exchange(user, mine.data(), count, all.data(), all.size());
+                if (got <= 0 || (size_t)got * count > all.size() || (size_t)got > one.size()) {
                     std::lock_guard<std::mutex> lk(mu);
                     fail(got < 0 ? got : MI_ERR_BAD_ARGS);
                     break;
                 }
-                np = (size_t)got;
-                parts = all.data();
+                world = (size_t)got;
+                src = all.data();
             }
-            if ((int)tickets.size() >= products) wait_oldest();
-            uint64_t tk = 0;
-            const int32_t st = mi_vs_finalize_async(ctx, parts, np, &tk);
-            if (st != MI_OK) {
-                std::lock_guard<std::mutex> lk(mu);
-                fail(st);
-                break;
+            for (size_t k = 0; k < count && !failed; k++) {
+                for (size_t r = 0; r < world; r++) one[r] = src[r * count + k];
+                if ((int)tickets.size() >= products) wait_oldest();
+                uint64_t tk = 0;
+                int32_t st = mi_vs_finalize_async(ctx, one.data(), world, &tk);
+                while (st == MI_ERR_BAD_ARGS && !tickets.empty()) {  // fewer product slots than `products` (MI_SNARK_VS_SLOTS)
+                    wait_oldest();
+                    st = mi_vs_finalize_async(ctx, one.data(), world, &tk);
+                }
+                if (st != MI_OK) {
+                    std::lock_guard<std::mutex> lk(mu);
+                    fail(st);
+                    failed = true;
+                    break;
+                }
+                tickets.push_back(tk);
             }
-            tickets.push_back(tk);
         }
         while (!tickets.empty()) wait_oldest();  // products already in flight still get their verdicts
         std::lock_guard<std::mutex> lk(mu);
@@ -130,7 +152,7 @@ std::shared_ptr<Stream> find(uint64_t id) {
 extern "C" {
 
 int32_t mi_vs_stream_open(uint64_t ctx, int32_t fold_threads, int32_t products, int32_t lanes, mi_vs_exchange_fn exchange,
-                          void *user, uint64_t *stream_out) {
+                          void *user, int32_t exchange_group, uint64_t *stream_out) {
     if (!stream_out) return MI_ERR_BAD_ARGS;
     auto s = std::make_shared<Stream>();
     s->ctx = ctx;
@@ -138,6 +160,7 @@ int32_t mi_vs_stream_open(uint64_t ctx, int32_t fold_threads, int32_t products, 
     s->lanes = lanes < 1 ? 1 : (lanes > MI_VS_MAX_OPEN_ACCUMULATIONS ? MI_VS_MAX_OPEN_ACCUMULATIONS : lanes);
     s->exchange = exchange;
     s->user = user;
+    s->group = exchange_group < 1 ? 1 : (exchange_group > 8 ? 8 : exchange_group);
     if (fold_threads < 1) fold_threads = 1;
     if (fold_threads > 8) fold_threads = 8;
     Stream *raw = s.get();

@@ -151,7 +151,7 @@ struct VsAcc {  // an accumulation whose kernels are enqueued but whose host fol
 // (measured: 45 MB of device memory per create/destroy cycle when every context made its own 20 streams).
 struct VsPipe {
     bool ready = false;
-    int lanes = 12;
+    int lanes = 12, nslots = VS_SLOTS;
     VsAcc acc[VS_ACC_DEPTH];
     hipStream_t acc_st[VS_ACC_DEPTH] = {};  // one stream per accumulation lane
     hipEvent_t acc_ev[VS_ACC_DEPTH] = {};
@@ -180,7 +180,13 @@ static void vs_pipe_init() {
         MI_HIP(hipStreamCreateWithFlags(&pp.acc_st[p], hipStreamNonBlocking));
         MI_HIP(hipEventCreateWithFlags(&pp.acc_ev[p], hipEventDisableTiming));
     }
-    for (auto &sl : pp.slots) {
+    pp.nslots = VS_SLOTS;
+    if (const char *e = getenv("MI_SNARK_VS_SLOTS")) {  // product slots (1..8): fewer streams when queues are scarce
+        const int x = atoi(e);
+        if (x >= 1 && x <= VS_SLOTS) pp.nslots = x;
+    }
+    for (int i = 0; i < pp.nslots; i++) {
+        VsSlot &sl = pp.slots[i];
         MI_HIP(hipStreamCreateWithFlags(&sl.stream, hipStreamNonBlocking));
         MI_HIP(hipEventCreateWithFlags(&sl.done, hipEventDisableTiming));
         MI_HIP(hipHostMalloc((void **)&sl.h_out, sizeof(Fq12), hipHostMallocDefault));
@@ -729,7 +735,7 @@ int32_t vs_finalize_async(Context &cx, uint64_t id, const mi_vs_partial *parts, 
     if (it == vs_ctxs().end()) return MI_ERR_BAD_ARGS;
     VsCtx &v = it->second;
     int slot = -1;
-    for (int i = 0; i < VS_SLOTS; i++)
+    for (int i = 0; i < vs_pipe().nslots; i++)
         if (!vs_pipe().slots[i].busy) {
             slot = i;
             break;

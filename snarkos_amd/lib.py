@@ -16,8 +16,8 @@ MI_OK = 0
 MI_ERR_KERNEL = -4
 MI_ERR_AGAIN = -6
 MI_ERR_DONE = -7
-# int32_t (*mi_vs_exchange_fn)(void *user, const mi_vs_partial *mine, mi_vs_partial *all, size_t max_partials)
-VS_EXCHANGE_FN = C.CFUNCTYPE(C.c_int32, C.c_void_p, C.POINTER(C.c_uint8), C.POINTER(C.c_uint8), C.c_size_t)
+# int32_t (*mi_vs_exchange_fn)(void *user, const mi_vs_partial *mine, size_t count, mi_vs_partial *all, size_t max_partials)
+VS_EXCHANGE_FN = C.CFUNCTYPE(C.c_int32, C.c_void_p, C.POINTER(C.c_uint8), C.c_size_t, C.POINTER(C.c_uint8), C.c_size_t)
 G1_AFFINE_U64 = 12
 G1_JAC_U64 = 18
 G2_AFFINE_U64 = 24
@@ -78,7 +78,7 @@ def lib():
         for name in EXPORTS:
             getattr(l, name).restype = C.c_int32
         l.mi_error_string.restype = C.c_char_p
-        l.mi_vs_stream_open.argtypes = [C.c_uint64, C.c_int32, C.c_int32, C.c_int32, VS_EXCHANGE_FN, C.c_void_p, C.POINTER(C.c_uint64)]
+        l.mi_vs_stream_open.argtypes = [C.c_uint64, C.c_int32, C.c_int32, C.c_int32, VS_EXCHANGE_FN, C.c_void_p, C.c_int32, C.POINTER(C.c_uint64)]
         l.mi_vs_stream_submit.argtypes = [C.c_uint64, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
         l.mi_vs_stream_next.argtypes = [C.c_uint64, C.c_int32, C.POINTER(C.c_uint8)]
         l.mi_vs_stream_finish.argtypes = [C.c_uint64]

@@ -278,9 +278,9 @@ def test_native_stream_driver_api(orc, mi):
     other = v.accumulate(pb, rb)  # the second shard's partial, as another rank would hold it
     ok = C.c_uint8(9)
 
-    def run(cb, batches, n_each=24):
+    def run(cb, batches, group=1):
         sid = C.c_uint64(0)
-        L.check(lib.mi_vs_stream_open(C.c_uint64(v.ctx), 2, 4, 6, cb, None, C.byref(sid)), "open")
+        L.check(lib.mi_vs_stream_open(C.c_uint64(v.ctx), 2, 4, 6, cb, None, group, C.byref(sid)), "open")
         out = []
         try:
             for (pp, rr) in batches:
@@ -307,25 +307,28 @@ def test_native_stream_driver_api(orc, mi):
         assert run(none, [(p, r)] * 9) == [True] * 9
         # polling an empty, unfinished stream: not ready
         sid = C.c_uint64(0)
-        L.check(lib.mi_vs_stream_open(C.c_uint64(v.ctx), 1, 1, 1, none, None, C.byref(sid)), "open")
+        L.check(lib.mi_vs_stream_open(C.c_uint64(v.ctx), 1, 1, 1, none, None, 1, C.byref(sid)), "open")
         assert lib.mi_vs_stream_next(sid, 0, C.byref(ok)) == L.MI_ERR_AGAIN
         assert lib.mi_vs_stream_close(sid) == L.MI_OK
         assert lib.mi_vs_stream_next(sid, 0, C.byref(ok)) == -1  # closed
         # two shards: this rank submits the first half, the callback supplies the other rank's partial
         calls = []
 
-        def two(_u, mine, out, cap):
-            calls.append(cap)
-            np.ctypeslib.as_array(out, shape=(608,))[:304] = np.ctypeslib.as_array(mine, shape=(304,))
-            np.ctypeslib.as_array(out, shape=(608,))[304:] = other
+        def two(_u, mine, count, out, cap):  # rank-major: [this rank's count partials][the other rank's count partials]
+            calls.append(count)
+            o = np.ctypeslib.as_array(out, shape=(2 * count, 304))
+            o[:count] = np.ctypeslib.as_array(mine, shape=(count, 304))
+            o[count:] = other
             return 2
-        assert run(L.VS_EXCHANGE_FN(two), [(pa, ra)] * 5) == [True] * 5 and len(calls) == 5
+        assert run(L.VS_EXCHANGE_FN(two), [(pa, ra)] * 5) == [True] * 5 and calls == [1] * 5
+        del calls[:]
+        assert run(L.VS_EXCHANGE_FN(two), [(pa, ra)] * 7, group=3) == [True] * 7 and calls == [3, 3, 1]  # short last group
         # without the other shard's partial the first half alone still verifies; with a corrupted shard it does not
         assert run(none, [(pa, ra)]) == [True]
         bad = b.proofs.copy(); bad[3 * 2256 + 16 + 512 + 864 + 32 * 2] ^= 1
         assert run(L.VS_EXCHANGE_FN(two), [(torch.from_numpy(bad[:half]).cuda(), ra)]) == [False]
         # a failing exchange surfaces as an error status from next (after the verdicts that were already under way)
-        boom = L.VS_EXCHANGE_FN(lambda _u, mine, out, cap: -4)
+        boom = L.VS_EXCHANGE_FN(lambda _u, mine, count, out, cap: -4)
         res = run(boom, [(pa, ra)] * 3)
         assert res and res[-1] == ("next", -4) and all(x is True for x in res[:-1])
         assert v.verify_batch(p, r)[0]  # the context is still usable

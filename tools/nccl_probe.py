@@ -18,19 +18,18 @@ d = np.load(os.path.join(ROOT, "tests", "golden", "vs_batch_1024.npz"))
 v = A.VarunaShaped(d["vk"], d["circuits"])
 p = torch.from_numpy(d["proofs"]).cuda(); r = torch.from_numpy(d["randomizers"]).cuda()
 gdev = dev if backend == "nccl" else None
-def gather(part):
+def gather(part):  # (count, 304) -> (world = 1, count, 304), through a real collective
     torch.cuda.set_device(0)
-    if dist.get_world_size() == 1:  # gather_partials short-cuts world 1: force the collective
-        mine = torch.from_numpy(np.ascontiguousarray(part).copy())
-        mine = mine.to(gdev) if gdev is not None else mine
-        out = torch.empty_like(mine)
-        dist.all_gather_into_tensor(out, mine)
-        return out.cpu().numpy().reshape(1, 304)
-    return sharding.gather_partials(part, dist, gdev)
+    mine = torch.from_numpy(np.ascontiguousarray(part).reshape(-1).copy())
+    mine = mine.to(gdev) if gdev is not None else mine
+    out = torch.empty_like(mine)
+    dist.all_gather_into_tensor(out, mine)
+    return out.cpu().numpy().reshape(1, -1, 304)
+GROUP = int(os.environ.get("PROBE_GROUP", "1"))
 for g in (None, gather):
-    list(v.verify_stream(((p, r) for _ in range(10)), g))
+    list(v.verify_stream(((p, r) for _ in range(10)), g, exchange_group=GROUP))
     torch.cuda.synchronize(); t0 = time.perf_counter()
-    oks = list(v.verify_stream(((p, r) for _ in range(200)), g))
+    oks = list(v.verify_stream(((p, r) for _ in range(200)), g, exchange_group=GROUP))
     torch.cuda.synchronize()
     assert all(oks)
     print(backend, "gather" if g else "no gather", "%.3f ms/batch" % (1e3 * (time.perf_counter() - t0) / 200))
