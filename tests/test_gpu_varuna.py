@@ -98,6 +98,21 @@ def test_pipelined_stream_matches_batchwise(orc, mi):
         assert list(v.verify_stream(iter(seq))) == want
         assert [v.verify_batch(p, r)[0] for p, r in seq] == want
         assert list(v.verify_stream(iter([]))) == []
+        # the exchange hook of the Python wrapper (identity 'all-gather' of one rank), single batches and groups of three
+        seen = []
+
+        def gather(parts):
+            seen.append(parts.shape)
+            return parts[None]
+        assert list(v.verify_stream(iter(seq), gather)) == want and seen == [(1, 304)] * 7
+        del seen[:]
+        assert list(v.verify_stream(iter(seq), gather, exchange_group=3)) == want and seen == [(3, 304), (3, 304), (1, 304)]
+
+        def broken(parts):
+            raise ValueError("exchange failed")
+        with pytest.raises(ValueError):
+            list(v.verify_stream(iter(seq), broken))
+        assert list(v.verify_stream(iter(seq))) == want  # still usable afterwards
     finally:
         v.close()
 
