@@ -591,6 +591,110 @@ __global__ void __launch_bounds__(64) msm_bit_sums_wave_kernel(const G1Xyzz *__r
     if (lane == 0 && valid) store_xyzz(&out[g], acc);
 }
 
+// ---------------------------------------------------------------- large MSMs: tiled histogram in LDS
+// The global histogram atomics run at the memory-side atomic rate (21 G/s: 0.7 ms of a 2^20 MSM, 10.6 ms at 2^24).
+// Here a workgroup owns one (window, tile of points): the window's whole histogram (2^(c-1) counters, <= 128 KB) lives
+// in its LDS, the atomic that counts an entry and returns its rank is an LDS atomic, and the per-tile counts go out in
+// one coalesced store.  A column scan over the tiles turns them into per-tile bases (and the window's total counts);
+// a second pass over the tile adds the base to each entry's rank.  Scalars are re-read once per window (L2 / HBM
+// streaming) and the signed-digit carry into window w comes from one comparison instead of the chain through the
+// lower windows:  carry_w = [ k mod 2^(c w)  >  sum_{j < w} 2^(c j + c - 1) ]   (the recoding d = raw + carry > 2^(c-1)
+// ? raw + carry - 2^c : raw + carry, by induction on w).
+struct MsmTileConsts {
+    uint32_t half[24][8];  // half[w] = sum_{j < w} 2^(c j + c - 1), little-endian limbs (w >= 1)
+};
+__device__ __forceinline__ int32_t msm_digit_at(const uint32_t (&s)[8], int c, int w, const uint32_t *__restrict__ hw) {
+    // carry into window w (uniform w: every branch below is wave-uniform)
+    uint32_t carry = 0;
+    const int nbits = c * w;
+    if (w > 0) {
+        bool gt = false, decided = false;
+#pragma unroll
+        for (int j = 7; j >= 0; j--) {
+            uint32_t limb = 0;
+            if (32 * j < nbits) limb = 32 * (j + 1) <= nbits ? s[j] : (s[j] & ((1u << (nbits - 32 * j)) - 1u));
+            const uint32_t h = hw[j];
+            if (!decided && limb != h) {
+                gt = limb > h;
+                decided = true;
+            }
+        }
+        carry = gt ? 1u : 0u;
+    }
+    const int li = nbits >> 5, off = nbits & 31;
+    uint32_t lo = 0, hi = 0;
+    switch (li) {
+    case 0: lo = s[0]; hi = s[1]; break;
+    case 1: lo = s[1]; hi = s[2]; break;
+    case 2: lo = s[2]; hi = s[3]; break;
+    case 3: lo = s[3]; hi = s[4]; break;
+    case 4: lo = s[4]; hi = s[5]; break;
+    case 5: lo = s[5]; hi = s[6]; break;
+    case 6: lo = s[6]; hi = s[7]; break;
+    case 7: lo = s[7]; hi = 0; break;
+    default: break;
+    }
+    const uint32_t mask = (1u << c) - 1u, B = 1u << (c - 1);
+    const uint32_t raw = ((uint32_t)((((uint64_t)hi << 32) | lo) >> off) & mask) + carry;
+    return raw > B ? (int32_t)raw - (int32_t)(1u << c) : (int32_t)raw;
+}
+__global__ void __launch_bounds__(1024) msm_digits_tiled_kernel(const uint32_t *__restrict__ scalars, size_t n, size_t tile_size,
+                                                                int c, const MsmTileConsts *__restrict__ tc,
+                                                                int32_t *__restrict__ digits, uint32_t *__restrict__ ranks,
+                                                                uint32_t *__restrict__ tile_counts) {
+    extern __shared__ uint32_t hist[];
+    const uint32_t B = 1u << (c - 1);
+    const int w = blockIdx.y;
+    const size_t lo = (size_t)blockIdx.x * tile_size, hi = lo + tile_size < n ? lo + tile_size : n;
+    for (uint32_t b = threadIdx.x; b < B; b += 1024) hist[b] = 0;
+    __syncthreads();
+    const uint32_t *hw = tc->half[w];
+    for (size_t i = lo + threadIdx.x; i < hi; i += 1024) {
+        const uint4 *sp = reinterpret_cast<const uint4 *>(scalars + i * 8);
+        const uint4 x = sp[0], y = sp[1];
+        const uint32_t s[8] = {x.x, x.y, x.z, x.w, y.x, y.y, y.z, y.w};
+        const int32_t d = msm_digit_at(s, c, w, hw);
+        digits[(size_t)w * n + i] = d;
+        if (d != 0) {
+            const uint32_t mag = d < 0 ? (uint32_t)(-d) : (uint32_t)d;
+            ranks[(size_t)w * n + i] = atomicAdd(&hist[mag - 1], 1u);  // rank inside (tile, bucket)
+        }
+    }
+    __syncthreads();
+    uint32_t *out = tile_counts + ((size_t)w * gridDim.x + blockIdx.x) * B;
+    for (uint32_t b = threadIdx.x; b < B; b += 1024) out[b] = hist[b];
+}
+// lane per (window, bucket): exclusive scan of the tiles' counts in place; the total is the bucket's count
+__global__ void __launch_bounds__(256) msm_tile_scan_kernel(uint32_t *__restrict__ tile_counts, size_t nb, uint32_t B, uint32_t n_tiles,
+                                                            uint32_t *__restrict__ counts) {
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= nb) return;
+    const size_t w = t / B, b = t - w * B;
+    uint32_t run = 0;
+    for (uint32_t k = 0; k < n_tiles; k++) {
+        uint32_t *p = tile_counts + ((size_t)w * n_tiles + k) * B + b;
+        const uint32_t v = *p;
+        *p = run;
+        run += v;
+    }
+    counts[t] = run;
+}
+// ranks[w][i] += base of (tile of i, bucket of i)
+__global__ void __launch_bounds__(1024) msm_rank_fixup_kernel(const int32_t *__restrict__ digits, size_t n, size_t tile_size, int c,
+                                                              const uint32_t *__restrict__ tile_base, uint32_t *__restrict__ ranks) {
+    extern __shared__ uint32_t base[];
+    const uint32_t B = 1u << (c - 1);
+    const int w = blockIdx.y;
+    const size_t lo = (size_t)blockIdx.x * tile_size, hi = lo + tile_size < n ? lo + tile_size : n;
+    const uint32_t *src = tile_base + ((size_t)w * gridDim.x + blockIdx.x) * B;
+    for (uint32_t b = threadIdx.x; b < B; b += 1024) base[b] = src[b];
+    __syncthreads();
+    for (size_t i = lo + threadIdx.x; i < hi; i += 1024) {
+        const int32_t d = digits[(size_t)w * n + i];
+        if (d != 0) ranks[(size_t)w * n + i] += base[(d < 0 ? (uint32_t)(-d) : (uint32_t)d) - 1];
+    }
+}
+
 // ---------------------------------------------------------------- host driver
 template <int C>
 static void launch_digits(const uint32_t *scalars, size_t n, int32_t *digits, uint32_t *ranks, uint32_t *counts,
@@ -669,13 +773,53 @@ static void msm_enqueue_eager(Context &cx, const G1Affine *d_points, const uint3
     CleanMark &mark = clean_marks()[slot];
     const bool clean = small && mark.gen == counts_buf.gen && mark.nb >= nb && mark.p == counts;
     mark = CleanMark();
-    if (!clean) MI_HIP(hipMemsetAsync(counts, 0, sizeof(uint32_t) * nb, st));
+    static const bool tiled_front = !(getenv("MI_SNARK_MSM_TILED") && getenv("MI_SNARK_MSM_TILED")[0] == '0');
+    const bool tiled = !small && tiled_front && pl.nwin <= 24;
+    if (!clean && !tiled) MI_HIP(hipMemsetAsync(counts, 0, sizeof(uint32_t) * nb, st));
     HostSpan hs_launch("msm.launches");
     cx.prof.begin("msm_digits", st, n);
-    switch (pl.c) {
+    if (tiled) {
+        // tiles of >= 32 Ki points, at most 64 per window (the per-tile count table is nwin x tiles x B words)
+        unsigned n_tiles = (unsigned)((n + 32767) / 32768);
+        if (n_tiles > 64) n_tiles = 64;
+        const size_t tile_size = (n + n_tiles - 1) / n_tiles;
+        uint32_t *tile_counts = (uint32_t *)cx.buf(W("tile_counts"), sizeof(uint32_t) * (size_t)pl.nwin * n_tiles * pl.B);
+        DevBuf &tcb = cx.bufs[W("tile_consts")];
+        const uint64_t tc_gen = tcb.gen;
+        MsmTileConsts *d_tc = (MsmTileConsts *)tcb.get(sizeof(MsmTileConsts) * 17);  // one table per window width c
+        static bool tc_ready[64] = {};
+        if (tcb.gen != tc_gen) memset(tc_ready, 0, sizeof tc_ready);
+        if (slot < 64 && !tc_ready[slot]) {
+            static MsmTileConsts h[17];
+            memset(h, 0, sizeof h);
+            for (int cc = 6; cc <= 16; cc++)
+                for (int w = 1; w < 24; w++)
+                    for (int j = 0; j < w; j++) {
+                        const int bit = cc * j + cc - 1;
+                        if (bit < 256) h[cc].half[w][bit >> 5] |= 1u << (bit & 31);
+                    }
+            MI_HIP(hipMemcpyAsync(d_tc, h, sizeof h, hipMemcpyHostToDevice, st));
+            MI_HIP(hipStreamSynchronize(st));
+            tc_ready[slot] = true;
+        }
+        const size_t lds = sizeof(uint32_t) * pl.B;
+        static bool attr_set = false;
+        if (!attr_set) {
+            MI_HIP(hipFuncSetAttribute((const void *)msm_digits_tiled_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 131072));
+            MI_HIP(hipFuncSetAttribute((const void *)msm_rank_fixup_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 131072));
+            attr_set = true;
+        }
+        hipLaunchKernelGGL(msm_digits_tiled_kernel, dim3(n_tiles, (unsigned)pl.nwin), dim3(1024), lds, st, d_scalars, n, tile_size, pl.c,
+                           d_tc + pl.c, digits, ranks, tile_counts);
+        hipLaunchKernelGGL(msm_tile_scan_kernel, dim3(cdiv(nb, 256)), dim3(256), 0, st, tile_counts, nb, pl.B, n_tiles, counts);
+        hipLaunchKernelGGL(msm_rank_fixup_kernel, dim3(n_tiles, (unsigned)pl.nwin), dim3(1024), lds, st, digits, n, tile_size, pl.c,
+                           tile_counts, ranks);
+    } else {
+        switch (pl.c) {
 #define MI_CASE(C) case C: launch_digits<C>(d_scalars, n, digits, ranks, counts, scalar_bits, split, st); break;
-        MI_CASE(6) MI_CASE(7) MI_CASE(8) MI_CASE(9) MI_CASE(10) MI_CASE(11) MI_CASE(12) MI_CASE(13) MI_CASE(14) MI_CASE(15) MI_CASE(16)
+            MI_CASE(6) MI_CASE(7) MI_CASE(8) MI_CASE(9) MI_CASE(10) MI_CASE(11) MI_CASE(12) MI_CASE(13) MI_CASE(14) MI_CASE(15) MI_CASE(16)
 #undef MI_CASE
+        }
     }
     cx.prof.end("msm_digits", st);
     // chunking: T = twice the mean bucket load of a full window, so only over-full buckets are split
