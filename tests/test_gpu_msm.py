@@ -146,3 +146,31 @@ def test_msm_around_the_small_path_limit(orc, mi, n):
     scalars[1000:1200] = scalars[1000]                                      # 200 equal scalars in a row
     got = jac_affine(mi.VariableBase.msm(bases, scalars))
     assert (got == orc.msm_pippenger(bases, scalars, threads=8)).all()
+
+
+def test_msm_2_21_exact_by_known_discrete_logs(orc, mi):
+    """beyond what a CPU Pippenger checks in seconds: the generated points are k_i * G with k_i = splitmix64(seed + i) | 1,
+    so the MSM must equal (sum_i s_i k_i mod r) * G -- a host big-integer dot product and one oracle scalar
+    multiplication (the same check passes at 2^22 and 2^24: tools/msm_big_check.py)"""
+    import ctypes as C
+    import torch
+    import pyref
+    from snarkos_amd import lib as L
+    n, seed = 1 << 21, 0xB17
+    pts = torch.empty(n * 96, dtype=torch.uint8, device="cuda")
+    L.check(L.lib().mi_dbg_gen_points_device(C.c_uint64(seed), C.c_size_t(n), L.dptr(pts), L.stream_ptr()), "gen_points")
+    scalars = rng_scalars(0xB18, n)
+    got = jac_affine(mi.VariableBase.msm(pts, torch.from_numpy(scalars.view(np.int64)).cuda()))
+    M = 0xFFFFFFFFFFFFFFFF
+
+    def splitmix(x):
+        x = (x + 0x9E3779B97F4A7C15) & M
+        x = ((x ^ (x >> 30)) * 0xBF58476D1CE4E5B9) & M
+        x = ((x ^ (x >> 27)) * 0x94D049BB133111EB) & M
+        return x ^ (x >> 31)
+    lim = scalars.astype(object)
+    t = 0
+    for i in range(n):
+        s = lim[i, 0] | (lim[i, 1] << 64) | (lim[i, 2] << 128) | (lim[i, 3] << 192)
+        t += s * (splitmix(seed + i) | 1)
+    assert (got == orc.g1_mul(orc.g1_generator(), t % pyref.R)).all()
