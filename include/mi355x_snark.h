@@ -26,6 +26,17 @@
  *     device inside the library.  The caller owns every buffer for the duration of the call.
  *   - "_device" variants take HIP device pointers (inputs already resident in HBM) and a hipStream_t
  *     passed as void*; the plain variants take host pointers and stage them.
+ *   - one process drives any number of GPUs (snarkOS is one process: reference cli/src/commands/start.rs:616-642):
+ *     mi_init names the devices; host-pointer entry points run on the first of them (the primary), "_device" entry
+ *     points run on the device that owns their pointers, mi_vs_verify_block shards one block over all of them.
+ *   - PRECONDITIONS ON POINTS.  snarkVM validates group elements when it deserialises them; this ABI takes raw
+ *     coordinates and so bypasses that step.  The verifier entry points (mi_vs_*) check every G1 point of a proof
+ *     for y^2 = x^3 + 1 (or the (0,0) encoding of infinity) and every Fr field for < r, and reject the proof
+ *     otherwise.  What NO entry point checks is membership in the prime-order subgroup (cofactor
+ *     0x170b5d44300000000000000000000000): callers must pass points of G1 / G2 proper, as snarkVM's deserialiser
+ *     guarantees.  mi_msm_g1*, mi_kzg_*, mi_pairing* and mi_bases_register check nothing: their inputs (SRS powers,
+ *     verifying keys, the caller's own polynomials) are trusted data; an off-curve point there gives a meaningless
+ *     result, never a fault.
  */
 #ifndef MI355X_SNARK_H
 #define MI355X_SNARK_H
@@ -42,7 +53,7 @@ extern "C" {
 #define MI_ERR_OOM (-3)
 #define MI_ERR_KERNEL (-4)
 #define MI_ERR_NOT_INIT (-5)
-#define MI_ERR_AGAIN (-6) /* mi_vs_stream_next: the next verdict is not ready */
+#define MI_ERR_AGAIN (-6) /* mi_vs_stream_next: the next verdict is not ready; mi_vs_finalize_async: every product stream is busy */
 #define MI_ERR_DONE (-7)  /* mi_vs_stream_next: the stream is finished and drained */
 
 typedef struct { uint64_t l[4]; } mi_fr;        /* Fr, Montgomery */
@@ -55,7 +66,12 @@ typedef struct { mi_fq c[12]; } mi_fq12;        /* tower order c0.c0.c0, c0.c0.c
 typedef struct { mi_g1_affine g; mi_g2_affine h, tau_h; } mi_kzg_vk; /* kzg10::VerifierKey {g, h, beta_h} */
 
 /* ---- lifecycle ---- */
-int32_t mi_init(int32_t device);          /* device < 0: keep the current HIP device.  Idempotent. */
+/* SURVEY.md App. C.  device_ids[0] becomes the primary; n_devices == 0 (device_ids may be NULL): the current HIP
+ * device.  Idempotent: a second call adds the devices it names that are not in the list yet.  Optional: the first
+ * call of any entry point initialises the current device, and a "_device" entry point adds the device of its pointers. */
+int32_t mi_init(const int32_t *device_ids, int32_t n_devices);
+int32_t mi_device_count(void);          /* devices in the library's list */
+int32_t mi_device_id(int32_t index);    /* HIP ordinal of list entry `index` (negative: no such entry) */
 int32_t mi_shutdown(void);
 const char *mi_error_string(int32_t status);
 int32_t mi_abi_version(void);
@@ -66,7 +82,7 @@ int32_t mi_msm_g1_device(const void *d_bases, const void *d_scalars, size_t n, m
 /* sum of n partial results (each a normalised output of mi_msm_g1*: z = 1, or z = 0 for infinity): the combine step
  * of an MSM whose points are split across GPUs; host arithmetic, n is the number of ranks */
 int32_t mi_g1_sum(const mi_g1_jac *partials, size_t n, mi_g1_jac *out);
-/* bases kept resident in HBM (SRS powers, verifying-key commitments) */
+/* bases kept resident in HBM (SRS powers, verifying-key commitments), replicated to every device of the list */
 int32_t mi_bases_register(const mi_g1_affine *pts, size_t n, uint64_t *handle_out);
 int32_t mi_bases_release(uint64_t handle);
 int32_t mi_msm_g1_h(uint64_t bases_handle, size_t offset, const mi_bigint256 *scalars, size_t n, mi_g1_jac *out);
@@ -125,14 +141,25 @@ int32_t mi_vs_verify_batch(uint64_t ctx, const mi_vs_proof *proofs, size_t n, co
 /* device-pointer form (proofs and randomizers already in HBM) */
 int32_t mi_vs_verify_batch_device(uint64_t ctx, const void *d_proofs, size_t n, const void *d_randomizers128,
                                   uint8_t *verdicts, uint8_t *all_ok, void *stream);
-/* multi-GPU: each rank accumulates its shard, partials are exchanged (RCCL all-gather), any rank finalises */
+/* one block-validation batch over ALL devices of the process (SURVEY.md 8e inside one process): contiguous shards, one
+ * host thread per device (stage, derive, both MSMs, fold), the 304-byte partials all-gathered over RCCL (grouped
+ * ncclAllGather over an in-process communicator; added on the host when RCCL is unavailable or MI_SNARK_EXCHANGE=host),
+ * ONE pairing product on the primary; on failure every device names the invalid proofs of its shard.
+ * verdicts[n] in block order.  The _device form takes one (proofs, randomizers, count) triple per shard, each already
+ * resident on the device that is to verify it. */
+int32_t mi_vs_verify_block(uint64_t ctx, const mi_vs_proof *proofs, size_t n, const uint8_t *randomizers128,
+                           uint8_t *verdicts, uint8_t *all_ok);
+int32_t mi_vs_verify_block_device(uint64_t ctx, const void *const *d_proofs, const void *const *d_randomizers128,
+                                  const size_t *n_per_shard, int32_t n_shards, uint8_t *verdicts, uint8_t *all_ok);
+/* multi-GPU, one process per GPU: each rank accumulates its shard, partials are exchanged (RCCL all-gather), any rank finalises */
 int32_t mi_vs_accumulate_device(uint64_t ctx, const void *d_proofs, size_t n, const void *d_randomizers128,
                                 mi_vs_partial *partial_out, void *stream);
 int32_t mi_vs_finalize(uint64_t ctx, const mi_vs_partial *partials, size_t n_partials, uint8_t *all_ok);
 #define MI_VS_MAX_OPEN_ACCUMULATIONS 14 /* mi_vs_accumulate_begin without a matching _end: 12 by default, env
-                                           MI_SNARK_VS_LANES = 1..14, read when the first context is created.  Lanes
-                                           and product slots (streams, workspaces) belong to the process and are
-                                           shared by all contexts: the limits hold across contexts. */
+                                           MI_SNARK_VS_LANES = 1..14, read when a device is first used.  Lanes and
+                                           product slots (streams, workspaces) belong to the DEVICE and are shared by
+                                           all verifier contexts: the limits hold across contexts.  A begin (and
+                                           every call built on it) WAITS for a lane when all are taken. */
 #define MI_VS_MAX_TICKETS 8             /* mi_vs_finalize_async without a matching _wait */
 /* pipelined form: the pairing product of batch i runs on the context's own stream while the caller accumulates
  * batch i+1 (VM::check_transactions walks a block in chunks of <= 1000 executions; mempool admission streams).
@@ -169,6 +196,22 @@ int32_t mi_vs_stream_finish(uint64_t stream);
  * finished stream: MI_ERR_DONE.  A failure inside the pipeline is reported here (status of the failing call). */
 int32_t mi_vs_stream_next(uint64_t stream, int32_t block, uint8_t *all_ok);
 int32_t mi_vs_stream_close(uint64_t stream); /* finishes, drains and joins the threads */
+
+/* ---- the exchange itself, native: RCCL called from the library (librccl is dlopen'ed on first use) ----
+ * One process per GPU: rank 0 calls mi_comm_unique_id, the 128 bytes reach the other ranks over the caller's own
+ * transport, every rank calls mi_comm_init_rank (collective).  mi_vs_exchange_rccl is an mi_vs_exchange_fn: pass it to
+ * mi_vs_stream_open with user = (void *)(uintptr_t)comm.  MI_ERR_NO_DEVICE: no usable RCCL (keep your own exchange).
+ * One process, all GPUs: mi_comm_init_local (ncclCommInitAll over the library's device list; what mi_vs_verify_block
+ * uses by itself). */
+#define MI_COMM_ID_BYTES 128
+int32_t mi_comm_unique_id(uint8_t *id_out /* MI_COMM_ID_BYTES */);
+int32_t mi_comm_init_rank(const uint8_t *id, int32_t rank, int32_t world, uint64_t *comm_out);
+int32_t mi_comm_init_local(uint64_t *comm_out);
+int32_t mi_comm_world(uint64_t comm); /* ranks, or a negative status */
+int32_t mi_comm_destroy(uint64_t comm);
+/* all-gather of one `bytes`-sized host record per rank: all[rank * bytes ...] (rank-per-process communicators) */
+int32_t mi_comm_all_gather(uint64_t comm, const void *mine, size_t bytes, void *all);
+int32_t mi_vs_exchange_rccl(void *user, const mi_vs_partial *mine, size_t count, mi_vs_partial *all, size_t max_partials);
 
 /* ---- crypto_hash::PoseidonSponge<Fq, 2, 1>, many independent sponges at once ----
  * Structure as snarkVM's (width 3, S-box x^17, 8 full + 31 partial rounds); the round constants and MDS matrix

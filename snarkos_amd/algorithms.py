@@ -273,6 +273,32 @@ class VarunaShaped:
                                            L.ptr(all_ok)), "mi_vs_verify_batch")
         return bool(all_ok[0]), verdicts
 
+    def verify_block(self, proofs, randomizers128):
+        """One block-validation batch over ALL devices of the process (mi_vs_verify_block): host arrays in, contiguous
+        shards, one partial per device, all-gather (RCCL from the library), one pairing product.
+        Returns (all_ok, verdicts[n])."""
+        p = np.ascontiguousarray(proofs).view(np.uint8).reshape(-1)
+        n = p.size // L.VS_PROOF_BYTES
+        r = np.ascontiguousarray(randomizers128, dtype=np.uint8).reshape(-1)
+        assert r.size == 32 * n
+        verdicts, all_ok = np.zeros(n, dtype=np.uint8), np.zeros(1, dtype=np.uint8)
+        L.check(L.lib().mi_vs_verify_block(C.c_uint64(self.ctx), L.ptr(p), C.c_size_t(n), L.ptr(r), L.ptr(verdicts), L.ptr(all_ok)),
+                "mi_vs_verify_block")
+        return bool(all_ok[0]), verdicts
+
+    def verify_block_device(self, shards):
+        """The same with the shards already resident: `shards` = [(proofs_cuda, randomizers_cuda), ...], each pair on the
+        device that is to verify it (mi_vs_verify_block_device).  Returns (all_ok, verdicts) in shard order."""
+        k = len(shards)
+        dp = (C.c_void_p * k)(*[L.dptr(p).value for p, _ in shards])
+        dr = (C.c_void_p * k)(*[L.dptr(r).value for _, r in shards])
+        cnt = (C.c_size_t * k)(*[p.numel() * p.element_size() // L.VS_PROOF_BYTES for p, _ in shards])
+        n = sum(cnt)
+        verdicts, all_ok = np.zeros(n, dtype=np.uint8), np.zeros(1, dtype=np.uint8)
+        L.check(L.lib().mi_vs_verify_block_device(C.c_uint64(self.ctx), dp, dr, cnt, C.c_int32(k), L.ptr(verdicts), L.ptr(all_ok)),
+                "mi_vs_verify_block_device")
+        return bool(all_ok[0]), verdicts
+
     def accumulate(self, proofs_cuda, randomizers_cuda, stream=None):
         """One shard's accumulator (304 bytes): the unit exchanged between GPUs."""
         n = proofs_cuda.numel() * proofs_cuda.element_size() // L.VS_PROOF_BYTES
@@ -309,7 +335,7 @@ class VarunaShaped:
         L.check(L.lib().mi_vs_finalize_wait(C.c_uint64(self.ctx), C.c_uint64(ticket), L.ptr(ok)), "mi_vs_finalize_wait")
         return bool(ok[0])
 
-    def verify_stream(self, batches, gather=None, depth=8, acc_depth=12, fold_threads=3, exchange_group=1):
+    def verify_stream(self, batches, gather=None, depth=8, acc_depth=12, fold_threads=3, exchange_group=1, comm=None):
         """Pipelined verification of a stream of batches (chunks of a block, or mempool traffic): yields all_ok per
         batch, in order.
 
@@ -319,7 +345,9 @@ class VarunaShaped:
         exchanges them (`gather`, optional: maps this rank's (count, 304) partials of `exchange_group` consecutive
         batches to all ranks' (world, count, 304) -- one collective per group, issued from that one thread) and starts
         the pairing products; up to `depth` (<= 8) products are in flight, each on its own stream.  `batches` yields
-        (proofs_cuda, randomizers_cuda).
+        (proofs_cuda, randomizers_cuda).  `comm` (a handle of lib.comm_init_rank) makes the exchange native instead:
+        the library's own mi_vs_exchange_rccl (ncclAllGather from the finisher thread, no Python on the data path).
+        Submitted tensors are kept alive until their verdict has been yielded.
         """
         lib = L.lib()
         keep = {}
@@ -337,17 +365,26 @@ class VarunaShaped:
                 keep["error"] = e
                 return L.MI_ERR_KERNEL
 
-        cb = L.VS_EXCHANGE_FN(exchange) if gather is not None else C.cast(None, L.VS_EXCHANGE_FN)
+        user = None
+        if comm is not None:
+            cb, user = C.cast(lib.mi_vs_exchange_rccl, L.VS_EXCHANGE_FN), C.c_void_p(comm)
+        elif gather is not None:
+            cb = L.VS_EXCHANGE_FN(exchange)
+        else:
+            cb = C.cast(None, L.VS_EXCHANGE_FN)
         sid = C.c_uint64(0)
         L.check(lib.mi_vs_stream_open(C.c_uint64(self.ctx), C.c_int32(fold_threads), C.c_int32(depth),
-                                      C.c_int32(max(1, min(acc_depth, self.lanes))), cb, None, C.c_int32(exchange_group), C.byref(sid)),
+                                      C.c_int32(max(1, min(acc_depth, self.lanes))), cb, user, C.c_int32(exchange_group), C.byref(sid)),
                 "mi_vs_stream_open")
         ok = C.c_uint8(0)
+        held = []  # submitted tensors, oldest first: the lanes read them until the batch's verdict exists
 
         def drain(block):
             while True:
                 st = lib.mi_vs_stream_next(sid, 1 if block else 0, C.byref(ok))
                 if st == L.MI_OK:
+                    if held:
+                        held.pop(0)
                     yield bool(ok.value)
                 elif st == L.MI_ERR_AGAIN or st == L.MI_ERR_DONE:
                     return
@@ -359,6 +396,7 @@ class VarunaShaped:
         try:
             for proofs, rnd in batches:
                 n = proofs.numel() * proofs.element_size() // L.VS_PROOF_BYTES
+                held.append((proofs, rnd))
                 st = lib.mi_vs_stream_submit(sid, L.dptr(proofs), C.c_size_t(n), L.dptr(rnd), L.stream_ptr(None))
                 if st != L.MI_OK:
                     if "error" in keep:

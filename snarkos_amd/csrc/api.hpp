@@ -26,14 +26,12 @@ void msm_enqueue(Context &cx, const G1Affine *d_points, const uint32_t *d_scalar
                  int slot, MsmJob *job, int force_c = 0, int pin_parity = 0, size_t split = 0);
 // out_b: the second problem's result when the job was enqueued with a split
 void msm_finish(Context &cx, MsmJob *job, hipStream_t st, mi_g1_jac *out, mi_g1_jac *out_b = nullptr);
-void msm_release_graphs();
 size_t msm_small_limit();  // largest n on the latency-bound small path (the only one that takes a split)
 void msm_device(Context &cx, const G1Affine *d_points, const uint32_t *d_scalars, size_t n, mi_g1_jac *out,
                 hipStream_t st, int scalar_bits = 254, int force_c = 0);
 
 // ntt.hip -- in place on d_data (2^log_n elements)
 void ntt_device(Context &cx, Fr *d_data, uint32_t log_n, bool inverse, bool coset, hipStream_t st);
-void ntt_release_tables();
 Fr host_omega(uint32_t log_n);
 
 // pairing.hip
@@ -43,7 +41,6 @@ void pairing_product_host_args(Context &cx, const G1Affine *ps, const G2Affine *
                                hipStream_t st);
 void pairing_launch(Context &cx, const G1Affine *ps, const G2Prepared *const *d_qs, size_t n, Fq12 *d_out, hipStream_t st);
 const PairingConsts *pairing_consts(Context &cx, hipStream_t st);
-void pairing_release();
 
 // verify.hip
 int32_t kzg_batch_check_host(Context &cx, const mi_kzg_vk *vk, const mi_g1_affine *comms, const mi_fr *points,
@@ -61,6 +58,18 @@ int32_t vs_finalize_async(Context &cx, uint64_t id, const mi_vs_partial *parts, 
 int32_t vs_finalize_wait(Context &cx, uint64_t id, uint64_t ticket, uint8_t *all_ok);
 int32_t vs_verify_batch_device(Context &cx, uint64_t id, const void *d_proofs, size_t n, const void *d_rand,
                                uint8_t *verdicts, uint8_t *all_ok, hipStream_t st);
-void verify_release_all();
+void verify_release_keys();
+
+// one block-validation batch sharded over the devices of the process (shard s on the device that owns d_proofs[s], or
+// host arrays cut into contiguous shards over the whole device list); verdicts are laid out shard after shard
+int32_t vs_verify_block(uint64_t id, const void *const *proofs, const void *const *rand, const size_t *n_per_shard,
+                        int n_shards, bool device_ptrs, uint8_t *verdicts, uint8_t *all_ok);
+
+// stream.hip / comm.hip
+void stream_release_all();
+void comm_release_all();
+struct Comm;
+std::shared_ptr<Comm> comm_local();  // RCCL communicator over the library's device list; nullptr: exchange on the host
+int32_t comm_all_gather(Comm &c, const void *const *mine, size_t bytes, void *const *all);
 
 }  // namespace mi

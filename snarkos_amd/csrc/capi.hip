@@ -1,28 +1,70 @@
 // libmi355x_snark.so -- C ABI entry points (include/mi355x_snark.h) over the HIP kernels.
 #include <string.h>
+#include <atomic>
 #include <new>
+#include <vector>
 #include "api.hpp"
 #include "tower.hpp"
 
+extern "C" int mi_host_cpu_ok(void);  // cpu_probe.cpp (built without the x86-64-v3 / ADX flags)
+
 namespace mi {
 
-static Context g_ctx;
-Context &ctx() { return g_ctx; }
-static std::mutex g_init_mu;
+static bool host_cpu_ok() { return mi_host_cpu_ok() != 0; }
 
+// ------------------------------------------------------------ device registry
+static std::mutex g_reg_mu;
+static std::vector<std::unique_ptr<Context>> g_ctxs;  // index 0 = primary; entries are never removed before mi_shutdown
+
+static Context *create_context_locked(int dev) {  // g_reg_mu held
+    for (auto &c : g_ctxs)
+        if (c->device == dev) return c.get();
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || dev < 0 || dev >= count) return nullptr;
+    int prev = -1;
+    (void)hipGetDevice(&prev);
+    if (hipSetDevice(dev) != hipSuccess) return nullptr;
+    std::unique_ptr<Context> c(new Context());
+    c->device = dev;
+    c->index = (int)g_ctxs.size();
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, dev) == hipSuccess) c->n_cus = prop.multiProcessorCount;
+    const bool ok = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) == hipSuccess;
+    if (prev >= 0 && prev != dev) (void)hipSetDevice(prev);
+    if (!ok) return nullptr;
+    c->inited = true;
+    g_ctxs.push_back(std::move(c));
+    return g_ctxs.back().get();
+}
+Context &primary() { return *g_ctxs[0]; }  // callers hold ensure_init() == MI_OK
+int n_contexts() {
+    std::lock_guard<std::mutex> lk(g_reg_mu);
+    return (int)g_ctxs.size();
+}
+Context *context_at(int index) {
+    std::lock_guard<std::mutex> lk(g_reg_mu);
+    return index >= 0 && index < (int)g_ctxs.size() ? g_ctxs[index].get() : nullptr;
+}
+Context *context_for_device(int hip_device) {
+    std::lock_guard<std::mutex> lk(g_reg_mu);
+    return create_context_locked(hip_device);
+}
+Context *context_of_ptr(const void *device_ptr) {
+    hipPointerAttribute_t attr;
+    if (device_ptr && hipPointerGetAttributes(&attr, device_ptr) == hipSuccess && attr.type == hipMemoryTypeDevice)
+        return context_for_device(attr.device);
+    (void)hipGetLastError();  // not a HIP allocation we can place: the primary device decides (and faults loudly if wrong)
+    return &primary();
+}
 int32_t ensure_init() {
-    std::lock_guard<std::mutex> lk(g_init_mu);
-    if (g_ctx.inited) return MI_OK;
+    std::lock_guard<std::mutex> lk(g_reg_mu);
+    if (!g_ctxs.empty()) return MI_OK;
+    if (!host_cpu_ok()) return MI_ERR_NO_DEVICE;  // the host side of this build needs BMI2 + ADX + AVX2
     int count = 0;
     if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) return MI_ERR_NO_DEVICE;
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) return MI_ERR_NO_DEVICE;
-    g_ctx.device = dev;
-    hipDeviceProp_t prop;
-    if (hipGetDeviceProperties(&prop, dev) == hipSuccess) g_ctx.n_cus = prop.multiProcessorCount;
-    if (hipStreamCreateWithFlags(&g_ctx.stream, hipStreamNonBlocking) != hipSuccess) return MI_ERR_KERNEL;
-    g_ctx.inited = true;
-    return MI_OK;
+    return create_context_locked(dev) ? MI_OK : MI_ERR_NO_DEVICE;
 }
 
 // ------------------------------------------------------------ diagnostics kernels
@@ -118,25 +160,33 @@ __global__ void __launch_bounds__(64) poseidon_hash_many_kernel(const Fq *__rest
         if (produced < k) poseidon_permute(st, pc);
     }
 }
+struct PoseidonState {
+    DevBuf consts;
+    bool ready = false;
+    ~PoseidonState() { consts.release(); }
+};
 static const PoseidonConsts *poseidon_consts(Context &cx, hipStream_t st) {
-    static bool ready = false;
-    PoseidonConsts *d = (PoseidonConsts *)cx.buf("poseidon.consts", sizeof(PoseidonConsts));
-    if (!ready) {
+    PoseidonState &ps = cx.mod<PoseidonState>("poseidon");
+    if (!ps.ready) {
         static PoseidonConsts h;
-        auto cv = [](const uint64_t *l) {
-            Fq r;
-            for (int i = 0; i < 6; i++) { r.l[2 * i] = (uint32_t)l[i]; r.l[2 * i + 1] = (uint32_t)(l[i] >> 32); }
-            return r;
-        };
-        for (int r = 0; r < MI_POSEIDON_ROUNDS; r++)
-            for (int i = 0; i < 3; i++) h.ark[r][i] = cv(MI_POSEIDON_ARK[r][i]);
-        for (int i = 0; i < 3; i++)
-            for (int j = 0; j < 3; j++) h.mds[i][j] = cv(MI_POSEIDON_MDS[i][j]);
+        static std::once_flag once;
+        std::call_once(once, [] {
+            auto cv = [](const uint64_t *l) {
+                Fq r;
+                for (int i = 0; i < 6; i++) { r.l[2 * i] = (uint32_t)l[i]; r.l[2 * i + 1] = (uint32_t)(l[i] >> 32); }
+                return r;
+            };
+            for (int r = 0; r < MI_POSEIDON_ROUNDS; r++)
+                for (int i = 0; i < 3; i++) h.ark[r][i] = cv(MI_POSEIDON_ARK[r][i]);
+            for (int i = 0; i < 3; i++)
+                for (int j = 0; j < 3; j++) h.mds[i][j] = cv(MI_POSEIDON_MDS[i][j]);
+        });
+        void *d = ps.consts.get(sizeof(PoseidonConsts));
         MI_HIP(hipMemcpyAsync(d, &h, sizeof h, hipMemcpyHostToDevice, st));
         MI_HIP(hipStreamSynchronize(st));
-        ready = true;
+        ps.ready = true;
     }
-    return d;
+    return (const PoseidonConsts *)ps.consts.p;
 }
 static void poseidon_device(Context &cx, const Fq *d_in, size_t n, size_t m, size_t k, Fq *d_out, hipStream_t st) {
     const PoseidonConsts *pc = poseidon_consts(cx, st);
@@ -149,8 +199,7 @@ static void poseidon_device(Context &cx, const Fq *d_in, size_t n, size_t m, siz
 template <class T, class K>
 static int32_t dbg_binary(const T *a, const T *b, T *out, size_t n, K kernel) {
     if (!a || !b || !out) return MI_ERR_BAD_ARGS;
-    return guarded([&]() -> int32_t {
-        Context &cx = ctx();
+    return guarded([&](Context &cx) -> int32_t {
         T *da = (T *)cx.buf("dbg.a", sizeof(T) * n), *db = (T *)cx.buf("dbg.b", sizeof(T) * n), *dc = (T *)cx.buf("dbg.c", sizeof(T) * n);
         MI_HIP(hipMemcpyAsync(da, a, sizeof(T) * n, hipMemcpyHostToDevice, cx.stream));
         MI_HIP(hipMemcpyAsync(db, b, sizeof(T) * n, hipMemcpyHostToDevice, cx.stream));
@@ -168,36 +217,56 @@ using namespace mi;
 
 extern "C" {
 
-int32_t mi_init(int32_t device) {
-    if (device >= 0) {
-        if (hipSetDevice(device) != hipSuccess) return MI_ERR_NO_DEVICE;
+int32_t mi_init(const int32_t *device_ids, int32_t n_devices) {
+    if (n_devices < 0 || n_devices > 64 || (n_devices > 0 && !device_ids)) return MI_ERR_BAD_ARGS;
+    if (!host_cpu_ok()) return MI_ERR_NO_DEVICE;
+    if (n_devices == 0) return ensure_init();  // the current HIP device becomes the primary
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) return MI_ERR_NO_DEVICE;
+    for (int i = 0; i < n_devices; i++) {
+        if (device_ids[i] < 0 || device_ids[i] >= count) return MI_ERR_NO_DEVICE;
+        for (int j = 0; j < i; j++)
+            if (device_ids[j] == device_ids[i]) return MI_ERR_BAD_ARGS;
     }
-    return ensure_init();
+    std::lock_guard<std::mutex> lk(g_reg_mu);
+    for (int i = 0; i < n_devices; i++)  // idempotent: devices already in the list keep their place
+        if (!create_context_locked(device_ids[i])) return MI_ERR_NO_DEVICE;
+    return MI_OK;
+}
+int32_t mi_device_count(void) { return n_contexts(); }
+int32_t mi_device_id(int32_t index) {
+    Context *c = context_at(index);
+    return c ? c->device : MI_ERR_BAD_ARGS;
 }
 int32_t mi_shutdown(void) {
-    std::lock_guard<std::mutex> lk(g_init_mu);
-    if (!g_ctx.inited) return MI_OK;
-    std::lock_guard<std::mutex> lk2(g_ctx.mu);
-    (void)hipSetDevice(g_ctx.device);
-    (void)hipStreamSynchronize(g_ctx.stream);
-    for (auto &kv : g_ctx.bufs) kv.second.release();
-    for (auto &kv : g_ctx.handles) kv.second.release();
-    g_ctx.bufs.clear();
-    g_ctx.handles.clear();
-    g_ctx.handle_len.clear();
-    msm_release_graphs();
-    verify_release_all();
-    if (g_ctx.pinned) (void)hipHostFree(g_ctx.pinned);
-    g_ctx.pinned = nullptr;
-    g_ctx.pinned_cap = 0;
-    (void)hipStreamDestroy(g_ctx.stream);
-    g_ctx.stream = nullptr;
-    for (auto &kv : g_ctx.events) (void)hipEventDestroy(kv.second);
-    g_ctx.events.clear();
-    for (auto &kv : g_ctx.pins)
-        if (kv.second.first) (void)hipHostFree(kv.second.first);
-    g_ctx.pins.clear();
-    g_ctx.inited = false;
+    comm_release_all();
+    stream_release_all();
+    std::lock_guard<std::mutex> lk(g_reg_mu);
+    verify_release_keys();  // verifier contexts: per-device key copies are freed with the devices below
+    for (auto &c : g_ctxs) {
+        std::lock_guard<std::mutex> lk2(c->mu);
+        (void)hipSetDevice(c->device);
+        (void)hipDeviceSynchronize();
+        c->modules.clear();  // twiddle tables, pairing constants, the verifier pipeline's streams ...
+        c->scratch.free_all();
+        for (auto &kv : c->bufs) kv.second.release();
+        for (auto &kv : c->handles) kv.second.release();
+        c->bufs.clear();
+        c->handles.clear();
+        c->handle_len.clear();
+        if (c->pinned) (void)hipHostFree(c->pinned);
+        c->pinned = nullptr;
+        c->pinned_cap = 0;
+        (void)hipStreamDestroy(c->stream);
+        c->stream = nullptr;
+        for (auto &kv : c->events) (void)hipEventDestroy(kv.second);
+        c->events.clear();
+        for (auto &kv : c->pins)
+            if (kv.second.first) (void)hipHostFree(kv.second.first);
+        c->pins.clear();
+        c->inited = false;
+    }
+    g_ctxs.clear();
     return MI_OK;
 }
 const char *mi_error_string(int32_t s) {
@@ -213,7 +282,7 @@ const char *mi_error_string(int32_t s) {
     default: return "unknown status";
     }
 }
-int32_t mi_abi_version(void) { return 1; }
+int32_t mi_abi_version(void) { return 2; }
 
 // ------------------------------------------------------------ MSM
 // entries per MSM are indexed with 32 bits (index << 1 | sign; offsets over all windows): n <= 2^27
@@ -221,8 +290,7 @@ static const size_t MI_MSM_MAX_N = (size_t)1 << 27;
 
 int32_t mi_msm_g1(const mi_g1_affine *bases, const mi_bigint256 *scalars, size_t n, mi_g1_jac *out) {
     if (!out || (n && (!bases || !scalars)) || n > MI_MSM_MAX_N) return MI_ERR_BAD_ARGS;
-    return guarded([&]() -> int32_t {
-        Context &cx = ctx();
+    return guarded([&](Context &cx) -> int32_t {
         G1Affine *dp = (G1Affine *)cx.buf("msm.in_points", sizeof(G1Affine) * (n ? n : 1));
         uint32_t *ds = (uint32_t *)cx.buf("msm.in_scalars", 32 * (n ? n : 1));
         if (n) {
@@ -235,14 +303,14 @@ int32_t mi_msm_g1(const mi_g1_affine *bases, const mi_bigint256 *scalars, size_t
 }
 int32_t mi_msm_g1_device(const void *d_bases, const void *d_scalars, size_t n, mi_g1_jac *out, void *stream) {
     if (!out || (n && (!d_bases || !d_scalars)) || n > MI_MSM_MAX_N) return MI_ERR_BAD_ARGS;
-    return guarded([&]() -> int32_t {
-        msm_device(ctx(), (const G1Affine *)d_bases, (const uint32_t *)d_scalars, n, out, (hipStream_t)stream);
+    return guarded_ptr(d_bases, [&](Context &cx) -> int32_t {
+        msm_device(cx, (const G1Affine *)d_bases, (const uint32_t *)d_scalars, n, out, (hipStream_t)stream);
         return MI_OK;
     });
 }
 int32_t mi_g1_sum(const mi_g1_jac *partials, size_t n, mi_g1_jac *out) {
     if (!out || (n && !partials)) return MI_ERR_BAD_ARGS;
-    return guarded([&]() -> int32_t {
+    return guarded([&](Context &cx) -> int32_t {
         G1Xyzz acc = G1Xyzz::inf();
         const Fq one = Fq::one();
         for (size_t i = 0; i < n; i++) {
@@ -257,34 +325,49 @@ int32_t mi_g1_sum(const mi_g1_jac *partials, size_t n, mi_g1_jac *out) {
         return MI_OK;
     });
 }
+static std::atomic<uint64_t> g_next_handle{1};
 int32_t mi_bases_register(const mi_g1_affine *pts, size_t n, uint64_t *handle_out) {
     if (!pts || !n || !handle_out) return MI_ERR_BAD_ARGS;
-    return guarded([&]() -> int32_t {
-        Context &cx = ctx();
-        uint64_t h = cx.next_handle++;
-        void *d = cx.handles[h].get(sizeof(G1Affine) * n);
-        cx.handle_len[h] = n;
-        MI_HIP(hipMemcpy(d, pts, sizeof(G1Affine) * n, hipMemcpyHostToDevice));
-        *handle_out = h;
-        return MI_OK;
-    });
+    int32_t st = ensure_init();
+    if (st != MI_OK) return st;
+    const uint64_t h = g_next_handle++;
+    // resident on every device of the list: any of them may run the MSM
+    for (int i = 0; i < n_contexts(); i++) {
+        st = guarded_on(context_at(i), [&](Context &cx) -> int32_t {
+            void *d = cx.handles[h].get(sizeof(G1Affine) * n);
+            cx.handle_len[h] = n;
+            MI_HIP(hipMemcpy(d, pts, sizeof(G1Affine) * n, hipMemcpyHostToDevice));
+            return MI_OK;
+        });
+        if (st != MI_OK) {
+            (void)mi_bases_release(h);
+            return st;
+        }
+    }
+    *handle_out = h;
+    return MI_OK;
 }
 int32_t mi_bases_release(uint64_t handle) {
-    return guarded([&]() -> int32_t {
-        Context &cx = ctx();
-        auto it = cx.handles.find(handle);
-        if (it == cx.handles.end()) return MI_ERR_BAD_ARGS;
-        MI_HIP(hipStreamSynchronize(cx.stream));
-        it->second.release();
-        cx.handles.erase(it);
-        cx.handle_len.erase(handle);
-        return MI_OK;
-    });
+    int32_t st = ensure_init();
+    if (st != MI_OK) return st;
+    bool found = false;
+    for (int i = 0; i < n_contexts(); i++) {
+        st = guarded_on(context_at(i), [&](Context &cx) -> int32_t {
+            auto it = cx.handles.find(handle);
+            if (it == cx.handles.end()) return MI_OK;
+            found = true;
+            it->second.release();  // drains the device first
+            cx.handles.erase(it);
+            cx.handle_len.erase(handle);
+            return MI_OK;
+        });
+        if (st != MI_OK) return st;
+    }
+    return found ? MI_OK : MI_ERR_BAD_ARGS;
 }
 int32_t mi_msm_g1_h(uint64_t handle, size_t offset, const mi_bigint256 *scalars, size_t n, mi_g1_jac *out) {
     if (!out || (n && !scalars) || n > MI_MSM_MAX_N) return MI_ERR_BAD_ARGS;
-    return guarded([&]() -> int32_t {
-        Context &cx = ctx();
+    return guarded([&](Context &cx) -> int32_t {
         auto it = cx.handles.find(handle);
         if (it == cx.handles.end() || offset + n > cx.handle_len[handle]) return MI_ERR_BAD_ARGS;
         uint32_t *ds = (uint32_t *)cx.buf("msm.in_scalars", 32 * (n ? n : 1));
@@ -297,8 +380,7 @@ int32_t mi_msm_g1_h(uint64_t handle, size_t offset, const mi_bigint256 *scalars,
 // ------------------------------------------------------------ NTT
 int32_t mi_ntt_fr(mi_fr *data, uint32_t log_n, int32_t inverse, int32_t coset) {
     if (!data || log_n > 30) return MI_ERR_BAD_ARGS;  // 2^30 x 32 B = 32 GiB per buffer; the coset tables cover 30 bits
-    return guarded([&]() -> int32_t {
-        Context &cx = ctx();
+    return guarded([&](Context &cx) -> int32_t {
         size_t bytes = sizeof(Fr) << log_n;
         Fr *d = (Fr *)cx.buf("ntt.io", bytes);
         MI_HIP(hipMemcpyAsync(d, data, bytes, hipMemcpyHostToDevice, cx.stream));
@@ -310,8 +392,8 @@ int32_t mi_ntt_fr(mi_fr *data, uint32_t log_n, int32_t inverse, int32_t coset) {
 }
 int32_t mi_ntt_fr_device(void *d_data, uint32_t log_n, int32_t inverse, int32_t coset, void *stream) {
     if (!d_data || log_n > 30) return MI_ERR_BAD_ARGS;
-    return guarded([&]() -> int32_t {
-        ntt_device(ctx(), (Fr *)d_data, log_n, inverse != 0, coset != 0, (hipStream_t)stream);
+    return guarded_ptr(d_data, [&](Context &cx) -> int32_t {
+        ntt_device(cx, (Fr *)d_data, log_n, inverse != 0, coset != 0, (hipStream_t)stream);
         return MI_OK;
     });
 }
@@ -340,8 +422,7 @@ static int32_t kzg_commit_impl(Context &cx, uint64_t handle, size_t offset, cons
 }
 int32_t mi_kzg_commit_h(uint64_t handle, size_t offset, const mi_fr *coeffs, size_t n, mi_g1_jac *out) {
     if (!out || (n && !coeffs) || n > MI_MSM_MAX_N) return MI_ERR_BAD_ARGS;
-    return guarded([&]() -> int32_t {
-        Context &cx = ctx();
+    return guarded([&](Context &cx) -> int32_t {
         Fr *d = (Fr *)cx.buf("kzg.commit_coeffs", 32 * (n ? n : 1));
         if (n) MI_HIP(hipMemcpyAsync(d, coeffs, 32 * n, hipMemcpyHostToDevice, cx.stream));
         return kzg_commit_impl(cx, handle, offset, d, n, out, cx.stream);
@@ -349,8 +430,8 @@ int32_t mi_kzg_commit_h(uint64_t handle, size_t offset, const mi_fr *coeffs, siz
 }
 int32_t mi_kzg_commit_h_device(uint64_t handle, size_t offset, const void *d_coeffs, size_t n, mi_g1_jac *out, void *stream) {
     if (!out || (n && !d_coeffs) || n > MI_MSM_MAX_N) return MI_ERR_BAD_ARGS;
-    return guarded([&]() -> int32_t {
-        return kzg_commit_impl(ctx(), handle, offset, (const Fr *)d_coeffs, n, out, (hipStream_t)stream);
+    return guarded_ptr(d_coeffs, [&](Context &cx) -> int32_t {
+        return kzg_commit_impl(cx, handle, offset, (const Fr *)d_coeffs, n, out, (hipStream_t)stream);
     });
 }
 // ---- witness polynomial q(X) = (p(X) - p(z)) / (X - z): q_{i-1} = S_i, p(z) = S_0 with the suffix Horner sums
@@ -446,8 +527,7 @@ __global__ void __launch_bounds__(OPEN_BLOCK) open_apply_kernel(const Fr *__rest
 }
 int32_t mi_kzg_open_h(uint64_t handle, const mi_fr *coeffs, size_t n, const mi_fr *point, mi_fr *value_out, mi_g1_jac *witness_out) {
     if (!point || !value_out || !witness_out || (n && !coeffs) || n > MI_MSM_MAX_N) return MI_ERR_BAD_ARGS;
-    return guarded([&]() -> int32_t {
-        Context &cx = ctx();
+    return guarded([&](Context &cx) -> int32_t {
         hipStream_t st = cx.stream;
         if (n == 0) {
             memset(value_out, 0, sizeof *value_out);
@@ -478,8 +558,7 @@ int32_t mi_kzg_open_h(uint64_t handle, const mi_fr *coeffs, size_t n, const mi_f
 }
 int32_t mi_poly_mul_fr(const mi_fr *a, size_t na, const mi_fr *b, size_t nb, mi_fr *out) {
     if (!a || !b || !out || !na || !nb || na + nb - 1 > ((size_t)1 << 30)) return MI_ERR_BAD_ARGS;
-    return guarded([&]() -> int32_t {
-        Context &cx = ctx();
+    return guarded([&](Context &cx) -> int32_t {
         const size_t nout = na + nb - 1;
         uint32_t log_n = 0;
         while (((size_t)1 << log_n) < nout) log_n++;
@@ -503,18 +582,18 @@ int32_t mi_poly_mul_fr(const mi_fr *a, size_t na, const mi_fr *b, size_t nb, mi_
 // ------------------------------------------------------------ pairing / KZG
 int32_t mi_pairing_product_is_one(const mi_g1_affine *ps, const mi_g2_affine *qs, size_t n, uint8_t *is_one) {
     if (!ps || !qs || !is_one || n == 0 || n > MI_MAX_PAIRS) return MI_ERR_BAD_ARGS;
-    return guarded([&]() -> int32_t {
+    return guarded([&](Context &cx) -> int32_t {
         Fq12 f;
-        pairing_product_host_args(ctx(), (const G1Affine *)ps, (const G2Affine *)qs, n, &f, ctx().stream);
+        pairing_product_host_args(cx, (const G1Affine *)ps, (const G2Affine *)qs, n, &f, cx.stream);
         *is_one = f.is_one() ? 1 : 0;
         return MI_OK;
     });
 }
 int32_t mi_pairing(const mi_g1_affine *p, const mi_g2_affine *q, mi_fq12 *out) {
     if (!p || !q || !out) return MI_ERR_BAD_ARGS;
-    return guarded([&]() -> int32_t {
+    return guarded([&](Context &cx) -> int32_t {
         Fq12 f;
-        pairing_product_host_args(ctx(), (const G1Affine *)p, (const G2Affine *)q, 1, &f, ctx().stream);
+        pairing_product_host_args(cx, (const G1Affine *)p, (const G2Affine *)q, 1, &f, cx.stream);
         memcpy(out, &f, sizeof f);
         return MI_OK;
     });
@@ -522,16 +601,15 @@ int32_t mi_pairing(const mi_g1_affine *p, const mi_g2_affine *q, mi_fq12 *out) {
 int32_t mi_kzg_batch_check(const mi_kzg_vk *vk, const mi_g1_affine *comms, const mi_fr *points, const mi_fr *values,
                            const mi_g1_affine *witnesses, size_t n, const uint8_t *randomizers128, uint8_t *ok_out) {
     if (!vk || !comms || !points || !values || !witnesses || !randomizers128 || !ok_out || n == 0) return MI_ERR_BAD_ARGS;
-    return guarded([&]() -> int32_t {
-        return kzg_batch_check_host(ctx(), vk, comms, points, values, witnesses, n, randomizers128, ok_out);
+    return guarded([&](Context &cx) -> int32_t {
+        return kzg_batch_check_host(cx, vk, comms, points, values, witnesses, n, randomizers128, ok_out);
     });
 }
 
 // ------------------------------------------------------------ Poseidon
 int32_t mi_poseidon_fq_hash_many(const mi_fq *inputs, size_t n, size_t m, size_t k, mi_fq *outputs) {
     if (!n || !k || !outputs || (m && !inputs)) return MI_ERR_BAD_ARGS;
-    return guarded([&]() -> int32_t {
-        Context &cx = ctx();
+    return guarded([&](Context &cx) -> int32_t {
         Fq *din = (Fq *)cx.buf("poseidon.in", sizeof(Fq) * n * (m ? m : 1));
         Fq *dout = (Fq *)cx.buf("poseidon.out", sizeof(Fq) * n * k);
         if (m) MI_HIP(hipMemcpyAsync(din, inputs, sizeof(Fq) * n * m, hipMemcpyHostToDevice, cx.stream));
@@ -543,8 +621,8 @@ int32_t mi_poseidon_fq_hash_many(const mi_fq *inputs, size_t n, size_t m, size_t
 }
 int32_t mi_poseidon_fq_hash_many_device(const void *d_inputs, size_t n, size_t m, size_t k, void *d_outputs, void *stream) {
     if (!n || !k || !d_outputs || (m && !d_inputs)) return MI_ERR_BAD_ARGS;
-    return guarded([&]() -> int32_t {
-        poseidon_device(ctx(), (const Fq *)d_inputs, n, m, k, (Fq *)d_outputs, (hipStream_t)stream);
+    return guarded_ptr(d_outputs, [&](Context &cx) -> int32_t {
+        poseidon_device(cx, (const Fq *)d_inputs, n, m, k, (Fq *)d_outputs, (hipStream_t)stream);
         return MI_OK;
     });
 }
@@ -552,16 +630,21 @@ int32_t mi_poseidon_fq_hash_many_device(const void *d_inputs, size_t n, size_t m
 // ------------------------------------------------------------ VarunaShaped-v1
 int32_t mi_vs_ctx_create(const mi_kzg_vk *vk, const mi_vs_circuit_vk *circuits, size_t n_circuits, uint64_t *ctx_out) {
     if (!vk || !circuits || !n_circuits || !ctx_out) return MI_ERR_BAD_ARGS;
-    return guarded([&]() -> int32_t { return vs_ctx_create(ctx(), vk, circuits, n_circuits, ctx_out); });
+    return guarded([&](Context &cx) -> int32_t { return vs_ctx_create(cx, vk, circuits, n_circuits, ctx_out); });
 }
 int32_t mi_vs_ctx_destroy(uint64_t c) {
-    return guarded([&]() -> int32_t { return vs_ctx_destroy(ctx(), c); });
+    int32_t st = ensure_init();
+    if (st != MI_OK) return st;
+    for (int i = n_contexts() - 1; i >= 0; i--) {  // the primary last: its call drops the host master
+        const int32_t s = guarded_on(context_at(i), [&](Context &cx) -> int32_t { return vs_ctx_destroy(cx, c); });
+        if (s != MI_OK) st = s;
+    }
+    return st;
 }
 int32_t mi_vs_verify_batch(uint64_t c, const mi_vs_proof *proofs, size_t n, const uint8_t *randomizers128,
                            uint8_t *verdicts, uint8_t *all_ok) {
     if (!proofs || !n || !randomizers128 || !verdicts || !all_ok) return MI_ERR_BAD_ARGS;
-    return guarded([&]() -> int32_t {
-        Context &cx = ctx();
+    return guarded([&](Context &cx) -> int32_t {
         void *dp = cx.buf("vs.in_proofs", sizeof(mi_vs_proof) * n);
         void *dr = cx.buf("vs.in_rand", 32 * n);
         MI_HIP(hipMemcpyAsync(dp, proofs, sizeof(mi_vs_proof) * n, hipMemcpyHostToDevice, cx.stream));
@@ -572,40 +655,81 @@ int32_t mi_vs_verify_batch(uint64_t c, const mi_vs_proof *proofs, size_t n, cons
 int32_t mi_vs_verify_batch_device(uint64_t c, const void *d_proofs, size_t n, const void *d_randomizers128,
                                   uint8_t *verdicts, uint8_t *all_ok, void *stream) {
     if (!d_proofs || !n || !d_randomizers128 || !verdicts || !all_ok) return MI_ERR_BAD_ARGS;
-    return guarded([&]() -> int32_t {
-        return vs_verify_batch_device(ctx(), c, d_proofs, n, d_randomizers128, verdicts, all_ok, (hipStream_t)stream);
+    return guarded_ptr(d_proofs, [&](Context &cx) -> int32_t {
+        return vs_verify_batch_device(cx, c, d_proofs, n, d_randomizers128, verdicts, all_ok, (hipStream_t)stream);
     });
+}
+int32_t mi_vs_verify_block(uint64_t c, const mi_vs_proof *proofs, size_t n, const uint8_t *randomizers128, uint8_t *verdicts,
+                           uint8_t *all_ok) {
+    if (!proofs || !n || !randomizers128 || !verdicts || !all_ok) return MI_ERR_BAD_ARGS;
+    const int32_t st = ensure_init();
+    if (st != MI_OK) return st;
+    const int nd = n_contexts();
+    std::vector<const void *> p(nd), r(nd);
+    std::vector<size_t> cnt(nd);
+    const size_t base = n / nd, rem = n % nd;  // contiguous shards, sizes differ by at most one (sharding.shard_bounds)
+    size_t lo = 0;
+    for (int d = 0; d < nd; d++) {
+        cnt[d] = base + ((size_t)d < rem ? 1 : 0);
+        p[d] = proofs + lo;
+        r[d] = randomizers128 + 32 * lo;
+        lo += cnt[d];
+    }
+    try {
+        return vs_verify_block(c, p.data(), r.data(), cnt.data(), nd, false, verdicts, all_ok);
+    } catch (const HipError &h) {
+        return status_of(h);
+    } catch (...) {
+        return MI_ERR_KERNEL;
+    }
+}
+int32_t mi_vs_verify_block_device(uint64_t c, const void *const *d_proofs, const void *const *d_randomizers128,
+                                  const size_t *n_per_shard, int32_t n_shards, uint8_t *verdicts, uint8_t *all_ok) {
+    if (!d_proofs || !d_randomizers128 || !n_per_shard || n_shards < 1 || n_shards > 64 || !verdicts || !all_ok) return MI_ERR_BAD_ARGS;
+    for (int s = 0; s < n_shards; s++)
+        if (n_per_shard[s] && (!d_proofs[s] || !d_randomizers128[s])) return MI_ERR_BAD_ARGS;
+    const int32_t st = ensure_init();
+    if (st != MI_OK) return st;
+    try {
+        return vs_verify_block(c, d_proofs, d_randomizers128, n_per_shard, n_shards, true, verdicts, all_ok);
+    } catch (const HipError &h) {
+        return status_of(h);
+    } catch (...) {
+        return MI_ERR_KERNEL;
+    }
 }
 int32_t mi_vs_accumulate_device(uint64_t c, const void *d_proofs, size_t n, const void *d_randomizers128,
                                 mi_vs_partial *partial_out, void *stream) {
     if (!d_proofs || !n || !d_randomizers128 || !partial_out) return MI_ERR_BAD_ARGS;
-    return guarded([&]() -> int32_t {
-        return vs_accumulate_device(ctx(), c, d_proofs, n, d_randomizers128, partial_out, (hipStream_t)stream);
+    return guarded_ptr(d_proofs, [&](Context &cx) -> int32_t {
+        return vs_accumulate_device(cx, c, d_proofs, n, d_randomizers128, partial_out, (hipStream_t)stream);
     });
 }
 int32_t mi_vs_finalize(uint64_t c, const mi_vs_partial *partials, size_t n_partials, uint8_t *all_ok) {
     if (!partials || !n_partials || !all_ok) return MI_ERR_BAD_ARGS;
-    return guarded([&]() -> int32_t { return vs_finalize(ctx(), c, partials, n_partials, all_ok, ctx().stream); });
+    return guarded([&](Context &cx) -> int32_t { return vs_finalize(cx, c, partials, n_partials, all_ok, cx.stream); });
 }
 
 int32_t mi_vs_accumulate_begin(uint64_t c, const void *d_proofs, size_t n, const void *d_randomizers128, void *stream,
                                uint64_t *handle_out) {
     if (!d_proofs || !n || !d_randomizers128 || !handle_out) return MI_ERR_BAD_ARGS;
-    return guarded([&]() -> int32_t {
-        return vs_accumulate_begin(ctx(), c, d_proofs, n, d_randomizers128, (hipStream_t)stream, handle_out);
+    return guarded_ptr(d_proofs, [&](Context &cx) -> int32_t {
+        return vs_accumulate_begin(cx, c, d_proofs, n, d_randomizers128, (hipStream_t)stream, handle_out);
     });
 }
 int32_t mi_vs_accumulate_end(uint64_t c, uint64_t handle, mi_vs_partial *partial_out) {
     if (!partial_out) return MI_ERR_BAD_ARGS;
-    return guarded([&]() -> int32_t { return vs_accumulate_end(ctx(), c, handle, partial_out); });
+    if (ensure_init() != MI_OK) return MI_ERR_NO_DEVICE;
+    return guarded_on(context_at((int)((handle >> 8) & 0xff)), [&](Context &cx) -> int32_t { return vs_accumulate_end(cx, c, handle, partial_out); });
 }
 int32_t mi_vs_finalize_async(uint64_t c, const mi_vs_partial *partials, size_t n_partials, uint64_t *ticket_out) {
     if (!partials || !n_partials || !ticket_out) return MI_ERR_BAD_ARGS;
-    return guarded([&]() -> int32_t { return vs_finalize_async(ctx(), c, partials, n_partials, ticket_out); });
+    return guarded([&](Context &cx) -> int32_t { return vs_finalize_async(cx, c, partials, n_partials, ticket_out); });
 }
 int32_t mi_vs_finalize_wait(uint64_t c, uint64_t ticket, uint8_t *all_ok) {
     if (!all_ok) return MI_ERR_BAD_ARGS;
-    return guarded([&]() -> int32_t { return vs_finalize_wait(ctx(), c, ticket, all_ok); });
+    if (ensure_init() != MI_OK) return MI_ERR_NO_DEVICE;
+    return guarded_on(context_at((int)((ticket >> 8) & 0xff)), [&](Context &cx) -> int32_t { return vs_finalize_wait(cx, c, ticket, all_ok); });
 }
 
 // ------------------------------------------------------------ diagnostics
@@ -620,8 +744,7 @@ int32_t mi_dbg_g1_add(const mi_g1_affine *a, const mi_g1_affine *b, mi_g1_affine
 }
 int32_t mi_dbg_fq_mul_throughput(size_t n_threads, uint32_t iters, double *gmul_per_s) {
     if (!gmul_per_s || !n_threads) return MI_ERR_BAD_ARGS;
-    return guarded([&]() -> int32_t {
-        Context &cx = ctx();
+    return guarded([&](Context &cx) -> int32_t {
         n_threads = (n_threads + 255) / 256 * 256;
         Fq *d = (Fq *)cx.buf("dbg.c", sizeof(Fq) * n_threads);
         hipEvent_t e0, e1;
@@ -643,7 +766,7 @@ int32_t mi_dbg_fq_mul_throughput(size_t n_threads, uint32_t iters, double *gmul_
 
 int32_t mi_dbg_gen_points_device(uint64_t seed, size_t n, void *d_out, void *stream) {
     if (!d_out || !n) return MI_ERR_BAD_ARGS;
-    return guarded([&]() -> int32_t {
+    return guarded_ptr(d_out, [&](Context &cx) -> int32_t {
         G1Affine g;
         for (int i = 0; i < 6; i++) {
             g.x.l[2 * i] = (uint32_t)MI_G1_GEN_X[i]; g.x.l[2 * i + 1] = (uint32_t)(MI_G1_GEN_X[i] >> 32);
@@ -656,15 +779,15 @@ int32_t mi_dbg_gen_points_device(uint64_t seed, size_t n, void *d_out, void *str
 }
 
 int32_t mi_prof_enable(int32_t on) {
-    return guarded([&]() -> int32_t {
-        ctx().prof.level = on < 0 ? 0 : (on > 2 ? 2 : on);
+    return guarded([&](Context &cx) -> int32_t {
+        cx.prof.level = on < 0 ? 0 : (on > 2 ? 2 : on);
         return MI_OK;
     });
 }
 int32_t mi_prof_read(const char *kernel, double *total_ms, uint64_t *launches, uint64_t *units) {
     if (!kernel || !total_ms || !launches || !units) return MI_ERR_BAD_ARGS;
-    return guarded([&]() -> int32_t {
-        auto &v = ctx().prof.recs[kernel];
+    return guarded([&](Context &cx) -> int32_t {
+        auto &v = cx.prof.recs[kernel];
         double ms = 0;
         uint64_t u = 0;
         for (auto &r : v) {
@@ -673,8 +796,8 @@ int32_t mi_prof_read(const char *kernel, double *total_ms, uint64_t *launches, u
             MI_HIP(hipEventElapsedTime(&t, r.e0, r.e1));
             ms += t;
             u += r.units;
-            ctx().prof.pool.push_back(r.e0);
-            ctx().prof.pool.push_back(r.e1);
+            cx.prof.pool.push_back(r.e0);
+            cx.prof.pool.push_back(r.e1);
         }
         *total_ms = ms;
         *launches = v.size();

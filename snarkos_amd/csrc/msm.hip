@@ -727,16 +727,16 @@ struct CleanMark {
     size_t nb = 0;
     const void *p = nullptr;
 };
-static std::map<int, CleanMark> &clean_marks() {
-    static std::map<int, CleanMark> m;
-    return m;
-}
+struct MsmState {  // per device (Context::mod)
+    std::map<int, CleanMark> clean;  // per workspace slot: the small path's planning kernel left the histogram cleared
+    uint64_t tc_gen[64] = {};        // per slot: generation of the tile-constant buffer that holds an uploaded table
+    bool tc_ready[64] = {};
+};
 
 // Enqueue the whole device pipeline of one MSM on `st` (no host synchronisation); `slot` names the workspace set,
 // so two MSMs with different slots may run on two streams at once.  msm_finish() waits and folds on the host.
-static void msm_enqueue_eager(Context &cx, const G1Affine *d_points, const uint32_t *d_scalars, size_t n, hipStream_t st,
-                              int scalar_bits, int slot, MsmJob *job, int force_c, int pin_parity, bool record_done,
-                              size_t split) {
+void msm_enqueue(Context &cx, const G1Affine *d_points, const uint32_t *d_scalars, size_t n, hipStream_t st, int scalar_bits,
+                 int slot, MsmJob *job, int force_c, int pin_parity, size_t split) {
     job->n = n;
     job->groups = 0;
     job->problems = 1;
@@ -770,7 +770,8 @@ static void msm_enqueue_eager(Context &cx, const G1Affine *d_points, const uint3
 
     // the small path's planning kernel leaves the histogram cleared: skip the memset when this workspace's last
     // user was that kernel, on the same allocation, over at least as many buckets
-    CleanMark &mark = clean_marks()[slot];
+    MsmState &ms = cx.mod<MsmState>("msm");
+    CleanMark &mark = ms.clean[slot];
     const bool clean = small && mark.gen == counts_buf.gen && mark.nb >= nb && mark.p == counts;
     mark = CleanMark();
     static const bool tiled_front = !(getenv("MI_SNARK_MSM_TILED") && getenv("MI_SNARK_MSM_TILED")[0] == '0');
@@ -785,30 +786,30 @@ static void msm_enqueue_eager(Context &cx, const G1Affine *d_points, const uint3
         const size_t tile_size = (n + n_tiles - 1) / n_tiles;
         uint32_t *tile_counts = (uint32_t *)cx.buf(W("tile_counts"), sizeof(uint32_t) * (size_t)pl.nwin * n_tiles * pl.B);
         DevBuf &tcb = cx.bufs[W("tile_consts")];
-        const uint64_t tc_gen = tcb.gen;
         MsmTileConsts *d_tc = (MsmTileConsts *)tcb.get(sizeof(MsmTileConsts) * 17);  // one table per window width c
-        static bool tc_ready[64] = {};
-        if (tcb.gen != tc_gen) memset(tc_ready, 0, sizeof tc_ready);
-        if (slot < 64 && !tc_ready[slot]) {
+        const bool have_tc = slot >= 0 && slot < 64 && ms.tc_ready[slot] && ms.tc_gen[slot] == tcb.gen;
+        if (!have_tc) {
             static MsmTileConsts h[17];
-            memset(h, 0, sizeof h);
-            for (int cc = 6; cc <= 16; cc++)
-                for (int w = 1; w < 24; w++)
-                    for (int j = 0; j < w; j++) {
-                        const int bit = cc * j + cc - 1;
-                        if (bit < 256) h[cc].half[w][bit >> 5] |= 1u << (bit & 31);
-                    }
+            static std::once_flag once;
+            std::call_once(once, [] {
+                memset(h, 0, sizeof h);
+                for (int cc = 6; cc <= 16; cc++)
+                    for (int w = 1; w < 24; w++)
+                        for (int j = 0; j < w; j++) {
+                            const int bit = cc * j + cc - 1;
+                            if (bit < 256) h[cc].half[w][bit >> 5] |= 1u << (bit & 31);
+                        }
+            });
             MI_HIP(hipMemcpyAsync(d_tc, h, sizeof h, hipMemcpyHostToDevice, st));
             MI_HIP(hipStreamSynchronize(st));
-            tc_ready[slot] = true;
+            if (slot >= 0 && slot < 64) {
+                ms.tc_ready[slot] = true;
+                ms.tc_gen[slot] = tcb.gen;
+            }
         }
         const size_t lds = sizeof(uint32_t) * pl.B;
-        static bool attr_set = false;
-        if (!attr_set) {
-            MI_HIP(hipFuncSetAttribute((const void *)msm_digits_tiled_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 131072));
-            MI_HIP(hipFuncSetAttribute((const void *)msm_rank_fixup_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 131072));
-            attr_set = true;
-        }
+        cx.raise_lds_limit((const void *)msm_digits_tiled_kernel, 131072);
+        cx.raise_lds_limit((const void *)msm_rank_fixup_kernel, 131072);
         hipLaunchKernelGGL(msm_digits_tiled_kernel, dim3(n_tiles, (unsigned)pl.nwin), dim3(1024), lds, st, d_scalars, n, tile_size, pl.c,
                            d_tc + pl.c, digits, ranks, tile_counts);
         hipLaunchKernelGGL(msm_tile_scan_kernel, dim3(cdiv(nb, 256)), dim3(256), 0, st, tile_counts, nb, pl.B, n_tiles, counts);
@@ -929,78 +930,13 @@ static void msm_enqueue_eager(Context &cx, const G1Affine *d_points, const uint3
         MI_HIP(hipMemcpyAsync(job->h, result, sizeof(G1Xyzz) * job->groups * problems, hipMemcpyDeviceToHost, st));
     }
     job->done = cx.event_named(pn);
-    if (record_done) MI_HIP(hipEventRecord(job->done, st));
-}
-
-// A small MSM is ~25 launches of a few microseconds each, so issuing them costs the host more than the GPU needs
-// to run them.  When the same MSM (same slot, buffers, size) comes again the launch sequence is captured once into
-// a hipGraph and replayed; HIP-event profiling (mi_prof_enable) switches back to eager launches.
-struct MsmGraph {
-    hipGraphExec_t exec = nullptr;
-    const void *pts = nullptr, *sc = nullptr;
-    size_t n = 0;
-    int bits = 0, parity = -1, seen = 0;
-    MsmJob job;
-};
-static std::map<int, MsmGraph> &msm_graphs() {
-    static std::map<int, MsmGraph> g;
-    return g;
-}
-static bool msm_graphs_enabled() {
-    static int on = -1;
-    if (on < 0) {
-        // EXPERIMENTAL, off by default: replay works for a pure stream of equal batches, but a later synchronous
-        // verify_batch on the same context faulted on the GPU box ("write access to a read-only page"); until that
-        // is understood the launch sequences are issued eagerly.
-        const char *e = getenv("MI_SNARK_GRAPHS");
-        on = (e && e[0] == '1') ? 1 : 0;
-    }
-    return on == 1;
-}
-void msm_release_graphs() {
-    for (auto &kv : msm_graphs())
-        if (kv.second.exec) (void)hipGraphExecDestroy(kv.second.exec);
-    msm_graphs().clear();
-}
-
-void msm_enqueue(Context &cx, const G1Affine *d_points, const uint32_t *d_scalars, size_t n, hipStream_t st, int scalar_bits,
-                 int slot, MsmJob *job, int force_c, int pin_parity, size_t split) {
-    const bool graphable = msm_graphs_enabled() && cx.prof.level == 0 && force_c == 0 && n > 0 && n <= ((size_t)1 << 16) && split == 0;
-    if (!graphable) {
-        msm_enqueue_eager(cx, d_points, d_scalars, n, st, scalar_bits, slot, job, force_c, pin_parity, true, split);
-        return;
-    }
-    MsmGraph &g = msm_graphs()[slot];
-    const bool same = g.pts == d_points && g.sc == d_scalars && g.n == n && g.bits == scalar_bits && g.parity == pin_parity;
-    if (!same) {  // new shape: forget the old graph, run eagerly (this also sizes every workspace)
-        if (g.exec) (void)hipGraphExecDestroy(g.exec);
-        g = MsmGraph();
-        g.pts = d_points; g.sc = d_scalars; g.n = n; g.bits = scalar_bits; g.parity = pin_parity; g.seen = 1;
-        msm_enqueue_eager(cx, d_points, d_scalars, n, st, scalar_bits, slot, job, force_c, pin_parity, true, 0);
-        return;
-    }
-    if (!g.exec) {  // second sighting: capture the identical launch sequence
-        hipGraph_t graph = nullptr;
-        MI_HIP(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
-        try {
-            msm_enqueue_eager(cx, d_points, d_scalars, n, st, scalar_bits, slot, &g.job, force_c, pin_parity, false, 0);
-        } catch (...) {
-            (void)hipStreamEndCapture(st, &graph);
-            if (graph) (void)hipGraphDestroy(graph);
-            throw;
-        }
-        MI_HIP(hipStreamEndCapture(st, &graph));
-        hipError_t e = hipGraphInstantiate(&g.exec, graph, nullptr, nullptr, 0);
-        (void)hipGraphDestroy(graph);
-        if (e != hipSuccess) {
-            g.exec = nullptr;
-            throw HipError{e, "hipGraphInstantiate", __LINE__};
-        }
-    }
-    MI_HIP(hipGraphLaunch(g.exec, st));
-    *job = g.job;
     MI_HIP(hipEventRecord(job->done, st));
 }
+
+// (A hipGraph replay of the small path's launch sequence existed in round 1 and was removed: an instantiated graph bakes
+// in the addresses of name-keyed workspaces and pinned buffers and the "histogram already clear" decision of the moment
+// of capture, and nothing invalidated it when an eager call on the same slot regrew a workspace or left the histogram
+// dirty -- stale pointers and an unzeroed histogram turn into out-of-range scatter writes.  DESIGN.md "Workspace lifetime".)
 
 // wait for the job's stream, fold on the host (Horner over windows or bit positions), normalise to z = 1
 // Horner over the per-bit sums h[lo..hi): sum_g 2^(g-lo) h[g]

@@ -281,16 +281,19 @@ __global__ void __launch_bounds__(256) ntt_coset_kernel(Fr *a, size_t n, const F
     ntt_store(a + i, mul(mul(ntt_load(a + i), g), scale));
 }
 
-struct NttTables {
+struct NttTables {  // per device (Context::mod)
     DevBuf tw[48];
     DevBuf tw_hi[48];
     DevBuf coset_fwd, coset_inv;  // 3 x 1024 entries each: g^i, g^(1024 i), g^(2^20 i)
     bool coset_ready = false;
+    ~NttTables() {
+        for (auto &b : tw) b.release();
+        for (auto &b : tw_hi) b.release();
+        coset_fwd.release();
+        coset_inv.release();
+    }
 };
-static NttTables &ntt_tables() {
-    static NttTables t;
-    return t;
-}
+static NttTables &ntt_tables(Context &cx) { return cx.mod<NttTables>("ntt.tables"); }
 
 static Fr host_fr_from_limbs(const uint64_t *l) {
     Fr r;
@@ -304,7 +307,7 @@ Fr host_omega(uint32_t log_n) {
 }
 
 static const Fr *ntt_get_table(Context &cx, uint32_t log_n, hipStream_t st) {
-    NttTables &t = ntt_tables();
+    NttTables &t = ntt_tables(cx);
     if (log_n == 0) return nullptr;
     size_t count = (size_t)1 << (log_n - 1);
     if (t.tw[log_n].p) return (const Fr *)t.tw[log_n].p;
@@ -327,7 +330,7 @@ static const Fr *ntt_get_table(Context &cx, uint32_t log_n, hipStream_t st) {
     return d;
 }
 static void ntt_get_coset_tables(Context &cx, hipStream_t st) {
-    NttTables &t = ntt_tables();
+    NttTables &t = ntt_tables(cx);
     if (t.coset_ready) return;
     std::vector<Fr> h(3 * 1024);
     for (int dir = 0; dir < 2; dir++) {
@@ -342,7 +345,6 @@ static void ntt_get_coset_tables(Context &cx, hipStream_t st) {
         MI_HIP(hipMemcpyAsync(d, h.data(), sizeof(Fr) * h.size(), hipMemcpyHostToDevice, st));
         MI_HIP(hipStreamSynchronize(st));
     }
-    (void)cx;
     t.coset_ready = true;
 }
 
@@ -355,16 +357,11 @@ static void ntt_launch_pass(const Fr *in, Fr *out, const Fr *tw, uint32_t log_n,
 }
 
 template <int P>
-static void ntt_launch_lds_pass(const Fr *in, Fr *out, const Fr *tw, const Fr *tw_hi, uint32_t log_n, uint32_t log_ns,
+static void ntt_launch_lds_pass(Context &cx, const Fr *in, Fr *out, const Fr *tw, const Fr *tw_hi, uint32_t log_n, uint32_t log_ns,
                                 bool inverse, bool scale_out, const Fr &scale, hipStream_t st) {
     constexpr int R = 1 << P, C = 1024 / R;
     const size_t lds_bytes = sizeof(Fr) * (size_t)C * (R + 1);
-    static bool attr_set = false;
-    if (!attr_set) {
-        MI_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&ntt_lds_pass_kernel<P>),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-        attr_set = true;
-    }
+    cx.raise_lds_limit(reinterpret_cast<const void *>(&ntt_lds_pass_kernel<P>), (int)lds_bytes);
     const size_t T = (size_t)1 << (log_n - P);
     hipLaunchKernelGGL(ntt_lds_pass_kernel<P>, dim3((unsigned)(T / C)), dim3(128), lds_bytes, st, in, out, tw, tw_hi, log_n,
                        log_ns, inverse ? 1 : 0, scale_out ? 1 : 0, scale);
@@ -375,10 +372,14 @@ void ntt_device(Context &cx, Fr *d_data, uint32_t log_n, bool inverse, bool cose
     const size_t n = (size_t)1 << log_n;
     if (coset) ntt_get_coset_tables(cx, st);
     if (coset && !inverse)
-        hipLaunchKernelGGL(ntt_coset_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, d_data, n, (const Fr *)ntt_tables().coset_fwd.p, Fr::one());
+        hipLaunchKernelGGL(ntt_coset_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, d_data, n, (const Fr *)ntt_tables(cx).coset_fwd.p, Fr::one());
     if (log_n > 0) {
         const Fr *tw = ntt_get_table(cx, log_n, st);
-        Fr *tmp = (Fr *)cx.buf("ntt.tmp", sizeof(Fr) * n);
+        // The Stockham twin.  This call may return with its passes still running on the caller's stream (the
+        // `_device` entry point), and the next call may come on another stream: every call takes a buffer that no
+        // in-flight transform is using (event-guarded pool), never a name-keyed workspace.
+        ScratchPool::Entry *scr = cx.scratch.acquire(sizeof(Fr) * n);
+        Fr *tmp = (Fr *)scr->buf.p;
         // split log_n into passes of at most 4 bits, an even number of them when log_n >= 2
         int npass = (int)(log_n + 3) / 4;
         if ((npass & 1) && log_n >= 2) npass++;
@@ -395,7 +396,7 @@ void ntt_device(Context &cx, Fr *d_data, uint32_t log_n, bool inverse, bool cose
         // both are bound by the same integer work and the six register-radix-16 passes are marginally faster (0.78 vs 0.80)
         const bool force_lds = getenv("MI_SNARK_NTT_LDS") != nullptr;
         const bool use_lds = log_n >= 11 && (log_n <= 20 || force_lds) && !getenv("MI_SNARK_NTT_REGS");
-        const Fr *tw_hi = (const Fr *)ntt_tables().tw_hi[log_n].p;  // null below 2^25
+        const Fr *tw_hi = (const Fr *)ntt_tables(cx).tw_hi[log_n].p;  // null below 2^25
         if (use_lds) {
             // an even number of LDS-tiled passes of 4..9 bits each
             int np = 2 * (int)((log_n + 15) / 16);  // <= 8 bits per pass
@@ -404,12 +405,12 @@ void ntt_device(Context &cx, Fr *d_data, uint32_t log_n, bool inverse, bool cose
                 bool last = p == np - 1;
                 cx.prof.begin("ntt_pass", st, n);
                 switch (P) {
-                case 4: ntt_launch_lds_pass<4>(src, dst, tw, tw_hi, log_n, log_ns, inverse, last && fold_scale, n_inv, st); break;
-                case 5: ntt_launch_lds_pass<5>(src, dst, tw, tw_hi, log_n, log_ns, inverse, last && fold_scale, n_inv, st); break;
-                case 6: ntt_launch_lds_pass<6>(src, dst, tw, tw_hi, log_n, log_ns, inverse, last && fold_scale, n_inv, st); break;
-                case 7: ntt_launch_lds_pass<7>(src, dst, tw, tw_hi, log_n, log_ns, inverse, last && fold_scale, n_inv, st); break;
-                case 8: ntt_launch_lds_pass<8>(src, dst, tw, tw_hi, log_n, log_ns, inverse, last && fold_scale, n_inv, st); break;
-                default: ntt_launch_lds_pass<9>(src, dst, tw, tw_hi, log_n, log_ns, inverse, last && fold_scale, n_inv, st); break;
+                case 4: ntt_launch_lds_pass<4>(cx, src, dst, tw, tw_hi, log_n, log_ns, inverse, last && fold_scale, n_inv, st); break;
+                case 5: ntt_launch_lds_pass<5>(cx, src, dst, tw, tw_hi, log_n, log_ns, inverse, last && fold_scale, n_inv, st); break;
+                case 6: ntt_launch_lds_pass<6>(cx, src, dst, tw, tw_hi, log_n, log_ns, inverse, last && fold_scale, n_inv, st); break;
+                case 7: ntt_launch_lds_pass<7>(cx, src, dst, tw, tw_hi, log_n, log_ns, inverse, last && fold_scale, n_inv, st); break;
+                case 8: ntt_launch_lds_pass<8>(cx, src, dst, tw, tw_hi, log_n, log_ns, inverse, last && fold_scale, n_inv, st); break;
+                default: ntt_launch_lds_pass<9>(cx, src, dst, tw, tw_hi, log_n, log_ns, inverse, last && fold_scale, n_inv, st); break;
                 }
                 cx.prof.end("ntt_pass", st);
                 log_ns += P;
@@ -433,19 +434,12 @@ void ntt_device(Context &cx, Fr *d_data, uint32_t log_n, bool inverse, bool cose
         }
         if (src != d_data) MI_HIP(hipMemcpyAsync(d_data, src, sizeof(Fr) * n, hipMemcpyDeviceToDevice, st));
         if (inverse && coset)
-            hipLaunchKernelGGL(ntt_coset_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, d_data, n, (const Fr *)ntt_tables().coset_inv.p, n_inv);
+            hipLaunchKernelGGL(ntt_coset_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, d_data, n, (const Fr *)ntt_tables(cx).coset_inv.p, n_inv);
+        ScratchPool::release(scr, st);
     } else if (inverse && coset) {
         // n = 1: g^0 * 1 = identity
     }
     MI_HIP(hipGetLastError());
-}
-
-void ntt_release_tables() {
-    for (auto &b : ntt_tables().tw) b.release();
-    for (auto &b : ntt_tables().tw_hi) b.release();
-    ntt_tables().coset_fwd.release();
-    ntt_tables().coset_inv.release();
-    ntt_tables().coset_ready = false;
 }
 
 }  // namespace mi

@@ -19,21 +19,18 @@ __global__ void __launch_bounds__(PW_THREADS) pairing_product_kernel(PairingArgs
     pw_pairing_product(S, args.p, args.q, args.n, pc, out);
 }
 
-struct PairingState {
+struct PairingState {  // per device (Context::mod)
     DevBuf consts;
     bool ready = false;
+    ~PairingState() { consts.release(); }
 };
-static PairingState &pairing_state() {
-    static PairingState s;
-    return s;
-}
 static Fq host_fq_from_limbs(const uint64_t *l) {
     Fq r;
     for (int i = 0; i < 6; i++) { r.l[2 * i] = (uint32_t)l[i]; r.l[2 * i + 1] = (uint32_t)(l[i] >> 32); }
     return r;
 }
 const PairingConsts *pairing_consts(Context &cx, hipStream_t st) {
-    PairingState &s = pairing_state();
+    PairingState &s = cx.mod<PairingState>("pairing");
     if (!s.ready) {
         PairingConsts h;
         for (int e = 0; e < 3; e++)
@@ -43,7 +40,6 @@ const PairingConsts *pairing_consts(Context &cx, hipStream_t st) {
         MI_HIP(hipStreamSynchronize(st));
         s.ready = true;
     }
-    (void)cx;
     return (const PairingConsts *)s.consts.p;
 }
 
@@ -82,11 +78,6 @@ void pairing_product_host_args(Context &cx, const G1Affine *ps, const G2Affine *
     const G2Prepared *dq[MI_MAX_PAIRS];
     for (size_t i = 0; i < n; i++) dq[i] = d + i;
     pairing_product_prepared(cx, ps, dq, n, out_host, st);
-}
-
-void pairing_release() {
-    pairing_state().consts.release();
-    pairing_state().ready = false;
 }
 
 }  // namespace mi

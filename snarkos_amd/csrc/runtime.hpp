@@ -90,6 +90,10 @@ inline WorkerPool &worker_pool() {
 }
 
 // A grow-only device buffer (no hipMalloc on the steady-state path).
+// Lifetime rule (DESIGN.md "Workspace lifetime"): a regrow never frees memory that enqueued work may still touch --
+// it drains the device first (regrows are rare: first call, or a larger problem than ever before).  Buffers that an
+// asynchronous entry point leaves in flight on a CALLER's stream must not be name-keyed at all: they come from a
+// ScratchPool (below), whose entries are guarded by an event.
 struct DevBuf {
     void *p = nullptr;
     size_t cap = 0;
@@ -97,7 +101,10 @@ struct DevBuf {
     void *get(size_t bytes) {
         if (bytes > cap) {
             gen++;
-            if (p) MI_HIP(hipFree(p));
+            if (p) {
+                MI_HIP(hipDeviceSynchronize());  // nothing enqueued earlier, on any stream, may still use the old block
+                MI_HIP(hipFree(p));
+            }
             p = nullptr;
             cap = 0;
             size_t want = bytes + bytes / 8 + 256;
@@ -107,9 +114,56 @@ struct DevBuf {
         return p;
     }
     void release() {
-        if (p) (void)hipFree(p);
+        if (p) {
+            (void)hipDeviceSynchronize();
+            (void)hipFree(p);
+        }
         p = nullptr;
         cap = 0;
+    }
+};
+
+// Scratch buffers for entry points that return while their kernels are still running on the caller's stream
+// (mi_ntt_fr_device): every acquisition gets a buffer no other in-flight call is using.  An entry is reusable once
+// the event recorded after its last user's final kernel has completed; a regrow of such an entry is then safe.
+struct ScratchPool {
+    struct Entry {
+        DevBuf buf;
+        hipEvent_t done = nullptr;
+        bool used = false;  // `done` has been recorded at least once
+    };
+    std::vector<std::unique_ptr<Entry>> entries;
+    // returns an idle entry holding >= bytes (the context lock is held by the caller)
+    Entry *acquire(size_t bytes) {
+        Entry *pick = nullptr;
+        for (auto &e : entries) {
+            if (e->used && hipEventQuery(e->done) != hipSuccess) continue;  // still in flight
+            if (!pick || (e->buf.cap >= bytes && (pick->buf.cap < bytes || e->buf.cap < pick->buf.cap))) pick = e.get();
+        }
+        if (!pick) {
+            if (entries.size() >= 16) {  // bound the pool: wait for the oldest user instead of growing without limit
+                pick = entries.front().get();
+                MI_HIP(hipEventSynchronize(pick->done));
+            } else {
+                entries.emplace_back(new Entry());
+                pick = entries.back().get();
+                MI_HIP(hipEventCreateWithFlags(&pick->done, hipEventDisableTiming));
+            }
+        }
+        pick->buf.get(bytes);
+        return pick;
+    }
+    // call after the last kernel that touches the entry has been enqueued on `st`
+    static void release(Entry *e, hipStream_t st) {
+        MI_HIP(hipEventRecord(e->done, st));
+        e->used = true;
+    }
+    void free_all() {
+        for (auto &e : entries) {
+            e->buf.release();
+            if (e->done) (void)hipEventDestroy(e->done);
+        }
+        entries.clear();
     }
 };
 
@@ -191,12 +245,35 @@ struct Profiler {
     }
 };
 
+// One Context per HIP device the process uses (mi_init(device_ids, n), or created on first use of a device pointer).
+// Everything bound to a device lives here -- streams, workspaces, cached tables, the verifier's lanes and product
+// slots (module slots below) -- so one host process can drive all GPUs of a node (the reference is one process:
+// reference cli/src/commands/start.rs:616-642).
 struct Context {
-    std::mutex mu;  // serialises GPU work issued through the library (callers are rayon / tokio threads)
+    std::mutex mu;  // serialises GPU work issued to THIS device through the library (callers are rayon / tokio threads)
+    std::condition_variable lane_cv;  // signalled when an accumulation lane or a product slot of this device frees up
     Profiler prof;
     bool inited = false;
-    int device = 0;
+    int device = 0;   // HIP ordinal
+    int index = 0;    // position in the library's device list (0 = primary)
     int n_cus = 256;
+    ScratchPool scratch;
+    // device-bound state of the other translation units (twiddle tables, pairing constants, verifier pipeline, ...),
+    // created on first use, destroyed by release_modules() while the device is still alive
+    std::map<std::string, std::shared_ptr<void>> modules;
+    template <class T>
+    T &mod(const char *name) {
+        auto it = modules.find(name);
+        if (it == modules.end()) it = modules.emplace(name, std::shared_ptr<void>(new T(), [](void *p) { delete (T *)p; })).first;
+        return *(T *)it->second.get();
+    }
+    // kernels whose dynamic-LDS limit has been raised on this device (hipFuncSetAttribute is per device)
+    std::map<const void *, bool> func_attr_done;
+    void raise_lds_limit(const void *fn, int bytes) {
+        if (func_attr_done[fn]) return;
+        MI_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+        func_attr_done[fn] = true;
+    }
     hipStream_t stream = nullptr;  // library-owned stream for host-pointer entry points
     std::map<std::string, DevBuf> bufs;
     std::map<uint64_t, DevBuf> handles;  // registered bases
@@ -237,8 +314,13 @@ struct Context {
     }
 };
 
-Context &ctx();
-int32_t ensure_init();
+// ---- device registry (capi.hip)
+Context &primary();                                  // device_ids[0] of mi_init, or the current HIP device
+int32_t ensure_init();                               // the primary exists
+Context *context_at(int index);                      // nullptr when out of range
+int n_contexts();
+Context *context_for_device(int hip_device);         // created on first use; nullptr if the device cannot be used
+Context *context_of_ptr(const void *device_ptr);     // the device that owns a device pointer (primary if unknown)
 
 // The context mutex guards the context's maps and the verifier contexts' bookkeeping.  Entry points hold it for
 // their whole body, except around long host-side waits and folds (Unlocked below), so that one host thread can
@@ -253,19 +335,21 @@ struct Unlocked {
         if (lk) lk->lock();
     }
 };
+// run f(cx) with the device's lock held and the device current
 template <class F>
-int32_t guarded(F &&f) {
+int32_t guarded_on(Context *cxp, F &&f) {
     struct Reset {
-        ~Reset() { tl_ctx_lock = nullptr; }
+        std::unique_lock<std::mutex> *prev;
+        ~Reset() { tl_ctx_lock = prev; }
     };
     try {
-        int32_t s = ensure_init();
-        if (s != MI_OK) return s;
-        std::unique_lock<std::mutex> lk(ctx().mu);
-        Reset reset;  // destroyed before lk
+        if (!cxp) return MI_ERR_NO_DEVICE;
+        Context &cx = *cxp;
+        std::unique_lock<std::mutex> lk(cx.mu);
+        Reset reset{tl_ctx_lock};  // destroyed before lk
         tl_ctx_lock = &lk;
-        MI_HIP(hipSetDevice(ctx().device));  // never rely on a foreign thread's current device
-        return f();
+        MI_HIP(hipSetDevice(cx.device));  // never rely on a foreign thread's current device
+        return f(cx);
     } catch (const HipError &h) {
         return status_of(h);
     } catch (const std::bad_alloc &) {
@@ -273,6 +357,20 @@ int32_t guarded(F &&f) {
     } catch (...) {
         return MI_ERR_KERNEL;
     }
+}
+// host-pointer entry points run on the primary device
+template <class F>
+int32_t guarded(F &&f) {
+    const int32_t s = ensure_init();
+    if (s != MI_OK) return s;
+    return guarded_on(&primary(), std::forward<F>(f));
+}
+// device-pointer entry points run on the device that owns the pointer
+template <class F>
+int32_t guarded_ptr(const void *device_ptr, F &&f) {
+    const int32_t s = ensure_init();
+    if (s != MI_OK) return s;
+    return guarded_on(context_of_ptr(device_ptr), std::forward<F>(f));
 }
 
 inline unsigned cdiv(size_t a, size_t b) { return (unsigned)((a + b - 1) / b); }

@@ -117,7 +117,7 @@ struct Stream {
                 if ((int)tickets.size() >= products) wait_oldest();
                 uint64_t tk = 0;
                 int32_t st = mi_vs_finalize_async(ctx, one.data(), world, &tk);
-                while (st == MI_ERR_BAD_ARGS && !tickets.empty()) {  // fewer product slots than `products` (MI_SNARK_VS_SLOTS)
+                while (st == MI_ERR_AGAIN && !tickets.empty()) {  // fewer product slots than `products` (MI_SNARK_VS_SLOTS), or another stream holds them
                     wait_oldest();
                     st = mi_vs_finalize_async(ctx, one.data(), world, &tk);
                 }
@@ -243,3 +243,15 @@ int32_t mi_vs_stream_close(uint64_t stream) {
 }
 
 }  // extern "C"
+
+namespace mi {
+// mi_shutdown: no driver thread may outlive the devices
+void stream_release_all() {
+    std::vector<uint64_t> ids;
+    {
+        std::lock_guard<std::mutex> lk(g_mu);
+        for (auto &kv : g_streams) ids.push_back(kv.first);
+    }
+    for (uint64_t id : ids) (void)mi_vs_stream_close(id);
+}
+}  // namespace mi

@@ -130,10 +130,29 @@ struct VsSlot {  // one in-flight pairing product (pipelined finalize)
     hipStream_t stream = nullptr;  // each slot has its own stream: products of different batches run side by side
     Fq12 *h_out = nullptr;  // pinned
 };
-struct VsCtx {  // the keys of one verifier: circuit commitments, G, the two prepared G2 line tables
+// The keys of one verifier.  The host copy is the master; every device that is handed work for this verifier gets
+// its own resident copy on first use (VsKeys, kept in that device's Context), so one verifier context serves all GPUs
+// of the process.
+struct VsCtx {
+    uint64_t id = 0;
     size_t n_circuits = 0;
-    DevBuf circuits, h_prep, tauh_prep, consts;
     mi_kzg_vk vk;
+    std::vector<mi_vs_circuit_vk> circuits;
+    G2Prepared h_prep, tauh_prep;  // prepared once on the host (as the reference prepares prepared_h / prepared_beta_h)
+    VsConsts consts;
+};
+struct VsKeys {  // one device's copy
+    DevBuf circuits, h_prep, tauh_prep, consts;
+    size_t n_circuits = 0;
+    ~VsKeys() {
+        circuits.release();
+        h_prep.release();
+        tauh_prep.release();
+        consts.release();
+    }
+};
+struct VsKeyTable {
+    std::map<uint64_t, std::unique_ptr<VsKeys>> of;
 };
 struct VsAcc {  // an accumulation whose kernels are enqueued but whose host fold is still to come
     bool open = false;
@@ -145,114 +164,115 @@ struct VsAcc {  // an accumulation whose kernels are enqueued but whose host fol
     bool closing = false;
     uint8_t *h_alg = nullptr;
 };
-// The pipeline -- accumulation lanes and product slots, each with its stream, workspaces (named per lane in the
-// Context) and pinned result buffer -- belongs to the PROCESS, not to a verifier context: lanes index shared
-// workspaces, so two contexts must never hold the same lane, and HIP keeps a destroyed stream's queue and scratch
-// (measured: 45 MB of device memory per create/destroy cycle when every context made its own 20 streams).
+// The pipeline of one DEVICE -- accumulation lanes and product slots, each with its stream, workspaces (named per
+// lane in the Context) and pinned result buffer.  It belongs to the device, not to a verifier context: lanes index
+// shared workspaces, so two verifier contexts must never hold the same lane, and HIP keeps a destroyed stream's queue
+// and scratch (measured: 45 MB of device memory per create/destroy cycle when every context made its own 20 streams).
+// All streams are created at once, lanes first, then product slots.  Measured on the box: HIP spreads streams over
+// at most 24 hardware queues in creation order; with this order 12 lanes + 8 slots run side by side (4.3e6 proofs/s),
+// created lazily in order of first use (lane, slot, lane, ...) the same streams reach 2.7e6, and with more than ~24
+// streams on the device a 1.6 ms pairing kernel ends up queued in front of other batches' MSMs.
+// MI_SNARK_VS_LANES (1..14, default 12; read once) trims the lane count when the process needs queues for something
+// else (RCCL, other libraries).
 struct VsPipe {
-    bool ready = false;
     int lanes = 12, nslots = VS_SLOTS;
     VsAcc acc[VS_ACC_DEPTH];
     hipStream_t acc_st[VS_ACC_DEPTH] = {};  // one stream per accumulation lane
     hipEvent_t acc_ev[VS_ACC_DEPTH] = {};
     VsSlot slots[VS_SLOTS];  // pairing products run on the slots' streams, beside the next batches' accumulation
     uint64_t next_acc = 2, next_ticket = 1;
+    VsPipe() {  // the device is current (Context::mod is only called under guarded_on)
+        if (const char *e = getenv("MI_SNARK_VS_LANES")) {
+            const int x = atoi(e);
+            if (x >= 1 && x <= VS_ACC_DEPTH) lanes = x;
+        }
+        for (int p = 0; p < lanes; p++) {
+            MI_HIP(hipStreamCreateWithFlags(&acc_st[p], hipStreamNonBlocking));
+            MI_HIP(hipEventCreateWithFlags(&acc_ev[p], hipEventDisableTiming));
+        }
+        if (const char *e = getenv("MI_SNARK_VS_SLOTS")) {  // product slots (1..8): fewer streams when queues are scarce
+            const int x = atoi(e);
+            if (x >= 1 && x <= VS_SLOTS) nslots = x;
+        }
+        for (int i = 0; i < nslots; i++) {
+            VsSlot &sl = slots[i];
+            MI_HIP(hipStreamCreateWithFlags(&sl.stream, hipStreamNonBlocking));
+            MI_HIP(hipEventCreateWithFlags(&sl.done, hipEventDisableTiming));
+            MI_HIP(hipHostMalloc((void **)&sl.h_out, sizeof(Fq12), hipHostMallocDefault));
+        }
+    }
+    ~VsPipe() {
+        for (auto &sl : slots) {
+            if (sl.stream) (void)hipStreamSynchronize(sl.stream);
+            if (sl.done) (void)hipEventDestroy(sl.done);
+            if (sl.stream) (void)hipStreamDestroy(sl.stream);
+            if (sl.h_out) (void)hipHostFree(sl.h_out);
+        }
+        for (int p = 0; p < VS_ACC_DEPTH; p++) {
+            if (acc_st[p]) {
+                (void)hipStreamSynchronize(acc_st[p]);
+                (void)hipStreamDestroy(acc_st[p]);
+            }
+            if (acc_ev[p]) (void)hipEventDestroy(acc_ev[p]);
+        }
+    }
+    void sync() {
+        for (auto &sl : slots)
+            if (sl.stream) MI_HIP(hipStreamSynchronize(sl.stream));
+        for (int p = 0; p < VS_ACC_DEPTH; p++)
+            if (acc_st[p]) MI_HIP(hipStreamSynchronize(acc_st[p]));
+    }
 };
-static VsPipe &vs_pipe() {
-    static VsPipe p;
-    return p;
-}
-// All streams are created at once, lanes first, then product slots.  Measured on the box: HIP spreads streams over
-// at most 24 hardware queues in creation order; with this order 12 lanes + 8 slots run side by side (4.3e6 proofs/s),
-// created lazily in order of first use (lane, slot, lane, ...) the same streams reach 2.7e6, and with more than ~24
-// streams in the process a 1.6 ms pairing kernel ends up queued in front of other batches' MSMs.
-// MI_SNARK_VS_LANES (1..14, default 12; read once) trims the lane count when the process needs queues for something
-// else (RCCL, other libraries).
-static void vs_pipe_init() {
-    VsPipe &pp = vs_pipe();
-    if (pp.ready) return;
-    pp.lanes = 12;
-    if (const char *e = getenv("MI_SNARK_VS_LANES")) {
-        const int x = atoi(e);
-        if (x >= 1 && x <= VS_ACC_DEPTH) pp.lanes = x;
-    }
-    for (int p = 0; p < pp.lanes; p++) {
-        MI_HIP(hipStreamCreateWithFlags(&pp.acc_st[p], hipStreamNonBlocking));
-        MI_HIP(hipEventCreateWithFlags(&pp.acc_ev[p], hipEventDisableTiming));
-    }
-    pp.nslots = VS_SLOTS;
-    if (const char *e = getenv("MI_SNARK_VS_SLOTS")) {  // product slots (1..8): fewer streams when queues are scarce
-        const int x = atoi(e);
-        if (x >= 1 && x <= VS_SLOTS) pp.nslots = x;
-    }
-    for (int i = 0; i < pp.nslots; i++) {
-        VsSlot &sl = pp.slots[i];
-        MI_HIP(hipStreamCreateWithFlags(&sl.stream, hipStreamNonBlocking));
-        MI_HIP(hipEventCreateWithFlags(&sl.done, hipEventDisableTiming));
-        MI_HIP(hipHostMalloc((void **)&sl.h_out, sizeof(Fq12), hipHostMallocDefault));
-    }
-    pp.ready = true;
-}
-static void vs_pipe_sync() {
-    VsPipe &pp = vs_pipe();
-    for (auto &sl : pp.slots)
-        if (sl.stream) MI_HIP(hipStreamSynchronize(sl.stream));
-    for (int p = 0; p < VS_ACC_DEPTH; p++)
-        if (pp.acc_st[p]) MI_HIP(hipStreamSynchronize(pp.acc_st[p]));
-}
-static void vs_pipe_free() {
-    VsPipe &pp = vs_pipe();
-    for (auto &sl : pp.slots) {
-        if (sl.done) (void)hipEventDestroy(sl.done);
-        if (sl.stream) (void)hipStreamDestroy(sl.stream);
-        if (sl.h_out) (void)hipHostFree(sl.h_out);
-    }
-    for (int p = 0; p < VS_ACC_DEPTH; p++) {
-        if (pp.acc_st[p]) (void)hipStreamDestroy(pp.acc_st[p]);
-        if (pp.acc_ev[p]) (void)hipEventDestroy(pp.acc_ev[p]);
-    }
-    pp = VsPipe();
-}
-static void vs_ctx_free(VsCtx &v) {
-    v.circuits.release();
-    v.h_prep.release();
-    v.tauh_prep.release();
-    v.consts.release();
-}
-static std::map<uint64_t, VsCtx> &vs_ctxs() {
-    static std::map<uint64_t, VsCtx> m;
+static VsPipe &vs_pipe(Context &cx) { return cx.mod<VsPipe>("vs.pipe"); }
+
+// ---- verifier contexts: process-wide table of host masters
+static std::mutex g_vs_mu;
+static std::map<uint64_t, std::shared_ptr<VsCtx>> &vs_ctxs() {
+    static std::map<uint64_t, std::shared_ptr<VsCtx>> m;
     return m;
 }
 static uint64_t g_vs_next = 1;
-void verify_release_all() {
-    for (auto &kv : vs_ctxs()) vs_ctx_free(kv.second);
+static std::shared_ptr<VsCtx> vs_find(uint64_t id) {
+    std::lock_guard<std::mutex> lk(g_vs_mu);
+    auto it = vs_ctxs().find(id);
+    return it == vs_ctxs().end() ? nullptr : it->second;
+}
+void verify_release_keys() {
+    std::lock_guard<std::mutex> lk(g_vs_mu);
     vs_ctxs().clear();
-    vs_pipe_free();
-    ntt_release_tables();
-    pairing_release();
+}
+// this device's copy of the keys (uploaded on first use; the device lock is held)
+static VsKeys &vs_keys(Context &cx, const VsCtx &v) {
+    VsKeyTable &t = cx.mod<VsKeyTable>("vs.keys");
+    auto it = t.of.find(v.id);
+    if (it != t.of.end()) return *it->second;
+    std::unique_ptr<VsKeys> k(new VsKeys());
+    k->n_circuits = v.n_circuits;
+    hipStream_t st = cx.stream;
+    MI_HIP(hipMemcpyAsync(k->circuits.get(sizeof(mi_vs_circuit_vk) * v.n_circuits), v.circuits.data(),
+                          sizeof(mi_vs_circuit_vk) * v.n_circuits, hipMemcpyHostToDevice, st));
+    MI_HIP(hipMemcpyAsync(k->h_prep.get(sizeof(G2Prepared)), &v.h_prep, sizeof(G2Prepared), hipMemcpyHostToDevice, st));
+    MI_HIP(hipMemcpyAsync(k->tauh_prep.get(sizeof(G2Prepared)), &v.tauh_prep, sizeof(G2Prepared), hipMemcpyHostToDevice, st));
+    MI_HIP(hipMemcpyAsync(k->consts.get(sizeof(VsConsts)), &v.consts, sizeof(VsConsts), hipMemcpyHostToDevice, st));
+    MI_HIP(hipStreamSynchronize(st));  // sources are the master's members: alive, but later users run on other streams
+    (void)vs_pipe(cx);                 // all of the device's streams exist before the first launch (creation order)
+    (void)pairing_consts(cx, st);      // the Frobenius table, before any pipelined launch
+    VsKeys &ref = *k;
+    t.of[v.id] = std::move(k);
+    return ref;
 }
 
-static void upload_prepared(DevBuf &buf, const mi_g2_affine *q, hipStream_t st) {
-    G2Prepared prep;
+int32_t vs_ctx_create(Context &cx, const mi_kzg_vk *vk, const mi_vs_circuit_vk *circuits, size_t n_circuits, uint64_t *out) {
+    std::shared_ptr<VsCtx> v(new VsCtx());
+    v->n_circuits = n_circuits;
+    v->vk = *vk;
+    v->circuits.assign(circuits, circuits + n_circuits);
     G2Affine qa;
-    memcpy(&qa, q, sizeof qa);
-    g2_prepare_host(prep, qa);
-    void *d = buf.get(sizeof prep);
-    MI_HIP(hipMemcpyAsync(d, &prep, sizeof prep, hipMemcpyHostToDevice, st));
-    MI_HIP(hipStreamSynchronize(st));
-}
-
-int32_t vs_ctx_create(Context &cx, const mi_kzg_vk *vk, const mi_vs_circuit_vk *circuits, size_t n_circuits,
-                             uint64_t *out) {
-    uint64_t id = g_vs_next++;
-    VsCtx &v = vs_ctxs()[id];
-    v.n_circuits = n_circuits;
-    v.vk = *vk;
-    void *dc = v.circuits.get(sizeof(mi_vs_circuit_vk) * n_circuits);
-    MI_HIP(hipMemcpyAsync(dc, circuits, sizeof(mi_vs_circuit_vk) * n_circuits, hipMemcpyHostToDevice, cx.stream));
-    upload_prepared(v.h_prep, &vk->h, cx.stream);
-    upload_prepared(v.tauh_prep, &vk->tau_h, cx.stream);
-    VsConsts hc;
+    memcpy(&qa, &vk->h, sizeof qa);
+    g2_prepare_host(v->h_prep, qa);
+    memcpy(&qa, &vk->tau_h, sizeof qa);
+    g2_prepare_host(v->tauh_prep, qa);
+    VsConsts &hc = v->consts;
     Fr w = host_omega(4);
     hc.omega16[0] = Fr::one();
     for (int k = 1; k < MI_VS_INPUTS; k++) hc.omega16[k] = mul(hc.omega16[k - 1], w);
@@ -262,24 +282,34 @@ int32_t vs_ctx_create(Context &cx, const mi_kzg_vk *vk, const mi_vs_circuit_vk *
         hc.tag[i] = ((uint32_t)(uint8_t)TAG[4 * i] << 24) | ((uint32_t)(uint8_t)TAG[4 * i + 1] << 16) |
                     ((uint32_t)(uint8_t)TAG[4 * i + 2] << 8) | (uint32_t)(uint8_t)TAG[4 * i + 3];
     memcpy(&hc.g, &vk->g, sizeof hc.g);
-    void *dk = v.consts.get(sizeof hc);
-    MI_HIP(hipMemcpyAsync(dk, &hc, sizeof hc, hipMemcpyHostToDevice, cx.stream));
-    MI_HIP(hipStreamSynchronize(cx.stream));
-    vs_pipe_init();
-    (void)pairing_consts(cx, cx.stream);  // upload the Frobenius table before any pipelined launch
-    *out = id;
+    {
+        std::lock_guard<std::mutex> lk(g_vs_mu);
+        v->id = g_vs_next++;
+        vs_ctxs()[v->id] = v;
+    }
+    (void)vs_keys(cx, *v);  // resident on the calling device now; on the others at their first batch
+    *out = v->id;
     return MI_OK;
 }
+// called once per device (capi.hip walks the device list); the master goes with the primary's call
 int32_t vs_ctx_destroy(Context &cx, uint64_t id) {
-    auto it = vs_ctxs().find(id);
-    if (it == vs_ctxs().end()) return MI_ERR_BAD_ARGS;
-    MI_HIP(hipStreamSynchronize(cx.stream));
-    vs_pipe_sync();  // nothing of this context's may still be running
-    VsPipe &pp = vs_pipe();
-    for (auto &a : pp.acc)
-        if (a.open && a.ctx == id && !a.closing) a.open = false;  // abandoned accumulations give their lanes back
-    vs_ctx_free(it->second);
-    vs_ctxs().erase(it);
+    std::shared_ptr<VsCtx> v = vs_find(id);
+    if (!v) return MI_ERR_BAD_ARGS;
+    VsKeyTable &t = cx.mod<VsKeyTable>("vs.keys");
+    auto it = t.of.find(id);
+    if (it != t.of.end()) {
+        MI_HIP(hipStreamSynchronize(cx.stream));
+        VsPipe &pp = vs_pipe(cx);
+        pp.sync();  // nothing of this verifier's may still be running here
+        for (auto &a : pp.acc)
+            if (a.open && a.ctx == id && !a.closing) a.open = false;  // abandoned accumulations give their lanes back
+        cx.lane_cv.notify_all();
+        t.of.erase(it);
+    }
+    if (cx.index == 0) {
+        std::lock_guard<std::mutex> lk(g_vs_mu);
+        vs_ctxs().erase(id);
+    }
     return MI_OK;
 }
 
@@ -546,15 +576,15 @@ struct VsWork {
     size_t n1, n2;
 };
 
-static VsWork vs_run_derive(Context &cx, VsCtx &v, const void *d_proofs, size_t n, const void *d_rand, hipStream_t st,
-                            int parity = 0) {
+static VsWork vs_run_derive(Context &cx, VsKeys &v, const void *d_proofs, size_t n, const void *d_rand, hipStream_t st,
+                            int lane) {
     VsWork w;
     w.n1 = n * VS_PER_PROOF_POINTS + v.n_circuits * MI_VS_VK_COMMS + 1;
     w.n2 = n * 2;
-    // every operand array exists twice (parity of the batch): two batches are in flight on different streams
+    // every operand array exists once per lane: several batches are in flight on different streams
     char nm[32];
     auto W = [&](const char *name) {
-        snprintf(nm, sizeof nm, "vs%d.%s", parity, name);
+        snprintf(nm, sizeof nm, "vs%d.%s", lane, name);
         return nm;
     };
     // one array for both MSMs' operands (H side first, tau-H side behind it): they run as ONE launch sequence
@@ -589,22 +619,35 @@ static G1Affine host_jac_to_affine_normalised(const mi_g1_jac &j) {
     return G1Affine{r.x, r.y};  // library outputs always carry z = 1
 }
 
+// handles and tickets name their device and their lane / slot: (sequence << 16) | (device index << 8) | lane
+static inline uint64_t vs_make_id(uint64_t seq, int dev_index, int unit) { return (seq << 16) | ((uint64_t)dev_index << 8) | (uint64_t)unit; }
+static void vs_release_lane(Context &cx, VsAcc &a) {
+    a.open = a.closing = false;
+    cx.lane_cv.notify_all();
+}
+
 // accumulate one shard: partial sums + algebraic failures (+ optional per-proof alg flags to host)
 // accumulate = begin (enqueue derive + both MSMs, no host synchronisation) + end (wait, fold on the host).
-// VS_ACC_DEPTH begin/end pairs may be open at once (lane p = handle & 0xff): every lane has its own stream
-// pair, device workspaces and pinned result buffers, so the next batches' kernels run while batch k is folded.
-static int32_t vs_accumulate_begin_impl(Context &cx, uint64_t ctx_id, VsCtx &v, const void *d_proofs, size_t n,
-                                        const void *d_rand, hipStream_t st, uint64_t *handle, VsWork *work_out) {
-    // any free lane (ends may complete out of order when several host threads fold); the handle names its lane
+// VS_ACC_DEPTH begin/end pairs may be open at once per device: every lane has its own stream, device workspaces and
+// pinned result buffers, so the next batches' kernels run while batch k is folded.  When every lane is taken the call
+// WAITS for one (the device lock is released meanwhile): a synchronous verify beside a saturated stream is late, not
+// refused.
+static int32_t vs_accumulate_begin_impl(Context &cx, const VsCtx &vc, const void *d_proofs, size_t n, const void *d_rand,
+                                        hipStream_t st, uint64_t *handle, VsWork *work_out) {
+    VsKeys &v = vs_keys(cx, vc);
+    VsPipe &pp = vs_pipe(cx);
     int par = -1;
-    VsPipe &pp = vs_pipe();
-    for (int p = 0; p < pp.lanes; p++)
-        if (!pp.acc[p].open) {
-            par = p;
-            break;
-        }
-    if (par < 0) return MI_ERR_BAD_ARGS;  // every lane is taken
-    const uint64_t hd = (pp.next_acc++ << 8) | (uint64_t)par;
+    for (;;) {
+        for (int p = 0; p < pp.lanes; p++)
+            if (!pp.acc[p].open) {
+                par = p;
+                break;
+            }
+        if (par >= 0) break;
+        if (!tl_ctx_lock) return MI_ERR_AGAIN;
+        cx.lane_cv.wait(*tl_ctx_lock);  // ends (any thread) and context destruction signal it
+    }
+    const uint64_t hd = vs_make_id(pp.next_acc++, cx.index, par);
     VsAcc &a = pp.acc[par];
     // Each lane has its own stream, so the next batches' derive and MSMs run beside this one's.  The inputs were
     // produced on the caller's stream: order ours behind it.
@@ -638,21 +681,21 @@ static int32_t vs_accumulate_begin_impl(Context &cx, uint64_t ctx_id, VsCtx &v, 
         msm_enqueue(cx, w.pts1, w.sc1, w.n1, sa, 254, 4 + 2 * par, &a.j1, 0, par);
         a.fused = false;
     }
-    st = sa;
     a.n = n;
-    a.st = st;
+    a.st = sa;
     a.handle = hd;
-    a.ctx = ctx_id;
+    a.ctx = vc.id;
     a.open = true;
     if (work_out) *work_out = w;
     *handle = hd;
     return MI_OK;
 }
-static int32_t vs_accumulate_end_impl(Context &cx, VsCtx &v, uint64_t handle, mi_vs_partial *out) {
-    if ((handle & 0xff) >= VS_ACC_DEPTH) return MI_ERR_BAD_ARGS;
-    VsAcc &a = vs_pipe().acc[handle & 0xff];
+// keep_lane: the caller goes on using the lane's workspaces (per-proof fallback) and releases it itself
+static int32_t vs_accumulate_end_impl(Context &cx, uint64_t handle, mi_vs_partial *out, bool keep_lane = false) {
+    if ((handle & 0xff) >= VS_ACC_DEPTH || (int)((handle >> 8) & 0xff) != cx.index) return MI_ERR_BAD_ARGS;
+    VsAcc &a = vs_pipe(cx).acc[handle & 0xff];
     if (!a.open || a.handle != handle || a.closing) return MI_ERR_BAD_ARGS;
-    a.closing = true;  // the lane stays taken until the fold is done; the context lock is not held meanwhile
+    a.closing = true;  // the lane stays taken until the fold is done; the device lock is not held meanwhile
     // host folds (~250 doublings + ~250 additions for 254-bit scalars, half that for the randomizer side), each
     // split over two pool threads
     uint64_t fails = 0;
@@ -666,52 +709,56 @@ static int32_t vs_accumulate_end_impl(Context &cx, VsCtx &v, uint64_t handle, mi
         }
         for (size_t i = 0; i < a.n; i++) fails += a.h_alg[i] ? 0 : 1;
     } catch (...) {
-        a.open = a.closing = false;
+        vs_release_lane(cx, a);
         throw;
     }
-    a.open = a.closing = false;
     out->n_proofs = a.n;
     out->n_alg_fail = fails;
+    if (keep_lane) a.closing = false;  // still open: nobody else can take it
+    else vs_release_lane(cx, a);
     return MI_OK;
-}
-static int32_t vs_accumulate_impl(Context &cx, uint64_t id, const void *d_proofs, size_t n, const void *d_rand,
-                                  mi_vs_partial *out, VsWork *work_out, hipStream_t st) {
-    auto it = vs_ctxs().find(id);
-    if (it == vs_ctxs().end()) return MI_ERR_BAD_ARGS;
-    uint64_t hd;
-    int32_t s = vs_accumulate_begin_impl(cx, id, it->second, d_proofs, n, d_rand, st, &hd, work_out);
-    if (s != MI_OK) return s;
-    return vs_accumulate_end_impl(cx, it->second, hd, out);
 }
 int32_t vs_accumulate_begin(Context &cx, uint64_t id, const void *d_proofs, size_t n, const void *d_rand, hipStream_t st,
                             uint64_t *handle) {
-    auto it = vs_ctxs().find(id);
-    if (it == vs_ctxs().end()) return MI_ERR_BAD_ARGS;
-    return vs_accumulate_begin_impl(cx, id, it->second, d_proofs, n, d_rand, st, handle, nullptr);
+    std::shared_ptr<VsCtx> v = vs_find(id);
+    if (!v) return MI_ERR_BAD_ARGS;
+    return vs_accumulate_begin_impl(cx, *v, d_proofs, n, d_rand, st, handle, nullptr);
 }
 int32_t vs_accumulate_end(Context &cx, uint64_t id, uint64_t handle, mi_vs_partial *out) {
-    auto it = vs_ctxs().find(id);
-    if (it == vs_ctxs().end()) return MI_ERR_BAD_ARGS;
-    return vs_accumulate_end_impl(cx, it->second, handle, out);
+    if (!vs_find(id)) return MI_ERR_BAD_ARGS;
+    return vs_accumulate_end_impl(cx, handle, out);
 }
-
 int32_t vs_accumulate_device(Context &cx, uint64_t id, const void *d_proofs, size_t n, const void *d_rand,
                              mi_vs_partial *out, hipStream_t st) {
-    return vs_accumulate_impl(cx, id, d_proofs, n, d_rand, out, nullptr, st);
+    std::shared_ptr<VsCtx> v = vs_find(id);
+    if (!v) return MI_ERR_BAD_ARGS;
+    uint64_t hd;
+    int32_t s = vs_accumulate_begin_impl(cx, *v, d_proofs, n, d_rand, st, &hd, nullptr);
+    if (s != MI_OK) return s;
+    return vs_accumulate_end_impl(cx, hd, out);
 }
 
-int32_t vs_finalize(Context &cx, uint64_t id, const mi_vs_partial *parts, size_t np, uint8_t *all_ok, hipStream_t st) {
-    auto it = vs_ctxs().find(id);
-    if (it == vs_ctxs().end()) return MI_ERR_BAD_ARGS;
-    VsCtx &v = it->second;
+// sum the shards' partials on the host: the two points of the pairing check and the count of algebraic failures
+static void vs_sum_partials(const mi_vs_partial *parts, size_t np, G1Affine ps[2], uint64_t *fails) {
     G1Xyzz tc = G1Xyzz::inf(), tw = G1Xyzz::inf();
-    uint64_t fails = 0;
+    uint64_t f = 0;
     for (size_t k = 0; k < np; k++) {
         tc = add_mixed(tc, host_jac_to_affine_normalised(parts[k].total_c));
         tw = add_mixed(tw, host_jac_to_affine_normalised(parts[k].total_w));
-        fails += parts[k].n_alg_fail;
+        f += parts[k].n_alg_fail;
     }
-    G1Affine ps[2] = {to_affine(tc), neg(to_affine(tw))};
+    ps[0] = to_affine(tc);
+    ps[1] = neg(to_affine(tw));
+    *fails = f;
+}
+
+int32_t vs_finalize(Context &cx, uint64_t id, const mi_vs_partial *parts, size_t np, uint8_t *all_ok, hipStream_t st) {
+    std::shared_ptr<VsCtx> vc = vs_find(id);
+    if (!vc) return MI_ERR_BAD_ARGS;
+    VsKeys &v = vs_keys(cx, *vc);
+    G1Affine ps[2];
+    uint64_t fails = 0;
+    vs_sum_partials(parts, np, ps, &fails);
     const G2Prepared *qs[2] = {(const G2Prepared *)v.h_prep.p, (const G2Prepared *)v.tauh_prep.p};
     Fq12 f;
     pairing_product_prepared(cx, ps, qs, 2, &f, st);
@@ -719,8 +766,8 @@ int32_t vs_finalize(Context &cx, uint64_t id, const mi_vs_partial *parts, size_t
     return MI_OK;
 }
 
-// pipelined finalize: sum the partials on the host, enqueue the pairing product on the context's own stream and
-// return a ticket; the caller goes on to accumulate the next batch while the product runs
+// pipelined finalize: sum the partials on the host, enqueue the pairing product on one of the device's product
+// streams and return a ticket; the caller goes on to accumulate the next batch while the product runs
 static int32_t vs_slot_wait(VsSlot &sl, uint8_t *all_ok) {
     {
         Unlocked unlocked;  // other threads keep enqueueing and folding while this one waits for the product
@@ -731,27 +778,23 @@ static int32_t vs_slot_wait(VsSlot &sl, uint8_t *all_ok) {
     return MI_OK;
 }
 int32_t vs_finalize_async(Context &cx, uint64_t id, const mi_vs_partial *parts, size_t np, uint64_t *ticket) {
-    auto it = vs_ctxs().find(id);
-    if (it == vs_ctxs().end()) return MI_ERR_BAD_ARGS;
-    VsCtx &v = it->second;
+    std::shared_ptr<VsCtx> vc = vs_find(id);
+    if (!vc) return MI_ERR_BAD_ARGS;
+    VsKeys &v = vs_keys(cx, *vc);
+    VsPipe &pp = vs_pipe(cx);
     int slot = -1;
-    for (int i = 0; i < vs_pipe().nslots; i++)
-        if (!vs_pipe().slots[i].busy) {
+    for (int i = 0; i < pp.nslots; i++)
+        if (!pp.slots[i].busy) {
             slot = i;
             break;
         }
-    if (slot < 0) return MI_ERR_BAD_ARGS;  // VS_SLOTS products in flight: wait for a ticket first
-    const uint64_t tk = (vs_pipe().next_ticket++ << 8) | (uint64_t)slot;  // the ticket names its slot
-    VsSlot &sl = vs_pipe().slots[slot];
+    if (slot < 0) return MI_ERR_AGAIN;  // every product stream is busy: wait for a ticket first
+    const uint64_t tk = vs_make_id(pp.next_ticket++, cx.index, slot);
+    VsSlot &sl = pp.slots[slot];
     HostSpan hs("finalize_async");
-    G1Xyzz tc = G1Xyzz::inf(), tw = G1Xyzz::inf();
+    G1Affine ps[2];
     uint64_t fails = 0;
-    for (size_t k = 0; k < np; k++) {
-        tc = add_mixed(tc, host_jac_to_affine_normalised(parts[k].total_c));
-        tw = add_mixed(tw, host_jac_to_affine_normalised(parts[k].total_w));
-        fails += parts[k].n_alg_fail;
-    }
-    G1Affine ps[2] = {to_affine(tc), neg(to_affine(tw))};
+    vs_sum_partials(parts, np, ps, &fails);
     const G2Prepared *qs[2] = {(const G2Prepared *)v.h_prep.p, (const G2Prepared *)v.tauh_prep.p};
     pairing_launch(cx, ps, qs, 2, sl.h_out, sl.stream);  // the kernel stores its result in pinned host memory
     MI_HIP(hipEventRecord(sl.done, sl.stream));
@@ -762,42 +805,179 @@ int32_t vs_finalize_async(Context &cx, uint64_t id, const mi_vs_partial *parts, 
     return MI_OK;
 }
 int32_t vs_finalize_wait(Context &cx, uint64_t id, uint64_t ticket, uint8_t *all_ok) {
-    (void)cx;
-    auto it = vs_ctxs().find(id);
-    if (it == vs_ctxs().end()) return MI_ERR_BAD_ARGS;
-    if ((ticket & 0xff) >= VS_SLOTS) return MI_ERR_BAD_ARGS;
-    VsSlot &sl = vs_pipe().slots[ticket & 0xff];
+    if (!vs_find(id)) return MI_ERR_BAD_ARGS;
+    if ((ticket & 0xff) >= VS_SLOTS || (int)((ticket >> 8) & 0xff) != cx.index) return MI_ERR_BAD_ARGS;
+    VsSlot &sl = vs_pipe(cx).slots[ticket & 0xff];
     if (!sl.busy || sl.ticket != ticket) return MI_ERR_BAD_ARGS;
     return vs_slot_wait(sl, all_ok);
 }
 
-int32_t vs_verify_batch_device(Context &cx, uint64_t id, const void *d_proofs, size_t n, const void *d_rand,
-                                      uint8_t *verdicts, uint8_t *all_ok, hipStream_t st) {
-    mi_vs_partial part;
-    VsWork w;
-    int32_t s = vs_accumulate_impl(cx, id, d_proofs, n, d_rand, &part, &w, st);
-    if (s != MI_OK) return s;
-    s = vs_finalize(cx, id, &part, 1, all_ok, st);
-    if (s != MI_OK) return s;
-    if (*all_ok) {
-        memset(verdicts, 1, n);
-        return MI_OK;
-    }
-    // aggregate check failed: check every proof on its own to name the invalid ones
-    VsCtx &v = vs_ctxs()[id];
-    G1Xyzz *terms = (G1Xyzz *)cx.buf("vs.terms", sizeof(G1Xyzz) * n * VS_TERMS);
-    uint8_t *d_verdicts = (uint8_t *)cx.buf("vs.verdicts", n);
+// name the invalid proofs of a batch whose aggregate check failed: every proof on its own, on the lane's stream and
+// workspaces (the lane is still held by the caller)
+static void vs_identify(Context &cx, VsKeys &v, const VsWork &w, size_t n, int lane, hipStream_t st, uint8_t *verdicts) {
+    char nm[32];
+    snprintf(nm, sizeof nm, "vs%d.terms", lane);
+    G1Xyzz *terms = (G1Xyzz *)cx.buf(nm, sizeof(G1Xyzz) * n * VS_TERMS);
+    snprintf(nm, sizeof nm, "vs%d.verdicts", lane);
+    uint8_t *d_verdicts = (uint8_t *)cx.buf(nm, n);
     hipLaunchKernelGGL(vs_terms_kernel, dim3(cdiv(n * VS_TERMS, 128)), dim3(128), 0, st, n, w.pts1, w.sc1, w.sc2, w.vk_scal,
                        w.g_scal, w.circuit_of, (const mi_vs_circuit_vk *)v.circuits.p, (const VsConsts *)v.consts.p, terms);
     hipLaunchKernelGGL(vs_per_proof_pairing_kernel, dim3((unsigned)n), dim3(PW_THREADS), 0, st, n, terms,
                        (const G2Prepared *)v.h_prep.p, (const G2Prepared *)v.tauh_prep.p, pairing_consts(cx, st), w.alg_ok,
                        d_verdicts);
     MI_HIP(hipGetLastError());
-    uint8_t *h = (uint8_t *)cx.pin(n);
+    snprintf(nm, sizeof nm, "vs.verdict_pin%d", lane);
+    uint8_t *h = (uint8_t *)cx.pin_named(nm, n);
     MI_HIP(hipMemcpyAsync(h, d_verdicts, n, hipMemcpyDeviceToHost, st));
-    MI_HIP(hipStreamSynchronize(st));
+    {
+        Unlocked unlocked;
+        MI_HIP(hipStreamSynchronize(st));
+    }
     memcpy(verdicts, h, n);
-    return MI_OK;
+}
+
+int32_t vs_verify_batch_device(Context &cx, uint64_t id, const void *d_proofs, size_t n, const void *d_rand,
+                               uint8_t *verdicts, uint8_t *all_ok, hipStream_t st) {
+    std::shared_ptr<VsCtx> vc = vs_find(id);
+    if (!vc) return MI_ERR_BAD_ARGS;
+    mi_vs_partial part;
+    VsWork w;
+    uint64_t hd;
+    int32_t s = vs_accumulate_begin_impl(cx, *vc, d_proofs, n, d_rand, st, &hd, &w);
+    if (s != MI_OK) return s;
+    // the lane (its stream and workspaces: w points into them) stays ours until the verdicts are known
+    s = vs_accumulate_end_impl(cx, hd, &part, true);
+    if (s != MI_OK) return s;
+    VsAcc &a = vs_pipe(cx).acc[hd & 0xff];
+    try {
+        s = vs_finalize(cx, id, &part, 1, all_ok, a.st);
+        if (s == MI_OK) {
+            if (*all_ok) memset(verdicts, 1, n);
+            else vs_identify(cx, vs_keys(cx, *vc), w, n, (int)(hd & 0xff), a.st, verdicts);  // aggregate check failed
+        }
+    } catch (...) {
+        vs_release_lane(cx, a);
+        throw;
+    }
+    vs_release_lane(cx, a);
+    return s;
+}
+
+// ---------------------------------------------------------------- one block over all devices of the process
+// SURVEY.md 8e inside ONE process (the reference node is one process: reference cli/src/commands/start.rs:616-642,
+// the verifier is entered from Consensus::try_advance_to_next_block, reference node/consensus/src/lib.rs:499): the
+// block's proofs are cut into contiguous shards, one host thread per device stages and accumulates its shard
+// (derive + both MSMs + host fold -> one 304-byte partial), the partials are all-gathered over RCCL (one grouped
+// ncclAllGather over the devices' communicators; on the host when RCCL is not available: they are host values), the
+// primary device runs the single pairing product, and only if that fails every device names the invalid proofs of
+// its own shard.
+struct VsShardJob {
+    Context *cx = nullptr;
+    const void *proofs = nullptr, *rand = nullptr;
+    size_t n = 0, first = 0;  // first: index of the shard's first proof in the block
+    uint64_t handle = 0;
+    bool lane_held = false;
+    VsWork w;
+    mi_vs_partial part;
+    int32_t status = MI_OK;
+};
+int32_t vs_verify_block(uint64_t id, const void *const *proofs, const void *const *rand, const size_t *n_per_shard,
+                        int n_shards, bool device_ptrs, uint8_t *verdicts, uint8_t *all_ok) {
+    std::shared_ptr<VsCtx> vc = vs_find(id);
+    if (!vc) return MI_ERR_BAD_ARGS;
+    std::vector<VsShardJob> jobs;
+    size_t total = 0;
+    for (int s = 0; s < n_shards; s++) {
+        if (n_per_shard[s] == 0) {
+            continue;  // fewer proofs than devices
+        }
+        VsShardJob j;
+        j.proofs = proofs[s];
+        j.rand = rand[s];
+        j.n = n_per_shard[s];
+        j.first = total;
+        j.cx = device_ptrs ? context_of_ptr(proofs[s]) : context_at(s);
+        if (!j.cx) return MI_ERR_NO_DEVICE;
+        total += j.n;
+        jobs.push_back(j);
+    }
+    if (jobs.empty()) return MI_ERR_BAD_ARGS;
+    for (size_t a = 0; a < jobs.size(); a++)
+        for (size_t b = 0; b < a; b++)
+            if (jobs[a].cx == jobs[b].cx && !device_ptrs) return MI_ERR_BAD_ARGS;
+    auto on_all = [&](const std::function<void(VsShardJob &)> &f) {  // one host thread per shard beyond the first
+        std::vector<std::thread> th;
+        for (size_t k = 1; k < jobs.size(); k++) th.emplace_back([&, k] { f(jobs[k]); });
+        f(jobs[0]);
+        for (auto &t : th) t.join();
+    };
+    auto release = [&](VsShardJob &j) {
+        if (!j.lane_held) return;
+        (void)guarded_on(j.cx, [&](Context &cx) -> int32_t {
+            vs_release_lane(cx, vs_pipe(cx).acc[j.handle & 0xff]);
+            return MI_OK;
+        });
+        j.lane_held = false;
+    };
+    // ---- phase 1: every shard's partial accumulator
+    on_all([&](VsShardJob &j) {
+        j.status = guarded_on(j.cx, [&](Context &cx) -> int32_t {
+            const void *dp = j.proofs, *dr = j.rand;
+            hipStream_t st = cx.stream;
+            if (!device_ptrs) {
+                void *p = cx.buf("blk.in_proofs", sizeof(mi_vs_proof) * j.n);
+                void *r = cx.buf("blk.in_rand", 32 * j.n);
+                MI_HIP(hipMemcpyAsync(p, j.proofs, sizeof(mi_vs_proof) * j.n, hipMemcpyHostToDevice, st));
+                MI_HIP(hipMemcpyAsync(r, j.rand, 32 * j.n, hipMemcpyHostToDevice, st));
+                dp = p;
+                dr = r;
+            }
+            int32_t s = vs_accumulate_begin_impl(cx, *vc, dp, j.n, dr, st, &j.handle, &j.w);
+            if (s != MI_OK) return s;
+            j.lane_held = true;
+            s = vs_accumulate_end_impl(cx, j.handle, &j.part, true);
+            if (s != MI_OK) j.lane_held = false;  // the end released it
+            return s;
+        });
+    });
+    int32_t status = MI_OK;
+    for (auto &j : jobs)
+        if (j.status != MI_OK) status = j.status;
+    // ---- the exchange: all shards' partials to the primary (RCCL all-gather; host values if there is no RCCL)
+    std::vector<mi_vs_partial> parts(jobs.size());
+    if (status == MI_OK) {
+        bool gathered = false;
+        std::shared_ptr<Comm> comm = jobs.size() > 1 && !device_ptrs ? comm_local() : nullptr;
+        if (comm && (int)jobs.size() == n_contexts()) {
+            std::vector<const void *> mine(jobs.size());
+            std::vector<void *> all(jobs.size(), nullptr);
+            for (size_t k = 0; k < jobs.size(); k++) mine[jobs[k].cx->index] = &jobs[k].part;
+            all[0] = parts.data();  // the primary's copy is the one that is used
+            gathered = comm_all_gather(*comm, mine.data(), sizeof(mi_vs_partial), all.data()) == MI_OK;
+        }
+        if (!gathered)
+            for (size_t k = 0; k < jobs.size(); k++) parts[k] = jobs[k].part;
+        // ---- the single pairing product
+        status = guarded([&](Context &cx) -> int32_t { return vs_finalize(cx, id, parts.data(), parts.size(), all_ok, cx.stream); });
+    }
+    // ---- phase 2, only when the aggregate failed: every device names the invalid proofs of its shard
+    if (status == MI_OK) {
+        if (*all_ok) {
+            memset(verdicts, 1, total);
+        } else {
+            on_all([&](VsShardJob &j) {
+                j.status = guarded_on(j.cx, [&](Context &cx) -> int32_t {
+                    VsAcc &a = vs_pipe(cx).acc[j.handle & 0xff];
+                    vs_identify(cx, vs_keys(cx, *vc), j.w, j.n, (int)(j.handle & 0xff), a.st, verdicts + j.first);
+                    return MI_OK;
+                });
+            });
+            for (auto &j : jobs)
+                if (j.status != MI_OK) status = j.status;
+        }
+    }
+    for (auto &j : jobs) release(j);
+    return status;
 }
 
 // ---------------------------------------------------------------- KZG10::batch_check

@@ -13,6 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmi355x_snark.so")
 
 MI_OK = 0
+MI_ERR_NO_DEVICE = -2
 MI_ERR_KERNEL = -4
 MI_ERR_AGAIN = -6
 MI_ERR_DONE = -7
@@ -32,14 +33,17 @@ VS_MAX_TICKETS = 8
 
 # every symbol include/mi355x_snark.h declares
 EXPORTS = [
-    "mi_init", "mi_shutdown", "mi_error_string", "mi_abi_version",
+    "mi_init", "mi_device_count", "mi_device_id", "mi_shutdown", "mi_error_string", "mi_abi_version",
     "mi_msm_g1", "mi_msm_g1_device", "mi_g1_sum", "mi_bases_register", "mi_bases_release", "mi_msm_g1_h",
     "mi_ntt_fr", "mi_ntt_fr_device", "mi_kzg_commit_h", "mi_kzg_commit_h_device", "mi_kzg_open_h", "mi_poly_mul_fr",
     "mi_pairing_product_is_one", "mi_pairing", "mi_kzg_batch_check",
     "mi_poseidon_fq_hash_many", "mi_poseidon_fq_hash_many_device",
     "mi_vs_ctx_create", "mi_vs_ctx_destroy", "mi_vs_verify_batch", "mi_vs_verify_batch_device",
     "mi_vs_accumulate_device", "mi_vs_accumulate_begin", "mi_vs_accumulate_end", "mi_vs_finalize", "mi_vs_finalize_async", "mi_vs_finalize_wait",
+    "mi_vs_verify_block", "mi_vs_verify_block_device",
     "mi_vs_stream_open", "mi_vs_stream_submit", "mi_vs_stream_finish", "mi_vs_stream_next", "mi_vs_stream_close",
+    "mi_comm_unique_id", "mi_comm_init_rank", "mi_comm_init_local", "mi_comm_world", "mi_comm_destroy", "mi_comm_all_gather",
+    "mi_vs_exchange_rccl",
     "mi_dbg_fq_mul", "mi_dbg_fr_mul", "mi_dbg_g1_add", "mi_dbg_fq_mul_throughput", "mi_dbg_gen_points_device",
     "mi_prof_enable", "mi_prof_read",
 ]
@@ -84,6 +88,17 @@ def lib():
         l.mi_vs_stream_finish.argtypes = [C.c_uint64]
         l.mi_vs_stream_close.argtypes = [C.c_uint64]
         l.mi_error_string.argtypes = [C.c_int32]
+        l.mi_init.argtypes = [C.POINTER(C.c_int32), C.c_int32]
+        l.mi_device_id.argtypes = [C.c_int32]
+        l.mi_comm_unique_id.argtypes = [C.c_void_p]
+        l.mi_comm_init_rank.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.POINTER(C.c_uint64)]
+        l.mi_comm_init_local.argtypes = [C.POINTER(C.c_uint64)]
+        l.mi_comm_world.argtypes = [C.c_uint64]
+        l.mi_comm_destroy.argtypes = [C.c_uint64]
+        l.mi_comm_all_gather.argtypes = [C.c_uint64, C.c_void_p, C.c_size_t, C.c_void_p]
+        l.mi_vs_verify_block.argtypes = [C.c_uint64, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p]
+        l.mi_vs_verify_block_device.argtypes = [C.c_uint64, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_size_t),
+                                                C.c_int32, C.c_void_p, C.c_void_p]
         _LIB = l
     return _LIB
 
@@ -117,8 +132,42 @@ def stream_ptr(stream=None):
     return C.c_void_p(s.cuda_stream)
 
 
-def init(device=-1):
-    check(lib().mi_init(C.c_int32(device)), "mi_init")
+def init(devices=None):
+    """mi_init(device_ids, n): `devices` = None (the current HIP device), one ordinal, or a list whose first entry
+    becomes the primary device.  Idempotent; later calls may add devices."""
+    if devices is None or (isinstance(devices, int) and devices < 0):
+        check(lib().mi_init(None, 0), "mi_init")
+        return
+    ids = [int(devices)] if isinstance(devices, int) else [int(d) for d in devices]
+    arr = (C.c_int32 * len(ids))(*ids)
+    check(lib().mi_init(arr, len(ids)), "mi_init")
+
+
+def device_count():
+    return int(lib().mi_device_count())
+
+
+COMM_ID_BYTES = 128
+
+
+def comm_unique_id():
+    """128 opaque bytes to hand to every rank (mi_comm_unique_id); raises MiError(MI_ERR_NO_DEVICE) without RCCL."""
+    buf = (C.c_uint8 * COMM_ID_BYTES)()
+    check(lib().mi_comm_unique_id(buf), "mi_comm_unique_id")
+    return bytes(buf)
+
+
+def comm_init_rank(uid, rank, world):
+    """Collective: every rank calls it with rank 0's id.  Returns the communicator handle."""
+    assert len(uid) == COMM_ID_BYTES
+    h = C.c_uint64(0)
+    buf = (C.c_uint8 * COMM_ID_BYTES).from_buffer_copy(uid)
+    check(lib().mi_comm_init_rank(buf, C.c_int32(rank), C.c_int32(world), C.byref(h)), "mi_comm_init_rank")
+    return h.value
+
+
+def comm_destroy(comm):
+    check(lib().mi_comm_destroy(C.c_uint64(comm)), "mi_comm_destroy")
 
 
 def shutdown():

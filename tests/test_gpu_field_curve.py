@@ -99,3 +99,52 @@ def test_entry_points_are_thread_safe(orc, mi):
     for t in threads:
         t.join()
     assert not errors, errors
+
+
+def test_device_entry_points_on_two_streams_from_two_threads(orc, mi):
+    """the asynchronous `_device` entry points leave their kernels running on the CALLER's stream: two host threads on
+    two streams must not share scratch (round 1's name-keyed "ntt.tmp" did), whatever the order of sizes -- a larger
+    transform arriving while a smaller one is in flight regrows nothing that is in use.  Bit-exact against the oracle;
+    an MSM on a third stream runs beside them."""
+    import threading
+    import torch
+    from helpers import jac_affine, rng_fr_mont
+    sizes = [12, 16, 10, 17, 9, 14]
+    data = {lg: rng_fr_mont(900 + lg, 1 << lg) for lg in set(sizes)}
+    want = {lg: orc.ntt(data[lg], threads=4) for lg in data}
+    bases, scalars = rng_points(91, 3000), rng_scalars(92, 3000)
+    want_msm = orc.msm_pippenger(bases, scalars, threads=4)
+    d_bases, d_scalars = torch.from_numpy(bases).cuda(), torch.from_numpy(scalars.view(np.int64)).cuda()
+    errors = []
+
+    def ntt_worker(order):
+        try:
+            st = torch.cuda.Stream()
+            with torch.cuda.stream(st):
+                bufs = []
+                for rep in range(3):
+                    for lg in order:
+                        t = torch.from_numpy(data[lg].view(np.int64)).cuda()
+                        mi.EvaluationDomain(1 << lg).fft(t, stream=st)  # returns with the passes still in flight
+                        bufs.append((lg, t))
+                st.synchronize()
+                for lg, t in bufs:
+                    assert (t.cpu().numpy().view(np.uint64) == want[lg]).all(), lg
+        except Exception as e:  # noqa: BLE001
+            errors.append(repr(e))
+
+    def msm_worker():
+        try:
+            st = torch.cuda.Stream()
+            for _ in range(4):
+                assert (jac_affine(mi.VariableBase.msm(d_bases, d_scalars, stream=st)) == want_msm).all()
+        except Exception as e:  # noqa: BLE001
+            errors.append(repr(e))
+
+    threads = [threading.Thread(target=ntt_worker, args=(sizes,)), threading.Thread(target=ntt_worker, args=(sizes[::-1],)),
+               threading.Thread(target=msm_worker)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors

@@ -174,3 +174,45 @@ def test_msm_2_21_exact_by_known_discrete_logs(orc, mi):
         s = lim[i, 0] | (lim[i, 1] << 64) | (lim[i, 2] << 128) | (lim[i, 3] << 192)
         t += s * (splitmix(seed + i) | 1)
     assert (got == orc.g1_mul(orc.g1_generator(), t % pyref.R)).all()
+
+
+def _uniform_scalars(seed, n):
+    """canonical scalars uniform in [0, r), (n, 4) uint64: rejection sampling on 253 bits"""
+    import pyref
+    g = np.random.default_rng(seed)
+    out = np.zeros((n, 4), dtype=np.uint64)
+    r_limbs = [(pyref.R >> (64 * k)) & ((1 << 64) - 1) for k in range(4)]
+    todo = np.arange(n)
+    while len(todo):
+        a = g.integers(0, 1 << 63, size=(len(todo), 4), dtype=np.uint64) * np.uint64(2) + g.integers(0, 2, size=(len(todo), 4), dtype=np.uint64)
+        a[:, 3] &= np.uint64((1 << 61) - 1)  # 253 bits
+        lt = np.zeros(len(todo), dtype=bool)
+        eq = np.ones(len(todo), dtype=bool)
+        for k in (3, 2, 1, 0):
+            lt |= eq & (a[:, k] < np.uint64(r_limbs[k]))
+            eq &= a[:, k] == np.uint64(r_limbs[k])
+        out[todo[lt]] = a[lt]
+        todo = todo[~lt]
+    return out
+
+
+@pytest.mark.parametrize("log_n", [15, 17, 18, 20])
+def test_msm_full_range_scalars_large_path(orc, mi, log_n):
+    """scalars uniform in [0, r) -- a 253-bit top digit in the last window -- with r - 1, r - 2, 2^252 and the window
+    boundaries planted, on both MSM paths (2^15: small / per-bit; 2^17..2^20: tiled-histogram large path, one and two
+    bits of window-width bias).  Bit-exact against the oracle's Pippenger."""
+    import pyref
+    n = 1 << log_n
+    small = rng_points(300 + log_n, 1 << 12)
+    bases = np.tile(small, (n >> 12, 1))
+    scalars = _uniform_scalars(400 + log_n, n)
+    assert (scalars[:, 3] >> np.uint64(60)).any()  # the 253rd bit is in use
+    plant = [pyref.R - 1, pyref.R - 2, 1 << 252, (1 << 252) - 1, pyref.R >> 1, (1 << 253) - (1 << 200)]
+    for c in (13, 14, 15, 16, 17):  # every window at its extreme digits for the widths the planner may pick
+        plant.append(sum(((1 << (c - 1)) << (c * w)) for w in range(253 // c)) % pyref.R)
+        plant.append(sum((((1 << c) - 1) << (c * w)) for w in range(253 // c)) % pyref.R)
+    for k, x in enumerate(plant):
+        scalars[(k * 7919) % n] = orc.int_to_limbs(x % pyref.R, 4)
+    got = jac_affine(mi.VariableBase.msm(bases, scalars))
+    want = orc.msm_pippenger(bases, scalars, threads=16)
+    assert (got == want).all()

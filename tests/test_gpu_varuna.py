@@ -134,10 +134,18 @@ def test_pipeline_lanes_out_of_order_and_threads(orc, mi):
         want_good = as_bytes(orc.vs_partial_from_oracle(good, threads=8))
         want_bad = as_bytes(orc.vs_partial_from_oracle(orc.VSArrays(good.vk, good.circuits, bad_np, good.randomizers), threads=8))
         from snarkos_amd.lib import VS_DEFAULT_LANES
+        import time
         hs = [v.accumulate_begin(bp if k == 5 else gp, gr) for k in range(VS_DEFAULT_LANES)]
-        with pytest.raises(MiError):
-            v.accumulate_begin(gp, gr)  # all lanes taken
-        for h in hs[8:]:
+        # all lanes taken: one more begin WAITS for a lane (round 1 refused it) and goes through once one is ended
+        late = {}
+        waiter = threading.Thread(target=lambda: late.setdefault("h", v.accumulate_begin(gp, gr)))
+        waiter.start()
+        time.sleep(0.3)
+        assert waiter.is_alive() and "h" not in late
+        assert (v.accumulate_end(hs[8]) == want_good).all()
+        waiter.join(30)
+        assert not waiter.is_alive() and (v.accumulate_end(late["h"]) == want_good).all()
+        for h in hs[9:]:
             assert (v.accumulate_end(h) == want_good).all()
         got = {}
 
