@@ -757,6 +757,7 @@ void msm_enqueue(Context &cx, const G1Affine *d_points, const uint32_t *d_scalar
     if (problems == 1) split = n;
     job->problems = problems;
     cx.prof.begin("msm_total", st, n);
+    HostSpan hs_bufs("msm.enqueue_all");
     const size_t nb = (size_t)problems * pl.nwin * pl.B;  // all buckets (both problems' windows)
     const int vwin = problems * pl.nwin;
     int32_t *digits = (int32_t *)cx.buf(W("digits"), sizeof(int32_t) * n * pl.nwin);

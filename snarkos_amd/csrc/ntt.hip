@@ -378,7 +378,7 @@ void ntt_device(Context &cx, Fr *d_data, uint32_t log_n, bool inverse, bool cose
         // The Stockham twin.  This call may return with its passes still running on the caller's stream (the
         // `_device` entry point), and the next call may come on another stream: every call takes a buffer that no
         // in-flight transform is using (event-guarded pool), never a name-keyed workspace.
-        ScratchPool::Entry *scr = cx.scratch.acquire(sizeof(Fr) * n);
+        ScratchPool::Entry *scr = cx.scratch.acquire(sizeof(Fr) * n, st);
         Fr *tmp = (Fr *)scr->buf.p;
         // split log_n into passes of at most 4 bits, an even number of them when log_n >= 2
         int npass = (int)(log_n + 3) / 4;

@@ -89,84 +89,6 @@ inline WorkerPool &worker_pool() {
     return p;
 }
 
-// A grow-only device buffer (no hipMalloc on the steady-state path).
-// Lifetime rule (DESIGN.md "Workspace lifetime"): a regrow never frees memory that enqueued work may still touch --
-// it drains the device first (regrows are rare: first call, or a larger problem than ever before).  Buffers that an
-// asynchronous entry point leaves in flight on a CALLER's stream must not be name-keyed at all: they come from a
-// ScratchPool (below), whose entries are guarded by an event.
-struct DevBuf {
-    void *p = nullptr;
-    size_t cap = 0;
-    uint64_t gen = 0;  // bumped by every (re)allocation: content-carrying users compare it
-    void *get(size_t bytes) {
-        if (bytes > cap) {
-            gen++;
-            if (p) {
-                MI_HIP(hipDeviceSynchronize());  // nothing enqueued earlier, on any stream, may still use the old block
-                MI_HIP(hipFree(p));
-            }
-            p = nullptr;
-            cap = 0;
-            size_t want = bytes + bytes / 8 + 256;
-            MI_HIP(hipMalloc(&p, want));
-            cap = want;
-        }
-        return p;
-    }
-    void release() {
-        if (p) {
-            (void)hipDeviceSynchronize();
-            (void)hipFree(p);
-        }
-        p = nullptr;
-        cap = 0;
-    }
-};
-
-// Scratch buffers for entry points that return while their kernels are still running on the caller's stream
-// (mi_ntt_fr_device): every acquisition gets a buffer no other in-flight call is using.  An entry is reusable once
-// the event recorded after its last user's final kernel has completed; a regrow of such an entry is then safe.
-struct ScratchPool {
-    struct Entry {
-        DevBuf buf;
-        hipEvent_t done = nullptr;
-        bool used = false;  // `done` has been recorded at least once
-    };
-    std::vector<std::unique_ptr<Entry>> entries;
-    // returns an idle entry holding >= bytes (the context lock is held by the caller)
-    Entry *acquire(size_t bytes) {
-        Entry *pick = nullptr;
-        for (auto &e : entries) {
-            if (e->used && hipEventQuery(e->done) != hipSuccess) continue;  // still in flight
-            if (!pick || (e->buf.cap >= bytes && (pick->buf.cap < bytes || e->buf.cap < pick->buf.cap))) pick = e.get();
-        }
-        if (!pick) {
-            if (entries.size() >= 16) {  // bound the pool: wait for the oldest user instead of growing without limit
-                pick = entries.front().get();
-                MI_HIP(hipEventSynchronize(pick->done));
-            } else {
-                entries.emplace_back(new Entry());
-                pick = entries.back().get();
-                MI_HIP(hipEventCreateWithFlags(&pick->done, hipEventDisableTiming));
-            }
-        }
-        pick->buf.get(bytes);
-        return pick;
-    }
-    // call after the last kernel that touches the entry has been enqueued on `st`
-    static void release(Entry *e, hipStream_t st) {
-        MI_HIP(hipEventRecord(e->done, st));
-        e->used = true;
-    }
-    void free_all() {
-        for (auto &e : entries) {
-            e->buf.release();
-            if (e->done) (void)hipEventDestroy(e->done);
-        }
-        entries.clear();
-    }
-};
-
 // Host-side wall-clock accounting of code sections (MI_SNARK_HOSTPROF=1; report on stderr at mi_shutdown / exit).
 struct HostProf {
     struct Acc { double s = 0; uint64_t n = 0; };
@@ -202,6 +124,92 @@ struct HostSpan {
         auto &a = host_prof().acc[name];
         a.s += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
         a.n++;
+    }
+};
+
+// A grow-only device buffer (no hipMalloc on the steady-state path).
+// Lifetime rule (DESIGN.md "Workspace lifetime"): a regrow never frees memory that enqueued work may still touch --
+// it drains the device first (regrows are rare: first call, or a larger problem than ever before).  Buffers that an
+// asynchronous entry point leaves in flight on a CALLER's stream must not be name-keyed at all: they come from a
+// ScratchPool (below), whose entries are guarded by an event.
+struct DevBuf {
+    void *p = nullptr;
+    size_t cap = 0;
+    uint64_t gen = 0;  // bumped by every (re)allocation: content-carrying users compare it
+    void *get(size_t bytes) {
+        if (bytes > cap) {
+            HostSpan hs(p ? "devbuf.regrow" : "devbuf.alloc");
+            gen++;
+            if (p) {
+                MI_HIP(hipDeviceSynchronize());  // nothing enqueued earlier, on any stream, may still use the old block
+                MI_HIP(hipFree(p));
+            }
+            p = nullptr;
+            cap = 0;
+            size_t want = bytes + bytes / 8 + 256;
+            MI_HIP(hipMalloc(&p, want));
+            cap = want;
+        }
+        return p;
+    }
+    void release() {
+        if (p) {
+            (void)hipDeviceSynchronize();
+            (void)hipFree(p);
+        }
+        p = nullptr;
+        cap = 0;
+    }
+};
+
+// Scratch buffers for entry points that return while their kernels are still running on the caller's stream
+// (mi_ntt_fr_device): every acquisition gets a buffer no other in-flight call is using.  An entry is reusable once
+// the event recorded after its last user's final kernel has completed; a regrow of such an entry is then safe.
+struct ScratchPool {
+    struct Entry {
+        DevBuf buf;
+        hipEvent_t done = nullptr;
+        hipStream_t last = nullptr;  // the stream of the last user
+        bool used = false;           // `done` has been recorded at least once
+    };
+    std::vector<std::unique_ptr<Entry>> entries;
+    // returns an entry holding >= bytes that the new user may write as soon as its kernels run on `st`: one whose last
+    // user ran on the same stream (stream order does the rest), or one whose last user has finished (the context lock
+    // is held by the caller)
+    Entry *acquire(size_t bytes, hipStream_t st) {
+        Entry *pick = nullptr;
+        for (auto &e : entries)
+            if (e->used && e->last == st && (!pick || (e->buf.cap >= bytes && pick->buf.cap < bytes))) pick = e.get();
+        if (!pick)
+            for (auto &e : entries) {
+                if (e->used && hipEventQuery(e->done) != hipSuccess) continue;  // in flight on another stream
+                if (!pick || (e->buf.cap >= bytes && (pick->buf.cap < bytes || e->buf.cap < pick->buf.cap))) pick = e.get();
+            }
+        if (!pick) {
+            if (entries.size() >= 16) {  // bound the pool: wait for the oldest user instead of growing without limit
+                pick = entries.front().get();
+                MI_HIP(hipEventSynchronize(pick->done));
+            } else {
+                entries.emplace_back(new Entry());
+                pick = entries.back().get();
+                MI_HIP(hipEventCreateWithFlags(&pick->done, hipEventDisableTiming));
+            }
+        }
+        pick->buf.get(bytes);
+        return pick;
+    }
+    // call after the last kernel that touches the entry has been enqueued on `st`
+    static void release(Entry *e, hipStream_t st) {
+        MI_HIP(hipEventRecord(e->done, st));
+        e->last = st;
+        e->used = true;
+    }
+    void free_all() {
+        for (auto &e : entries) {
+            e->buf.release();
+            if (e->done) (void)hipEventDestroy(e->done);
+        }
+        entries.clear();
     }
 };
 
@@ -370,7 +378,12 @@ template <class F>
 int32_t guarded_ptr(const void *device_ptr, F &&f) {
     const int32_t s = ensure_init();
     if (s != MI_OK) return s;
-    return guarded_on(context_of_ptr(device_ptr), std::forward<F>(f));
+    Context *cx;
+    {
+        HostSpan hs("route.ptr");
+        cx = context_of_ptr(device_ptr);
+    }
+    return guarded_on(cx, std::forward<F>(f));
 }
 
 inline unsigned cdiv(size_t a, size_t b) { return (unsigned)((a + b - 1) / b); }

@@ -181,6 +181,7 @@ struct VsPipe {
     hipEvent_t acc_ev[VS_ACC_DEPTH] = {};
     VsSlot slots[VS_SLOTS];  // pairing products run on the slots' streams, beside the next batches' accumulation
     uint64_t next_acc = 2, next_ticket = 1;
+    bool primed = false;  // every lane has run one accumulation (workspaces, pinned buffers, hardware queues exist)
     VsPipe() {  // the device is current (Context::mod is only called under guarded_on)
         if (const char *e = getenv("MI_SNARK_VS_LANES")) {
             const int x = atoi(e);
@@ -200,6 +201,15 @@ struct VsPipe {
             MI_HIP(hipEventCreateWithFlags(&sl.done, hipEventDisableTiming));
             MI_HIP(hipHostMalloc((void **)&sl.h_out, sizeof(Fq12), hipHostMallocDefault));
         }
+        // HIP creates a stream's hardware queue at its first use (milliseconds each): do that now, in creation order,
+        // not inside the first block a node verifies
+        void *scratch = nullptr;
+        MI_HIP(hipMalloc(&scratch, 256));
+        for (int p = 0; p < lanes; p++) MI_HIP(hipMemsetAsync(scratch, 0, 4, acc_st[p]));
+        for (int i = 0; i < nslots; i++) MI_HIP(hipMemsetAsync((char *)scratch + 64, 0, 4, slots[i].stream));
+        for (int p = 0; p < lanes; p++) MI_HIP(hipStreamSynchronize(acc_st[p]));
+        for (int i = 0; i < nslots; i++) MI_HIP(hipStreamSynchronize(slots[i].stream));
+        MI_HIP(hipFree(scratch));
     }
     ~VsPipe() {
         for (auto &sl : slots) {
@@ -646,6 +656,32 @@ static int32_t vs_accumulate_begin_impl(Context &cx, const VsCtx &vc, const void
         if (par >= 0) break;
         if (!tl_ctx_lock) return MI_ERR_AGAIN;
         cx.lane_cv.wait(*tl_ctx_lock);  // ends (any thread) and context destruction signal it
+    }
+    if (!pp.primed) {
+        // The first batch a device sees runs once on EVERY lane (results discarded): each lane's ~25 workspaces, its
+        // pinned result buffers and its events then exist, sized for this batch shape, before the pipeline fills --
+        // otherwise the first dozen batches of a stream each pay the allocations of the lane they land on.
+        pp.primed = true;
+        HostSpan hs("begin.prime");
+        for (int p = 0; p < pp.lanes; p++) {
+            if (p == par || pp.acc[p].open) continue;
+            hipStream_t sp = pp.acc_st[p];
+            MI_HIP(hipEventRecord(pp.acc_ev[p], st));
+            MI_HIP(hipStreamWaitEvent(sp, pp.acc_ev[p], 0));
+            VsWork w = vs_run_derive(cx, v, d_proofs, n, d_rand, sp, p);
+            char nm[32];
+            snprintf(nm, sizeof nm, "vs.alg_pin%d", p);
+            (void)cx.pin_named(nm, n);
+            MsmJob j1, j2;
+            if (w.n1 + w.n2 <= msm_small_limit()) {
+                msm_enqueue(cx, w.pts1, w.sc1, w.n1 + w.n2, sp, 254, 4 + 2 * p, &j1, 0, p, w.n1);
+            } else {
+                msm_enqueue(cx, w.pts2, w.sc2, w.n2, sp, 128, 4 + 2 * p + 1, &j2, 0, p);
+                msm_enqueue(cx, w.pts1, w.sc1, w.n1, sp, 254, 4 + 2 * p, &j1, 0, p);
+            }
+        }
+        for (int p = 0; p < pp.lanes; p++)
+            if (p != par && !pp.acc[p].open) MI_HIP(hipStreamSynchronize(pp.acc_st[p]));
     }
     const uint64_t hd = vs_make_id(pp.next_acc++, cx.index, par);
     VsAcc &a = pp.acc[par];
