@@ -15,7 +15,8 @@ struct PairingArgs {
 // one workgroup of 192 lanes per pairing product (pairing_wg.hpp)
 __global__ void __launch_bounds__(PW_THREADS) pairing_product_kernel(PairingArgs args, const PairingConsts *__restrict__ pc,
                                                                      Fq12 *out) {
-    __shared__ PwShared S;
+    extern __shared__ uint4 pw_lds[];  // PW_LDS_BYTES
+    LShared &S = *(LShared *)pw_lds;
     pw_pairing_product(S, args.p, args.q, args.n, pc, out);
 }
 
@@ -35,6 +36,23 @@ const PairingConsts *pairing_consts(Context &cx, hipStream_t st) {
         PairingConsts h;
         for (int e = 0; e < 3; e++)
             for (int k = 0; k < 12; k++) h.frob[e][k] = host_fq_from_limbs(MI_FROB[e][k]);
+        // D[12 + i] = 2^(32 i) (i < 12), D[24] = 2^384 mod q; below 12, D[m - 1] = D[m] / 2^32 mod q by 32 halvings
+        for (int m = 12; m < 24; m++) {
+            h.dtab[m] = Fq::zero();
+            h.dtab[m].l[m - 12] = 1u;
+        }
+        h.dtab[24] = Fq::one();  // R mod q as an integer
+        for (int m = 11; m >= 0; m--) {
+            Fq v = h.dtab[m + 1];
+            for (int b = 0; b < 32; b++) {
+                uint32_t carry = 0;
+                if (v.l[0] & 1u)
+                    for (int i = 0; i < 12; i++) v.l[i] = addc32(v.l[i], FqP::MOD[i], carry, &carry);
+                for (int i = 0; i < 11; i++) v.l[i] = (v.l[i] >> 1) | (v.l[i + 1] << 31);
+                v.l[11] = (v.l[11] >> 1) | (carry << 31);
+            }
+            h.dtab[m] = v;
+        }
         void *d = s.consts.get(sizeof h);
         MI_HIP(hipMemcpyAsync(d, &h, sizeof h, hipMemcpyHostToDevice, st));
         MI_HIP(hipStreamSynchronize(st));
@@ -52,7 +70,8 @@ void pairing_launch(Context &cx, const G1Affine *ps, const G2Prepared *const *d_
     for (size_t i = 0; i < n; i++) { a.p[i] = ps[i]; a.q[i] = d_qs[i]; }
     const PairingConsts *pc = pairing_consts(cx, st);
     cx.prof.begin("pairing", st, n);
-    hipLaunchKernelGGL(pairing_product_kernel, dim3(1), dim3(PW_THREADS), 0, st, a, pc, d_out);
+    cx.raise_lds_limit((const void *)pairing_product_kernel, (int)PW_LDS_BYTES);
+    hipLaunchKernelGGL(pairing_product_kernel, dim3(1), dim3(PW_THREADS), PW_LDS_BYTES, st, a, pc, d_out);
     cx.prof.end("pairing", st);
     MI_HIP(hipGetLastError());
 }

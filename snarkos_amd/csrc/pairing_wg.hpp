@@ -1,225 +1,259 @@
 // Workgroup-cooperative pairing product for gfx950: 192 lanes (3 waves) share one Fq12 value in LDS.
 //
-// A pairing product is one long dependency chain (63 squarings + 69 line multiplications per pair in the
-// Miller loop, ~350 more Fq12 operations in the final exponentiation), so one lane per pairing is purely
-// latency bound (~90 ms).  Here every Fq12 operation is one "round": Fq12 is held in the power basis
-// Fq[w]/(w^12 + 5) (the tower basis element u^b v^j w^i IS w^(6b+2j+i), so this is a relabelling), the
-// 144 coefficient products a_i * b_j go one per lane, and each 16-lane row folds its twelve:
-// c_k = sum_{i+j=k} - 5 sum_{i+j=k+12}, with lazy 384-bit sums and a single reduction; the rows' four spare lanes
-// can carry the product of two sparse line functions in the same round (pb_round).
+// A pairing product is one long dependency chain (63 squarings + 69 line multiplications per couple of pairs in the
+// Miller loop, ~350 more Fq12 operations in the final exponentiation), so one lane per pairing is purely latency
+// bound (~90 ms).  Here every Fq12 operation is one "round": Fq12 is held in the power basis Fq[w]/(w^12 + 5) (the
+// tower basis element u^b v^j w^i IS w^(6b+2j+i), so this is a relabelling) and a round is bounded by the instruction
+// count of its longest lane, which is what this file is organised around (round 2; arithmetic and bounds are modelled
+// and checked in tools/model_pround.py):
+//   * one 16-lane DPP row per output coefficient c_k = sum_s a_(k-s) b'_s, all 16 lanes busy: lane (j, g) forms
+//     sum_{s = 3g..3g+2} a_(k-s) * (limbs 3j..3j+2 of b'_s) -- a 12 x 3-limb product-scanning pass over three products,
+//     108 limb products, NO Montgomery reduction per product;
+//   * the wrap w^12 = -5 costs nothing inside the round: every value in LDS carries its twin 10q - 5c (written by the
+//     round that produced it), and a wrapped term simply reads the twin;
+//   * the four lanes of a quad (same limb offset) add up with two DPP quad_perm steps; the Montgomery reduction of the
+//     row's 768-bit sum is DISTRIBUTED: every lane multiplies four words of its quad's sum by constants
+//     D[m] = 2^(32m - 384) mod q (36..48 limb products), four DPP row-rotate steps add the 16 lanes' 13-limb results
+//     (every lane ends with the total), and one Barrett step with a two-word quotient leaves c_k in [0, 2q);
+//   * one barrier per round (results ping-pong between buffers).
+// Round 1's layout (one lane per full Montgomery product, 12 of 16 lanes active, 763-instruction product + 4 row-scan
+// steps + reduction ~ 1 000 instructions per round) measured 1.95 us per round; this one is ~600 instructions.
+// The line functions of a couple of pairs are multiplied together up front (69 products l_1 l_2), so a doubling step of
+// the Miller loop is two rounds (f^2, then (l_1 l_2) f) and an addition step one more.
 // Frobenius is diagonal in this basis (c_k *= gamma_e^k), conjugation negates the odd coefficients.
 // Replaces Bls12_377::{miller_loop, final_exponentiation, product_of_pairings}.
 #pragma once
 #include "tower.hpp"
+#include "pround_gen.hpp"
 
 namespace mi {
 
 constexpr int PW_THREADS = 192;
 
 struct alignas(16) PB {
-    Fq c[12];  // coefficient of w^k
+    Fq c[12];   // coefficient of w^k, in [0, 2q)
+    Fq c5[12];  // its twin 10q - 5 c_k (= -5 c_k mod q, in (0, 10q]): what a wrapped term of the next round multiplies by
 };
 
 struct alignas(16) PwShared {
-    PB f, t, a, b, c, d, x, y, z, g;
-    alignas(16) Fq one;  // the constant line of a couple's missing second pair
+    PB f, g, t, a, b, c, d, x, y, z;
+    alignas(16) Fq dtab[25];  // fold constants D[m]
+    alignas(16) Fq one;       // the constant line of a couple's missing second pair
     alignas(16) Fq px[MI_MAX_PAIRS], py[MI_MAX_PAIRS];
-    // every line of the current couple's Miller loop evaluated at its P up front, [step][pair][w^1, w^3, w^7, w^9]
+    // every line of the current couple's Miller loop evaluated at its P, [step][pair][w^1, w^3, w^7, w^9]
     // (the w^0 coefficient is py[pair]); 26 KB
     alignas(16) Fq lines2[MI_MILLER_LINES][2][4];
+    // the couple's line products l_1 l_2, one dense Fq12 per Miller step (operand A of a round: no twin needed); 39 KB
+    alignas(16) Fq lprod[MI_MILLER_LINES][12];
 };
+constexpr size_t PW_LDS_BYTES = sizeof(PwShared);  // dynamic LDS of every kernel that runs a pairing product
+// Everything below addresses the workgroup's PwShared through LDS-qualified pointers (32-bit, ds_* instructions, no
+// generic-pointer null checks), also across the out-of-line rounds.
+#define PW_LDS __attribute__((address_space(3)))
+typedef PW_LDS PwShared LShared;
+typedef PW_LDS PB LPB;
+typedef PW_LDS Fq LFq;
 
 // ---- LDS <-> register copies, 16 bytes at a time (PwShared members are 16-byte aligned)
-__device__ __forceinline__ Fq lds_load(const Fq *p) {
-    const uint4 *q = reinterpret_cast<const uint4 *>(p);
-    uint4 v0 = q[0], v1 = q[1], v2 = q[2];
+typedef uint32_t pw_u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ Fq lds_load(const LFq *p) {
+    const PW_LDS pw_u32x4 *q = (const PW_LDS pw_u32x4 *)p;
+    const pw_u32x4 v0 = q[0], v1 = q[1], v2 = q[2];
     Fq r;
     r.l[0] = v0.x; r.l[1] = v0.y; r.l[2] = v0.z; r.l[3] = v0.w;
     r.l[4] = v1.x; r.l[5] = v1.y; r.l[6] = v1.z; r.l[7] = v1.w;
     r.l[8] = v2.x; r.l[9] = v2.y; r.l[10] = v2.z; r.l[11] = v2.w;
     return r;
 }
-__device__ __forceinline__ void lds_store(Fq *p, const Fq &v) {
-    uint4 *q = reinterpret_cast<uint4 *>(p);
-    q[0] = make_uint4(v.l[0], v.l[1], v.l[2], v.l[3]);
-    q[1] = make_uint4(v.l[4], v.l[5], v.l[6], v.l[7]);
-    q[2] = make_uint4(v.l[8], v.l[9], v.l[10], v.l[11]);
+__device__ __forceinline__ void lds_store(LFq *p, const Fq &v) {
+    PW_LDS pw_u32x4 *q = (PW_LDS pw_u32x4 *)p;
+    q[0] = pw_u32x4{v.l[0], v.l[1], v.l[2], v.l[3]};
+    q[1] = pw_u32x4{v.l[4], v.l[5], v.l[6], v.l[7]};
+    q[2] = pw_u32x4{v.l[8], v.l[9], v.l[10], v.l[11]};
 }
 
-// ---------------------------------------------------------------------------------------------------------------
-// The round (every Fq12 operation of the Miller loop and of the final exponentiation).  out = A * B: lane (k = t / 16,
-// s = t % 16 < 12) of the 16-lane row k multiplies a_((k - s) mod 12) by b_s; the row's sum is coefficient k.
-//   * products are taken without their final conditional subtraction (< 1.007 q); a wrapped product p contributes
-//     6q - 5p; a row's lazy sum stays < 67 q < 2^384;
-//   * the row sum is an inclusive scan over the 16-lane row with DPP row_shr:1/2/4/8 -- no LDS traffic; lane 11 ends
-//     with the sum of lanes 0..11;
-//   * one reduction: quotient estimate from the top limb (k <= floor(acc / q) <= k + 1), acc - k q, one conditional
-//     subtraction;
-//   * the four spare lanes of every row (s = 12..15) can carry a second, independent product in the same round: the
-//     product of two sparse line functions (5 x 5 coefficients -> 10 non-zero rows of at most 4 products each, table
-//     below), summed after the first two scan steps in lane 15.
-struct Q6 {
+struct Q12 {
     uint32_t l[12];
 };
-constexpr Q6 pw_make_q6() {
-    Q6 r{};
+constexpr Q12 pw_make_q10() {
+    Q12 r{};
     uint64_t c = 0;
     for (int j = 0; j < 12; j++) {
-        const uint64_t v = (uint64_t)FqP::MOD[j] * 6u + c;
+        const uint64_t v = (uint64_t)FqP::MOD[j] * 10u + c;
         r.l[j] = (uint32_t)v;
         c = v >> 32;
     }
     return r;
 }
-// line x line: for output row k, up to four products l1[i] * l2[j] (stored-coefficient indices; positions 0,1,3,7,9);
-// code = i | j << 3 | wrapped << 6 | valid << 7
-#define PW_LL(i, j, w) (uint8_t)((i) | ((j) << 3) | ((w) << 6) | 0x80)
-__device__ const uint8_t PW_LL_TABLE[12][4] = {
-    {PW_LL(0, 0, 0), PW_LL(2, 4, 1), PW_LL(4, 2, 1), 0},               // w^0: 0+0, 3+9, 9+3
-    {PW_LL(0, 1, 0), PW_LL(1, 0, 0), 0, 0},                            // w^1
-    {PW_LL(1, 1, 0), PW_LL(3, 3, 1), 0, 0},                            // w^2: 1+1, 7+7
-    {PW_LL(0, 2, 0), PW_LL(2, 0, 0), 0, 0},                            // w^3
-    {PW_LL(1, 2, 0), PW_LL(2, 1, 0), PW_LL(3, 4, 1), PW_LL(4, 3, 1)},  // w^4: 1+3, 3+1, 7+9, 9+7
-    {0, 0, 0, 0},                                                      // w^5
-    {PW_LL(2, 2, 0), PW_LL(4, 4, 1), 0, 0},                            // w^6: 3+3, 9+9
-    {PW_LL(0, 3, 0), PW_LL(3, 0, 0), 0, 0},                            // w^7
-    {PW_LL(1, 3, 0), PW_LL(3, 1, 0), 0, 0},                            // w^8
-    {PW_LL(0, 4, 0), PW_LL(4, 0, 0), 0, 0},                            // w^9
-    {PW_LL(1, 4, 0), PW_LL(4, 1, 0), PW_LL(2, 3, 0), PW_LL(3, 2, 0)},  // w^10: 1+9, 9+1, 3+7, 7+3
-    {0, 0, 0, 0},                                                      // w^11
-};
-#undef PW_LL
-
-// acc += (acc of the lane N places lower in the 16-lane row), 384 bits: the DPP shift is fused into the add / add-with-
-// carry instructions themselves (row_shr:N, lanes without a source read 0), 12 instructions per step instead of a
-// v_mov_b32_dpp + v_addc pair per limb (measured: the four steps are 0.38 us of a 2.3 us round).
-template <int N>
-__device__ __forceinline__ void pw_row_scan_step(uint32_t (&acc)[12]) {
-    // s_nop 1: a DPP source written by the preceding VALU instruction needs two wait states, and the compiler does not
-    // look inside the asm statement
-    asm volatile(
-        "s_nop 1\n\t"
-        "v_add_co_u32_dpp %0, vcc, %0, %0 row_shr:%12 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
-        "v_addc_co_u32_dpp %1, vcc, %1, %1, vcc row_shr:%12 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
-        "v_addc_co_u32_dpp %2, vcc, %2, %2, vcc row_shr:%12 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
-        "v_addc_co_u32_dpp %3, vcc, %3, %3, vcc row_shr:%12 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
-        "v_addc_co_u32_dpp %4, vcc, %4, %4, vcc row_shr:%12 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
-        "v_addc_co_u32_dpp %5, vcc, %5, %5, vcc row_shr:%12 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
-        "v_addc_co_u32_dpp %6, vcc, %6, %6, vcc row_shr:%12 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
-        "v_addc_co_u32_dpp %7, vcc, %7, %7, vcc row_shr:%12 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
-        "v_addc_co_u32_dpp %8, vcc, %8, %8, vcc row_shr:%12 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
-        "v_addc_co_u32_dpp %9, vcc, %9, %9, vcc row_shr:%12 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
-        "v_addc_co_u32_dpp %10, vcc, %10, %10, vcc row_shr:%12 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
-        "v_addc_co_u32_dpp %11, vcc, %11, %11, vcc row_shr:%12 row_mask:0xf bank_mask:0xf bound_ctrl:0"
-        : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]), "+v"(acc[4]), "+v"(acc[5]), "+v"(acc[6]), "+v"(acc[7]),
-          "+v"(acc[8]), "+v"(acc[9]), "+v"(acc[10]), "+v"(acc[11])
-        : "n"(N)
-        : "vcc");
+// twin of c in [0, 2q]: 10q - 5c in [0, 10q]
+__device__ __forceinline__ Fq pw_twin(const Fq &v) {
+    constexpr Q12 q10 = pw_make_q10();
+    uint32_t t5[12], c = 0, bw = 0;
+    Fq r;
+#pragma unroll
+    for (int j = 0; j < 12; j++) t5[j] = addc32((v.l[j] << 2) | (j ? (v.l[j - 1] >> 30) : 0u), v.l[j], c, &c);
+#pragma unroll
+    for (int j = 0; j < 12; j++) r.l[j] = subc32(q10.l[j], t5[j], bw, &bw);
+    return r;
 }
 
-// out = A * B (dense).  WITH_L: also outL = l1 * l2, l1 / l2 the five stored coefficients of two line functions
-// (pointer to the w^0 coefficient and to the four others).  All PW_THREADS lanes must call.
-// NOALIAS: out / outL are not read by this round (the callers ping-pong between buffers), so the barrier between the
-// operand reads and the result stores is dropped: one barrier per round instead of two (measured 0.12 us of 2.3).
-template <bool WITH_L, bool NOALIAS = false>
-__device__ __attribute__((noinline)) void pb_round(PwShared &S, PB *out, const PB *A, const PB *B, PB *outL, const Fq *l1_0,
-                                                   const Fq *l1_r, const Fq *l2_0, const Fq *l2_r) {
-    constexpr Q6 q6 = pw_make_q6();
-    const int t = threadIdx.x, k = t >> 4, s = t & 15;
-    uint32_t acc[12];
+// x += (x of the quad lane named by the permutation), N limbs with carry: DPP fused into the add instructions
+#define PW_DPP_ADD16(ctrl)                                                                                              \
+    asm volatile("s_nop 1\n\t"                                                                                          \
+                 "v_add_co_u32_dpp %0, vcc, %0, %0 " ctrl " row_mask:0xf bank_mask:0xf\n\t"                             \
+                 "v_addc_co_u32_dpp %1, vcc, %1, %1, vcc " ctrl " row_mask:0xf bank_mask:0xf\n\t"                       \
+                 "v_addc_co_u32_dpp %2, vcc, %2, %2, vcc " ctrl " row_mask:0xf bank_mask:0xf\n\t"                       \
+                 "v_addc_co_u32_dpp %3, vcc, %3, %3, vcc " ctrl " row_mask:0xf bank_mask:0xf\n\t"                       \
+                 "v_addc_co_u32_dpp %4, vcc, %4, %4, vcc " ctrl " row_mask:0xf bank_mask:0xf\n\t"                       \
+                 "v_addc_co_u32_dpp %5, vcc, %5, %5, vcc " ctrl " row_mask:0xf bank_mask:0xf\n\t"                       \
+                 "v_addc_co_u32_dpp %6, vcc, %6, %6, vcc " ctrl " row_mask:0xf bank_mask:0xf\n\t"                       \
+                 "v_addc_co_u32_dpp %7, vcc, %7, %7, vcc " ctrl " row_mask:0xf bank_mask:0xf\n\t"                       \
+                 "v_addc_co_u32_dpp %8, vcc, %8, %8, vcc " ctrl " row_mask:0xf bank_mask:0xf\n\t"                       \
+                 "v_addc_co_u32_dpp %9, vcc, %9, %9, vcc " ctrl " row_mask:0xf bank_mask:0xf\n\t"                       \
+                 "v_addc_co_u32_dpp %10, vcc, %10, %10, vcc " ctrl " row_mask:0xf bank_mask:0xf\n\t"                    \
+                 "v_addc_co_u32_dpp %11, vcc, %11, %11, vcc " ctrl " row_mask:0xf bank_mask:0xf\n\t"                    \
+                 "v_addc_co_u32_dpp %12, vcc, %12, %12, vcc " ctrl " row_mask:0xf bank_mask:0xf\n\t"                    \
+                 "v_addc_co_u32_dpp %13, vcc, %13, %13, vcc " ctrl " row_mask:0xf bank_mask:0xf\n\t"                    \
+                 "v_addc_co_u32_dpp %14, vcc, %14, %14, vcc " ctrl " row_mask:0xf bank_mask:0xf\n\t"                    \
+                 "v_addc_co_u32_dpp %15, vcc, %15, %15, vcc " ctrl " row_mask:0xf bank_mask:0xf"                        \
+                 : "+v"(P[0]), "+v"(P[1]), "+v"(P[2]), "+v"(P[3]), "+v"(P[4]), "+v"(P[5]), "+v"(P[6]), "+v"(P[7]),      \
+                   "+v"(P[8]), "+v"(P[9]), "+v"(P[10]), "+v"(P[11]), "+v"(P[12]), "+v"(P[13]), "+v"(P[14]), "+v"(P[15]) \
+                 :                                                                                                      \
+                 : "vcc")
+#define PW_DPP_ADD13(ctrl)                                                                                              \
+    asm volatile("s_nop 1\n\t"                                                                                          \
+                 "v_add_co_u32_dpp %0, vcc, %0, %0 " ctrl " row_mask:0xf bank_mask:0xf\n\t"                             \
+                 "v_addc_co_u32_dpp %1, vcc, %1, %1, vcc " ctrl " row_mask:0xf bank_mask:0xf\n\t"                       \
+                 "v_addc_co_u32_dpp %2, vcc, %2, %2, vcc " ctrl " row_mask:0xf bank_mask:0xf\n\t"                       \
+                 "v_addc_co_u32_dpp %3, vcc, %3, %3, vcc " ctrl " row_mask:0xf bank_mask:0xf\n\t"                       \
+                 "v_addc_co_u32_dpp %4, vcc, %4, %4, vcc " ctrl " row_mask:0xf bank_mask:0xf\n\t"                       \
+                 "v_addc_co_u32_dpp %5, vcc, %5, %5, vcc " ctrl " row_mask:0xf bank_mask:0xf\n\t"                       \
+                 "v_addc_co_u32_dpp %6, vcc, %6, %6, vcc " ctrl " row_mask:0xf bank_mask:0xf\n\t"                       \
+                 "v_addc_co_u32_dpp %7, vcc, %7, %7, vcc " ctrl " row_mask:0xf bank_mask:0xf\n\t"                       \
+                 "v_addc_co_u32_dpp %8, vcc, %8, %8, vcc " ctrl " row_mask:0xf bank_mask:0xf\n\t"                       \
+                 "v_addc_co_u32_dpp %9, vcc, %9, %9, vcc " ctrl " row_mask:0xf bank_mask:0xf\n\t"                       \
+                 "v_addc_co_u32_dpp %10, vcc, %10, %10, vcc " ctrl " row_mask:0xf bank_mask:0xf\n\t"                    \
+                 "v_addc_co_u32_dpp %11, vcc, %11, %11, vcc " ctrl " row_mask:0xf bank_mask:0xf\n\t"                    \
+                 "v_addc_co_u32_dpp %12, vcc, %12, %12, vcc " ctrl " row_mask:0xf bank_mask:0xf"                        \
+                 : "+v"(F[0]), "+v"(F[1]), "+v"(F[2]), "+v"(F[3]), "+v"(F[4]), "+v"(F[5]), "+v"(F[6]), "+v"(F[7]),      \
+                   "+v"(F[8]), "+v"(F[9]), "+v"(F[10]), "+v"(F[11]), "+v"(F[12])                                        \
+                 :                                                                                                      \
+                 : "vcc")
+
+// ---------------------------------------------------------------------------------------------------------------
+// The round: out = A * B.  A: 12 coefficients (only plain values are read: a line product or a PB's c[]); B: a PB (its
+// twin supplies the wrapped terms).  All PW_THREADS lanes must call.  NOALIAS: out is neither A nor B (the callers
+// ping-pong between buffers), so no barrier separates the operand reads from the result stores: one barrier per round.
+// PROF (tools/round_bench.hip only): wave 0 adds the shader-clock ticks of each stage of the round to prof[0..7]
+// (loads, product, quad reduction, fold, row reduction, Barrett + twin, stores + barrier)
+#define PW_STAMP(i)                                                   \
+    if (PROF) {                                                       \
+        const uint64_t now_ = __builtin_amdgcn_s_memtime();          \
+        if (threadIdx.x == 0) prof[i] += now_ - stamp_;               \
+        stamp_ = now_;                                                \
+    }
+template <bool NOALIAS, bool PROF = false>
+__device__ __forceinline__ void pb_round_impl(LShared &S, LPB *out, const LFq *A, const LPB *B, const Fq &d0, const Fq &d1,
+                                              const Fq &d2, const Fq &d3, uint64_t *prof = nullptr) {
+    constexpr uint32_t MU0 = 0x54234331u, MU1 = 0x98u;  // floor(2^416 / q)
+    const int t = threadIdx.x, k = t >> 4, L = t & 15, j = L >> 2, g = L & 3;
+    uint64_t stamp_ = PROF ? __builtin_amdgcn_s_memtime() : 0;
+    Fq a[3];
+    uint32_t b[3][3];
 #pragma unroll
-    for (int j = 0; j < 12; j++) acc[j] = 0;
-    Fq a, b;
-    bool active = false, wrap = false;
-    if (s < 12) {
+    for (int tt = 0; tt < 3; tt++) {
+        const int s = 3 * g + tt;
         int i = k - s;
-        wrap = i < 0;
+        const bool wrap = i < 0;
         if (wrap) i += 12;
-        a = lds_load(&A->c[i]);
-        b = lds_load(&B->c[s]);
-        active = true;
-    } else if (WITH_L) {
-        const uint32_t code = PW_LL_TABLE[k][s - 12];
-        if (code & 0x80u) {
-            const uint32_t i = code & 7u, j = (code >> 3) & 7u;
-            a = lds_load(i == 0 ? l1_0 : &l1_r[i - 1]);
-            b = lds_load(j == 0 ? l2_0 : &l2_r[j - 1]);
-            wrap = (code & 0x40u) != 0;
-            active = true;
-        }
+        a[tt] = lds_load(&A[i]);
+        const PW_LDS uint32_t *bl = (wrap ? B->c5[s].l : B->c[s].l) + 3 * j;
+        b[tt][0] = bl[0];
+        b[tt][1] = bl[1];
+        b[tt][2] = bl[2];
     }
-    if (active) {
-        const Fq p = mul_nr(a, b);
+    if (PROF) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    PW_STAMP(0)
+    uint32_t P[16];
+    pr_qprod(P, a[0], a[1], a[2], b[0], b[1], b[2]);
+    PW_STAMP(1)
+    // the quad's sum Q_j (limb offset 3j), in all four lanes
+    PW_DPP_ADD16("quad_perm:[1,0,3,2]");
+    PW_DPP_ADD16("quad_perm:[2,3,0,1]");
+    PW_STAMP(2)
+    // distributed Montgomery reduction: this lane's four words of Q_j (limbs g, g+4, g+8, g+12) times D[position]
+    // (lane-dependent choice by masks, branch-free: the compiler turns the nested conditional into exec-mask blocks)
+    const uint32_t m0 = g == 0 ? ~0u : 0u, m1 = g == 1 ? ~0u : 0u, m2 = g == 2 ? ~0u : 0u, m3 = g == 3 ? ~0u : 0u;
+    uint32_t w[4];
 #pragma unroll
-        for (int j = 0; j < 12; j++) acc[j] = p.l[j];
-        if (wrap) {  // w^12 = -5: 6q - 5p, in (0.9 q, 6 q]
-            uint32_t t5[12], c = 0, bw = 0;
+    for (int tt = 0; tt < 4; tt++)
+        w[tt] = (P[4 * tt] & m0) | (P[4 * tt + 1] & m1) | (P[4 * tt + 2] & m2) | (P[4 * tt + 3] & m3);
+    uint32_t F[13];
+    pr_fold(F, w[0], w[1], w[2], w[3], d0, d1, d2, d3);
+    PW_STAMP(3)
+    // the row's total, in every lane (rotations within the 16-lane row)
+    PW_DPP_ADD13("row_ror:8");
+    PW_DPP_ADD13("row_ror:4");
+    PW_DPP_ADD13("row_ror:2");
+    PW_DPP_ADD13("row_ror:1");
+    PW_STAMP(4)
+    // Barrett: F < 2^416, quotient estimate from the bits above 2^352, c = F - qhat q in [0, 2q)
+    uint64_t tq = ((uint64_t)F[11] * MU0) >> 32;
+    tq += (uint64_t)F[12] * MU0;
+    tq += (uint64_t)F[11] * MU1;
+    const uint64_t qh = (uint64_t)F[12] * MU1 + (tq >> 32);
+    uint32_t r[12];
+    pr_qhat_q(r, (uint32_t)qh, (uint32_t)(qh >> 32));
+    Fq c;
+    uint32_t bw = 0;
 #pragma unroll
-            for (int j = 0; j < 12; j++) t5[j] = addc32((p.l[j] << 2) | (j ? (p.l[j - 1] >> 30) : 0u), p.l[j], c, &c);
-#pragma unroll
-            for (int j = 0; j < 12; j++) acc[j] = subc32(q6.l[j], t5[j], bw, &bw);
-        }
-    }
-    pw_row_scan_step<1>(acc);
-    pw_row_scan_step<2>(acc);
-    uint32_t v[12];
-    if (WITH_L) {
-#pragma unroll
-        for (int j = 0; j < 12; j++) v[j] = acc[j];  // lane 15: lanes 12..15 summed = the line product's row
-    }
-    pw_row_scan_step<4>(acc);
-    pw_row_scan_step<8>(acc);
-    if (WITH_L) {
-#pragma unroll
-        for (int j = 0; j < 12; j++) v[j] = s == 15 ? v[j] : acc[j];
-    } else {
-#pragma unroll
-        for (int j = 0; j < 12; j++) v[j] = acc[j];
-    }
-    // v < 67 q: k = floor(v11 * floor(2^40 / (q11 + 1)) / 2^40) <= v / q < k + 2
-    {
-        // (independent 32 x 32 products for k q were tried: v_mul_lo / v_mul_hi are slower than this chain of
-        // v_mad_u64_u32: 2.70 -> 2.89 us per round)
-        const uint32_t kq = __umulhi(v[11], 38996u) >> 8;
-        uint32_t carry = 0, borrow = 0;
-#pragma unroll
-        for (int j = 0; j < 12; j++) {
-            const uint64_t pr = (uint64_t)kq * FqP::MOD[j] + carry;
-            carry = (uint32_t)(pr >> 32);
-            v[j] = subc32(v[j], (uint32_t)pr, borrow, &borrow);
-        }
-        // no final conditional subtraction: v is left in [0, 2q).  The next round's unreduced products of operands
-        // below 2q stay below 1.03 q (4 q^2 / R + q), so every bound above holds; the few consumers that need the
-        // canonical representative (negation, inversion, the result) reduce once themselves.
-    }
+    for (int i = 0; i < 12; i++) c.l[i] = subc32(F[i], r[i], bw, &bw);
+    const Fq c5 = pw_twin(c);
+    PW_STAMP(5)
     if (!NOALIAS) __syncthreads();
-    if (s == 11 || (WITH_L && s == 15)) {
-        Fq r;
-#pragma unroll
-        for (int j = 0; j < 12; j++) r.l[j] = v[j];
-        lds_store(s == 11 ? &out->c[k] : &outL->c[k], r);
-    }
+    if (L == 0) lds_store(&out->c[k], c);
+    if (L == 1) lds_store(&out->c5[k], c5);
     __syncthreads();
+    PW_STAMP(6)
 }
-__device__ __forceinline__ void pb_mul(PwShared &S, PB *out, const PB *A, const PB *B) {
-    pb_round<false>(S, out, A, B, nullptr, nullptr, nullptr, nullptr, nullptr);
+#undef PW_STAMP
+#undef PW_DPP_ADD16
+#undef PW_DPP_ADD13
+// the fold constants of this lane (they depend on the lane only: loops keep them in registers across rounds)
+struct PwFold {
+    Fq d0, d1, d2, d3;
+};
+__device__ __forceinline__ PwFold pw_fold_consts(LShared &S) {
+    const int L = threadIdx.x & 15;
+    const LFq *dt = &S.dtab[3 * (L >> 2) + (L & 3)];
+    return PwFold{lds_load(dt), lds_load(dt + 4), lds_load(dt + 8), lds_load(dt + 12)};
 }
-// out must not be A or B
-__device__ __forceinline__ void pb_mul_na(PwShared &S, PB *out, const PB *A, const PB *B) {
-    pb_round<false, true>(S, out, A, B, nullptr, nullptr, nullptr, nullptr, nullptr);
+template <bool NOALIAS>
+__device__ __attribute__((noinline)) void pb_round(LShared &S, LPB *out, const LFq *A, const LPB *B) {
+    const PwFold fc = pw_fold_consts(S);
+    pb_round_impl<NOALIAS>(S, out, A, B, fc.d0, fc.d1, fc.d2, fc.d3);
 }
 
+__device__ __forceinline__ void pb_mul(LShared &S, LPB *out, const LPB *A, const LPB *B) { pb_round<false>(S, out, A->c, B); }
+// out must not be A or B
+__device__ __forceinline__ void pb_mul_na(LShared &S, LPB *out, const LPB *A, const LPB *B) { pb_round<true>(S, out, A->c, B); }
+
+// store coefficient t of a value computed by lanes t < 12, with its twin
+__device__ __forceinline__ void pb_put(LPB *out, int t, const Fq &v) {
+    lds_store(&out->c[t], v);
+    lds_store(&out->c5[t], pw_twin(v));
+}
 // out = frobenius^e(A): c_k *= gamma_e^k
-__device__ __forceinline__ void pb_frob(PwShared &S, PB *out, const PB *A, const Fq *gamma /* global, 12 */) {
+__device__ __forceinline__ void pb_frob(LShared &S, LPB *out, const LPB *A, const Fq *gamma /* global, 12 */) {
     const int t = threadIdx.x;
     Fq v;
     if (t < 12) v = mul(lds_load(&A->c[t]), gamma[t]);
     __syncthreads();
-    if (t < 12) lds_store(&out->c[t], v);
+    if (t < 12) pb_put(out, t, v);
     __syncthreads();
 }
 // out = conj(A): negate the odd coefficients
-__device__ __forceinline__ void pb_conj(PwShared &S, PB *out, const PB *A) {
+__device__ __forceinline__ void pb_conj(LShared &S, LPB *out, const LPB *A) {
     const int t = threadIdx.x;
     Fq v;
     if (t < 12) {
@@ -228,27 +262,32 @@ __device__ __forceinline__ void pb_conj(PwShared &S, PB *out, const PB *A) {
         if (t & 1) v = neg(v);
     }
     __syncthreads();
-    if (t < 12) lds_store(&out->c[t], v);
+    if (t < 12) pb_put(out, t, v);
     __syncthreads();
 }
-__device__ __forceinline__ void pb_copy(PwShared &S, PB *out, const PB *A) {
+__device__ __forceinline__ void pb_copy(LShared &S, LPB *out, const LPB *A) {
     const int t = threadIdx.x;
     Fq v;
-    if (t < 12) v = lds_load(&A->c[t]);
+    if (t < 24) v = lds_load(t < 12 ? &A->c[t] : &A->c5[t - 12]);
     __syncthreads();
-    if (t < 12) lds_store(&out->c[t], v);
+    if (t < 24) lds_store(t < 12 ? &out->c[t] : &out->c5[t - 12], v);
     __syncthreads();
 }
-// out = A^x (x = BLS seed); uses S.y as the running value
-__device__ __attribute__((noinline)) void pb_exp_by_x(PwShared &S, PB *out, const PB *A) {
+__device__ __forceinline__ void pb_set_one(LPB *out) {  // followed by the caller's barrier
+    const int t = threadIdx.x;
+    if (t < 12) pb_put(out, t, t == 0 ? Fq::one() : Fq::zero());
+}
+// out = A^x (x = BLS seed)
+__device__ __attribute__((noinline)) void pb_exp_by_x(LShared &S, LPB *out, const LPB *A) {
     // ping-pong between S.y and S.z so that no round writes an operand (one barrier per round); A is neither
-    PB *cur = &S.y, *alt = &S.z;
+    LPB *cur = &S.y, *alt = &S.z;
     pb_copy(S, cur, A);
+    const PwFold fc = pw_fold_consts(S);  // in registers across the 69 rounds (a round that reloads them: 1.74 vs 1.44 us)
     for (int i = 62; i >= 0; i--) {
-        pb_mul_na(S, alt, cur, cur);
-        PB *sw = cur; cur = alt; alt = sw;
+        pb_round_impl<true>(S, alt, cur->c, cur, fc.d0, fc.d1, fc.d2, fc.d3);
+        LPB *sw = cur; cur = alt; alt = sw;
         if ((MI_BLS_X >> i) & 1) {
-            pb_mul_na(S, alt, cur, A);
+            pb_round_impl<true>(S, alt, cur->c, A, fc.d0, fc.d1, fc.d2, fc.d3);
             sw = cur; cur = alt; alt = sw;
         }
     }
@@ -259,7 +298,7 @@ __device__ __attribute__((noinline)) void pb_exp_by_x(PwShared &S, PB *out, cons
 // inversion in Fq on a single lane.  With U = A frob1(A) frob2(A) (e = 0,1,2) and P2 = A frob1(A):
 //   W = U * frob3(U) * frob6(U) * frob9(P2)   covers e = 0..10,   Abar = frob1(W),   frob6 = conj, frob9 = conj o frob3.
 // Uses S.x, S.y, S.c, S.d as scratch (callers invert before they use those).
-__device__ __attribute__((noinline)) void pb_inv(PwShared &S, PB *out, const PB *A, const PairingConsts *pc) {
+__device__ __attribute__((noinline)) void pb_inv(LShared &S, LPB *out, const LPB *A, const PairingConsts *pc) {
     pb_frob(S, &S.x, A, pc->frob[0]);         // x = frob1(A)
     pb_mul(S, &S.c, A, &S.x);                 // c = P2 = A frob1(A)
     pb_frob(S, &S.x, A, pc->frob[1]);         // x = frob2(A)
@@ -283,16 +322,35 @@ __device__ __attribute__((noinline)) void pb_inv(PwShared &S, PB *out, const PB 
     Fq v;
     if (t < 12) v = mul(lds_load(&S.x.c[t]), lds_load(&S.y.c[1]));
     __syncthreads();
-    if (t < 12) lds_store(&out->c[t], v);
+    if (t < 12) pb_put(out, t, v);
     __syncthreads();
 }
 
-// Miller loop of one COUPLE of live pairs (p0, p0 + 1) -- every KZG / verifier check is one couple -- into S.f.  All
-// line coefficients first (552 values, three per lane), then per doubling step TWO rounds -- [f^2 beside l_1 l_2] and
-// [f^2 * (l_1 l_2)] -- instead of three rounds plus a line evaluation; an addition step costs one more round (its line
-// product rides in the second round's spare lanes).  A single pair (np = 1) runs as a couple whose second line is the
-// constant 1.  Products over more pairs multiply the couples' values (pw_pairing_product).
-__device__ __attribute__((noinline)) void pw_miller2(PwShared &S, const G2Prepared *const *qs, int p0, int np) {
+// line x line: for output row k, up to four products l1[i] * l2[j] (stored-coefficient indices; positions 0,1,3,7,9);
+// code = i | j << 3 | wrapped << 6 | valid << 7
+#define PW_LL(i, j, w) (uint8_t)((i) | ((j) << 3) | ((w) << 6) | 0x80)
+__device__ const uint8_t PW_LL_TABLE[12][4] = {
+    {PW_LL(0, 0, 0), PW_LL(2, 4, 1), PW_LL(4, 2, 1), 0},               // w^0: 0+0, 3+9, 9+3
+    {PW_LL(0, 1, 0), PW_LL(1, 0, 0), 0, 0},                            // w^1
+    {PW_LL(1, 1, 0), PW_LL(3, 3, 1), 0, 0},                            // w^2: 1+1, 7+7
+    {PW_LL(0, 2, 0), PW_LL(2, 0, 0), 0, 0},                            // w^3
+    {PW_LL(1, 2, 0), PW_LL(2, 1, 0), PW_LL(3, 4, 1), PW_LL(4, 3, 1)},  // w^4: 1+3, 3+1, 7+9, 9+7
+    {0, 0, 0, 0},                                                      // w^5
+    {PW_LL(2, 2, 0), PW_LL(4, 4, 1), 0, 0},                            // w^6: 3+3, 9+9
+    {PW_LL(0, 3, 0), PW_LL(3, 0, 0), 0, 0},                            // w^7
+    {PW_LL(1, 3, 0), PW_LL(3, 1, 0), 0, 0},                            // w^8
+    {PW_LL(0, 4, 0), PW_LL(4, 0, 0), 0, 0},                            // w^9
+    {PW_LL(1, 4, 0), PW_LL(4, 1, 0), PW_LL(2, 3, 0), PW_LL(3, 2, 0)},  // w^10: 1+9, 9+1, 3+7, 7+3
+    {0, 0, 0, 0},                                                      // w^11
+};
+#undef PW_LL
+
+// Miller loop of one COUPLE of live pairs (p0, p0 + 1) -- every KZG / verifier check is one couple -- into S.f.
+// Up front: all line coefficients at their P (552 values, three per lane), then the 69 line products l_1 l_2
+// (828 coefficients: up to four Montgomery products each, a lane per coefficient).  The loop itself is two rounds per
+// doubling step -- f^2, then (l_1 l_2) f -- and one more per addition step.  A single pair (np = 1) runs as a couple
+// whose second line is the constant 1.  Products over more pairs multiply the couples' values (pw_pairing_product).
+__device__ __attribute__((noinline)) void pw_miller2(LShared &S, const G2Prepared *const *qs, int p0, int np) {
     const int t = threadIdx.x;
     for (int item = t; item < MI_MILLER_LINES * 8; item += PW_THREADS) {
         const int idx = item >> 3, p = (item >> 2) & 1, role = item & 3;
@@ -306,29 +364,42 @@ __device__ __attribute__((noinline)) void pw_miller2(PwShared &S, const G2Prepar
         }
         lds_store(&S.lines2[idx][p][role], v);
     }
-    if (t < 12) lds_store(&S.f.c[t], t == 0 ? Fq::one() : Fq::zero());
     if (t == 12) lds_store(&S.one, Fq::one());
     __syncthreads();
-    const Fq *y1 = &S.py[p0], *y2 = np == 2 ? &S.py[p0 + 1] : &S.one;
+    const LFq *y1 = &S.py[p0], *y2 = np == 2 ? &S.py[p0 + 1] : &S.one;
+    for (int item = t; item < MI_MILLER_LINES * 12; item += PW_THREADS) {
+        const int idx = item / 12, k = item - 12 * idx;
+        Fq acc = Fq::zero();
+#pragma unroll 1
+        for (int e = 0; e < 4; e++) {
+            const uint32_t code = PW_LL_TABLE[k][e];
+            if (!(code & 0x80u)) break;
+            const uint32_t i = code & 7u, j = (code >> 3) & 7u;
+            const Fq p = mul(lds_load(i == 0 ? y1 : &S.lines2[idx][0][i - 1]), lds_load(j == 0 ? y2 : &S.lines2[idx][1][j - 1]));
+            acc = (code & 0x40u) ? sub(acc, mul5(p)) : add(acc, p);  // w^12 = -5
+        }
+        lds_store(&S.lprod[idx][k], acc);
+    }
+    pb_set_one(&S.f);
+    __syncthreads();
     int idx = 0;
-    PB *cur = &S.f, *alt = &S.g;  // ping-pong: no round writes one of its operands
+    LPB *cur = &S.f, *alt = &S.g;  // ping-pong: no round writes one of its operands
+    const PwFold fc = pw_fold_consts(S);
     for (int i = 62; i >= 0; i--) {
-        pb_round<true, true>(S, alt, cur, cur, &S.t, y1, S.lines2[idx][0], y2, S.lines2[idx][1]);  // alt = cur^2, t = l l'
+        pb_round_impl<true>(S, alt, cur->c, cur, fc.d0, fc.d1, fc.d2, fc.d3);           // alt = cur^2
+        pb_round_impl<true>(S, cur, S.lprod[idx], alt, fc.d0, fc.d1, fc.d2, fc.d3);     // cur = (l l') alt
         idx++;
         if ((MI_BLS_X >> i) & 1) {
-            pb_round<true, true>(S, cur, alt, &S.t, &S.a, y1, S.lines2[idx][0], y2, S.lines2[idx][1]);  // cur = alt t
+            pb_round_impl<true>(S, alt, S.lprod[idx], cur, fc.d0, fc.d1, fc.d2, fc.d3);  // the addition step's lines
             idx++;
-            pb_mul_na(S, alt, cur, &S.a);
-            PB *sw = cur; cur = alt; alt = sw;
-        } else {
-            pb_mul_na(S, cur, alt, &S.t);
+            LPB *sw = cur; cur = alt; alt = sw;
         }
     }
     if (cur != &S.f) pb_copy(S, &S.f, cur);
 }
 
 // S.f <- S.f ^ (3 (q^12 - 1) / r)
-__device__ __attribute__((noinline)) void pw_final_exp(PwShared &S, const PairingConsts *pc) {
+__device__ __attribute__((noinline)) void pw_final_exp(LShared &S, const PairingConsts *pc) {
     // easy part
     pb_inv(S, &S.a, &S.f, pc);
     pb_conj(S, &S.t, &S.f);
@@ -357,7 +428,7 @@ __device__ __attribute__((noinline)) void pw_final_exp(PwShared &S, const Pairin
 }
 
 // full product over the pairs whose P is not infinity and whose Q is not infinity; result (tower order) to out
-__device__ __forceinline__ void pw_pairing_product(PwShared &S, const G1Affine *ps, const G2Prepared *const *qs, int n,
+__device__ __forceinline__ void pw_pairing_product(LShared &S, const G1Affine *ps, const G2Prepared *const *qs, int n,
                                                    const PairingConsts *pc, Fq12 *out) {
     __shared__ const G2Prepared *live_q[MI_MAX_PAIRS];
     __shared__ int live_n;
@@ -367,15 +438,16 @@ __device__ __forceinline__ void pw_pairing_product(PwShared &S, const G1Affine *
         for (int p = 0; p < n; p++) {
             if (qs[p]->infinity || ps[p].is_inf()) continue;
             live_q[m] = qs[p];
-            S.px[m] = ps[p].x;
-            S.py[m] = ps[p].y;
+            lds_store(&S.px[m], ps[p].x);
+            lds_store(&S.py[m], ps[p].y);
             m++;
         }
         live_n = m;
     }
+    if (t >= 64 && t < 64 + 25) lds_store(&S.dtab[t - 64], pc->dtab[t - 64]);
     __syncthreads();
     if (live_n == 0) {
-        if (t < 12) lds_store(&S.f.c[t], t == 0 ? Fq::one() : Fq::zero());
+        pb_set_one(&S.f);
         __syncthreads();
     }
     for (int c = 0; c < live_n; c += 2) {

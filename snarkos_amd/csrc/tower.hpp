@@ -180,6 +180,9 @@ static void g2_prepare_host(G2Prepared &out, const G2Affine &q) {
 // ---------------------------------------------------------------- Miller loop + final exponentiation
 struct PairingConsts {
     Fq frob[3][12];
+    // fold constants of the workgroup-cooperative rounds (pairing_wg.hpp): plain integers, D[m] = 2^(32 m - 384) mod q
+    // for m < 12, 2^(32 (m - 12)) mod q for m >= 12
+    Fq dtab[25];
 };
 
 inline MI_NI Fq12 exp_by_x(const Fq12 &a) {

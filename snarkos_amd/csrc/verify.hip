@@ -557,7 +557,8 @@ __global__ void __launch_bounds__(PW_THREADS) vs_per_proof_pairing_kernel(size_t
                                                                           const PairingConsts *__restrict__ pc,
                                                                           const uint8_t *__restrict__ alg_ok,
                                                                           uint8_t *__restrict__ verdicts) {
-    __shared__ PwShared S;
+    extern __shared__ uint4 pw_lds[];  // PW_LDS_BYTES
+    LShared &S = *(LShared *)pw_lds;
     __shared__ G1Affine ps[2];
     __shared__ const G2Prepared *qs[2];
     __shared__ Fq12 result;
@@ -858,7 +859,8 @@ static void vs_identify(Context &cx, VsKeys &v, const VsWork &w, size_t n, int l
     uint8_t *d_verdicts = (uint8_t *)cx.buf(nm, n);
     hipLaunchKernelGGL(vs_terms_kernel, dim3(cdiv(n * VS_TERMS, 128)), dim3(128), 0, st, n, w.pts1, w.sc1, w.sc2, w.vk_scal,
                        w.g_scal, w.circuit_of, (const mi_vs_circuit_vk *)v.circuits.p, (const VsConsts *)v.consts.p, terms);
-    hipLaunchKernelGGL(vs_per_proof_pairing_kernel, dim3((unsigned)n), dim3(PW_THREADS), 0, st, n, terms,
+    cx.raise_lds_limit((const void *)vs_per_proof_pairing_kernel, (int)PW_LDS_BYTES);
+    hipLaunchKernelGGL(vs_per_proof_pairing_kernel, dim3((unsigned)n), dim3(PW_THREADS), PW_LDS_BYTES, st, n, terms,
                        (const G2Prepared *)v.h_prep.p, (const G2Prepared *)v.tauh_prep.p, pairing_consts(cx, st), w.alg_ok,
                        d_verdicts);
     MI_HIP(hipGetLastError());

@@ -19,8 +19,10 @@ void hc_fr_mul32(const Fr *a, const Fr *b, Fr *o) { *o = mul32(*a, *b); }
 void hc_fq_add(const Fq *a, const Fq *b, Fq *o) { *o = add(*a, *b); }
 void hc_fq_sub(const Fq *a, const Fq *b, Fq *o) { *o = sub(*a, *b); }
 void hc_fq_inv(const Fq *a, Fq *o) { *o = inv(*a); }
-void hc_fq_inv_egcd(const Fq *a, Fq *o) { *o = invq(*a); }
-void hc_fr_inv_egcd(const Fr *a, Fr *o) { *o = invr(*a); }
+void hc_fq_inv_egcd(const Fq *a, Fq *o) { *o = inv_egcd(*a); }
+void hc_fr_inv_egcd(const Fr *a, Fr *o) { *o = inv_egcd(*a); }
+void hc_fq_inv_bingcd(const Fq *a, Fq *o) { *o = invq(*a); }  // what the library uses (field.hpp: inv_bingcd)
+void hc_fr_inv_bingcd(const Fr *a, Fr *o) { *o = invr(*a); }
 void hc_fr_mul(const Fr *a, const Fr *b, Fr *o) { *o = mul(*a, *b); }
 void hc_fr_inv(const Fr *a, Fr *o) { *o = inv(*a); }
 void hc_fr_to_mont(const Fr *a, Fr *o) { *o = to_mont(*a); }

@@ -52,6 +52,31 @@ def test_fq_ops(hc, orc):
         assert (out == want).all()
         hc.hc_fq_inv_egcd(_p(a), _p(out))
         assert (out == want).all()
+        hc.hc_fq_inv_bingcd(_p(a), _p(out))
+        assert (out == want).all()
+
+
+def test_fast_inversion_many_inputs(hc, orc):
+    """inv_bingcd (Pornin's approximated binary GCD, what invq / invr run on the device and on the host) against the
+    Fermat inverse of the oracle: random values, values of every length (short values exercise the exact small-operand
+    branch and the 63 / 64-bit window), p - 1, p - 2, 1, 2, 0"""
+    g = np.random.default_rng(77)
+    out, want = np.zeros(6, dtype=np.uint64), np.zeros(6, dtype=np.uint64)
+    ints = [0, 1, 2, 3, P.Q - 1, P.Q - 2, (P.Q + 1) // 2, P.FQ_MONT_R]
+    ints += [(1 << k) % P.Q for k in range(1, 384, 7)] + [((1 << k) - 1) % P.Q for k in (30, 31, 32, 33, 61, 62, 63, 64, 65, 95, 96, 97)]
+    ints += [int(g.integers(1, 1 << 62)) for _ in range(20)]
+    ints += [int.from_bytes(g.bytes(48), "little") % P.Q for _ in range(300)]
+    for x in ints:
+        a = np.ascontiguousarray(orc.int_to_limbs(x, 6))  # any residue is a valid Montgomery representative
+        hc.hc_fq_inv_bingcd(_p(a), _p(out)); orc.lib().orc_fq_inv(_p(want), _p(a))
+        assert (out == want).all(), hex(x)
+    out, want = np.zeros(4, dtype=np.uint64), np.zeros(4, dtype=np.uint64)
+    ints = [0, 1, 2, P.R - 1, P.R - 2, (P.R + 1) // 2] + [(1 << k) % P.R for k in range(1, 256, 5)]
+    ints += [int.from_bytes(g.bytes(32), "little") % P.R for _ in range(300)]
+    for x in ints:
+        a = np.ascontiguousarray(orc.int_to_limbs(x, 4))
+        hc.hc_fr_inv_bingcd(_p(a), _p(out)); orc.lib().orc_fr_inv(_p(want), _p(a))
+        assert (out == want).all(), hex(x)
 
 
 def test_fr_ops(hc, orc):
@@ -66,6 +91,8 @@ def test_fr_ops(hc, orc):
         hc.hc_fr_inv(_p(a[i]), _p(out)); orc.lib().orc_fr_inv(_p(want), _p(a[i]))
         assert (out == want).all()
         hc.hc_fr_inv_egcd(_p(a[i]), _p(out))
+        assert (out == want).all()
+        hc.hc_fr_inv_bingcd(_p(a[i]), _p(out))
         assert (out == want).all()
         hc.hc_fr_to_mont(_p(a[i]), _p(out)); orc.lib().orc_fr_from_canonical(_p(want), _p(a[i]))
         assert (out == want).all()

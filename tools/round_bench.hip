@@ -1,4 +1,5 @@
-// Time of one pairing "round" (pb_round) in isolation: one workgroup, N dependent rounds.
+// Time of one pairing "round" (pb_round) in isolation: one workgroup, N dependent rounds; and of the single-lane Fq
+// inversion inside pb_inv.
 //   hipcc -O3 --offload-arch=gfx950 -std=c++17 -o build/round_bench tools/round_bench.hip && ./build/round_bench
 #include <hip/hip_runtime.h>
 #include <stdio.h>
@@ -7,29 +8,59 @@ using namespace mi;
 
 template <int MODE>
 __global__ void __launch_bounds__(PW_THREADS) rounds_kernel(int n, Fq *out) {
-    __shared__ PwShared S;
+    extern __shared__ uint4 pw_lds[];
+    LShared &S = *(LShared *)pw_lds;
     const int t = threadIdx.x;
     if (t < 12) {
         Fq v = Fq::one();
         v.l[0] += 7 * t + 3;
-        lds_store(&S.f.c[t], v);
-        lds_store(&S.t.c[t], v);
+        pb_put(&S.f, t, v);
+        pb_put(&S.t, t, v);
     }
-    if (t < 8) {
+    if (t >= 64 && t < 64 + 25) {  // any constants below q do for timing
         Fq v = Fq::one();
-        v.l[1] += t;
-        lds_store(&S.lines2[0][t >> 2][t & 3], v);
+        v.l[2] ^= t;
+        lds_store(&S.dtab[t - 64], v);
     }
-    if (t == 12) { lds_store(&S.py[0], Fq::one()); lds_store(&S.py[1], Fq::one()); }
     __syncthreads();
-    PB *cur = &S.f, *alt = &S.g;
+    LPB *cur = &S.f, *alt = &S.g;
+    if (MODE == 2) {
+        Fq x = Fq::one();
+        x.l[0] += t;
+        for (int i = 0; i < n; i++) {
+            if (t == 0) x = invq(x);
+            __syncthreads();
+        }
+        if (t == 0) out[0] = x;
+        return;
+    }
+    if (MODE == 3) {  // stage profile of the ping-pong round (fold constants in registers)
+        __shared__ uint64_t prof[8];
+        if (t < 8) prof[t] = 0;
+        __syncthreads();
+        const PwFold fc = pw_fold_consts(S);
+        for (int i = 0; i < n; i++) {
+            pb_round_impl<true, true>(S, alt, cur->c, cur, fc.d0, fc.d1, fc.d2, fc.d3, prof);
+            LPB *sw = cur; cur = alt; alt = sw;
+        }
+        if (t < 8) ((uint64_t *)out)[16 + t] = prof[t];
+        if (t < 12) out[t] = lds_load(&cur->c[t]);
+        return;
+    }
+    if (MODE == 4) {  // ping-pong rounds with the fold constants kept in registers
+        const PwFold fc = pw_fold_consts(S);
+        for (int i = 0; i < n; i++) {
+            pb_round_impl<true>(S, alt, cur->c, cur, fc.d0, fc.d1, fc.d2, fc.d3);
+            LPB *sw = cur; cur = alt; alt = sw;
+        }
+        if (t < 12) out[t] = lds_load(&cur->c[t]);
+        return;
+    }
     for (int i = 0; i < n; i++) {
         if (MODE == 0) pb_mul(S, &S.f, &S.f, &S.f);
-        else if (MODE == 1) pb_round<true>(S, &S.f, &S.f, &S.f, &S.t, &S.py[0], S.lines2[0][0], &S.py[1], S.lines2[0][1]);
         else {
-            if (MODE == 2) pb_mul_na(S, alt, cur, cur);
-            else pb_round<true, true>(S, alt, cur, cur, &S.t, &S.py[0], S.lines2[0][0], &S.py[1], S.lines2[0][1]);
-            PB *sw = cur; cur = alt; alt = sw;
+            pb_mul_na(S, alt, cur, cur);
+            LPB *sw = cur; cur = alt; alt = sw;
         }
     }
     if (t < 12) out[t] = lds_load(&cur->c[t]);
@@ -37,24 +68,36 @@ __global__ void __launch_bounds__(PW_THREADS) rounds_kernel(int n, Fq *out) {
 
 int main() {
     Fq *d;
-    hipMalloc(&d, sizeof(Fq) * 12);
+    hipMalloc(&d, sizeof(Fq) * 12 + 1024);
     hipEvent_t e0, e1;
     hipEventCreate(&e0); hipEventCreate(&e1);
-    const int N = 2000;
-    const char *names[4] = {"dense round, in place (2 barriers)", "round with line product, in place", "dense round, ping-pong (1 barrier)",
-                            "round with line product, ping-pong"};
-    for (int mode = 0; mode < 4; mode++) {
+    const char *names[5] = {"dense round, in place (2 barriers)", "dense round, ping-pong (1 barrier)", "Fq inversion on one lane",
+                            "ping-pong round with stage stamps", "ping-pong round, fold constants in registers"};
+    hipFuncSetAttribute((const void *)rounds_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)PW_LDS_BYTES);
+    hipFuncSetAttribute((const void *)rounds_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)PW_LDS_BYTES);
+    hipFuncSetAttribute((const void *)rounds_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)PW_LDS_BYTES);
+    hipFuncSetAttribute((const void *)rounds_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)PW_LDS_BYTES);
+    hipFuncSetAttribute((const void *)rounds_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)PW_LDS_BYTES);
+    for (int mode = 0; mode < 5; mode++) {
+        const int N = mode == 2 ? 50 : 2000;
         for (int rep = 0; rep < 2; rep++) {
             hipEventRecord(e0, 0);
-            if (mode == 0) hipLaunchKernelGGL(rounds_kernel<0>, dim3(1), dim3(PW_THREADS), 0, 0, N, d);
-            else if (mode == 1) hipLaunchKernelGGL(rounds_kernel<1>, dim3(1), dim3(PW_THREADS), 0, 0, N, d);
-            else if (mode == 2) hipLaunchKernelGGL(rounds_kernel<2>, dim3(1), dim3(PW_THREADS), 0, 0, N, d);
-            else hipLaunchKernelGGL(rounds_kernel<3>, dim3(1), dim3(PW_THREADS), 0, 0, N, d);
+            if (mode == 0) hipLaunchKernelGGL(rounds_kernel<0>, dim3(1), dim3(PW_THREADS), PW_LDS_BYTES, 0, N, d);
+            else if (mode == 1) hipLaunchKernelGGL(rounds_kernel<1>, dim3(1), dim3(PW_THREADS), PW_LDS_BYTES, 0, N, d);
+            else if (mode == 2) hipLaunchKernelGGL(rounds_kernel<2>, dim3(1), dim3(PW_THREADS), PW_LDS_BYTES, 0, N, d);
+            else if (mode == 3) hipLaunchKernelGGL(rounds_kernel<3>, dim3(1), dim3(PW_THREADS), PW_LDS_BYTES, 0, N, d);
+            else hipLaunchKernelGGL(rounds_kernel<4>, dim3(1), dim3(PW_THREADS), PW_LDS_BYTES, 0, N, d);
             hipEventRecord(e1, 0);
             hipEventSynchronize(e1);
             float ms = 0;
             hipEventElapsedTime(&ms, e0, e1);
-            if (rep) printf("%s: %.3f us per round\n", names[mode], ms * 1e3 / N);
+            if (rep) printf("%s: %.3f us each\n", names[mode], ms * 1e3 / N);
+            if (rep && mode == 3) {
+                uint64_t h[8];
+                hipMemcpy(h, (char *)d + 16 * 8, sizeof h, hipMemcpyDeviceToHost);
+                const char *st[7] = {"loads", "product", "quad reduction", "fold", "row reduction", "Barrett + twin", "stores + barrier"};
+                for (int k = 0; k < 7; k++) printf("    %-18s %7.1f ticks per round\n", st[k], (double)h[k] / N);
+            }
         }
     }
     return 0;
