@@ -134,6 +134,14 @@ typedef struct { mi_g1_jac total_c, total_w; uint64_t n_proofs, n_alg_fail; } mi
 
 /* keys resident on the device: KZG vk (G2 lines prepared once) + circuit verifying keys */
 int32_t mi_vs_ctx_create(const mi_kzg_vk *vk, const mi_vs_circuit_vk *circuits, size_t n_circuits, uint64_t *ctx_out);
+/* flags: MI_VS_FS_POSEIDON -- the Fiat-Shamir transcript is a Poseidon sponge over Fq (row A9: width 3, x^17, 8 + 31
+ * rounds, this library's own constants) with the reference's absorb volume, 37 permutations per proof (tag, circuit
+ * digest, the 16 public inputs as two 128-bit limbs each, the coordinates of C_0..C_8, the 21 evaluations; z_beta,
+ * z_gamma, xi = low 128 bits of the first rate element after the 22nd, 26th and 37th permutation), instead of the
+ * SHA-256 stand-in of mi_vs_ctx_create.  Proofs are bound to their transcript kind. */
+#define MI_VS_FS_POSEIDON 1
+int32_t mi_vs_ctx_create_ex(const mi_kzg_vk *vk, const mi_vs_circuit_vk *circuits, size_t n_circuits, uint32_t flags,
+                            uint64_t *ctx_out);
 int32_t mi_vs_ctx_destroy(uint64_t ctx);
 /* host-pointer form: verdicts[n] (1 = valid) and *all_ok.  randomizers128: n x 2 x 16 bytes. */
 int32_t mi_vs_verify_batch(uint64_t ctx, const mi_vs_proof *proofs, size_t n, const uint8_t *randomizers128,

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""Write tests/golden/vs_batch_1024.npz: 1024 valid VarunaShaped-v1 proofs over 8 circuits (seed
-0xA1E00004), made by the oracle's synthetic prover (toy SRS).  bench.py and the full-size GPU tests load
+"""Write tests/golden/vs_batch_1024.npz (SHA-256 transcript) and vs_batch_1024_poseidon.npz (Poseidon transcript): 1024
+valid VarunaShaped-v1 proofs over 8 circuits (seed 0xA1E00004), made by the oracle's synthetic prover (toy SRS).  bench.py and the full-size GPU tests load
 this file, so the measured path never runs the prover.  Run:  python oracle/gen_vs_fixture.py"""
 import os
 import sys
@@ -11,8 +11,10 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, HERE)
 import orc_py as O  # noqa: E402
 
-b = O.VSBatch(0xA1E00004, 1024, 8, 0)
-assert b.expected.all() and b.verify_cpu(8).all() and b.verify_aggregated(8)[0]
-out = os.path.join(os.path.dirname(HERE), "tests", "golden", "vs_batch_1024.npz")
-np.savez(out, vk=b.vk, circuits=b.circuits, proofs=b.proofs, randomizers=b.randomizers, seed=np.uint64(b.seed))
-print("wrote", out, os.path.getsize(out), "bytes")
+for name, kind in (("vs_batch_1024.npz", O.FS_SHA256), ("vs_batch_1024_poseidon.npz", O.FS_POSEIDON)):
+    # the same seed under both Fiat-Shamir kinds: same keys, inputs and commitments; evaluations and witnesses differ
+    b = O.VSBatch(0xA1E00004, 1024, 8, 0, transcript=kind)
+    assert b.expected.all() and b.verify_cpu(8).all() and b.verify_aggregated(8)[0]
+    out = os.path.join(os.path.dirname(HERE), "tests", "golden", name)
+    np.savez(out, vk=b.vk, circuits=b.circuits, proofs=b.proofs, randomizers=b.randomizers, seed=np.uint64(b.seed))
+    print("wrote", out, os.path.getsize(out), "bytes")

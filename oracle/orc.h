@@ -138,6 +138,10 @@ typedef struct {
 void orc_vs_generate(uint64_t seed, size_t n_proofs, size_t n_circuits, uint32_t corrupt_per_1024,
                      orc_kzg_vk *vk, orc_vs_circuit_vk *circuits, orc_vs_proof *proofs,
                      uint8_t *randomizers128 /* n_proofs*2*16 */, uint8_t *expected);
+/* Fiat-Shamir kind for everything below (generate, challenges, verify): 0 SHA-256, 1 Poseidon over Fq */
+void orc_vs_set_transcript(int kind);
+int orc_vs_get_transcript(void);
+int orc_vs_proof_is_well_formed(const orc_vs_proof *p);
 /* transcript only: z_beta, z_gamma, xi (Montgomery Fr) */
 void orc_vs_challenges(const orc_vs_circuit_vk *cvk, const orc_vs_proof *p, orc_fr *z_beta, orc_fr *z_gamma,
                        orc_fr *xi);

@@ -354,8 +354,75 @@ void orc_sha256(uint8_t out[32], const uint8_t *data, size_t len) {
 /* ------------------------------------------------------------------ VarunaShaped-v1 */
 static const char VS_TAG[32] = "MI355X-VarunaShaped-v1";
 
+/* Fiat-Shamir kind of the synthetic shape: 0 = SHA-256 over the in-memory bytes, 1 = Poseidon sponge over Fq with the
+ * reference's absorb volume (37 permutations per proof).  Process-wide switch (test infrastructure: set it before a
+ * run, never two kinds at once). */
+static int g_vs_fs_kind = 0;
+void orc_vs_set_transcript(int kind) { g_vs_fs_kind = kind ? 1 : 0; }
+int orc_vs_get_transcript(void) { return g_vs_fs_kind; }
+
+/* bytes (<= 48) -> the Fq element whose Montgomery limbs are those bytes, zero-extended */
+static void fs_embed(fq_t *r, const void *b, size_t n) {
+    memset(r, 0, sizeof *r);
+    memcpy(r, b, n);
+}
+/* the e-th of the 73 absorbed elements (oracle/pyref.py: vs_fs_elements) */
+static void fs_element(fq_t *r, const orc_vs_circuit_vk *cvk, const orc_vs_proof *p, int e) {
+    const uint8_t *comms = (const uint8_t *)p->comms;
+    if (e == 0) fs_embed(r, VS_TAG, 32);
+    else if (e == 1) fs_embed(r, cvk->digest, 32);
+    else if (e < 34) fs_embed(r, (const uint8_t *)&p->inputs[(e - 2) >> 1] + 16 * ((e - 2) & 1), 16);
+    else if (e < 52) fs_embed(r, comms + 48 * (e - 34), 48);
+    else fs_embed(r, &p->evals[e - 52], 32);
+}
+static void vs_challenges_poseidon(const orc_vs_circuit_vk *cvk, const orc_vs_proof *p, fr_t *z_beta, fr_t *z_gamma, fr_t *xi) {
+    orc_fq st[3];
+    memset(st, 0, sizeof st);
+    for (int b = 0; b < 37; b++) {
+        fq_t e;
+        fs_element(&e, cvk, p, 2 * b);
+        fq_add((fq_t *)&st[1], (fq_t *)&st[1], &e);
+        if (2 * b + 1 < 73) {
+            fs_element(&e, cvk, p, 2 * b + 1);
+            fq_add((fq_t *)&st[2], (fq_t *)&st[2], &e);
+        }
+        orc_poseidon_permute(st);
+        if (b == 21 || b == 25 || b == 36) {
+            uint64_t c[6];
+            fq_to_canonical(c, (const fq_t *)&st[1]);
+            fr_from_u128le(b == 21 ? z_beta : (b == 25 ? z_gamma : xi), (const uint8_t *)c); /* low 128 bits */
+        }
+    }
+}
+
+/* what snarkVM's deserialiser guarantees and a raw-coordinate ABI must check itself (include/mi355x_snark.h,
+ * "PRECONDITIONS ON POINTS"): coordinates < q, points on the curve or (0,0), Fr fields < r */
+static int limbs_lt(const uint64_t *a, const uint64_t *m, int n) {
+    for (int i = n - 1; i >= 0; i--) {
+        if (a[i] < m[i]) return 1;
+        if (a[i] > m[i]) return 0;
+    }
+    return 0;
+}
+int orc_vs_proof_is_well_formed(const orc_vs_proof *p) {
+    for (int k = 0; k < ORC_VS_INPUTS; k++)
+        if (!limbs_lt((const uint64_t *)&p->inputs[k], ORC_FR_MODULUS, 4)) return 0;
+    for (int k = 0; k < ORC_VS_EVALS; k++)
+        if (!limbs_lt((const uint64_t *)&p->evals[k], ORC_FR_MODULUS, 4)) return 0;
+    for (int k = 0; k < ORC_VS_PROOF_COMMS + 2; k++) {
+        const orc_g1_affine *pt = k < ORC_VS_PROOF_COMMS ? &p->comms[k] : &p->w[k - ORC_VS_PROOF_COMMS];
+        if (!limbs_lt((const uint64_t *)&pt->x, ORC_FQ_MODULUS, 6) || !limbs_lt((const uint64_t *)&pt->y, ORC_FQ_MODULUS, 6)) return 0;
+        if (!orc_g1_is_on_curve(pt)) return 0;
+    }
+    return 1;
+}
+
 void orc_vs_challenges(const orc_vs_circuit_vk *cvk, const orc_vs_proof *p, orc_fr *z_beta, orc_fr *z_gamma,
                        orc_fr *xi) {
+    if (g_vs_fs_kind) {
+        vs_challenges_poseidon(cvk, p, S(z_beta), S(z_gamma), S(xi));
+        return;
+    }
     uint8_t buf[32 + 21 * 32 + 64], h[32];
     size_t o = 0;
     memcpy(buf + o, VS_TAG, 32); o += 32;
@@ -450,9 +517,9 @@ static void vs_derive(vs_fr_work *o, const orc_vs_circuit_vk *cvk, const orc_vs_
         fr_mul(&t, &r[q], &val[q]);
         fr_sub(&o->g_scalar, &o->g_scalar, &t);
     }
-    /* public-input consistency: v_0 == x_hat(z_beta) + (z_beta^16 - 1) v_1 */
+    /* public-input consistency: v_0 == x_hat(z_beta) + (z_beta^16 - 1) v_1; a malformed proof fails here too */
     o->alg_ok = 0;
-    if (vs_input_eval(&xhat, &znm1, (const fr_t *)p->inputs, &z[0])) {
+    if (orc_vs_proof_is_well_formed(p) && vs_input_eval(&xhat, &znm1, (const fr_t *)p->inputs, &z[0])) {
         fr_mul(&t, &znm1, S(&p->evals[1]));
         fr_add(&t, &t, &xhat);
         o->alg_ok = fr_eq(&t, S(&p->evals[0]));

@@ -270,11 +270,22 @@ def sha256(b):
     return out.tobytes()
 
 
-class VSBatch:
-    """A synthetic VarunaShaped-v1 batch in ABI layout."""
+FS_SHA256, FS_POSEIDON = 0, 1
 
-    def __init__(self, seed, n, n_circuits=8, corrupt_per_1024=0):
+
+class VSBatch:
+    """A synthetic VarunaShaped-v1 batch in ABI layout.  `transcript`: FS_SHA256 or FS_POSEIDON (the oracle's
+    process-wide switch is set before every call that derives challenges)."""
+
+    transcript = FS_SHA256
+
+    def _fs(self):
+        lib().orc_vs_set_transcript(C.c_int(self.transcript))
+
+    def __init__(self, seed, n, n_circuits=8, corrupt_per_1024=0, transcript=FS_SHA256):
         self.n, self.n_circuits, self.seed = n, n_circuits, seed
+        self.transcript = transcript
+        self._fs()
         self.vk = np.zeros(KZG_VK_BYTES, dtype=np.uint8)
         self.circuits = np.zeros(n_circuits * VS_CIRCUIT_VK_BYTES, dtype=np.uint8)
         self.proofs = np.zeros(n * VS_PROOF_BYTES, dtype=np.uint8)
@@ -284,12 +295,14 @@ class VSBatch:
                               _p(self.vk), _p(self.circuits), _p(self.proofs), _p(self.randomizers), _p(self.expected))
 
     def verify_cpu(self, threads=1):
+        self._fs()
         v = np.zeros(self.n, dtype=np.uint8)
         lib().orc_vs_verify_batch_cpu(_p(self.vk), _p(self.circuits), _p(self.proofs), C.c_size_t(self.n),
                                       _p(self.randomizers), _p(v), C.c_int(threads))
         return v
 
     def verify_aggregated(self, threads=1):
+        self._fs()
         alg = np.zeros(self.n, dtype=np.uint8)
         tc, tw = u64(12), u64(12)
         ok = lib().orc_vs_verify_aggregated(_p(self.vk), _p(self.circuits), C.c_size_t(self.n_circuits), _p(self.proofs),
@@ -297,6 +310,7 @@ class VSBatch:
         return bool(ok), alg, tc, tw
 
     def challenges(self, i):
+        self._fs()
         p = self.proofs[i * VS_PROOF_BYTES:(i + 1) * VS_PROOF_BYTES]
         circuit = int(np.frombuffer(p[:4].tobytes(), dtype=np.uint32)[0])
         cvk = self.circuits[circuit * VS_CIRCUIT_VK_BYTES:(circuit + 1) * VS_CIRCUIT_VK_BYTES]
@@ -355,7 +369,8 @@ def vs_finalize_with_oracle(vk, partials):
 class VSArrays(VSBatch):
     """A VarunaShaped-v1 batch wrapped around existing ABI-layout arrays (e.g. a committed fixture)."""
 
-    def __init__(self, vk, circuits, proofs, randomizers, expected=None):  # noqa: D107
+    def __init__(self, vk, circuits, proofs, randomizers, expected=None, transcript=FS_SHA256):  # noqa: D107
+        self.transcript = transcript
         self.vk = np.ascontiguousarray(vk, dtype=np.uint8).reshape(-1)
         self.circuits = np.ascontiguousarray(circuits, dtype=np.uint8).reshape(-1)
         self.proofs = np.ascontiguousarray(proofs, dtype=np.uint8).reshape(-1)

@@ -448,8 +448,79 @@ def vs_parse_circuit(b):
     return {"comms": [_rd_g1(b[96 * i:96 * i + 96]) for i in range(VS_VK_COMMS)], "digest": bytes(b[1152:1184])}
 
 
+# Fiat-Shamir transcript of the synthetic shape: SHA-256 over the in-memory bytes (round 1), or a Poseidon sponge over
+# Fq with the reference's absorb volume (37 permutations per proof).  A process-wide switch, like
+# the C oracle's: test infrastructure, never used concurrently with two kinds.
+VS_FS_SHA256, VS_FS_POSEIDON = 0, 1
+_VS_FS = [VS_FS_SHA256]
+
+
+def vs_set_transcript(kind):
+    assert kind in (VS_FS_SHA256, VS_FS_POSEIDON)
+    _VS_FS[0] = kind
+
+
+def _fs_embed(b):
+    """bytes (<= 48) -> the Fq element whose Montgomery limbs are those bytes, zero-extended (no arithmetic to absorb)"""
+    v = int.from_bytes(b, "little")
+    return v % Q * inv(FQ_MONT_R, Q) % Q
+
+
+def vs_fs_elements(cvk, proof):
+    """The 73 absorbed elements, in order: tag, circuit digest, the 16 public inputs as two 128-bit limbs each (the
+    nonnative absorb), the coordinates of C_0, C_1 | C_2..C_4 | C_5..C_8 | the 21 evaluations (the opening witnesses are
+    made from xi and so come after it).  Two elements per permutation (the last block holds one): 19 + 3 + 4 + 11 = 37
+    permutations; z_beta, z_gamma, xi are squeezed after the 22nd, 26th and 37th."""
+    raw = proof["raw"]
+    inputs, comms, evals = raw[16:528], raw[528:1392], raw[1392:2064]
+    els = [_fs_embed(VS_TAG), _fs_embed(cvk["digest"])]
+    for k in range(VS_INPUTS):
+        els += [_fs_embed(inputs[32 * k:32 * k + 16]), _fs_embed(inputs[32 * k + 16:32 * k + 32])]
+    els += [_fs_embed(comms[48 * c:48 * c + 48]) for c in range(18)]
+    els += [_fs_embed(evals[32 * k:32 * k + 32]) for k in range(VS_EVALS)]
+    assert len(els) == 73
+    return els
+
+
+def vs_challenges_poseidon(cvk, proof):
+    els = vs_fs_elements(cvk, proof)
+    st = [0, 0, 0]
+    out = []
+    for b in range(37):
+        st[1] = (st[1] + els[2 * b]) % Q
+        if 2 * b + 1 < len(els):
+            st[2] = (st[2] + els[2 * b + 1]) % Q
+        st = poseidon_permute(st)
+        if b in (21, 25, 36):
+            out.append(st[1] & ((1 << 128) - 1))  # low 128 bits of the canonical value of the first rate element
+    return tuple(out)
+
+
+def vs_proof_is_well_formed(proof):
+    """what snarkVM's deserialiser guarantees and this ABI must check itself: every G1 point on the curve (or the (0,0)
+    encoding of infinity), every coordinate < q, every Fr field < r (subgroup membership is the caller's precondition)"""
+    raw = proof["raw"]
+    for k in range(VS_INPUTS):
+        if int.from_bytes(raw[16 + 32 * k:48 + 32 * k], "little") >= R:
+            return False
+    for k in range(VS_EVALS):
+        if int.from_bytes(raw[1392 + 32 * k:1424 + 32 * k], "little") >= R:
+            return False
+    for off in [528 + 96 * i for i in range(VS_PROOF_COMMS)] + [2064, 2160]:
+        xm, ym = int.from_bytes(raw[off:off + 48], "little"), int.from_bytes(raw[off + 48:off + 96], "little")
+        if xm >= Q or ym >= Q:
+            return False
+        if xm == 0 and ym == 0:
+            continue
+        if not g1_is_on_curve((fq_from_mont(xm), fq_from_mont(ym))):
+            return False
+    return True
+
+
 def vs_challenges(cvk, proof):
     """Transcript over the in-memory (Montgomery, little-endian) bytes of the proof."""
+    if _VS_FS[0] == VS_FS_POSEIDON:
+        return vs_challenges_poseidon(cvk, proof)
     raw = proof["raw"]
     inputs = raw[16:16 + 512]
     comms = raw[528:528 + 864]
@@ -472,6 +543,8 @@ def vs_query_of(p):
 
 def vs_verify_one(tau_h, circuits, proof, r_beta, r_gamma):
     """Per-proof verdict = public-input consistency AND the two KZG openings (randomised together)."""
+    if proof["circuit"] >= len(circuits) or not vs_proof_is_well_formed(proof):
+        return False
     cvk = circuits[proof["circuit"]]
     zb, zg, xi = vs_challenges(cvk, proof)
     z = (zb, zg)

@@ -234,13 +234,18 @@ class VarunaShaped:
     """Batch verifier for the synthetic VarunaShaped-v1 proofs; the role of
     VarunaSNARK::verify_batch inside VM::check_transactions."""
 
-    def __init__(self, kzg_vk, circuit_vks):
+    def __init__(self, kzg_vk, circuit_vks, transcript="sha256"):
+        """transcript: "sha256" (the round-1 stand-in) or "poseidon" (sponge over Fq with the reference's absorb volume,
+        mi_vs_ctx_create_ex(..., MI_VS_FS_POSEIDON)); proofs are bound to their transcript kind."""
         vk = np.ascontiguousarray(kzg_vk).view(np.uint8).reshape(-1)
         cv = np.ascontiguousarray(circuit_vks).view(np.uint8).reshape(-1)
         assert vk.size == L.KZG_VK_BYTES and cv.size % L.VS_CIRCUIT_VK_BYTES == 0
+        assert transcript in ("sha256", "poseidon")
         self.n_circuits = cv.size // L.VS_CIRCUIT_VK_BYTES
         h = C.c_uint64(0)
-        L.check(L.lib().mi_vs_ctx_create(L.ptr(vk), L.ptr(cv), C.c_size_t(self.n_circuits), C.byref(h)), "mi_vs_ctx_create")
+        flags = L.VS_FS_POSEIDON if transcript == "poseidon" else 0
+        L.check(L.lib().mi_vs_ctx_create_ex(L.ptr(vk), L.ptr(cv), C.c_size_t(self.n_circuits), C.c_uint32(flags), C.byref(h)),
+                "mi_vs_ctx_create_ex")
         self.ctx = h.value
         # accumulation lanes of this context (the library reads the same variable when it creates the context)
         try:

@@ -42,11 +42,19 @@ void pairing_product_host_args(Context &cx, const G1Affine *ps, const G2Affine *
 void pairing_launch(Context &cx, const G1Affine *ps, const G2Prepared *const *d_qs, size_t n, Fq12 *d_out, hipStream_t st);
 const PairingConsts *pairing_consts(Context &cx, hipStream_t st);
 
+// capi.hip: Poseidon over Fq (width 3, x^17, 4 + 31 + 4 rounds), constants resident per device
+struct PoseidonConsts {
+    Fq ark[MI_POSEIDON_ROUNDS][3];
+    Fq mds[3][3];
+};
+const PoseidonConsts *poseidon_consts(Context &cx, hipStream_t st);
+
 // verify.hip
 int32_t kzg_batch_check_host(Context &cx, const mi_kzg_vk *vk, const mi_g1_affine *comms, const mi_fr *points,
                              const mi_fr *values, const mi_g1_affine *witnesses, size_t n, const uint8_t *rand128,
                              uint8_t *ok_out);
-int32_t vs_ctx_create(Context &cx, const mi_kzg_vk *vk, const mi_vs_circuit_vk *circuits, size_t n_circuits, uint64_t *out);
+int32_t vs_ctx_create(Context &cx, const mi_kzg_vk *vk, const mi_vs_circuit_vk *circuits, size_t n_circuits, uint32_t flags,
+                      uint64_t *out);
 int32_t vs_ctx_destroy(Context &cx, uint64_t id);
 int32_t vs_accumulate_device(Context &cx, uint64_t id, const void *d_proofs, size_t n, const void *d_rand,
                              mi_vs_partial *out, hipStream_t st);

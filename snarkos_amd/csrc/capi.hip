@@ -116,10 +116,6 @@ __global__ void __launch_bounds__(256) dbg_fq_mul_throughput_kernel(Fq *out, uin
 }
 
 // ------------------------------------------------------------ Poseidon sponge over Fq, one lane per sponge
-struct PoseidonConsts {
-    Fq ark[MI_POSEIDON_ROUNDS][3];
-    Fq mds[3][3];
-};
 __device__ __forceinline__ Fq pow17(const Fq &x) {
     Fq x2 = mul(x, x), x4 = mul(x2, x2), x8 = mul(x4, x4), x16 = mul(x8, x8);
     return mul(x16, x);
@@ -165,7 +161,7 @@ struct PoseidonState {
     bool ready = false;
     ~PoseidonState() { consts.release(); }
 };
-static const PoseidonConsts *poseidon_consts(Context &cx, hipStream_t st) {
+const PoseidonConsts *poseidon_consts(Context &cx, hipStream_t st) {
     PoseidonState &ps = cx.mod<PoseidonState>("poseidon");
     if (!ps.ready) {
         static PoseidonConsts h;
@@ -630,7 +626,11 @@ int32_t mi_poseidon_fq_hash_many_device(const void *d_inputs, size_t n, size_t m
 // ------------------------------------------------------------ VarunaShaped-v1
 int32_t mi_vs_ctx_create(const mi_kzg_vk *vk, const mi_vs_circuit_vk *circuits, size_t n_circuits, uint64_t *ctx_out) {
     if (!vk || !circuits || !n_circuits || !ctx_out) return MI_ERR_BAD_ARGS;
-    return guarded([&](Context &cx) -> int32_t { return vs_ctx_create(cx, vk, circuits, n_circuits, ctx_out); });
+    return guarded([&](Context &cx) -> int32_t { return vs_ctx_create(cx, vk, circuits, n_circuits, 0, ctx_out); });
+}
+int32_t mi_vs_ctx_create_ex(const mi_kzg_vk *vk, const mi_vs_circuit_vk *circuits, size_t n_circuits, uint32_t flags, uint64_t *ctx_out) {
+    if (!vk || !circuits || !n_circuits || !ctx_out || (flags & ~(uint32_t)MI_VS_FS_POSEIDON)) return MI_ERR_BAD_ARGS;
+    return guarded([&](Context &cx) -> int32_t { return vs_ctx_create(cx, vk, circuits, n_circuits, flags, ctx_out); });
 }
 int32_t mi_vs_ctx_destroy(uint64_t c) {
     int32_t st = ensure_init();

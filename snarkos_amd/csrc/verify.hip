@@ -119,6 +119,9 @@ struct VsConsts {
     Fr n_inv;                  // 1/16
     uint32_t tag[8];           // big-endian words of the 32-byte domain tag
     G1Affine g;
+    Fq tag_elem;               // the tag as an absorbed Fq element (its 32 bytes as Montgomery limbs)
+    uint32_t fs_kind;          // 0: SHA-256 transcript, MI_VS_FS_POSEIDON: Poseidon sponge over Fq
+    uint32_t _pad[3];
 };
 #define VS_SLOTS MI_VS_MAX_TICKETS
 #define VS_ACC_DEPTH MI_VS_MAX_OPEN_ACCUMULATIONS  // accumulations (derive + both MSMs) that may be enqueued before the oldest is folded
@@ -135,6 +138,7 @@ struct VsSlot {  // one in-flight pairing product (pipelined finalize)
 // of the process.
 struct VsCtx {
     uint64_t id = 0;
+    uint32_t flags = 0;
     size_t n_circuits = 0;
     mi_kzg_vk vk;
     std::vector<mi_vs_circuit_vk> circuits;
@@ -144,6 +148,7 @@ struct VsCtx {
 struct VsKeys {  // one device's copy
     DevBuf circuits, h_prep, tauh_prep, consts;
     size_t n_circuits = 0;
+    bool fs_poseidon = false;
     ~VsKeys() {
         circuits.release();
         h_prep.release();
@@ -258,6 +263,7 @@ static VsKeys &vs_keys(Context &cx, const VsCtx &v) {
     if (it != t.of.end()) return *it->second;
     std::unique_ptr<VsKeys> k(new VsKeys());
     k->n_circuits = v.n_circuits;
+    k->fs_poseidon = (v.flags & MI_VS_FS_POSEIDON) != 0;
     hipStream_t st = cx.stream;
     MI_HIP(hipMemcpyAsync(k->circuits.get(sizeof(mi_vs_circuit_vk) * v.n_circuits), v.circuits.data(),
                           sizeof(mi_vs_circuit_vk) * v.n_circuits, hipMemcpyHostToDevice, st));
@@ -272,9 +278,11 @@ static VsKeys &vs_keys(Context &cx, const VsCtx &v) {
     return ref;
 }
 
-int32_t vs_ctx_create(Context &cx, const mi_kzg_vk *vk, const mi_vs_circuit_vk *circuits, size_t n_circuits, uint64_t *out) {
+int32_t vs_ctx_create(Context &cx, const mi_kzg_vk *vk, const mi_vs_circuit_vk *circuits, size_t n_circuits, uint32_t flags,
+                      uint64_t *out) {
     std::shared_ptr<VsCtx> v(new VsCtx());
     v->n_circuits = n_circuits;
+    v->flags = flags;
     v->vk = *vk;
     v->circuits.assign(circuits, circuits + n_circuits);
     G2Affine qa;
@@ -292,6 +300,10 @@ int32_t vs_ctx_create(Context &cx, const mi_kzg_vk *vk, const mi_vs_circuit_vk *
         hc.tag[i] = ((uint32_t)(uint8_t)TAG[4 * i] << 24) | ((uint32_t)(uint8_t)TAG[4 * i + 1] << 16) |
                     ((uint32_t)(uint8_t)TAG[4 * i + 2] << 8) | (uint32_t)(uint8_t)TAG[4 * i + 3];
     memcpy(&hc.g, &vk->g, sizeof hc.g);
+    hc.tag_elem = Fq::zero();
+    memcpy(hc.tag_elem.l, TAG, 32);
+    hc.fs_kind = flags & MI_VS_FS_POSEIDON;
+    memset(hc._pad, 0, sizeof hc._pad);
     {
         std::lock_guard<std::mutex> lk(g_vs_mu);
         v->id = g_vs_next++;
@@ -340,6 +352,36 @@ __host__ __device__ __forceinline__ int vs_query_of(int p) {
 // Two waves per 64 proofs.  Wave 0 walks the transcript (four chained SHA-256, ~140 us: the serial spine) and then the
 // opening-challenge loop that needs xi; wave 1 meanwhile copies the points into MSM order and, as soon as z_beta is
 // known (after the second hash), runs the public-input check.  z_beta crosses through LDS at the one barrier.
+// (a Fq / Fr field of a proof as delivered: canonical range checks on the raw limbs)
+__device__ __forceinline__ bool vs_limbs_below(const uint32_t *__restrict__ v, const uint32_t *mod, int nl) {
+    bool lt = false, decided = false;
+    for (int k = nl - 1; k >= 0; k--) {
+        const uint32_t a = v[k], m = mod[k];
+        if (!decided && a != m) {
+            lt = a < m;
+            decided = true;
+        }
+    }
+    return lt;
+}
+// y^2 == x^3 + 1, or the (0,0) encoding of infinity; coordinates below q
+__device__ __attribute__((noinline)) bool vs_point_ok(const uint32_t *__restrict__ pt) {
+    Fq x, y;
+    uint32_t any = 0;
+#pragma unroll
+    for (int k = 0; k < 12; k++) {
+        x.l[k] = pt[k];
+        y.l[k] = pt[12 + k];
+        any |= x.l[k] | y.l[k];
+    }
+    if (!vs_limbs_below(x.l, FqP::MOD, 12) || !vs_limbs_below(y.l, FqP::MOD, 12)) return false;
+    if (!any) return true;
+    return mulq(y, y) == add(mulq(mulq(x, x), x), Fq::one());
+}
+
+// FS = 0: the SHA-256 transcript is walked here; FS = 1: the challenges come from `chal` (n x 3 x 128 bits: z_beta,
+// z_gamma, xi), written by vs_fs_poseidon_kernel
+template <int FS>
 __global__ void __launch_bounds__(128) vs_derive_kernel(const mi_vs_proof *__restrict__ proofs, size_t n,
                                                         const uint8_t *__restrict__ rand128,
                                                         const mi_vs_circuit_vk *__restrict__ circuits, size_t n_circuits,
@@ -347,7 +389,7 @@ __global__ void __launch_bounds__(128) vs_derive_kernel(const mi_vs_proof *__res
                                                         uint32_t *__restrict__ sc1, G1Affine *__restrict__ pts2,
                                                         uint32_t *__restrict__ sc2, Fr *__restrict__ vk_scal,
                                                         Fr *__restrict__ g_scal, uint8_t *__restrict__ alg_ok,
-                                                        uint32_t *__restrict__ circuit_of) {
+                                                        uint32_t *__restrict__ circuit_of, const uint32_t *__restrict__ chal) {
     __shared__ uint32_t zb_lds[64][4];
     const int lane = threadIdx.x & 63, role = threadIdx.x >> 6;  // role 0: transcript + scalars, role 1: points + check
     const size_t i = (size_t)blockIdx.x * 64 + lane;
@@ -362,8 +404,9 @@ __global__ void __launch_bounds__(128) vs_derive_kernel(const mi_vs_proof *__res
     const uint32_t *comms = inputs + 128;            // 9 x 24 words
     const uint32_t *evals = comms + 216;             // 21 x 8 words
     uint32_t h[8], zw[2][4], xw[4];
+    bool well_formed = true;
     if (role == 0) {
-        if (live) {
+        if (live && FS == 0) {
             uint32_t tag[8];
 #pragma unroll
             for (int k = 0; k < 8; k++) tag[k] = kc->tag[k];
@@ -376,6 +419,12 @@ __global__ void __launch_bounds__(128) vs_derive_kernel(const mi_vs_proof *__res
             }
         }
     } else if (live) {
+        // ---- what snarkVM's deserialiser guarantees and raw coordinates do not: points on the curve (or (0,0)),
+        // coordinates below q, Fr fields below r (include/mi355x_snark.h, PRECONDITIONS ON POINTS)
+        for (int k = 0; k < MI_VS_PROOF_COMMS; k++) well_formed = well_formed && vs_point_ok(comms + 24 * k);
+        for (int q = 0; q < 2; q++) well_formed = well_formed && vs_point_ok(evals + 168 + 24 * q);
+        for (int k = 0; k < MI_VS_INPUTS; k++) well_formed = well_formed && vs_limbs_below(inputs + 8 * k, FrP::MOD, 8);
+        for (int k = 0; k < MI_VS_EVALS; k++) well_formed = well_formed && vs_limbs_below(evals + 8 * k, FrP::MOD, 8);
         circuit_of[i] = circuit;
         // ---- points into MSM order, randomizers as the tau-H side's scalars
         const G1Affine *pc = reinterpret_cast<const G1Affine *>(comms);
@@ -394,12 +443,20 @@ __global__ void __launch_bounds__(128) vs_derive_kernel(const mi_vs_proof *__res
     __syncthreads();
     if (!live) return;
     if (role == 0) {
-        sha256_prefixed(h, h, comms + 120, 96, nullptr, 0);
+        if (FS == 0) {
+            sha256_prefixed(h, h, comms + 120, 96, nullptr, 0);
 #pragma unroll
-        for (int k = 0; k < 4; k++) zw[1][k] = __builtin_bswap32(h[k]);
-        sha256_prefixed(h, h, evals, 168, nullptr, 0);
+            for (int k = 0; k < 4; k++) zw[1][k] = __builtin_bswap32(h[k]);
+            sha256_prefixed(h, h, evals, 168, nullptr, 0);
 #pragma unroll
-        for (int k = 0; k < 4; k++) xw[k] = __builtin_bswap32(h[k]);
+            for (int k = 0; k < 4; k++) xw[k] = __builtin_bswap32(h[k]);
+        } else {
+            const uint4 c0 = reinterpret_cast<const uint4 *>(chal)[3 * i], c1 = reinterpret_cast<const uint4 *>(chal)[3 * i + 1],
+                        c2 = reinterpret_cast<const uint4 *>(chal)[3 * i + 2];
+            zw[0][0] = c0.x; zw[0][1] = c0.y; zw[0][2] = c0.z; zw[0][3] = c0.w;
+            zw[1][0] = c1.x; zw[1][1] = c1.y; zw[1][2] = c1.z; zw[1][3] = c1.w;
+            xw[0] = c2.x; xw[1] = c2.y; xw[2] = c2.z; xw[3] = c2.w;
+        }
         Fr z[2] = {fr_from_u128(zw[0]), fr_from_u128(zw[1])};
         Fr xi = fr_from_u128(xw);
         // ---- randomizers
@@ -431,14 +488,19 @@ __global__ void __launch_bounds__(128) vs_derive_kernel(const mi_vs_proof *__res
     // The right-hand side takes prefix/suffix products: 4 * 16 multiplications instead of a field inversion
     // (which is ~380 sequential multiplications per lane).
     uint32_t zbw[4];
+    if (FS == 0) {
 #pragma unroll
-    for (int k = 0; k < 4; k++) zbw[k] = zb_lds[lane][k];
+        for (int k = 0; k < 4; k++) zbw[k] = zb_lds[lane][k];
+    } else {
+        const uint4 c0 = reinterpret_cast<const uint4 *>(chal)[3 * i];
+        zbw[0] = c0.x; zbw[1] = c0.y; zbw[2] = c0.z; zbw[3] = c0.w;
+    }
     const Fr zb = fr_from_u128(zbw);
     Fr zn = zb;
 #pragma unroll
     for (int k = 0; k < 4; k++) zn = sqr(zn);
     Fr znm1 = sub(zn, Fr::one());
-    bool ok = !znm1.is_zero() && !bad_circuit;  // z^16 = 1 rejects, as in the oracle
+    bool ok = !znm1.is_zero() && !bad_circuit && well_formed;  // z^16 = 1 rejects, as in the oracle
     Fr pre[MI_VS_INPUTS], acc = Fr::one();
     for (int k = 0; k < MI_VS_INPUTS; k++) {  // pre[k] = prod_{j < k} d_j
         pre[k] = acc;
@@ -455,6 +517,106 @@ __global__ void __launch_bounds__(128) vs_derive_kernel(const mi_vs_proof *__res
     for (int k = 0; k < 4; k++) lhs = dbl(lhs);  // * 16
     ok = ok && (lhs == rhs);
     alg_ok[i] = ok ? 1 : 0;
+}
+
+// ---------------------------------------------------------------- Poseidon Fiat-Shamir transcript (row A9 on the path)
+// 37 permutations per proof (include/mi355x_snark.h, MI_VS_FS_POSEIDON), each 39 rounds
+// of (round constants, x^17, 3x3 MDS): one lane per proof would walk 37 x 626 dependent Fq products (~30 ms).  Here a
+// QUAD of lanes owns a proof -- lane l < 3 holds state element l -- and a round costs six product slots instead of
+// fourteen: in a partial round lane 0 walks the S-box chain (x^2, x^4, x^8, x^16, x^17) while lanes 1 and 2 spend the
+// first three of those slots on their MDS columns (mds[i][l] s_l, i = 0..2: same instruction, other operands); one
+// more slot multiplies the new s_0 into every row; the partial sums cross the quad through LDS.  A full round is the
+// S-box on all three lanes and three slots for the rows.  Sixteen proofs per wave, one wave per workgroup.
+__device__ __forceinline__ Fq fq_sel(bool c, const Fq &a, const Fq &b) {
+    Fq r;
+#pragma unroll
+    for (int k = 0; k < 12; k++) r.l[k] = c ? a.l[k] : b.l[k];
+    return r;
+}
+__device__ __forceinline__ Fq vs_fs_element(const mi_vs_proof *__restrict__ p, const uint32_t *__restrict__ digest,
+                                            const VsConsts *__restrict__ kc, int e) {
+    // element e of the transcript: a run of 16 / 32 / 48 bytes of the proof taken as Montgomery limbs (zero-extended)
+    const uint32_t *pw = reinterpret_cast<const uint32_t *>(p);
+    const uint32_t *src;
+    int words;
+    if (e == 0) { src = kc->tag_elem.l; words = 8; }
+    else if (e == 1) { src = digest; words = 8; }
+    else if (e < 34) { src = pw + 4 + 4 * (e - 2); words = 4; }     // halves of the 16 inputs
+    else if (e < 52) { src = pw + 132 + 12 * (e - 34); words = 12; }  // coordinates of C_0..C_8
+    else { src = pw + 348 + 8 * (e - 52); words = 8; }               // evaluations
+    Fq r;
+#pragma unroll
+    for (int q = 0; q < 3; q++) {
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (4 * q < words) v = *reinterpret_cast<const uint4 *>(src + 4 * q);
+        r.l[4 * q] = v.x; r.l[4 * q + 1] = v.y; r.l[4 * q + 2] = v.z; r.l[4 * q + 3] = v.w;
+    }
+    return r;
+}
+#define VS_FS_BLOCKS 37
+#define VS_FS_ELEMS 73
+__global__ void __launch_bounds__(64) vs_fs_poseidon_kernel(const mi_vs_proof *__restrict__ proofs, size_t n,
+                                                             const mi_vs_circuit_vk *__restrict__ circuits, size_t n_circuits,
+                                                             const VsConsts *__restrict__ kc, const PoseidonConsts *__restrict__ pc,
+                                                             uint32_t *__restrict__ chal) {
+    __shared__ Fq xs[16][3];     // the state of each proof (full rounds), or lane 0's new element in slot 0 (partial)
+    __shared__ Fq xt[16][2][3];  // partial rounds: lane l's products mds[i][l] s_l, l = 1, 2
+    const int t = threadIdx.x, ps = t >> 2, l = t & 3, lc = l < 3 ? l : 0;
+    const size_t i = (size_t)blockIdx.x * 16 + ps;
+    const mi_vs_proof *p = proofs + (i < n ? i : 0);
+    uint32_t circuit = reinterpret_cast<const uint32_t *>(p)[0];
+    if (circuit >= n_circuits) circuit = 0;
+    const uint32_t *digest = reinterpret_cast<const uint32_t *>(circuits[circuit].digest);
+    // this lane's constants: its MDS column (partial rounds), its row (full rounds)
+    Fq mcol[3], mrow[3];
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        mcol[k] = pc->mds[k][lc];
+        mrow[k] = pc->mds[lc][k];
+    }
+    Fq s = Fq::zero();
+    for (int b = 0; b < VS_FS_BLOCKS; b++) {
+        // ---- absorb: lane 1 takes element 2b, lane 2 element 2b + 1 (the last block holds one)
+        const int e = 2 * b + (l == 2 ? 1 : 0);
+        if ((l == 1 || l == 2) && e < VS_FS_ELEMS) s = add(s, vs_fs_element(p, digest, kc, e));
+        // ---- permutation
+        for (int r = 0; r < MI_POSEIDON_ROUNDS; r++) {
+            s = add(s, pc->ark[r][lc]);
+            const bool full = r < MI_POSEIDON_FULL_HALF || r >= MI_POSEIDON_FULL_HALF + MI_POSEIDON_PARTIAL;  // uniform
+            if (full) {
+                const Fq x2 = mul(s, s), x4 = mul(x2, x2), x8 = mul(x4, x4), x16 = mul(x8, x8);
+                s = mul(x16, s);
+                if (l < 3) xs[ps][l] = s;
+                __syncthreads();
+                const Fq a0 = xs[ps][0], a1 = xs[ps][1], a2 = xs[ps][2];
+                s = add(add(mul(mrow[0], a0), mul(mrow[1], a1)), mul(mrow[2], a2));
+                __syncthreads();
+            } else {
+                const bool sb = l == 0;  // the S-box lane; lanes 1, 2 run their MDS column beside it
+                const Fq x2 = mul(fq_sel(sb, s, mcol[0]), s);
+                const Fq x4 = mul(fq_sel(sb, x2, mcol[1]), fq_sel(sb, x2, s));
+                const Fq x8 = mul(fq_sel(sb, x4, mcol[2]), fq_sel(sb, x4, s));
+                const Fq x16 = mul(x8, x8);   // lanes 1, 2: idle slots (results unused)
+                const Fq x17 = mul(x16, s);
+                if (l == 0) xs[ps][0] = x17;
+                if (l == 1 || l == 2) {
+                    xt[ps][l - 1][0] = x2;
+                    xt[ps][l - 1][1] = x4;
+                    xt[ps][l - 1][2] = x8;
+                }
+                __syncthreads();
+                const Fq s0 = xs[ps][0];
+                s = add(add(mul(mrow[0], s0), xt[ps][0][lc]), xt[ps][1][lc]);
+                __syncthreads();
+            }
+        }
+        // ---- squeeze: the low 128 bits of the canonical value of the first rate element
+        if ((b == 21 || b == 25 || b == VS_FS_BLOCKS - 1) && l == 1 && i < n) {
+            const Fq c = from_mont(s);
+            const int which = b == 21 ? 0 : (b == 25 ? 1 : 2);
+            reinterpret_cast<uint4 *>(chal)[3 * i + which] = make_uint4(c.l[0], c.l[1], c.l[2], c.l[3]);
+        }
+    }
 }
 
 // one block per merged slot: slot < n_circuits*12 -> sum of vk_scal over the proofs of that circuit;
@@ -607,11 +769,27 @@ static VsWork vs_run_derive(Context &cx, VsKeys &v, const void *d_proofs, size_t
     w.g_scal = (Fr *)cx.buf(W("g_scal"), sizeof(Fr) * n);
     w.alg_ok = (uint8_t *)cx.buf(W("alg_ok"), n);
     w.circuit_of = (uint32_t *)cx.buf(W("circuit_of"), 4 * n);
-    cx.prof.begin("vs_derive", st, n);
-    hipLaunchKernelGGL(vs_derive_kernel, dim3(cdiv(n, 64)), dim3(128), 0, st, (const mi_vs_proof *)d_proofs, n,
-                       (const uint8_t *)d_rand, (const mi_vs_circuit_vk *)v.circuits.p, v.n_circuits,
-                       (const VsConsts *)v.consts.p, w.pts1, w.sc1, w.pts2, w.sc2, w.vk_scal, w.g_scal, w.alg_ok, w.circuit_of);
-    cx.prof.end("vs_derive", st);
+    if (v.fs_poseidon) {
+        uint32_t *chal = (uint32_t *)cx.buf(W("chal"), 48 * n);
+        const PoseidonConsts *pc = poseidon_consts(cx, st);
+        cx.prof.begin("vs_fs_poseidon", st, n);
+        hipLaunchKernelGGL(vs_fs_poseidon_kernel, dim3(cdiv(n, 16)), dim3(64), 0, st, (const mi_vs_proof *)d_proofs, n,
+                           (const mi_vs_circuit_vk *)v.circuits.p, v.n_circuits, (const VsConsts *)v.consts.p, pc, chal);
+        cx.prof.end("vs_fs_poseidon", st);
+        cx.prof.begin("vs_derive", st, n);
+        hipLaunchKernelGGL(vs_derive_kernel<1>, dim3(cdiv(n, 64)), dim3(128), 0, st, (const mi_vs_proof *)d_proofs, n,
+                           (const uint8_t *)d_rand, (const mi_vs_circuit_vk *)v.circuits.p, v.n_circuits,
+                           (const VsConsts *)v.consts.p, w.pts1, w.sc1, w.pts2, w.sc2, w.vk_scal, w.g_scal, w.alg_ok, w.circuit_of,
+                           (const uint32_t *)chal);
+        cx.prof.end("vs_derive", st);
+    } else {
+        cx.prof.begin("vs_derive", st, n);
+        hipLaunchKernelGGL(vs_derive_kernel<0>, dim3(cdiv(n, 64)), dim3(128), 0, st, (const mi_vs_proof *)d_proofs, n,
+                           (const uint8_t *)d_rand, (const mi_vs_circuit_vk *)v.circuits.p, v.n_circuits,
+                           (const VsConsts *)v.consts.p, w.pts1, w.sc1, w.pts2, w.sc2, w.vk_scal, w.g_scal, w.alg_ok, w.circuit_of,
+                           (const uint32_t *)nullptr);
+        cx.prof.end("vs_derive", st);
+    }
     hipLaunchKernelGGL(vs_merge_kernel, dim3((unsigned)(v.n_circuits * MI_VS_VK_COMMS + 1)), dim3(256), 0, st, w.vk_scal,
                        w.g_scal, w.circuit_of, n, (const mi_vs_circuit_vk *)v.circuits.p, v.n_circuits,
                        (const VsConsts *)v.consts.p, w.pts1, w.sc1);

@@ -30,6 +30,7 @@ VS_PARTIAL_BYTES = 304
 VS_MAX_OPEN_ACCUMULATIONS = 14  # compile-time cap; a context has MI_SNARK_VS_LANES (default 12) lanes
 VS_DEFAULT_LANES = 12
 VS_MAX_TICKETS = 8
+VS_FS_POSEIDON = 1  # mi_vs_ctx_create_ex flag: Poseidon Fiat-Shamir transcript
 
 # every symbol include/mi355x_snark.h declares
 EXPORTS = [
@@ -38,7 +39,7 @@ EXPORTS = [
     "mi_ntt_fr", "mi_ntt_fr_device", "mi_kzg_commit_h", "mi_kzg_commit_h_device", "mi_kzg_open_h", "mi_poly_mul_fr",
     "mi_pairing_product_is_one", "mi_pairing", "mi_kzg_batch_check",
     "mi_poseidon_fq_hash_many", "mi_poseidon_fq_hash_many_device",
-    "mi_vs_ctx_create", "mi_vs_ctx_destroy", "mi_vs_verify_batch", "mi_vs_verify_batch_device",
+    "mi_vs_ctx_create", "mi_vs_ctx_create_ex", "mi_vs_ctx_destroy", "mi_vs_verify_batch", "mi_vs_verify_batch_device",
     "mi_vs_accumulate_device", "mi_vs_accumulate_begin", "mi_vs_accumulate_end", "mi_vs_finalize", "mi_vs_finalize_async", "mi_vs_finalize_wait",
     "mi_vs_verify_block", "mi_vs_verify_block_device",
     "mi_vs_stream_open", "mi_vs_stream_submit", "mi_vs_stream_finish", "mi_vs_stream_next", "mi_vs_stream_close",

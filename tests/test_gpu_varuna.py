@@ -1,4 +1,6 @@
 """-m gpu: VarunaShaped-v1 batch verification, verdict-for-verdict against the CPU oracle."""
+import os
+
 import numpy as np
 import pytest
 
@@ -355,5 +357,73 @@ def test_native_stream_driver_api(orc, mi):
         res = run(boom, [(pa, ra)] * 3)
         assert res and res[-1] == ("next", -4) and all(x is True for x in res[:-1])
         assert v.verify_batch(p, r)[0]  # the context is still usable
+    finally:
+        v.close()
+
+
+def test_poseidon_transcript_batches(orc, mi):
+    """MI_VS_FS_POSEIDON: the Fiat-Shamir challenges come from the Poseidon sponge over Fq (37 permutations per proof,
+    quad-of-lanes kernel).  Partial accumulator bit-exact with the oracle's, verdicts proof for proof, a corrupted
+    batch, the streamed form, and the committed 1024-proof fixture."""
+    import torch
+    as_bytes = lambda a: np.frombuffer(np.ascontiguousarray(a).tobytes(), dtype=np.uint8)
+    b = orc.VSBatch(0xF5A0, 70, 3, 0, transcript=orc.FS_POSEIDON)
+    v = mi.VarunaShaped(b.vk, b.circuits, transcript="poseidon")
+    try:
+        p, r = torch.from_numpy(b.proofs).cuda(), torch.from_numpy(b.randomizers).cuda()
+        assert (v.accumulate(p, r) == as_bytes(orc.vs_partial_from_oracle(b, threads=8))).all()
+        ok, verdicts = v.verify_batch(p, r)
+        assert ok and verdicts.all()
+        bad = orc.VSBatch(0xF5A1, 50, 3, 300, transcript=orc.FS_POSEIDON)
+        assert 0 < bad.expected.sum() < 50
+        v2 = mi.VarunaShaped(bad.vk, bad.circuits, transcript="poseidon")
+        try:
+            ok, verdicts = v2.verify_batch(bad.proofs, bad.randomizers)
+            assert not ok and (verdicts == bad.expected).all() and (verdicts == bad.verify_cpu(8)).all()
+        finally:
+            v2.close()
+        # a SHA-256 verifier over the same keys rejects these proofs (other challenges), and vice versa
+        vs = mi.VarunaShaped(b.vk, b.circuits)
+        try:
+            ok, verdicts = vs.verify_batch(p, r)
+            assert not ok and not verdicts.any()
+        finally:
+            vs.close()
+        assert list(v.verify_stream(iter([(p, r)] * 5))) == [True] * 5
+    finally:
+        v.close()
+    d = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "vs_batch_1024_poseidon.npz"))
+    v = mi.VarunaShaped(d["vk"], d["circuits"], transcript="poseidon")
+    try:
+        ok, verdicts = v.verify_batch(d["proofs"], d["randomizers"])
+        assert ok and verdicts.all()
+        part = v.accumulate(torch.from_numpy(d["proofs"]).cuda(), torch.from_numpy(d["randomizers"]).cuda())
+        fx = orc.VSArrays(d["vk"], d["circuits"], d["proofs"], d["randomizers"], transcript=orc.FS_POSEIDON)
+        assert (part == as_bytes(orc.vs_partial_from_oracle(fx, threads=16))).all()
+    finally:
+        v.close()
+
+
+@pytest.mark.parametrize("transcript", ["sha256", "poseidon"])
+def test_malformed_proofs_are_rejected(orc, mi, transcript):
+    """snarkVM validates group elements at deserialisation; this ABI takes raw coordinates, so the verifier checks
+    them itself: an off-curve point, a coordinate >= q, an Fr field >= r make the proof invalid, exactly where the
+    oracle says so; an off-curve point must not poison its neighbours' verdicts"""
+    import pyref
+    kind = orc.FS_POSEIDON if transcript == "poseidon" else orc.FS_SHA256
+    b = orc.VSBatch(0xBADC0DE, 24, 2, 0, transcript=kind)
+    proofs = b.proofs.copy()
+    o_in, o_comm, o_eval, o_w = 16, 16 + 512, 16 + 512 + 864, 16 + 512 + 864 + 672
+    proofs[1 * 2256 + o_comm + 96 * 3 + 48] ^= 1                                                     # C_3.y off the curve
+    proofs[5 * 2256 + o_w + 96:5 * 2256 + o_w + 144] = np.frombuffer(orc.int_to_limbs(pyref.Q, 6).tobytes(), dtype=np.uint8)   # W_gamma.x = q
+    proofs[9 * 2256 + o_eval + 32 * 4:9 * 2256 + o_eval + 32 * 5] = np.frombuffer(orc.int_to_limbs(pyref.R, 4).tobytes(), dtype=np.uint8)  # eval = r
+    proofs[13 * 2256 + o_in + 32 * 15:13 * 2256 + o_in + 32 * 16] = 0xFF                              # input = 2^256 - 1
+    proofs[17 * 2256 + o_comm + 96 * 8:17 * 2256 + o_comm + 96 * 8 + 4] = 7                            # C_8.x garbage low word
+    want = orc.VSArrays(b.vk, b.circuits, proofs, b.randomizers, transcript=kind).verify_cpu(8)
+    assert want.sum() == 19 and not want[[1, 5, 9, 13, 17]].any()
+    v = mi.VarunaShaped(b.vk, b.circuits, transcript=transcript)
+    try:
+        ok, verdicts = v.verify_batch(proofs, b.randomizers)
+        assert not ok and (verdicts == want).all()
     finally:
         v.close()
