@@ -74,7 +74,15 @@ def main():
     ap.add_argument("--fold-threads", type=int, default=3, help="host threads folding finished accumulations")
     ap.add_argument("--products", type=int, default=8, help="pairing products in flight (<= 8)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for rehearsals on one GPU)")
+    ap.add_argument("--exchange", default="auto", choices=["auto", "native", "torch"],
+                    help="partial exchange when sharded: the library's own RCCL all-gather (native) or the torch.distributed "
+                         "callback; auto = native when RCCL can be initialised from the library, else torch")
+    ap.add_argument("--single-process", action="store_true",
+                    help="ONE process drives --gpus N devices: mi_init(device list), one 1024 x N-proof block per step through "
+                         "mi_vs_verify_block_device (in-library sharding, RCCL exchange from C++, one pairing product)")
     args = ap.parse_args()
+    if args.single_process:
+        return single_process(args)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if args.acc_depth <= 0:
@@ -120,10 +128,25 @@ def main():
         return sharding.gather_bytes(part, part.size, torch.distributed, gather_dev).reshape(world, -1, L.VS_PARTIAL_BYTES)
 
     gather = gather_all if dist_on else None
+    # the exchange itself: RCCL called from the library (mi_comm_init_rank + mi_vs_exchange_rccl: an ncclAllGather from
+    # the native driver's finisher thread); the unique id travels over torch.distributed once.  Falls back to the
+    # torch.distributed callback when the library cannot bring RCCL up on every rank.
+    comm = None
+    if dist_on and args.exchange != "torch":
+        comm = native_comm(rank, world, dev if args.backend == "nccl" else "cpu")
+        if comm is None and args.exchange == "native":
+            raise SystemExit("native RCCL exchange requested but not available on every rank")
+    exchange_kind = "native-rccl" if comm is not None else ("torch.distributed" if dist_on else "none")
+    stamps = []
 
-    def run(k):
-        oks = list(verifier.verify_stream(((d_proofs, d_rnd) for _ in range(k)), gather, depth=args.products, acc_depth=args.acc_depth,
-                                          fold_threads=args.fold_threads, exchange_group=args.exchange_group))
+    def run(k, stamp=False):
+        oks = []
+        for ok in verifier.verify_stream(((d_proofs, d_rnd) for _ in range(k)), None if comm is not None else gather,
+                                         depth=args.products, acc_depth=args.acc_depth, fold_threads=args.fold_threads,
+                                         exchange_group=args.exchange_group, comm=comm):
+            oks.append(ok)
+            if stamp:
+                stamps.append(time.perf_counter())
         assert len(oks) == k and all(oks), "synthetic batch must verify"
 
     if args.warmup:
@@ -139,6 +162,13 @@ def main():
         t = torch.tensor([dt], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = float(t.item())
+    # ---- outside the timed region: the steady state of the same stream (pipeline full).  K batches include ~2 ms of
+    # pipeline fill and drain -- a third of the timed region at K = 20 -- so a longer stream is run once more and the
+    # verdict-to-verdict spacing of its middle half reported beside ms_per_step.
+    run(max(args.steps, 240), stamp=True)
+    sync_all(dist_on)
+    lo, hi = len(stamps) // 4, len(stamps) - 1 - len(stamps) // 4
+    steady = 1e3 * (stamps[hi] - stamps[lo]) / (hi - lo)
     # ---- the same K batches again with HIP-event brackets around the headline kernels, on the streams they run on
     # (the brackets cost host time, so they stay out of the timed region; kernel durations agree with
     # profiles/*_rocprofv3_kernel_stats.csv)
@@ -190,14 +220,16 @@ def main():
     out = {
         "metric": "varuna_proofs_verified_per_sec", "value": world * PROOFS_PER_GPU * args.steps / dt,
         "unit": "proofs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "ms_per_step": 1e3 * dt / args.steps, "steady_state_ms_per_step": steady,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "u32-limb Montgomery (Fq 12x32, Fr 8x32)", "data": "synthetic",
         "config": {"workload": "configs[3]: batch verify of 1024 synthetic VarunaShaped-v1 proofs per GPU "
                                "(KZG open + pairing check); N GPUs = one %d-proof block sharded, partials all-gathered over RCCL" % (world * PROOFS_PER_GPU),
                    "proofs_per_gpu": PROOFS_PER_GPU, "circuits": 8, "all_valid": True, "parallelism": "shard%d" % world,
+                   "exchange": exchange_kind,
                    "pipeline": "batches streamed: %d accumulation lanes, %d pairing products in flight, %d host fold threads"
                                % (args.acc_depth, args.products, args.fold_threads)},
-        "roofline": roofline, "kernels": kernels,
+        "roofline": roofline, "alu": alu_view(kernels), "kernels": kernels,
     }
     if world == 1:
         verifier.verify_batch(d_proofs, d_rnd)
@@ -222,6 +254,99 @@ def main():
     print(json.dumps(out), flush=True)
     if dist_on:
         torch.distributed.destroy_process_group()
+
+
+# ---- integer-ALU view of the dominant kernel (the verifier is latency / ALU bound: SURVEY.md 8d)
+# A pairing product launch is ONE workgroup of 3 waves on one compute unit.  Work per launch in 32x32-bit limb products
+# (v_mad_u64_u32): ~530 Fq12 rounds x 192 lanes x 179 limb products (108 product + 48 fold + 23 Barrett), plus the
+# up-front line evaluation / line products (~1 700 Montgomery products of 288 limb products).  Peak for the waves the
+# kernel owns: tools/ubench at one wave per SIMD sustains 50.25 G Fq products/s chip-wide = 49.1 M products/s per wave
+# = 14.1 G limb products/s per wave.
+PAIRING_LIMB_PRODUCTS = 530 * 192 * 179 + 1700 * 288
+WAVE_LIMB_PRODUCT_RATE = 50.25e9 / 1024 * 288
+
+
+def alu_view(kernels):
+    k = kernels.get("pairing")
+    if not k:
+        return None
+    t = k["avg_us"] * 1e-6
+    ach = PAIRING_LIMB_PRODUCTS / t
+    return {"kernel": "pairing", "unit": "32x32-bit limb products/s", "work_per_launch": PAIRING_LIMB_PRODUCTS,
+            "achieved": ach, "waves": 3, "peak_for_those_waves": 3 * WAVE_LIMB_PRODUCT_RATE, "frac": ach / (3 * WAVE_LIMB_PRODUCT_RATE),
+            "note": "one workgroup (3 waves, one CU) per launch; several launches run side by side in the streamed region, so avg_us "
+                    "includes their mutual slowdown"}
+
+
+def native_comm(rank, world, flag_device):
+    """Bring up the library's own RCCL communicator on every rank (the unique id travels over torch.distributed once) and
+    prove it with one all-gather before the timed region relies on it.  Each step runs on a watchdog thread: a rank where
+    RCCL does not come up within the limit votes no, and every rank then keeps the torch.distributed callback."""
+    import ctypes as C
+    import threading
+
+    state = {"comm": None, "ok": 0}
+
+    def bring_up(uid):
+        try:
+            c = L.comm_init_rank(uid, rank, world)
+            mine = np.full(8, rank, dtype=np.uint8)
+            out = np.zeros(8 * world, dtype=np.uint8)
+            L.check(L.lib().mi_comm_all_gather(C.c_uint64(c), L.ptr(mine), C.c_size_t(8), L.ptr(out)), "mi_comm_all_gather")
+            if (out.reshape(world, 8) == np.arange(world, dtype=np.uint8)[:, None]).all():
+                state["comm"], state["ok"] = c, 1
+        except Exception:  # noqa: BLE001 -- any failure means: keep the torch exchange
+            pass
+
+    uid = [None]
+    if rank == 0:
+        try:
+            uid[0] = L.comm_unique_id()
+        except L.MiError:
+            uid[0] = None
+    torch.distributed.broadcast_object_list(uid, src=0)
+    if uid[0] is not None:
+        t = threading.Thread(target=bring_up, args=(uid[0],), daemon=True)
+        t.start()
+        t.join(90.0)
+    flag = torch.tensor([state["ok"]], dtype=torch.int32, device=flag_device)
+    torch.distributed.all_reduce(flag, op=torch.distributed.ReduceOp.MIN)
+    return state["comm"] if int(flag.item()) == 1 else None
+
+
+def single_process(args):
+    """One process, N devices: a block of N x 1024 proofs per step, shards resident on their devices."""
+    n_dev = args.gpus
+    assert torch.cuda.device_count() >= n_dev, "not enough visible GPUs"
+    L.init(list(range(n_dev)))
+    vk, circuits, proofs, rnd = load_fixture()
+    verifier = A.VarunaShaped(vk, circuits)
+    shards = []
+    for d in range(n_dev):
+        r = rnd.copy()
+        r[::16] ^= np.uint8(d)
+        dev = torch.device("cuda", d)
+        shards.append((torch.from_numpy(proofs).to(dev), torch.from_numpy(r).to(dev)))
+    for d in range(n_dev):
+        torch.cuda.synchronize(d)
+    for _ in range(max(1, args.warmup)):
+        ok, _ = verifier.verify_block_device(shards)
+        assert ok
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        ok, verdicts = verifier.verify_block_device(shards)
+    dt = time.perf_counter() - t0
+    assert ok and verdicts.all()
+    out = {"metric": "varuna_proofs_verified_per_sec", "value": n_dev * PROOFS_PER_GPU * args.steps / dt, "unit": "proofs/s",
+           "n_gpus": n_dev, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
+           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u32-limb Montgomery (Fq 12x32, Fr 8x32)",
+           "data": "synthetic",
+           "config": {"workload": "configs[4] shape in ONE process: a %d-proof block per step, mi_vs_verify_block_device over %d "
+                                  "device(s): one host thread and one 1024-proof shard per device, partials all-gathered (RCCL from the "
+                                  "library), one pairing product; blocks are sequential (SURVEY.md 3.3), so this is block LATENCY, not "
+                                  "the streamed rate" % (n_dev * PROOFS_PER_GPU, n_dev),
+                      "proofs_per_gpu": PROOFS_PER_GPU, "parallelism": "single-process x%d" % n_dev}}
+    print(json.dumps(out), flush=True)
 
 
 def usable_cores():
@@ -417,6 +542,39 @@ def extras(dev, verifier, proofs, rnd):
     ex["poseidon_fq"] = {"sponges": npos, "absorbed_each": mpos, "ms": 1e3 * dt, "permutations_per_s": npos * (mpos // 2) / dt,
                          "fq_products_per_s": npos * (mpos // 2) * 626 / dt}
     del x
+    # --- the 1024-proof batch under the Poseidon Fiat-Shamir transcript (row A9 on the path: 37 permutations per proof)
+    try:
+        dp = np.load(os.path.join(ROOT, "tests", "golden", "vs_batch_1024_poseidon.npz"))
+        vp = A.VarunaShaped(dp["vk"], dp["circuits"], transcript="poseidon")
+        pp, pr = torch.from_numpy(dp["proofs"]).to(dev), torch.from_numpy(dp["randomizers"]).to(dev)
+        ok, _ = vp.verify_batch(pp, pr)
+        assert ok
+        L.prof_enable(2)
+        L.prof_read("vs_fs_poseidon")
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(5):
+            ok, _ = vp.verify_batch(pp, pr)
+        torch.cuda.synchronize()
+        lat = (time.perf_counter() - t0) / 5
+        ms, launches, _ = L.prof_read("vs_fs_poseidon")
+        L.prof_enable(0)
+        nb = 60
+        list(vp.verify_stream(((pp, pr) for _ in range(12))))
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        oks = list(vp.verify_stream(((pp, pr) for _ in range(nb))))
+        torch.cuda.synchronize()
+        dts = time.perf_counter() - t0
+        assert all(oks)
+        ex["batch_1024_poseidon_fs"] = {
+            "latency_ms_one_batch_unpipelined": 1e3 * lat, "transcript_kernel_ms": ms / max(1, launches),
+            "permutations_per_proof": 37, "fq_products_per_batch": 1024 * 37 * 626,
+            "streamed_proofs_per_s": 1024 * nb / dts, "streamed_ms_per_batch": 1e3 * dts / nb,
+            "note": "Poseidon sponge over Fq (own constants), a quad of lanes per proof; the SHA-256 headline above does not pay this"}
+        vp.close()
+    except FileNotFoundError:
+        pass
     # --- the same 1024-proof batch with 1 % corrupted proofs: aggregate check fails, fallback names them
     bad = proofs.copy()
     idx = np.arange(5, 1024, 101)  # 11 proofs
