@@ -413,8 +413,9 @@ def cpu_side_by_side(dev):
     pts = torch.empty(n * 96, dtype=torch.uint8, device=dev)
     L.check(L.lib().mi_dbg_gen_points_device(C.c_uint64(0xA1E00001), C.c_size_t(n), L.dptr(pts), L.stream_ptr()), "gen_points")
     g = torch.Generator(device="cpu").manual_seed(0xA1E00001)
-    sc = torch.randint(0, 1 << 62, (n, 4), dtype=torch.int64, generator=g)
-    sc[:, 3] &= (1 << 60) - 1
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from uniform_scalars import uniform_scalars
+    sc = uniform_scalars(n, 0xA1E00001)
     d_sc = sc.to(dev)
     torch.cuda.synchronize()
     A.VariableBase.msm(pts, d_sc)
@@ -469,9 +470,9 @@ def extras(dev, verifier, proofs, rnd):
     import ctypes as C
     L.check(L.lib().mi_dbg_gen_points_device(C.c_uint64(0xA1E00002), C.c_size_t(n), L.dptr(pts), L.stream_ptr(st)), "gen_points")
     g = torch.Generator(device="cpu").manual_seed(0xA1E00002)
-    sc = torch.randint(0, 1 << 62, (n, 4), dtype=torch.int64, generator=g)
-    sc[:, 3] &= (1 << 60) - 1  # uniform below 2^252 < r
-    sc = sc.to(dev)
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from uniform_scalars import uniform_scalars
+    sc = uniform_scalars(n, 0xA1E00002).to(dev)  # uniform in [0, r): the top window sees full 253-bit digits
     torch.cuda.synchronize()
     A.VariableBase.msm(pts, sc)
     L.prof_enable(True)

@@ -1,9 +1,13 @@
 #!/usr/bin/env python3
-"""Copy the judged summaries of a GPU profiling run (tools/profile_round.sh) from gpurun_out/<tag>/ into
-profiles/ and derive profiles/pmc_traffic.json (HBM bytes per launch per kernel, read by bench.py).
+"""Copy the judged summaries of a GPU profiling run (tools/profile_round.sh <tag>) from gpurun_out/<tag>/ into
+profiles/ and derive
+  profiles/<tag>_pmc_summary.csv   HBM bytes per launch per kernel, all three workloads
+  profiles/pmc_traffic.json        the same as a table bench.py reads for roofline.traffic
+  profiles/<tag>_overlap.json      how many pairing products run side by side in the streamed region, from the kernel
+                                   trace (reconciles "a ~1 ms kernel inside a ~0.2 ms step")
 
-PMC handling follows MI355X_MICROARCH.md "HBM": FETCH_SIZE and WRITE_SIZE are collected in separate passes,
-both are in KiB, and on gfx950 FETCH_SIZE counts half the bytes of 16-B-per-lane reads, so it is doubled.
+PMC handling follows MI355X_MICROARCH.md "HBM": FETCH_SIZE and WRITE_SIZE are collected in separate passes, both are
+in KiB, and on gfx950 FETCH_SIZE counts half the bytes of 16-B-per-lane reads, so it is doubled.
 """
 import collections
 import csv
@@ -14,46 +18,90 @@ import shutil
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
 src = os.path.join(ROOT, "gpurun_out", tag)
 dst = os.path.join(ROOT, "profiles")
 os.makedirs(dst, exist_ok=True)
 
 SHORT = {"pairing_product_kernel": "pairing", "msm_accumulate_kernel": "msm_accumulate", "vs_derive_kernel": "vs_derive",
-         "ntt_pass_kernel": "ntt_pass", "msm_bit_sums_kernel": "msm_bit_sums"}
+         "ntt_pass_kernel": "ntt_pass", "ntt_lds_pass_kernel": "ntt_lds_pass", "msm_bit_sums_queue_kernel": "msm_bit_sums_queue"}
 
 
 def short(name):
     for k, v in SHORT.items():
         if k in name:
             return v
-    return name.split("(")[0].replace("mi::", "").replace("void ", "")
+    return name.split("(")[0].split("<")[0].replace("mi::", "").replace("void ", "").strip()
+
+
+def newest(pattern):
+    files = sorted(glob.glob(os.path.join(src, pattern)), key=os.path.getmtime)
+    return files[-1] if files else None
 
 
 for pat, out in (("stats/*/*_kernel_stats.csv", "%s_rocprofv3_kernel_stats.csv" % tag), ("bench.json", "%s_bench.json" % tag),
-                 ("stats_bench.json", "%s_bench_under_rocprofv3.json" % tag)):
-    files = sorted(glob.glob(os.path.join(src, pat)), key=os.path.getmtime)
-    if files:
-        shutil.copy(files[-1], os.path.join(dst, out))  # newest run only
+                 ("stats_bench.json", "%s_bench_under_rocprofv3.json" % tag),
+                 ("msm20_stats/*/*_kernel_stats.csv", "%s_msm20_kernel_stats.csv" % tag),
+                 ("ntt22_stats/*/*_kernel_stats.csv", "%s_ntt22_kernel_stats.csv" % tag)):
+    f = newest(pat)
+    if f:
+        shutil.copy(f, os.path.join(dst, out))
 
-per = {}
-for sub, cn in (("pmc_fetch", "FETCH_SIZE"), ("pmc_write", "WRITE_SIZE")):
-    agg = collections.defaultdict(list)
-    files = sorted(glob.glob(os.path.join(src, sub, "*", "*_counter_collection.csv")), key=os.path.getmtime)
-    for f in files[-1:]:
-        for r in csv.DictReader(open(f)):
-            if r["Counter_Name"] == cn:
-                agg[short(r["Kernel_Name"])].append(float(r["Counter_Value"]))
-    per[cn] = {k: sum(v) / len(v) for k, v in agg.items()}
-rows = []
-traffic = {}
-for k in sorted(set(per["FETCH_SIZE"]) | set(per["WRITE_SIZE"])):
-    fe, wr = per["FETCH_SIZE"].get(k, 0.0), per["WRITE_SIZE"].get(k, 0.0)
-    traffic[k] = (2.0 * fe + wr) * 1024.0
-    rows.append((k, fe, wr, traffic[k]))
+# ---- PMC traffic per launch
+rows, traffic = [], {}
+for work, pf, pw in (("verifier", "pmc_fetch", "pmc_write"), ("msm20", "msm20_pmc_fetch", "msm20_pmc_write"),
+                     ("ntt22", "ntt22_pmc_fetch", "ntt22_pmc_write")):
+    per = {}
+    for sub, cn in ((pf, "FETCH_SIZE"), (pw, "WRITE_SIZE")):
+        agg = collections.defaultdict(list)
+        f = newest(os.path.join(sub, "*", "*_counter_collection.csv"))
+        if f:
+            for r in csv.DictReader(open(f)):
+                if r["Counter_Name"] == cn:
+                    agg[short(r["Kernel_Name"])].append(float(r["Counter_Value"]))
+        per[cn] = {k: sum(v) / len(v) for k, v in agg.items()}
+    for k in sorted(set(per["FETCH_SIZE"]) | set(per["WRITE_SIZE"])):
+        fe, wr = per["FETCH_SIZE"].get(k, 0.0), per["WRITE_SIZE"].get(k, 0.0)
+        t = (2.0 * fe + wr) * 1024.0
+        rows.append((work, k, fe, wr, t))
+        traffic["%s:%s" % (work, k)] = t
+        if work == "verifier":
+            traffic[k] = t  # what bench.py's roofline.traffic looks up
 with open(os.path.join(dst, "%s_pmc_summary.csv" % tag), "w") as f:
-    f.write("kernel,FETCH_SIZE_KiB_per_launch(raw),WRITE_SIZE_KiB_per_launch,hbm_bytes_per_launch(2*FETCH+WRITE)\n")
-    for r in sorted(rows, key=lambda r: -r[3]):
-        f.write("%s,%.3f,%.3f,%.0f\n" % r)
+    f.write("workload,kernel,FETCH_SIZE_KiB_per_launch(raw),WRITE_SIZE_KiB_per_launch,hbm_bytes_per_launch(2*FETCH+WRITE)\n")
+    for r in sorted(rows, key=lambda r: (r[0], -r[4])):
+        f.write("%s,%s,%.3f,%.3f,%.0f\n" % r)
 json.dump(traffic, open(os.path.join(dst, "pmc_traffic.json"), "w"), indent=1, sort_keys=True)
+
+# ---- overlap of pairing products in the streamed region
+f = newest("stats/*/*_kernel_trace.csv")
+if f:
+    ev, durs, first, last = [], [], None, None
+    for r in csv.DictReader(open(f)):
+        if "pairing_product_kernel" not in r["Kernel_Name"]:
+            continue
+        s, e = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
+        ev.append((s, 1))
+        ev.append((e, -1))
+        durs.append(e - s)
+        first = s if first is None else min(first, s)
+        last = e if last is None else max(last, e)
+    ev.sort()
+    cur, mx, area, busy, prev = 0, 0, 0, 0, None
+    for t, d in ev:
+        if prev is not None and cur > 0:
+            area += cur * (t - prev)
+            busy += t - prev
+        cur += d
+        mx = max(mx, cur)
+        prev = t
+    n = len(durs)
+    out = {"kernel": "pairing_product_kernel", "launches": n, "avg_kernel_us": sum(durs) / n / 1e3 if n else None,
+           "max_concurrent": mx, "mean_concurrent_while_any_runs": area / busy if busy else None,
+           "wall_us_with_a_product_running": busy / 1e3, "wall_us_per_launch": busy / n / 1e3 if n else None,
+           "cu_busy_us_per_launch": area / n / 1e3 if n else None,
+           "note": "one workgroup (3 waves, one CU) per launch: a step's wall time is the kernel's duration divided by the "
+                   "number of products in flight; trace of `bench.py --steps 20 --warmup 5` (warm-up, timed, steady-state and "
+                   "event-bracketed passes together)"}
+    json.dump(out, open(os.path.join(dst, "%s_overlap.json" % tag), "w"), indent=1)
 print("profiles/ updated from", src)

@@ -9,7 +9,9 @@ n = 1 << int(sys.argv[1])
 pts = torch.empty(n * 96, dtype=torch.uint8, device="cuda")
 L.check(L.lib().mi_dbg_gen_points_device(C.c_uint64(7), C.c_size_t(n), L.dptr(pts), L.stream_ptr()), "gen")
 g = torch.Generator(device="cpu").manual_seed(1)
-sc = torch.randint(0, 1 << 62, (n, 4), dtype=torch.int64, generator=g); sc[:, 3] &= (1 << 60) - 1; sc = sc.cuda()
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+from uniform_scalars import uniform_scalars  # uniform in [0, r)
+sc = uniform_scalars(n, 1).cuda()
 torch.cuda.synchronize()
 for _ in range(4):
     A.VariableBase.msm(pts, sc)
