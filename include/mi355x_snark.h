@@ -104,6 +104,22 @@ int32_t mi_kzg_commit_h_device(uint64_t powers_handle, size_t offset, const void
  * with the same powers.  coeffs / point / value_out in Montgomery form.  n = 0: value 0, witness infinity. */
 int32_t mi_kzg_open_h(uint64_t powers_handle, const mi_fr *coeffs, size_t n, const mi_fr *point, mi_fr *value_out,
                       mi_g1_jac *witness_out);
+/* with a hiding polynomial (KZG10::commit / open with hiding_bound = Some(..)): the commitment adds
+ * sum rand_coeffs[j] * gamma_powers[j] (powers_of_beta_times_gamma_g, registered as a second handle); the opening proof
+ * carries random_v = rho(point) and the witness commits to both quotients */
+int32_t mi_kzg_commit_hiding_h(uint64_t powers_handle, uint64_t gamma_powers_handle, const mi_fr *coeffs, size_t n,
+                               const mi_fr *rand_coeffs, size_t m, mi_g1_jac *out);
+int32_t mi_kzg_open_hiding_h(uint64_t powers_handle, uint64_t gamma_powers_handle, const mi_fr *coeffs, size_t n,
+                             const mi_fr *rand_coeffs, size_t m, const mi_fr *point, mi_fr *value_out, mi_fr *random_v_out,
+                             mi_g1_jac *witness_out);
+/* KZG10::commit_lagrange: evaluations over the domain against the Lagrange-basis SRS (lagrange_handle =
+ * mi_bases_register of L_i(beta) G): the same MSM as mi_kzg_commit_h */
+int32_t mi_kzg_commit_lagrange_h(uint64_t lagrange_handle, const mi_fr *evals, size_t n, mi_g1_jac *out);
+/* EvaluationDomain::divide_by_vanishing_poly_on_coset_in_place: evals[i] = p(g w_M^i), M = 2^log_m (the output of
+ * mi_ntt_fr(.., coset = 1)), divided pointwise by Z_N(X) = X^N - 1, N = 2^log_n <= M (log_m - log_n <= 12); a coset
+ * inverse NTT of the result gives the quotient's coefficients */
+int32_t mi_ntt_divide_by_vanishing_on_coset(mi_fr *evals, uint32_t log_m, uint32_t log_n);
+int32_t mi_ntt_divide_by_vanishing_on_coset_device(void *d_evals, uint32_t log_m, uint32_t log_n, void *stream);
 /* fft::DensePolynomial multiplication through the evaluation domain of size >= na + nb - 1 (two forward NTTs, a
  * pointwise product, one inverse NTT): out[0 .. na + nb - 1).  na, nb >= 1. */
 int32_t mi_poly_mul_fr(const mi_fr *a, size_t na, const mi_fr *b, size_t nb, mi_fr *out);
@@ -115,6 +131,11 @@ int32_t mi_pairing(const mi_g1_affine *p, const mi_g2_affine *q, mi_fq12 *out); 
 /* ---- kzg10::KZG10::batch_check ----  randomizers128: n x 16 bytes from the caller's RNG */
 int32_t mi_kzg_batch_check(const mi_kzg_vk *vk, const mi_g1_affine *comms, const mi_fr *points, const mi_fr *values,
                            const mi_g1_affine *witnesses, size_t n, const uint8_t *randomizers128, uint8_t *ok_out);
+/* the same with hiding (VerifierKey.gamma_g, KZGProof.random_v): total_c also carries -(sum r_i random_v[i]) gamma_g.
+ * gamma_g and random_v both NULL: identical to mi_kzg_batch_check */
+int32_t mi_kzg_batch_check_hiding(const mi_kzg_vk *vk, const mi_g1_affine *gamma_g, const mi_g1_affine *comms,
+                                  const mi_fr *points, const mi_fr *values, const mi_g1_affine *witnesses, const mi_fr *random_v,
+                                  size_t n, const uint8_t *randomizers128, uint8_t *ok_out);
 
 /* ---- VarunaShaped-v1 batch verification ---- */
 #define MI_VS_VK_COMMS 12

@@ -90,6 +90,23 @@ def main():
         cases.append({"inputs": [hx(x) for x in ins], "outputs": [hx(x) for x in P.poseidon_hash(ins, k)]})
     perm = P.poseidon_permute([1, 2, 3])
     json.dump({"permute_1_2_3": [hx(x) for x in perm], "sponge": cases}, open(os.path.join(OUT, "poseidon.json"), "w"), indent=0)
+    # --- KZG batch instance WITH hiding (gamma_g, random_v): commitments C = p(tau) G + rho(tau) gamma_g
+    gam = rng.below(P.R, 5)
+    gamma_g = P.g1_mul(P.G1_GEN, gam)
+    rhos = [[rng.below(P.R, 5) for _ in range(3)] for _ in range(5)]
+    hcs = [P.g1_mul(P.G1_GEN, (ev(c, tau) + gam * ev(rh, tau)) % P.R) for c, rh in zip(polys, rhos)]
+    rbars = [ev(rh, z) for rh, z in zip(rhos, zs)]
+    hws = [P.g1_mul(P.G1_GEN, ((ev(c, tau) - v) + gam * (ev(rh, tau) - rb)) * P.inv((tau - z) % P.R, P.R) % P.R)
+           for c, rh, z, v, rb in zip(polys, rhos, zs, vs, rbars)]
+    assert P.kzg_batch_check_hiding(tau_h, gamma_g, hcs, zs, vs, hws, rbars, rs)
+    bad_rb = list(rbars)
+    bad_rb[1] = (bad_rb[1] + 1) % P.R
+    assert not P.kzg_batch_check_hiding(tau_h, gamma_g, hcs, zs, vs, hws, bad_rb, rs)
+    assert not P.kzg_batch_check(tau_h, hcs, zs, vs, hws, rs)  # the non-hiding check refuses hiding commitments
+    kzg_h = {"tau_h": kzg["tau_h"], "gamma_g": pt(gamma_g), "comms": [pt(c) for c in hcs], "points": [hx(z) for z in zs],
+             "values": [hx(v) for v in vs], "random_v": [hx(x) for x in rbars], "bad_random_v": [hx(x) for x in bad_rb],
+             "witnesses": [pt(w) for w in hws], "randomizers": [hx(r) for r in rs]}
+    json.dump(kzg_h, open(os.path.join(OUT, "kzg_hiding.json"), "w"), indent=0)
     print("golden vectors written to", OUT)
 
 

@@ -98,6 +98,9 @@ int orc_kzg_check(const orc_kzg_vk *vk, const orc_g1_affine *comm, const orc_fr 
 int orc_kzg_batch_check(const orc_kzg_vk *vk, const orc_g1_affine *comms, const orc_fr *points,
                         const orc_fr *values, const orc_g1_affine *witnesses, size_t n,
                         const uint8_t *randomizers128);
+int orc_kzg_batch_check_hiding(const orc_kzg_vk *vk, const orc_g1_affine *gamma_g, const orc_g1_affine *comms,
+                               const orc_fr *points, const orc_fr *values, const orc_g1_affine *witnesses,
+                               const orc_fr *random_v, size_t n, const uint8_t *randomizers128);
 
 /* prover side: KZG10::commit without hiding (coefficients Montgomery, converted with
  * to_bigint() as the reference does before its msm call); schoolbook polynomial product; Horner evaluation;

@@ -217,11 +217,20 @@ int orc_kzg_check(const orc_kzg_vk *vk, const orc_g1_affine *comm, const orc_fr 
 int orc_kzg_batch_check(const orc_kzg_vk *vk, const orc_g1_affine *comms, const orc_fr *points,
                         const orc_fr *values, const orc_g1_affine *witnesses, size_t n,
                         const uint8_t *randomizers128) {
+    return orc_kzg_batch_check_hiding(vk, NULL, comms, points, values, witnesses, NULL, n, randomizers128);
+}
+/* kzg10::KZG10::batch_check with hiding: VerifierKey.gamma_g and KZGProof.random_v,
+ *   total_c = sum r_i (C_i + z_i w_i) - (sum r_i v_i) g - (sum r_i rbar_i) gamma_g,  total_w = sum r_i w_i,
+ *   e(total_c, h) e(-total_w, beta_h) == 1.   gamma_g / random_v NULL: no hiding. */
+int orc_kzg_batch_check_hiding(const orc_kzg_vk *vk, const orc_g1_affine *gamma_g, const orc_g1_affine *comms,
+                               const orc_fr *points, const orc_fr *values, const orc_g1_affine *witnesses,
+                               const orc_fr *random_v, size_t n, const uint8_t *randomizers128) {
     orc_g1_jac total_c, total_w, t;
-    fr_t gs, r, rz, rv;
+    fr_t gs, hs, r, rz, rv;
     g1_set_inf(&total_c);
     g1_set_inf(&total_w);
     fr_zero(&gs);
+    fr_zero(&hs);
     for (size_t i = 0; i < n; i++) {
         fr_from_u128le(&r, randomizers128 + 16 * i);
         g1_mul_fr(&t, &comms[i], &r);
@@ -233,10 +242,19 @@ int orc_kzg_batch_check(const orc_kzg_vk *vk, const orc_g1_affine *comms, const 
         orc_g1_add(&total_w, &total_w, &t);
         fr_mul(&rv, &r, S(&values[i]));
         fr_add(&gs, &gs, &rv);
+        if (gamma_g && random_v) {
+            fr_mul(&rv, &r, S(&random_v[i]));
+            fr_add(&hs, &hs, &rv);
+        }
     }
     fr_neg(&gs, &gs);
     g1_mul_fr(&t, &vk->g, &gs);
     orc_g1_add(&total_c, &total_c, &t);
+    if (gamma_g && random_v) {
+        fr_neg(&hs, &hs);
+        g1_mul_fr(&t, gamma_g, &hs);
+        orc_g1_add(&total_c, &total_c, &t);
+    }
     orc_g1_affine ps[2];
     orc_g1_to_affine(&ps[0], &total_c);
     orc_g1_to_affine(&ps[1], &total_w);

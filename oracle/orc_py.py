@@ -32,7 +32,7 @@ def lib():
         _LIB = C.CDLL(build())
         _LIB.orc_self_test.restype = C.c_int
         _LIB.orc_ntt.restype = C.c_int
-        for f in ("orc_kzg_check", "orc_kzg_batch_check", "orc_vs_verify_one", "orc_vs_verify_aggregated",
+        for f in ("orc_kzg_check", "orc_kzg_batch_check", "orc_kzg_batch_check_hiding", "orc_vs_verify_one", "orc_vs_verify_aggregated",
                   "orc_g1_is_on_curve", "orc_g2_is_on_curve", "orc_fq12_is_one", "orc_pairing_product_is_one"):
             getattr(_LIB, f).restype = C.c_int
     return _LIB
@@ -221,6 +221,16 @@ def kzg_batch_check(vk, comms, points, values, witnesses, randomizers):
     return bool(lib().orc_kzg_batch_check(_p(vk), _p(np.ascontiguousarray(comms)), _p(np.ascontiguousarray(points)),
                                           _p(np.ascontiguousarray(values)), _p(np.ascontiguousarray(witnesses)),
                                           C.c_size_t(n), _p(rnd)))
+
+
+def kzg_batch_check_hiding(vk, gamma_g, comms, points, values, witnesses, random_v, randomizers):
+    n = len(comms)
+    rnd = np.ascontiguousarray(randomizers, dtype=np.uint8).reshape(-1)
+    assert rnd.size == 16 * n
+    return bool(lib().orc_kzg_batch_check_hiding(_p(vk), _p(np.ascontiguousarray(gamma_g)), _p(np.ascontiguousarray(comms)),
+                                                 _p(np.ascontiguousarray(points)), _p(np.ascontiguousarray(values)),
+                                                 _p(np.ascontiguousarray(witnesses)), _p(np.ascontiguousarray(random_v)),
+                                                 C.c_size_t(n), _p(rnd)))
 
 
 def kzg_commit(powers, coeffs, threads=1):

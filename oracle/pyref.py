@@ -364,6 +364,21 @@ def kzg_batch_check(vk_tau_h, Cs, zs, vs, Ws, rs):
     return pairing_product_is_one([(total_c, G2_GEN), (g1_neg(total_w), vk_tau_h)])
 
 
+def kzg_batch_check_hiding(vk_tau_h, gamma_g, Cs, zs, vs, Ws, rbars, rs):
+    """KZG10::batch_check with hiding: commitments C = p(tau) G + rho(tau) gamma_g, proofs (w, random_v = rho(z))"""
+    total_c = None
+    total_w = None
+    gs = hs = 0
+    for C, z, v, W, rb, r in zip(Cs, zs, vs, Ws, rbars, rs):
+        total_c = g1_add(total_c, g1_mul(g1_add(C, g1_mul(W, z)), r))
+        gs = (gs + r * v) % R
+        hs = (hs + r * rb) % R
+        total_w = g1_add(total_w, g1_mul(W, r))
+    total_c = g1_add(total_c, g1_neg(g1_mul(G1_GEN, gs)))
+    total_c = g1_add(total_c, g1_neg(g1_mul(gamma_g, hs)))
+    return pairing_product_is_one([(total_c, G2_GEN), (g1_neg(total_w), vk_tau_h)])
+
+
 # ----------------------------------------------------------------------------- byte / limb helpers (ABI layout)
 def to_limbs(v, n):
     return [(v >> (64 * i)) & 0xFFFFFFFFFFFFFFFF for i in range(n)]

@@ -96,6 +96,37 @@ class ResidentBases:
                                       L.ptr(value), L.ptr(wit)), "mi_kzg_open_h")
         return value, wit
 
+    def commit_lagrange(self, evals):
+        """kzg10::KZG10::commit_lagrange with these bases as the Lagrange-basis SRS L_i(beta) G: the same MSM, over the
+        polynomial's evaluations instead of its coefficients."""
+        evals = np.ascontiguousarray(evals, dtype=np.uint64).reshape(-1, 4)
+        out = np.zeros(L.G1_JAC_U64, dtype=np.uint64)
+        L.check(L.lib().mi_kzg_commit_lagrange_h(C.c_uint64(self.handle), L.ptr(evals), C.c_size_t(len(evals)), L.ptr(out)),
+                "mi_kzg_commit_lagrange_h")
+        return out
+
+    def commit_hiding(self, gamma_bases, coeffs, rand_coeffs):
+        """KZG10::commit with a hiding polynomial: sum c_i powers[i] + sum rho_j gamma_powers[j] (`gamma_bases`: the
+        ResidentBases of powers_of_beta_times_gamma_g)."""
+        coeffs = np.ascontiguousarray(coeffs, dtype=np.uint64).reshape(-1, 4)
+        rho = np.ascontiguousarray(rand_coeffs, dtype=np.uint64).reshape(-1, 4)
+        out = np.zeros(L.G1_JAC_U64, dtype=np.uint64)
+        L.check(L.lib().mi_kzg_commit_hiding_h(C.c_uint64(self.handle), C.c_uint64(gamma_bases.handle), L.ptr(coeffs),
+                                               C.c_size_t(len(coeffs)), L.ptr(rho), C.c_size_t(len(rho)), L.ptr(out)),
+                "mi_kzg_commit_hiding_h")
+        return out
+
+    def open_hiding(self, gamma_bases, coeffs, rand_coeffs, point):
+        """KZG10::open with hiding: (p(point), random_v = rho(point), witness commitment over both quotients)."""
+        coeffs = np.ascontiguousarray(coeffs, dtype=np.uint64).reshape(-1, 4)
+        rho = np.ascontiguousarray(rand_coeffs, dtype=np.uint64).reshape(-1, 4)
+        point = np.ascontiguousarray(point, dtype=np.uint64).reshape(4)
+        value, rv, wit = np.zeros(4, dtype=np.uint64), np.zeros(4, dtype=np.uint64), np.zeros(L.G1_JAC_U64, dtype=np.uint64)
+        L.check(L.lib().mi_kzg_open_hiding_h(C.c_uint64(self.handle), C.c_uint64(gamma_bases.handle), L.ptr(coeffs),
+                                             C.c_size_t(len(coeffs)), L.ptr(rho), C.c_size_t(len(rho)), L.ptr(point), L.ptr(value),
+                                             L.ptr(rv), L.ptr(wit)), "mi_kzg_open_hiding_h")
+        return value, rv, wit
+
     def release(self):
         if self.handle:
             L.check(L.lib().mi_bases_release(C.c_uint64(self.handle)), "mi_bases_release")
@@ -144,6 +175,22 @@ class EvaluationDomain:
 
     def coset_ifft(self, evals, stream=None):
         return self._run(evals, 1, 1, stream)
+
+    def divide_by_vanishing_poly_on_coset(self, evals, vanishing_size, stream=None):
+        """evals = the coset evaluations of a polynomial over THIS domain (coset_fft's output); divides them pointwise
+        by Z_N(X) = X^N - 1, N = vanishing_size (a power of two <= the domain size).  coset_ifft of the result is the
+        quotient.  In place for CUDA tensors."""
+        log_n = int(vanishing_size).bit_length() - 1
+        assert (1 << log_n) == vanishing_size and log_n <= self.log_size_of_group
+        if _is_torch_cuda(evals):
+            L.check(L.lib().mi_ntt_divide_by_vanishing_on_coset_device(L.dptr(evals), C.c_uint32(self.log_size_of_group),
+                                                                       C.c_uint32(log_n), L.stream_ptr(stream)),
+                    "mi_ntt_divide_by_vanishing_on_coset_device")
+            return evals
+        buf = np.ascontiguousarray(evals, dtype=np.uint64).reshape(self.size, 4).copy()
+        L.check(L.lib().mi_ntt_divide_by_vanishing_on_coset(L.ptr(buf), C.c_uint32(self.log_size_of_group), C.c_uint32(log_n)),
+                "mi_ntt_divide_by_vanishing_on_coset")
+        return buf
 
 
 class DensePolynomial:
@@ -207,8 +254,9 @@ class KZG10:
     """snarkvm_algorithms::polycommit::kzg10::KZG10"""
 
     @staticmethod
-    def batch_check(vk, commitments, points, values, proofs, randomizers128):
-        """vk: 480-byte VerifierKey {g, h, beta_h}; proofs: the opening witnesses w_i."""
+    def batch_check(vk, commitments, points, values, proofs, randomizers128, gamma_g=None, random_v=None):
+        """vk: 480-byte VerifierKey {g, h, beta_h}; proofs: the opening witnesses w_i.  With hiding: `gamma_g` (the
+        VerifierKey's gamma_g, (12,) uint64) and `random_v` (KZGProof.random_v per opening)."""
         vk = np.ascontiguousarray(vk).view(np.uint8).reshape(-1)
         assert vk.size == L.KZG_VK_BYTES
         comms = np.ascontiguousarray(commitments, dtype=np.uint64).reshape(-1, 12)
@@ -219,6 +267,12 @@ class KZG10:
         rnd = np.ascontiguousarray(randomizers128, dtype=np.uint8).reshape(-1)
         assert rnd.size == 16 * n
         ok = np.zeros(1, dtype=np.uint8)
+        if gamma_g is not None:
+            gg = np.ascontiguousarray(gamma_g, dtype=np.uint64).reshape(12)
+            rv = np.ascontiguousarray(random_v, dtype=np.uint64).reshape(n, 4)
+            L.check(L.lib().mi_kzg_batch_check_hiding(L.ptr(vk), L.ptr(gg), L.ptr(comms), L.ptr(pts), L.ptr(vals), L.ptr(wit),
+                                                      L.ptr(rv), C.c_size_t(n), L.ptr(rnd), L.ptr(ok)), "mi_kzg_batch_check_hiding")
+            return bool(ok[0])
         L.check(L.lib().mi_kzg_batch_check(L.ptr(vk), L.ptr(comms), L.ptr(pts), L.ptr(vals), L.ptr(wit), C.c_size_t(n),
                                            L.ptr(rnd), L.ptr(ok)), "mi_kzg_batch_check")
         return bool(ok[0])

@@ -50,9 +50,9 @@ struct PoseidonConsts {
 const PoseidonConsts *poseidon_consts(Context &cx, hipStream_t st);
 
 // verify.hip
-int32_t kzg_batch_check_host(Context &cx, const mi_kzg_vk *vk, const mi_g1_affine *comms, const mi_fr *points,
-                             const mi_fr *values, const mi_g1_affine *witnesses, size_t n, const uint8_t *rand128,
-                             uint8_t *ok_out);
+int32_t kzg_batch_check_host(Context &cx, const mi_kzg_vk *vk, const mi_g1_affine *gamma_g, const mi_g1_affine *comms,
+                             const mi_fr *points, const mi_fr *values, const mi_g1_affine *witnesses, const mi_fr *random_v,
+                             size_t n, const uint8_t *rand128, uint8_t *ok_out);
 int32_t vs_ctx_create(Context &cx, const mi_kzg_vk *vk, const mi_vs_circuit_vk *circuits, size_t n_circuits, uint32_t flags,
                       uint64_t *out);
 int32_t vs_ctx_destroy(Context &cx, uint64_t id);

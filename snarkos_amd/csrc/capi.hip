@@ -521,9 +521,9 @@ __global__ void __launch_bounds__(OPEN_BLOCK) open_apply_kernel(const Fr *__rest
         }
     }
 }
-int32_t mi_kzg_open_h(uint64_t handle, const mi_fr *coeffs, size_t n, const mi_fr *point, mi_fr *value_out, mi_g1_jac *witness_out) {
-    if (!point || !value_out || !witness_out || (n && !coeffs) || n > MI_MSM_MAX_N) return MI_ERR_BAD_ARGS;
-    return guarded([&](Context &cx) -> int32_t {
+static int32_t kzg_open_impl(Context &cx, uint64_t handle, const mi_fr *coeffs, size_t n, const mi_fr *point, mi_fr *value_out,
+                             mi_g1_jac *witness_out) {
+    {
         hipStream_t st = cx.stream;
         if (n == 0) {
             memset(value_out, 0, sizeof *value_out);
@@ -550,6 +550,108 @@ int32_t mi_kzg_open_h(uint64_t handle, const mi_fr *coeffs, size_t n, const mi_f
         MI_HIP(hipStreamSynchronize(st));
         memcpy(value_out, hv, sizeof(Fr));
         return MI_OK;
+    }
+}
+int32_t mi_kzg_open_h(uint64_t handle, const mi_fr *coeffs, size_t n, const mi_fr *point, mi_fr *value_out, mi_g1_jac *witness_out) {
+    if (!point || !value_out || !witness_out || (n && !coeffs) || n > MI_MSM_MAX_N) return MI_ERR_BAD_ARGS;
+    return guarded([&](Context &cx) -> int32_t { return kzg_open_impl(cx, handle, coeffs, n, point, value_out, witness_out); });
+}
+// host sum of two normalised results (z = 1, or z = 0 for infinity)
+static void g1_jac_add2(const mi_g1_jac &a, const mi_g1_jac &b, mi_g1_jac *out) {
+    G1Xyzz acc = G1Xyzz::inf();
+    for (const mi_g1_jac *j : {&a, &b}) {
+        G1Jac p;
+        memcpy(&p, j, sizeof p);
+        if (!p.z.is_zero()) acc = add_mixed(acc, G1Affine{p.x, p.y});
+    }
+    G1Jac res = affine_to_jac(to_affine(acc));
+    memcpy(out, &res, sizeof res);
+}
+// ---- hiding (KZG10::commit / open with a hiding polynomial): C = sum c_i powers_g[i] +
+// sum rho_j powers_gamma_g[j]; the opening proof carries random_v = rho(z) and the witness of both quotients
+int32_t mi_kzg_commit_hiding_h(uint64_t powers_handle, uint64_t gamma_powers_handle, const mi_fr *coeffs, size_t n,
+                               const mi_fr *rand_coeffs, size_t m, mi_g1_jac *out) {
+    if (!out || (n && !coeffs) || (m && !rand_coeffs) || n > MI_MSM_MAX_N || m > MI_MSM_MAX_N) return MI_ERR_BAD_ARGS;
+    return guarded([&](Context &cx) -> int32_t {
+        mi_g1_jac a, b;
+        Fr *d = (Fr *)cx.buf("kzg.commit_coeffs", 32 * ((n > m ? n : m) + 1));
+        if (n) MI_HIP(hipMemcpyAsync(d, coeffs, 32 * n, hipMemcpyHostToDevice, cx.stream));
+        int32_t s = kzg_commit_impl(cx, powers_handle, 0, d, n, &a, cx.stream);
+        if (s != MI_OK) return s;
+        if (m) MI_HIP(hipMemcpyAsync(d, rand_coeffs, 32 * m, hipMemcpyHostToDevice, cx.stream));
+        s = kzg_commit_impl(cx, gamma_powers_handle, 0, d, m, &b, cx.stream);
+        if (s != MI_OK) return s;
+        g1_jac_add2(a, b, out);
+        return MI_OK;
+    });
+}
+int32_t mi_kzg_open_hiding_h(uint64_t powers_handle, uint64_t gamma_powers_handle, const mi_fr *coeffs, size_t n,
+                             const mi_fr *rand_coeffs, size_t m, const mi_fr *point, mi_fr *value_out, mi_fr *random_v_out,
+                             mi_g1_jac *witness_out) {
+    if (!point || !value_out || !random_v_out || !witness_out || (n && !coeffs) || (m && !rand_coeffs) || n > MI_MSM_MAX_N ||
+        m > MI_MSM_MAX_N)
+        return MI_ERR_BAD_ARGS;
+    return guarded([&](Context &cx) -> int32_t {
+        mi_g1_jac wa, wb;
+        int32_t s = kzg_open_impl(cx, powers_handle, coeffs, n, point, value_out, &wa);
+        if (s != MI_OK) return s;
+        s = kzg_open_impl(cx, gamma_powers_handle, rand_coeffs, m, point, random_v_out, &wb);
+        if (s != MI_OK) return s;
+        g1_jac_add2(wa, wb, witness_out);
+        return MI_OK;
+    });
+}
+// KZG10::commit_lagrange: the polynomial is given by its evaluations over the domain and the bases are the
+// Lagrange-basis SRS elements L_i(beta) G -- the same MSM, named for the reference's entry point
+int32_t mi_kzg_commit_lagrange_h(uint64_t lagrange_handle, const mi_fr *evals, size_t n, mi_g1_jac *out) {
+    return mi_kzg_commit_h(lagrange_handle, 0, evals, n, out);
+}
+// fft::EvaluationDomain::divide_by_vanishing_poly_on_coset_in_place, generalised to an evaluation domain of size
+// M = 2^log_m >= N = 2^log_n: evals[i] = p(g w_M^i) is divided by Z_N(g w_M^i) = g^N (w_M^N)^i - 1, which takes M / N
+// values (all non-zero: g is not in the subgroup): a table of their inverses, one product per element
+__global__ void __launch_bounds__(256) fr_scale_periodic_kernel(Fr *__restrict__ a, size_t n, const Fr *__restrict__ tab, size_t period) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) a[i] = mul(a[i], tab[i & (period - 1)]);
+}
+static int32_t divide_by_vanishing_impl(Context &cx, Fr *d, uint32_t log_m, uint32_t log_n, hipStream_t st) {
+    const size_t K = (size_t)1 << (log_m - log_n);
+    std::vector<Fr> tab(K);
+    Fr gN = Fr::zero();  // g^N, g = 22 (the coset generator of mi_ntt_fr)
+    for (int i = 0; i < 4; i++) { gN.l[2 * i] = (uint32_t)MI_FR_GENERATOR[i]; gN.l[2 * i + 1] = (uint32_t)(MI_FR_GENERATOR[i] >> 32); }
+    for (uint32_t b = 0; b < log_n; b++) gN = sqr(gN);
+    const Fr wK = K > 1 ? host_omega(log_m - log_n) : Fr::one();  // w_M^N has order M / N
+    Fr cur = gN;
+    for (size_t k = 0; k < K; k++) {
+        tab[k] = inv(sub(cur, Fr::one()));
+        cur = mul(cur, wK);
+    }
+    char nm[40];
+    snprintf(nm, sizeof nm, "ntt.vanish_tab.%p", (void *)st);
+    Fr *dt = (Fr *)cx.buf(nm, sizeof(Fr) * K);
+    MI_HIP(hipMemcpyAsync(dt, tab.data(), sizeof(Fr) * K, hipMemcpyHostToDevice, st));
+    MI_HIP(hipStreamSynchronize(st));  // tab is a local
+    const size_t M = (size_t)1 << log_m;
+    hipLaunchKernelGGL(fr_scale_periodic_kernel, dim3(cdiv(M, 256)), dim3(256), 0, st, d, M, (const Fr *)dt, K);
+    MI_HIP(hipGetLastError());
+    return MI_OK;
+}
+int32_t mi_ntt_divide_by_vanishing_on_coset(mi_fr *evals, uint32_t log_m, uint32_t log_n) {
+    if (!evals || log_m > 30 || log_n > log_m || log_m - log_n > 12) return MI_ERR_BAD_ARGS;
+    return guarded([&](Context &cx) -> int32_t {
+        const size_t bytes = sizeof(Fr) << log_m;
+        Fr *d = (Fr *)cx.buf("ntt.io", bytes);
+        MI_HIP(hipMemcpyAsync(d, evals, bytes, hipMemcpyHostToDevice, cx.stream));
+        const int32_t s = divide_by_vanishing_impl(cx, d, log_m, log_n, cx.stream);
+        if (s != MI_OK) return s;
+        MI_HIP(hipMemcpyAsync(evals, d, bytes, hipMemcpyDeviceToHost, cx.stream));
+        MI_HIP(hipStreamSynchronize(cx.stream));
+        return MI_OK;
+    });
+}
+int32_t mi_ntt_divide_by_vanishing_on_coset_device(void *d_evals, uint32_t log_m, uint32_t log_n, void *stream) {
+    if (!d_evals || log_m > 30 || log_n > log_m || log_m - log_n > 12) return MI_ERR_BAD_ARGS;
+    return guarded_ptr(d_evals, [&](Context &cx) -> int32_t {
+        return divide_by_vanishing_impl(cx, (Fr *)d_evals, log_m, log_n, (hipStream_t)stream);
     });
 }
 int32_t mi_poly_mul_fr(const mi_fr *a, size_t na, const mi_fr *b, size_t nb, mi_fr *out) {
@@ -596,9 +698,15 @@ int32_t mi_pairing(const mi_g1_affine *p, const mi_g2_affine *q, mi_fq12 *out) {
 }
 int32_t mi_kzg_batch_check(const mi_kzg_vk *vk, const mi_g1_affine *comms, const mi_fr *points, const mi_fr *values,
                            const mi_g1_affine *witnesses, size_t n, const uint8_t *randomizers128, uint8_t *ok_out) {
+    return mi_kzg_batch_check_hiding(vk, nullptr, comms, points, values, witnesses, nullptr, n, randomizers128, ok_out);
+}
+int32_t mi_kzg_batch_check_hiding(const mi_kzg_vk *vk, const mi_g1_affine *gamma_g, const mi_g1_affine *comms, const mi_fr *points,
+                                  const mi_fr *values, const mi_g1_affine *witnesses, const mi_fr *random_v, size_t n,
+                                  const uint8_t *randomizers128, uint8_t *ok_out) {
     if (!vk || !comms || !points || !values || !witnesses || !randomizers128 || !ok_out || n == 0) return MI_ERR_BAD_ARGS;
+    if ((gamma_g == nullptr) != (random_v == nullptr)) return MI_ERR_BAD_ARGS;
     return guarded([&](Context &cx) -> int32_t {
-        return kzg_batch_check_host(cx, vk, comms, points, values, witnesses, n, randomizers128, ok_out);
+        return kzg_batch_check_host(cx, vk, gamma_g, comms, points, values, witnesses, random_v, n, randomizers128, ok_out);
     });
 }
 

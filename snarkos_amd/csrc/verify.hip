@@ -1196,12 +1196,12 @@ int32_t vs_verify_block(uint64_t id, const void *const *proofs, const void *cons
     return status;
 }
 
-// ---------------------------------------------------------------- KZG10::batch_check
-// lane i: sc[i] = r_i, sc[n+i] = r_i z_i (canonical), rv[i] = r_i v_i (Montgomery); sc2[i] = r_i
+// ---------------------------------------------------------------- KZG10::batch_check (with hiding: row A5)
+// lane i: sc[i] = r_i, sc[n+i] = r_i z_i (canonical), rv[i] = r_i v_i, rr[i] = r_i rbar_i (Montgomery); sc2[i] = r_i
 __global__ void __launch_bounds__(128) kzg_scalars_kernel(size_t n, const Fr *__restrict__ points,
-                                                          const Fr *__restrict__ values, const uint8_t *__restrict__ rand128,
-                                                          uint32_t *__restrict__ sc, uint32_t *__restrict__ sc2,
-                                                          Fr *__restrict__ rv) {
+                                                          const Fr *__restrict__ values, const Fr *__restrict__ random_v,
+                                                          const uint8_t *__restrict__ rand128, uint32_t *__restrict__ sc,
+                                                          uint32_t *__restrict__ sc2, Fr *__restrict__ rv, Fr *__restrict__ rr) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const uint32_t *rw = reinterpret_cast<const uint32_t *>(rand128 + 16 * i);
@@ -1212,9 +1212,10 @@ __global__ void __launch_bounds__(128) kzg_scalars_kernel(size_t n, const Fr *__
     for (int k = 0; k < 4; k++) { o[k] = r4[k]; o[4 + k] = 0; o2[k] = r4[k]; o2[4 + k] = 0; }
     fr_store(sc + (n + i) * 8, from_mont(mul(r, fr_load(points + i))));
     fr_store(rv + i, mul(r, fr_load(values + i)));
+    if (random_v) fr_store(rr + i, mul(r, fr_load(random_v + i)));
 }
-// single block: sc[2n] = -(sum rv) canonical
-__global__ void __launch_bounds__(256) kzg_gsum_kernel(size_t n, const Fr *__restrict__ rv, uint32_t *__restrict__ sc) {
+// single block: out = -(sum v) canonical
+__global__ void __launch_bounds__(256) kzg_gsum_kernel(size_t n, const Fr *__restrict__ rv, uint32_t *__restrict__ out) {
     __shared__ uint32_t lds[8 * 256];
     const int t = threadIdx.x;
     Fr acc = Fr::zero();
@@ -1232,28 +1233,38 @@ __global__ void __launch_bounds__(256) kzg_gsum_kernel(size_t n, const Fr *__res
         }
         __syncthreads();
     }
-    if (t == 0) fr_store(sc + 2 * n * 8, from_mont(neg(acc)));
+    if (t == 0) fr_store(out, from_mont(neg(acc)));
 }
 
-int32_t kzg_batch_check_host(Context &cx, const mi_kzg_vk *vk, const mi_g1_affine *comms, const mi_fr *points,
-                                    const mi_fr *values, const mi_g1_affine *witnesses, size_t n, const uint8_t *rand128,
-                                    uint8_t *ok_out) {
+// total_c = sum r_i (C_i + z_i w_i) - (sum r_i v_i) g - (sum r_i rbar_i) gamma_g, total_w = sum r_i w_i,
+// e(total_c, h) e(-total_w, beta_h) == 1; gamma_g / random_v null: no hiding
+int32_t kzg_batch_check_host(Context &cx, const mi_kzg_vk *vk, const mi_g1_affine *gamma_g, const mi_g1_affine *comms,
+                             const mi_fr *points, const mi_fr *values, const mi_g1_affine *witnesses, const mi_fr *random_v,
+                             size_t n, const uint8_t *rand128, uint8_t *ok_out) {
     hipStream_t st = cx.stream;
-    const size_t n1 = 2 * n + 1;
+    const bool hiding = gamma_g != nullptr;
+    const size_t n1 = 2 * n + 1 + (hiding ? 1 : 0);
     G1Affine *pts = (G1Affine *)cx.buf("kzg.pts", sizeof(G1Affine) * n1);
     uint32_t *sc = (uint32_t *)cx.buf("kzg.sc", 32 * n1);
     uint32_t *sc2 = (uint32_t *)cx.buf("kzg.sc2", 32 * n);
     Fr *dpts = (Fr *)cx.buf("kzg.points", sizeof(Fr) * n), *dval = (Fr *)cx.buf("kzg.values", sizeof(Fr) * n);
-    Fr *rv = (Fr *)cx.buf("kzg.rv", sizeof(Fr) * n);
+    Fr *drv = (Fr *)cx.buf("kzg.random_v", sizeof(Fr) * n);
+    Fr *rv = (Fr *)cx.buf("kzg.rv", sizeof(Fr) * n), *rr = (Fr *)cx.buf("kzg.rr", sizeof(Fr) * n);
     uint8_t *dr = (uint8_t *)cx.buf("kzg.rand", 16 * n);
     MI_HIP(hipMemcpyAsync(pts, comms, sizeof(G1Affine) * n, hipMemcpyHostToDevice, st));
     MI_HIP(hipMemcpyAsync(pts + n, witnesses, sizeof(G1Affine) * n, hipMemcpyHostToDevice, st));
     MI_HIP(hipMemcpyAsync(pts + 2 * n, &vk->g, sizeof(G1Affine), hipMemcpyHostToDevice, st));
+    if (hiding) {
+        MI_HIP(hipMemcpyAsync(pts + 2 * n + 1, gamma_g, sizeof(G1Affine), hipMemcpyHostToDevice, st));
+        MI_HIP(hipMemcpyAsync(drv, random_v, sizeof(Fr) * n, hipMemcpyHostToDevice, st));
+    }
     MI_HIP(hipMemcpyAsync(dpts, points, sizeof(Fr) * n, hipMemcpyHostToDevice, st));
     MI_HIP(hipMemcpyAsync(dval, values, sizeof(Fr) * n, hipMemcpyHostToDevice, st));
     MI_HIP(hipMemcpyAsync(dr, rand128, 16 * n, hipMemcpyHostToDevice, st));
-    hipLaunchKernelGGL(kzg_scalars_kernel, dim3(cdiv(n, 128)), dim3(128), 0, st, n, dpts, dval, dr, sc, sc2, rv);
-    hipLaunchKernelGGL(kzg_gsum_kernel, dim3(1), dim3(256), 0, st, n, rv, sc);
+    hipLaunchKernelGGL(kzg_scalars_kernel, dim3(cdiv(n, 128)), dim3(128), 0, st, n, dpts, dval, hiding ? (const Fr *)drv : (const Fr *)nullptr,
+                       dr, sc, sc2, rv, rr);
+    hipLaunchKernelGGL(kzg_gsum_kernel, dim3(1), dim3(256), 0, st, n, rv, sc + 2 * n * 8);
+    if (hiding) hipLaunchKernelGGL(kzg_gsum_kernel, dim3(1), dim3(256), 0, st, n, rr, sc + (2 * n + 1) * 8);
     MI_HIP(hipGetLastError());
     mi_g1_jac tc, tw;
     msm_device(cx, pts, sc, n1, &tc, st);

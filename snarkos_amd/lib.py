@@ -37,7 +37,9 @@ EXPORTS = [
     "mi_init", "mi_device_count", "mi_device_id", "mi_shutdown", "mi_error_string", "mi_abi_version",
     "mi_msm_g1", "mi_msm_g1_device", "mi_g1_sum", "mi_bases_register", "mi_bases_release", "mi_msm_g1_h",
     "mi_ntt_fr", "mi_ntt_fr_device", "mi_kzg_commit_h", "mi_kzg_commit_h_device", "mi_kzg_open_h", "mi_poly_mul_fr",
-    "mi_pairing_product_is_one", "mi_pairing", "mi_kzg_batch_check",
+    "mi_kzg_commit_hiding_h", "mi_kzg_open_hiding_h", "mi_kzg_commit_lagrange_h",
+    "mi_ntt_divide_by_vanishing_on_coset", "mi_ntt_divide_by_vanishing_on_coset_device",
+    "mi_pairing_product_is_one", "mi_pairing", "mi_kzg_batch_check", "mi_kzg_batch_check_hiding",
     "mi_poseidon_fq_hash_many", "mi_poseidon_fq_hash_many_device",
     "mi_vs_ctx_create", "mi_vs_ctx_create_ex", "mi_vs_ctx_destroy", "mi_vs_verify_batch", "mi_vs_verify_batch_device",
     "mi_vs_accumulate_device", "mi_vs_accumulate_begin", "mi_vs_accumulate_end", "mi_vs_finalize", "mi_vs_finalize_async", "mi_vs_finalize_wait",

@@ -135,3 +135,101 @@ def test_open_edge_cases_and_large(orc, mi):
         assert not value.any() and not jac_affine(wit).any()
     finally:
         rb.release()
+
+
+def test_kzg_hiding_vector_and_end_to_end(orc, mi):
+    """row A5 with hiding: the pyref-generated vector through mi_kzg_batch_check_hiding, then commit_hiding -> open_hiding ->
+    batch_check_hiding on the device with gamma_g powers as a second resident table; a wrong random_v is refused"""
+    import golden_util as G
+    d = G.load("kzg_hiding.json")
+    vk = orc.kzg_vk(1)
+    vk[36:60] = orc.g2_from_ints(G.g2_pt(d["tau_h"]))
+    gg = G.g1_arr([d["gamma_g"]])[0]
+    cs, ws = G.g1_arr(d["comms"]), G.g1_arr(d["witnesses"])
+    zs, vs, rnd = G.fr_arr(d["points"]), G.fr_arr(d["values"]), G.rand_arr(d["randomizers"])
+    assert mi.KZG10.batch_check(vk, cs, zs, vs, ws, rnd, gamma_g=gg, random_v=G.fr_arr(d["random_v"]))
+    assert not mi.KZG10.batch_check(vk, cs, zs, vs, ws, rnd, gamma_g=gg, random_v=G.fr_arr(d["bad_random_v"]))
+    assert not mi.KZG10.batch_check(vk, cs, zs, vs, ws, rnd)
+    # end to end with a toy SRS: gamma_g = gamma G, powers_of_beta_times_gamma_g[i] = gamma tau^i G
+    gamma = 0xC0FFEE1234567 % P.R
+    n, m = 700, 3
+    powers, vk = toy_srs(n, TAU)
+    gpw, acc = [], gamma
+    for _ in range(m):
+        gpw.append(acc)
+        acc = acc * TAU % P.R
+    gpowers = orc.fixed_base_batch(orc.fr_from_ints(gpw))
+    rb, rg = mi.ResidentBases(powers), mi.ResidentBases(gpowers)
+    try:
+        coeffs, rho = rng_fr_mont(4001, n), rng_fr_mont(4002, m)
+        c = jac_affine(rb.commit_hiding(rg, coeffs, rho))
+        want = orc.g1_add_affine(orc.kzg_commit(powers, coeffs, threads=8), orc.kzg_commit(gpowers, rho, threads=2))
+        assert (c == want).all()
+        z = orc.fr_from_ints([0x1337])[0]
+        v, rv, w = rb.open_hiding(rg, coeffs, rho, z)
+        assert (v == orc.poly_eval(coeffs, z)).all() and (rv == orc.poly_eval(rho, z)).all()
+        w = jac_affine(w)
+        q, _ = orc.poly_witness(coeffs, z)
+        qr, _ = orc.poly_witness(rho, z)
+        assert (w == orc.g1_add_affine(orc.kzg_commit(powers[:n - 1], q, threads=8), orc.kzg_commit(gpowers[:m - 1], qr, threads=2))).all()
+        one = np.zeros(16, dtype=np.uint8); one[0] = 1
+        assert mi.KZG10.batch_check(vk, [c], [z], [v], [w], one, gamma_g=gpowers[0], random_v=[rv])
+        assert orc.kzg_batch_check_hiding(vk, gpowers[0], np.stack([c]), np.stack([z]), np.stack([v]), np.stack([w]), np.stack([rv]), one)
+        bad = rv.copy(); bad[0] ^= np.uint64(1)
+        assert not mi.KZG10.batch_check(vk, [c], [z], [v], [w], one, gamma_g=gpowers[0], random_v=[bad])
+        assert not mi.KZG10.batch_check(vk, [c], [z], [v], [w], one)  # without the gamma_g term the hiding commitment does not open
+    finally:
+        rb.release()
+        rg.release()
+
+
+def test_commit_lagrange_equals_commit_of_the_interpolant(orc, mi):
+    """KZG10::commit_lagrange: evaluations over the domain against L_i(tau) G give the commitment of the interpolating
+    polynomial (ifft of the evaluations against the monomial powers)"""
+    n = 256
+    w = P.omega(8)
+    # L_i(tau) = (tau^n - 1) w^i / (n (tau - w^i))
+    zn = (pow(TAU, n, P.R) - 1) % P.R
+    lag = [zn * pow(w, i, P.R) % P.R * P.inv(n * (TAU - pow(w, i, P.R)) % P.R, P.R) % P.R for i in range(n)]
+    lbases = orc.fixed_base_batch(orc.fr_from_ints(lag))
+    powers, _ = toy_srs(n, TAU)
+    rl, rp = mi.ResidentBases(lbases), mi.ResidentBases(powers)
+    try:
+        evals = rng_fr_mont(5001, n)
+        coeffs = mi.EvaluationDomain(n).ifft(evals)
+        assert (jac_affine(rl.commit_lagrange(evals)) == jac_affine(rp.commit(coeffs))).all()
+        assert (jac_affine(rl.commit_lagrange(evals)) == orc.kzg_commit(lbases, evals, threads=4)).all()
+    finally:
+        rl.release()
+        rp.release()
+
+
+@pytest.mark.parametrize("log_m,log_n", [(10, 10), (12, 10), (14, 9), (16, 16)])
+def test_divide_by_vanishing_poly_on_coset(orc, mi, log_m, log_n):
+    """EvaluationDomain::divide_by_vanishing_poly_on_coset_in_place: p = q (X^N - 1) with deg q < M - N; coset_fft(p) over
+    the size-M domain, divided on the coset, coset_ifft -> q.  The quotient exists only when M > N; at M = N the pointwise
+    factor is the constant 1 / (g^N - 1), checked directly."""
+    import torch
+    M, N = 1 << log_m, 1 << log_n
+    d = mi.EvaluationDomain(M)
+    if M == N:
+        a = rng_fr_mont(6000 + log_m, M)
+        got = orc.fr_to_ints(d.divide_by_vanishing_poly_on_coset(a, N))
+        c = P.inv((pow(22, N, P.R) - 1) % P.R, P.R)
+        assert got == [x * c % P.R for x in orc.fr_to_ints(a)]
+        return
+    q = rng_fr_mont(6100 + log_m, M - N)
+    p = np.zeros((M, 4), dtype=np.uint64)
+    qi = orc.fr_to_ints(q)
+    pi = [0] * M
+    for i, x in enumerate(qi):
+        pi[i] = (pi[i] - x) % P.R
+        pi[i + N] = (pi[i + N] + x) % P.R
+    p[:] = orc.fr_from_ints(pi)
+    ev = d.coset_fft(p)
+    quot = d.coset_ifft(d.divide_by_vanishing_poly_on_coset(ev, N))
+    assert (quot[:M - N] == q).all() and not quot[M - N:].any()
+    t = torch.from_numpy(ev.view(np.int64)).cuda()
+    d.divide_by_vanishing_poly_on_coset(t, N)
+    d.coset_ifft(t)
+    assert (t.cpu().numpy().view(np.uint64)[:M - N] == q).all()
