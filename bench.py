@@ -7,7 +7,7 @@
 
 Headline (BASELINE.json metric / configs[3], configs[4] at N = 8): proofs verified per second on a
 batch of 1024 synthetic VarunaShaped-v1 proofs PER GPU (weak scaling: N GPUs verify N x 1024 proofs as
-one block-validation batch: every rank accumulates its shard, the 304-byte partial accumulators are
+one block-validation batch: every rank accumulates its shard, the 592-byte partial accumulators are
 all-gathered over RCCL, one pairing product decides the whole batch).  A "step" is one such batch.
 Inputs (proofs, randomizers, keys) are resident in HBM before the timed region.
 
@@ -124,7 +124,7 @@ def main():
     # its own, unpipelined.
     def gather_all(part):  # runs on verify_stream's finisher thread: every collective comes from that one thread
         torch.cuda.set_device(dev_index)
-        part = np.ascontiguousarray(part, dtype=np.uint8)  # (count, 304): one collective per group of batches
+        part = np.ascontiguousarray(part, dtype=np.uint8)  # (count, 592): one collective per group of batches
         return sharding.gather_bytes(part, part.size, torch.distributed, gather_dev).reshape(world, -1, L.VS_PARTIAL_BYTES)
 
     gather = gather_all if dist_on else None

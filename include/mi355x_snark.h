@@ -151,7 +151,27 @@ typedef struct {
     mi_fr evals[MI_VS_EVALS];
     mi_g1_affine w[2];
 } mi_vs_proof; /* 2256 B */
-typedef struct { mi_g1_jac total_c, total_w; uint64_t n_proofs, n_alg_fail; } mi_vs_partial; /* one shard's accumulator */
+/* ---- VarunaShaped-v2: the shape of SonicKZG10::check_combinations on top of v1 ----
+ *   - the query set is a table (which of the two query points each polynomial opens at);
+ *   - hiding: commitments carry rho gamma_g, the proof carries random_v per query (kzg10::VerifierKey.gamma_g,
+ *     KZGProof.random_v);
+ *   - degree bounds: proof polynomial j of class c comes with a shifted commitment, and e(C_j, shift_h[c]) = e(S_j, h) is
+ *     folded into the product with rho_j = r_3 xi^(21 + j): 2 + n_bounds pairs
+ *     (total_c - sum rho_j S_j, h), (-total_w, tau h), (sum_{j in c} rho_j C_j, shift_h[c]);
+ *   - records are mi_vs_proof2, 3184 B, and THREE 128-bit randomizers per proof (48 B).
+ * A context made by mi_vs_ctx_create_v2 takes such records through every mi_vs_* entry point (proof pointers are then
+ * pointers to mi_vs_proof2; the host-pointer prototypes keep their v1 pointer type, cast).  Not in the shape (stated
+ * in DESIGN.md): linear combinations with challenge-dependent coefficients, per-circuit batch sizes above one. */
+#define MI_VS_MAX_BOUNDS 2
+typedef struct {
+    uint8_t query_of[MI_VS_EVALS];         /* 0: the beta query, 1: the gamma query; polynomials 0 and 1 open at beta */
+    int8_t bound_class[MI_VS_PROOF_COMMS]; /* degree-bound class of each proof polynomial, -1: none */
+    uint8_t hiding, n_bounds;
+} mi_vs_shape; /* 32 B */
+typedef struct { mi_g1_affine gamma_g; mi_g2_affine shift_h[MI_VS_MAX_BOUNDS]; } mi_vs_key_ext; /* 480 B */
+typedef struct { mi_vs_proof base; mi_fr random_v[2]; mi_g1_affine shifted[MI_VS_PROOF_COMMS]; } mi_vs_proof2; /* 3184 B */
+/* one shard's accumulator (592 B); bound[c] is infinity for contexts without that class */
+typedef struct { mi_g1_jac total_c, total_w, bound[MI_VS_MAX_BOUNDS]; uint64_t n_proofs, n_alg_fail; } mi_vs_partial;
 
 /* keys resident on the device: KZG vk (G2 lines prepared once) + circuit verifying keys */
 int32_t mi_vs_ctx_create(const mi_kzg_vk *vk, const mi_vs_circuit_vk *circuits, size_t n_circuits, uint64_t *ctx_out);
@@ -163,6 +183,9 @@ int32_t mi_vs_ctx_create(const mi_kzg_vk *vk, const mi_vs_circuit_vk *circuits, 
 #define MI_VS_FS_POSEIDON 1
 int32_t mi_vs_ctx_create_ex(const mi_kzg_vk *vk, const mi_vs_circuit_vk *circuits, size_t n_circuits, uint32_t flags,
                             uint64_t *ctx_out);
+/* VarunaShaped-v2 context: ext may be NULL when the shape neither hides nor bounds; flags as above */
+int32_t mi_vs_ctx_create_v2(const mi_kzg_vk *vk, const mi_vs_key_ext *ext, const mi_vs_shape *shape,
+                            const mi_vs_circuit_vk *circuits, size_t n_circuits, uint32_t flags, uint64_t *ctx_out);
 int32_t mi_vs_ctx_destroy(uint64_t ctx);
 /* host-pointer form: verdicts[n] (1 = valid) and *all_ok.  randomizers128: n x 2 x 16 bytes. */
 int32_t mi_vs_verify_batch(uint64_t ctx, const mi_vs_proof *proofs, size_t n, const uint8_t *randomizers128,
@@ -171,7 +194,7 @@ int32_t mi_vs_verify_batch(uint64_t ctx, const mi_vs_proof *proofs, size_t n, co
 int32_t mi_vs_verify_batch_device(uint64_t ctx, const void *d_proofs, size_t n, const void *d_randomizers128,
                                   uint8_t *verdicts, uint8_t *all_ok, void *stream);
 /* one block-validation batch over ALL devices of the process (SURVEY.md 8e inside one process): contiguous shards, one
- * host thread per device (stage, derive, both MSMs, fold), the 304-byte partials all-gathered over RCCL (grouped
+ * host thread per device (stage, derive, both MSMs, fold), the 592-byte partials all-gathered over RCCL (grouped
  * ncclAllGather over an in-process communicator; added on the host when RCCL is unavailable or MI_SNARK_EXCHANGE=host),
  * ONE pairing product on the primary; on failure every device names the invalid proofs of its shard.
  * verdicts[n] in block order.  The _device form takes one (proofs, randomizers, count) triple per shard, each already
@@ -212,7 +235,7 @@ int32_t mi_vs_finalize_wait(uint64_t ctx, uint64_t ticket, uint8_t *all_ok);
  * enqueues.  `exchange` (may be NULL) runs on the finisher thread, in batch order, once per GROUP of `exchange_group`
  * consecutive batches (1..8; the last group of a finished stream may be shorter; larger groups mean fewer collectives
  * and later verdicts): it receives this rank's `count` partials and must write all ranks' partials rank-major
- * (all[rank * count + k] = rank's partial of the group's k-th batch; multi-GPU: one all-gather of count * 304 bytes per
+ * (all[rank * count + k] = rank's partial of the group's k-th batch; multi-GPU: one all-gather of count * 592 bytes per
  * rank) and return the number of RANKS (world * count <= max_partials), or a negative value on failure. */
 typedef int32_t (*mi_vs_exchange_fn)(void *user, const mi_vs_partial *mine, size_t count, mi_vs_partial *all, size_t max_partials);
 int32_t mi_vs_stream_open(uint64_t ctx, int32_t fold_threads, int32_t products, int32_t lanes, mi_vs_exchange_fn exchange,

@@ -158,6 +158,26 @@ int orc_vs_verify_aggregated(const orc_kzg_vk *vk, const orc_vs_circuit_vk *circ
                              const orc_vs_proof *proofs, size_t n, const uint8_t *randomizers128,
                              uint8_t *alg_ok, orc_g1_affine *total_c, orc_g1_affine *total_w, int threads);
 
+/* ---- VarunaShaped-v2: query-set table, hiding (gamma_g, random_v), degree-bound classes with their own G2 partners
+ * (orc_algo.c "VarunaShaped-v2"); three 128-bit randomizers per proof */
+#define ORC_VS_MAX_BOUNDS 2
+typedef struct {
+    uint8_t query_of[ORC_VS_EVALS];          /* 0: the beta query, 1: the gamma query */
+    int8_t bound_class[ORC_VS_PROOF_COMMS];  /* degree-bound class of each proof polynomial, -1: none */
+    uint8_t hiding, n_bounds;
+} orc_vs_shape; /* 32 B */
+typedef struct { orc_g1_affine gamma_g; orc_g2_affine shift_h[ORC_VS_MAX_BOUNDS]; } orc_vs_key_ext; /* 480 B */
+typedef struct { orc_vs_proof base; orc_fr random_v[2]; orc_g1_affine shifted[ORC_VS_PROOF_COMMS]; } orc_vs_proof2; /* 3184 B */
+void orc_vs2_generate(uint64_t seed, size_t n, size_t n_circuits, uint32_t corrupt_per_1024, const orc_vs_shape *shape,
+                      orc_kzg_vk *vk, orc_vs_key_ext *ext, orc_vs_circuit_vk *circuits, orc_vs_proof2 *proofs,
+                      uint8_t *randomizers /* n x 48 */, uint8_t *expected);
+void orc_vs2_verify_batch_cpu(const orc_kzg_vk *vk, const orc_vs_key_ext *ext, const orc_vs_shape *shape,
+                              const orc_vs_circuit_vk *circuits, const orc_vs_proof2 *proofs, size_t n,
+                              const uint8_t *randomizers, uint8_t *verdicts, int threads);
+int orc_vs2_verify_aggregated(const orc_kzg_vk *vk, const orc_vs_key_ext *ext, const orc_vs_shape *shape,
+                              const orc_vs_circuit_vk *circuits, const orc_vs_proof2 *proofs, size_t n,
+                              const uint8_t *randomizers, uint8_t *alg_ok, orc_g1_affine totals[4], int threads);
+
 int orc_self_test(void);
 
 #ifdef __cplusplus

@@ -783,6 +783,314 @@ void orc_vs_generate(uint64_t seed, size_t n, size_t n_circuits, uint32_t corrup
     free(cpoly); free(ctau); free(ccomm); free(ppoly); free(ptau); free(pcomm); free(wk); free(wc);
 }
 
+/* ------------------------------------------------------------------ VarunaShaped-v2
+ * The shape of SonicKZG10::check_combinations on top of v1:
+ *   - the query set is a TABLE (shape->query_of[p]: which of the two query points each of the 21 polynomials opens at),
+ *     not the hard-wired split of v1;
+ *   - hiding: commitments carry rho_p gamma_g, the proof carries random_v[q] = sum_{p at q} xi^p rho_p, the check
+ *     subtracts (sum_q r_q random_v[q]) gamma_g (kzg10::VerifierKey.gamma_g, KZGProof.random_v);
+ *   - degree bounds: proof polynomial j of class c = shape->bound_class[j] comes with a shifted commitment S_j; the
+ *     check e(C_j, shift_h[c]) = e(S_j, h) is folded with rho_j = r_3 xi^(21 + j): the product has 2 + n_bounds pairs
+ *     (total_c - sum rho_j S_j, h), (-total_w, tau h), (sum_{j in c} rho_j C_j, shift_h[c]).
+ * Three 128-bit caller randomizers per proof (r_beta, r_gamma, r_3).  The transcript (either kind) runs over the v1 part
+ * of the record.  Toy SRS as in v1: tau, gamma and the shift factors s_c (standing for tau^(D - d_c)) are known to the
+ * generator only. */
+static void vs2_derive(vs_fr_work *o, fr_t rho[ORC_VS_PROOF_COMMS], fr_t *h_scalar, const orc_vs_shape *sh,
+                       const orc_vs_circuit_vk *cvk, const orc_vs_proof2 *p2, const uint8_t *rand3x16) {
+    const orc_vs_proof *p = &p2->base;
+    fr_t z[2], xi, r[3], xip, val[2], t, xhat, znm1;
+    orc_vs_challenges(cvk, p, (orc_fr *)&z[0], (orc_fr *)&z[1], (orc_fr *)&xi);
+    for (int k = 0; k < 3; k++) fr_from_u128le(&r[k], rand3x16 + 16 * k);
+    fr_one(&xip);
+    fr_zero(&val[0]);
+    fr_zero(&val[1]);
+    for (int k = 0; k < ORC_VS_EVALS; k++) {
+        const int q = sh->query_of[k] & 1;
+        fr_mul(&o->poly_scalar[k], &r[q], &xip);
+        fr_mul(&t, &xip, S(&p->evals[k]));
+        fr_add(&val[q], &val[q], &t);
+        fr_mul(&xip, &xip, &xi);
+    }
+    for (int j = 0; j < ORC_VS_PROOF_COMMS; j++) { /* xip = xi^(21 + j) */
+        fr_mul(&rho[j], &r[2], &xip);
+        fr_mul(&xip, &xip, &xi);
+    }
+    fr_zero(&o->g_scalar);
+    fr_zero(h_scalar);
+    for (int q = 0; q < 2; q++) {
+        fr_mul(&o->w_scalar_c[q], &r[q], &z[q]);
+        o->w_scalar_w[q] = r[q];
+        fr_mul(&t, &r[q], &val[q]);
+        fr_sub(&o->g_scalar, &o->g_scalar, &t);
+        if (sh->hiding) {
+            fr_mul(&t, &r[q], S(&p2->random_v[q]));
+            fr_sub(h_scalar, h_scalar, &t);
+        }
+    }
+    o->alg_ok = 0;
+    int wf = orc_vs_proof_is_well_formed(p);
+    for (int q = 0; q < 2 && wf; q++) wf = limbs_lt((const uint64_t *)&p2->random_v[q], ORC_FR_MODULUS, 4);
+    for (int j = 0; j < ORC_VS_PROOF_COMMS && wf; j++) {
+        const orc_g1_affine *pt = &p2->shifted[j];
+        wf = limbs_lt((const uint64_t *)&pt->x, ORC_FQ_MODULUS, 6) && limbs_lt((const uint64_t *)&pt->y, ORC_FQ_MODULUS, 6) &&
+             orc_g1_is_on_curve(pt);
+    }
+    if (wf && vs_input_eval(&xhat, &znm1, (const fr_t *)p->inputs, &z[0])) {
+        fr_mul(&t, &znm1, S(&p->evals[1]));
+        fr_add(&t, &t, &xhat);
+        o->alg_ok = fr_eq(&t, S(&p->evals[0]));
+    }
+}
+/* the four accumulators of one proof (Jacobian) */
+static void vs2_accumulate_one(orc_g1_jac acc[4], int *alg_ok, const orc_kzg_vk *vk, const orc_vs_key_ext *ext,
+                               const orc_vs_shape *sh, const orc_vs_circuit_vk *circuits, const orc_vs_proof2 *p2,
+                               const uint8_t *rand3x16) {
+    const orc_vs_proof *p = &p2->base;
+    const orc_vs_circuit_vk *cvk = &circuits[p->circuit];
+    vs_fr_work fw;
+    fr_t rho[ORC_VS_PROOF_COMMS], hs, t;
+    vs2_derive(&fw, rho, &hs, sh, cvk, p2, rand3x16);
+    orc_g1_jac tj;
+    for (int k = 0; k < 4; k++) g1_set_inf(&acc[k]);
+    for (int k = 0; k < ORC_VS_EVALS; k++) {
+        const orc_g1_affine *c = k < ORC_VS_PROOF_COMMS ? &p->comms[k] : &cvk->comms[k - ORC_VS_PROOF_COMMS];
+        g1_mul_fr(&tj, c, &fw.poly_scalar[k]);
+        orc_g1_add(&acc[0], &acc[0], &tj);
+    }
+    for (int q = 0; q < 2; q++) {
+        g1_mul_fr(&tj, &p->w[q], &fw.w_scalar_c[q]);
+        orc_g1_add(&acc[0], &acc[0], &tj);
+        g1_mul_fr(&tj, &p->w[q], &fw.w_scalar_w[q]);
+        orc_g1_add(&acc[1], &acc[1], &tj);
+    }
+    g1_mul_fr(&tj, &vk->g, &fw.g_scalar);
+    orc_g1_add(&acc[0], &acc[0], &tj);
+    if (sh->hiding) {
+        g1_mul_fr(&tj, &ext->gamma_g, &hs);
+        orc_g1_add(&acc[0], &acc[0], &tj);
+    }
+    for (int j = 0; j < ORC_VS_PROOF_COMMS; j++) {
+        const int c = sh->bound_class[j];
+        if (c < 0 || c >= sh->n_bounds) continue;
+        fr_neg(&t, &rho[j]);
+        g1_mul_fr(&tj, &p2->shifted[j], &t);
+        orc_g1_add(&acc[0], &acc[0], &tj);
+        g1_mul_fr(&tj, &p->comms[j], &rho[j]);
+        orc_g1_add(&acc[2 + c], &acc[2 + c], &tj);
+    }
+    *alg_ok = fw.alg_ok;
+}
+static int vs2_product_is_one(const orc_g1_jac acc[4], const orc_g2_prepared *const preps[4], int n_bounds) {
+    orc_g1_affine ps[4];
+    for (int k = 0; k < 2 + n_bounds; k++) orc_g1_to_affine(&ps[k], &acc[k]);
+    orc_g1_neg_affine(&ps[1], &ps[1]); /* infinity is (0, 0) and stays so */
+    return orc_pairing_product_is_one(ps, preps, (size_t)(2 + n_bounds)) == 1;
+}
+void orc_vs2_verify_batch_cpu(const orc_kzg_vk *vk, const orc_vs_key_ext *ext, const orc_vs_shape *sh,
+                              const orc_vs_circuit_vk *circuits, const orc_vs_proof2 *proofs, size_t n,
+                              const uint8_t *randomizers /* n x 48 */, uint8_t *verdicts, int threads) {
+    orc_g2_prepared *pr = (orc_g2_prepared *)malloc(sizeof(orc_g2_prepared) * 4);
+    orc_g2_prepare(&pr[0], &vk->h);
+    orc_g2_prepare(&pr[1], &vk->tau_h);
+    for (int c = 0; c < sh->n_bounds; c++) orc_g2_prepare(&pr[2 + c], &ext->shift_h[c]);
+    const orc_g2_prepared *preps[4] = {&pr[0], &pr[1], &pr[2], &pr[3]};
+    if (threads < 1) threads = 1;
+#pragma omp parallel for schedule(dynamic, 4) num_threads(threads)
+    for (size_t i = 0; i < n; i++) {
+        orc_g1_jac acc[4];
+        int alg;
+        vs2_accumulate_one(acc, &alg, vk, ext, sh, circuits, &proofs[i], randomizers + 48 * i);
+        verdicts[i] = (uint8_t)(alg && vs2_product_is_one(acc, preps, sh->n_bounds));
+    }
+    free(pr);
+}
+/* the aggregated form: per-proof accumulators summed (the group result is what the library's RLC MSMs produce);
+ * totals[0..3] = total_c, total_w, bound[0], bound[1] as affine points ((0,0) = infinity) */
+int orc_vs2_verify_aggregated(const orc_kzg_vk *vk, const orc_vs_key_ext *ext, const orc_vs_shape *sh,
+                              const orc_vs_circuit_vk *circuits, const orc_vs_proof2 *proofs, size_t n,
+                              const uint8_t *randomizers, uint8_t *alg_ok, orc_g1_affine totals[4], int threads) {
+    if (threads < 1) threads = 1;
+    orc_g1_jac *part = (orc_g1_jac *)malloc(sizeof(orc_g1_jac) * 4 * (size_t)threads);
+    for (int k = 0; k < 4 * threads; k++) g1_set_inf(&part[k]);
+#pragma omp parallel num_threads(threads)
+    {
+        const int tid = omp_get_thread_num();
+#pragma omp for schedule(dynamic, 8)
+        for (size_t i = 0; i < n; i++) {
+            orc_g1_jac acc[4];
+            int alg;
+            vs2_accumulate_one(acc, &alg, vk, ext, sh, circuits, &proofs[i], randomizers + 48 * i);
+            alg_ok[i] = (uint8_t)alg;
+            for (int k = 0; k < 4; k++) orc_g1_add(&part[4 * tid + k], &part[4 * tid + k], &acc[k]);
+        }
+    }
+    orc_g1_jac tot[4];
+    for (int k = 0; k < 4; k++) {
+        g1_set_inf(&tot[k]);
+        for (int t = 0; t < threads; t++) orc_g1_add(&tot[k], &tot[k], &part[4 * t + k]);
+    }
+    free(part);
+    int all_alg = 1;
+    for (size_t i = 0; i < n; i++) all_alg &= alg_ok[i];
+    orc_g2_prepared *pr = (orc_g2_prepared *)malloc(sizeof(orc_g2_prepared) * 4);
+    orc_g2_prepare(&pr[0], &vk->h);
+    orc_g2_prepare(&pr[1], &vk->tau_h);
+    for (int c = 0; c < sh->n_bounds; c++) orc_g2_prepare(&pr[2 + c], &ext->shift_h[c]);
+    const orc_g2_prepared *preps[4] = {&pr[0], &pr[1], &pr[2], &pr[3]};
+    const int ok = vs2_product_is_one(tot, preps, sh->n_bounds);
+    free(pr);
+    for (int k = 0; k < 4; k++) orc_g1_to_affine(&totals[k], &tot[k]); /* (0, 0) for infinity */
+    return ok && all_alg;
+}
+void orc_vs2_generate(uint64_t seed, size_t n, size_t n_circuits, uint32_t corrupt_per_1024, const orc_vs_shape *sh,
+                      orc_kzg_vk *vk, orc_vs_key_ext *ext, orc_vs_circuit_vk *circuits, orc_vs_proof2 *proofs,
+                      uint8_t *randomizers /* n x 48 */, uint8_t *expected) {
+    smix g = {seed};
+    fr_t tau, gam, shf[ORC_VS_MAX_BOUNDS];
+    smix_fr(&g, &tau);
+    smix_fr(&g, &gam);
+    for (int c = 0; c < ORC_VS_MAX_BOUNDS; c++) smix_fr(&g, &shf[c]);
+    orc_g1_generator(&vk->g);
+    orc_g2_generator(&vk->h);
+    orc_bigint256 kc;
+    fr_to_canonical(kc.l, &tau);
+    orc_g2_mul(&vk->tau_h, &vk->h, &kc);
+    {
+        orc_g1_jac tj;
+        g1_mul_fr(&tj, &vk->g, &gam);
+        orc_g1_to_affine(&ext->gamma_g, &tj);
+    }
+    for (int c = 0; c < ORC_VS_MAX_BOUNDS; c++) {
+        fr_to_canonical(kc.l, &shf[c]);
+        orc_g2_mul(&ext->shift_h[c], &vk->h, &kc);
+    }
+    /* circuit polynomials and commitments (never hiding, never bounded) */
+    fr_t *cpoly = (fr_t *)malloc(sizeof(fr_t) * n_circuits * ORC_VS_VK_COMMS * VS_DEG);
+    fr_t *ctau = (fr_t *)malloc(sizeof(fr_t) * n_circuits * ORC_VS_VK_COMMS);
+    for (size_t i = 0; i < n_circuits * ORC_VS_VK_COMMS; i++) {
+        for (int d = 0; d < VS_DEG; d++) smix_fr(&g, &cpoly[i * VS_DEG + d]);
+        poly_eval(&ctau[i], &cpoly[i * VS_DEG], &tau);
+    }
+    orc_g1_affine *ccomm = (orc_g1_affine *)malloc(sizeof(orc_g1_affine) * n_circuits * ORC_VS_VK_COMMS);
+    orc_g1_fixed_base_batch(ccomm, (const orc_fr *)ctau, n_circuits * ORC_VS_VK_COMMS);
+    for (size_t c = 0; c < n_circuits; c++) {
+        memcpy(circuits[c].comms, &ccomm[c * ORC_VS_VK_COMMS], sizeof circuits[c].comms);
+        orc_sha256(circuits[c].digest, (const uint8_t *)circuits[c].comms, sizeof circuits[c].comms);
+    }
+    const size_t PC = ORC_VS_PROOF_COMMS;
+    fr_t *ppoly = (fr_t *)malloc(sizeof(fr_t) * n * PC * VS_DEG);
+    fr_t *ptau = (fr_t *)malloc(sizeof(fr_t) * n * PC);   /* p_k(tau) */
+    fr_t *prho = (fr_t *)malloc(sizeof(fr_t) * n * PC);   /* hiding constants rho_k */
+    fr_t *cval = (fr_t *)malloc(sizeof(fr_t) * n * PC * 2); /* commitment exponents: C_k, then S_k */
+    for (size_t i = 0; i < n; i++) {
+        orc_vs_proof2 *p2 = &proofs[i];
+        orc_vs_proof *p = &p2->base;
+        memset(p2, 0, sizeof *p2);
+        p->circuit = (uint32_t)(smix_next(&g) % n_circuits);
+        for (int k = 0; k < ORC_VS_INPUTS; k++) smix_fr(&g, S(&p->inputs[k]));
+        for (size_t k = 0; k < PC; k++)
+            for (int d = 0; d < VS_DEG; d++) smix_fr(&g, &ppoly[(i * PC + k) * VS_DEG + d]);
+        for (size_t k = 1; k < PC; k++) poly_eval(&ptau[i * PC + k], &ppoly[(i * PC + k) * VS_DEG], &tau);
+        fr_t xh, znm1, t;
+        vs_input_eval(&xh, &znm1, (const fr_t *)p->inputs, &tau);
+        fr_mul(&t, &znm1, &ptau[i * PC + 1]);
+        fr_add(&ptau[i * PC + 0], &xh, &t);
+        for (size_t k = 0; k < PC; k++) {
+            if (sh->hiding) smix_fr(&g, &prho[i * PC + k]);
+            else fr_zero(&prho[i * PC + k]);
+            fr_mul(&t, &gam, &prho[i * PC + k]);
+            fr_add(&cval[(i * PC + k) * 2], &ptau[i * PC + k], &t);
+            const int c = sh->bound_class[k];
+            if (c >= 0 && c < sh->n_bounds) fr_mul(&cval[(i * PC + k) * 2 + 1], &cval[(i * PC + k) * 2], &shf[c]);
+            else fr_zero(&cval[(i * PC + k) * 2 + 1]);
+        }
+        for (int k = 0; k < 48; k++) randomizers[48 * i + k] = (uint8_t)smix_next(&g);
+    }
+    orc_g1_affine *pcomm = (orc_g1_affine *)malloc(sizeof(orc_g1_affine) * n * PC * 2);
+    orc_g1_fixed_base_batch(pcomm, (const orc_fr *)cval, n * PC * 2);
+    for (size_t i = 0; i < n; i++)
+        for (size_t k = 0; k < PC; k++) {
+            proofs[i].base.comms[k] = pcomm[(i * PC + k) * 2];
+            const int c = sh->bound_class[k];
+            if (c >= 0 && c < sh->n_bounds) proofs[i].shifted[k] = pcomm[(i * PC + k) * 2 + 1];
+        }
+    fr_t *wk = (fr_t *)malloc(sizeof(fr_t) * n * 2);
+    for (size_t i = 0; i < n; i++) {
+        orc_vs_proof2 *p2 = &proofs[i];
+        orc_vs_proof *p = &p2->base;
+        const orc_vs_circuit_vk *cvk = &circuits[p->circuit];
+        fr_t z[2], xi, xip, t, num[2], rv[2];
+        orc_vs_challenges(cvk, p, (orc_fr *)&z[0], (orc_fr *)&z[1], (orc_fr *)&xi);
+        for (int k = 0; k < ORC_VS_EVALS; k++) {
+            const int q = sh->query_of[k] & 1;
+            const fr_t *poly = k < ORC_VS_PROOF_COMMS ? &ppoly[(i * PC + k) * VS_DEG]
+                                                      : &cpoly[(p->circuit * ORC_VS_VK_COMMS + (k - ORC_VS_PROOF_COMMS)) * VS_DEG];
+            poly_eval(S(&p->evals[k]), poly, &z[q]);
+        }
+        { /* p_0(z_beta) = x_hat(z_beta) + (z_beta^16-1) p_1(z_beta): p_0 and p_1 must open at the beta query */
+            fr_t xh, znm1;
+            if (vs_input_eval(&xh, &znm1, (const fr_t *)p->inputs, &z[0])) {
+                fr_mul(&t, &znm1, S(&p->evals[1]));
+                fr_add(S(&p->evals[0]), &xh, &t);
+            }
+        }
+        orc_vs_challenges(cvk, p, (orc_fr *)&z[0], (orc_fr *)&z[1], (orc_fr *)&xi);
+        fr_one(&xip);
+        for (int q = 0; q < 2; q++) { fr_zero(&num[q]); fr_zero(&rv[q]); }
+        for (int k = 0; k < ORC_VS_EVALS; k++) {
+            const int q = sh->query_of[k] & 1;
+            const fr_t *at_tau = k < ORC_VS_PROOF_COMMS ? &ptau[i * PC + k] : &ctau[p->circuit * ORC_VS_VK_COMMS + (k - ORC_VS_PROOF_COMMS)];
+            fr_sub(&t, at_tau, S(&p->evals[k]));
+            fr_mul(&t, &t, &xip);
+            fr_add(&num[q], &num[q], &t);
+            if (k < ORC_VS_PROOF_COMMS) {
+                fr_mul(&t, &xip, &prho[i * PC + k]);
+                fr_add(&rv[q], &rv[q], &t);
+            }
+            fr_mul(&xip, &xip, &xi);
+        }
+        for (int q = 0; q < 2; q++) {
+            fr_sub(&t, &tau, &z[q]);
+            fr_inv(&t, &t);
+            fr_mul(&wk[2 * i + q], &num[q], &t);
+            *S(&p2->random_v[q]) = rv[q];
+        }
+    }
+    orc_g1_affine *wc = (orc_g1_affine *)malloc(sizeof(orc_g1_affine) * n * 2);
+    orc_g1_fixed_base_batch(wc, (const orc_fr *)wk, n * 2);
+    for (size_t i = 0; i < n; i++) {
+        proofs[i].base.w[0] = wc[2 * i];
+        proofs[i].base.w[1] = wc[2 * i + 1];
+        expected[i] = 1;
+    }
+    for (size_t i = 0; i < n; i++) {
+        if ((smix_next(&g) & 1023) >= corrupt_per_1024) continue;
+        orc_vs_proof2 *p2 = &proofs[i];
+        orc_vs_proof *p = &p2->base;
+        fr_t one;
+        fr_one(&one);
+        int kind = (int)(smix_next(&g) % 6);
+        if (kind == 4 && !sh->hiding) kind = 0;
+        if (kind == 5 && !sh->n_bounds) kind = 1;
+        switch (kind) {
+        case 0: { int k = 2 + (int)(smix_next(&g) % (ORC_VS_EVALS - 2)); fr_add(S(&p->evals[k]), S(&p->evals[k]), &one); break; }
+        case 1: p->w[smix_next(&g) & 1] = vk->g; break;
+        case 2: fr_add(S(&p->inputs[smix_next(&g) % ORC_VS_INPUTS]), S(&p->inputs[0]), &one); break;
+        case 3: p->comms[2 + smix_next(&g) % 7] = vk->g; break;
+        case 4: { int q = (int)(smix_next(&g) & 1); fr_add(S(&p2->random_v[q]), S(&p2->random_v[q]), &one); break; }
+        default: {
+            int j = 0;
+            for (int t2 = 0; t2 < ORC_VS_PROOF_COMMS; t2++)
+                if (sh->bound_class[t2] >= 0 && sh->bound_class[t2] < sh->n_bounds) j = t2; /* the last bounded polynomial */
+            p2->shifted[j] = vk->g;
+            break;
+        }
+        }
+        expected[i] = 0;
+    }
+    free(cpoly); free(ctau); free(ccomm); free(ppoly); free(ptau); free(prho); free(cval); free(pcomm); free(wk); free(wc);
+}
+
 /* ------------------------------------------------------------------ self test */
 int orc_self_test(void) {
     orc_g1_affine g;

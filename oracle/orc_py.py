@@ -32,7 +32,7 @@ def lib():
         _LIB = C.CDLL(build())
         _LIB.orc_self_test.restype = C.c_int
         _LIB.orc_ntt.restype = C.c_int
-        for f in ("orc_kzg_check", "orc_kzg_batch_check", "orc_kzg_batch_check_hiding", "orc_vs_verify_one", "orc_vs_verify_aggregated",
+        for f in ("orc_kzg_check", "orc_kzg_batch_check", "orc_kzg_batch_check_hiding", "orc_vs2_verify_aggregated", "orc_vs_verify_one", "orc_vs_verify_aggregated",
                   "orc_g1_is_on_curve", "orc_g2_is_on_curve", "orc_fq12_is_one", "orc_pairing_product_is_one"):
             getattr(_LIB, f).restype = C.c_int
     return _LIB
@@ -329,6 +329,66 @@ class VSBatch:
         return fr_to_ints(zb)[0], fr_to_ints(zg)[0], fr_to_ints(xi)[0]
 
 
+VS2_PROOF_BYTES, VS2_KEY_EXT_BYTES, VS2_SHAPE_BYTES, VS2_RAND_BYTES = 3184, 480, 32, 48
+VS1_QUERY_OF = [0] * 5 + [1] * 4 + [0] * 6 + [1] * 6
+
+
+def vs2_shape(query_of=None, bound_class=None, hiding=True, n_bounds=2):
+    """32-byte mi_vs_shape / orc_vs_shape: query table, degree-bound classes, hiding flag"""
+    q = list(query_of if query_of is not None else VS1_QUERY_OF)
+    bc = list(bound_class if bound_class is not None else [-1, -1, -1, -1, -1, 0, 0, 1, 1])
+    assert len(q) == 21 and len(bc) == 9 and q[0] == 0 and q[1] == 0, "p_0 and p_1 open at the beta query (public-input identity)"
+    out = np.zeros(32, dtype=np.uint8)
+    out[:21] = q
+    out[21:30] = np.array(bc, dtype=np.int8).view(np.uint8)
+    out[30], out[31] = int(bool(hiding)), n_bounds
+    return out
+
+
+class VS2Batch:
+    """A synthetic VarunaShaped-v2 batch in ABI layout (query-set table, hiding, degree-bound classes)."""
+
+    def __init__(self, seed, n, n_circuits=8, corrupt_per_1024=0, shape=None, transcript=FS_SHA256):
+        self.n, self.n_circuits, self.seed, self.transcript = n, n_circuits, seed, transcript
+        self.shape = vs2_shape() if shape is None else np.ascontiguousarray(shape, dtype=np.uint8)
+        self.vk = np.zeros(KZG_VK_BYTES, dtype=np.uint8)
+        self.ext = np.zeros(VS2_KEY_EXT_BYTES, dtype=np.uint8)
+        self.circuits = np.zeros(n_circuits * VS_CIRCUIT_VK_BYTES, dtype=np.uint8)
+        self.proofs = np.zeros(n * VS2_PROOF_BYTES, dtype=np.uint8)
+        self.randomizers = np.zeros(n * VS2_RAND_BYTES, dtype=np.uint8)
+        self.expected = np.zeros(n, dtype=np.uint8)
+        lib().orc_vs_set_transcript(C.c_int(transcript))
+        lib().orc_vs2_generate(C.c_uint64(seed), C.c_size_t(n), C.c_size_t(n_circuits), C.c_uint32(corrupt_per_1024), _p(self.shape),
+                               _p(self.vk), _p(self.ext), _p(self.circuits), _p(self.proofs), _p(self.randomizers), _p(self.expected))
+
+    @classmethod
+    def wrap(cls, vk, ext, shape, circuits, proofs, randomizers, transcript=FS_SHA256):
+        b = cls.__new__(cls)
+        b.vk, b.ext, b.shape = (np.ascontiguousarray(x, dtype=np.uint8).reshape(-1) for x in (vk, ext, shape))
+        b.circuits = np.ascontiguousarray(circuits, dtype=np.uint8).reshape(-1)
+        b.proofs = np.ascontiguousarray(proofs, dtype=np.uint8).reshape(-1)
+        b.randomizers = np.ascontiguousarray(randomizers, dtype=np.uint8).reshape(-1)
+        b.n, b.n_circuits = b.proofs.size // VS2_PROOF_BYTES, b.circuits.size // VS_CIRCUIT_VK_BYTES
+        b.transcript, b.seed, b.expected = transcript, None, None
+        return b
+
+    def verify_cpu(self, threads=1):
+        lib().orc_vs_set_transcript(C.c_int(self.transcript))
+        v = np.zeros(self.n, dtype=np.uint8)
+        lib().orc_vs2_verify_batch_cpu(_p(self.vk), _p(self.ext), _p(self.shape), _p(self.circuits), _p(self.proofs), C.c_size_t(self.n),
+                                       _p(self.randomizers), _p(v), C.c_int(threads))
+        return v
+
+    def verify_aggregated(self, threads=1):
+        """-> (all_ok, alg_ok[n], totals (4, 12): total_c, total_w, bound[0], bound[1] affine, zeros = infinity)"""
+        lib().orc_vs_set_transcript(C.c_int(self.transcript))
+        alg = np.zeros(self.n, dtype=np.uint8)
+        tot = u64((4, 12))
+        ok = lib().orc_vs2_verify_aggregated(_p(self.vk), _p(self.ext), _p(self.shape), _p(self.circuits), _p(self.proofs),
+                                             C.c_size_t(self.n), _p(self.randomizers), _p(alg), _p(tot), C.c_int(threads))
+        return bool(ok), alg, tot
+
+
 def g1_add_affine(a, b):
     ja, j = u64(18), u64(18)
     lib().orc_g1_from_affine(_p(ja), _p(np.ascontiguousarray(a, dtype=np.uint64)))
@@ -336,32 +396,49 @@ def g1_add_affine(a, b):
     return jac_to_affine(j)
 
 
-def vs_partial_from_oracle(batch, threads=1):
-    """The 304-byte mi_vs_partial the HIP library would produce for this shard, computed by the oracle."""
-    _, alg, tc, tw = batch.verify_aggregated(threads)
-    one = int_to_limbs((1 << 384) % 0x01AE3A4617C510EAC63B05C06CA1493B1A22D9F300F5138F1EF3622FBA094800170B5D44300000008508C00000000001, 6)
-    part = np.zeros(38, dtype=np.uint64)
-    for k, pt in enumerate((tc, tw)):
+PARTIAL_BYTES = 592
+_ONE6 = None
+
+
+def _partial_pack(points, n, n_alg_fail):
+    """(k, 12) affine points ((0,0) = infinity) -> the library's mi_vs_partial: four normalised Jacobian points
+    (total_c, total_w, bound[0], bound[1]; missing ones are infinity) and the two counts"""
+    global _ONE6
+    if _ONE6 is None:
+        _ONE6 = int_to_limbs((1 << 384) % 0x01AE3A4617C510EAC63B05C06CA1493B1A22D9F300F5138F1EF3622FBA094800170B5D44300000008508C00000000001, 6)
+    part = np.zeros(74, dtype=np.uint64)
+    for k in range(4):
+        pt = points[k] if k < len(points) else np.zeros(12, dtype=np.uint64)
         if pt.any():
             part[18 * k:18 * k + 12] = pt
-            part[18 * k + 12:18 * k + 18] = one
+            part[18 * k + 12:18 * k + 18] = _ONE6
         else:
-            part[18 * k:18 * k + 6] = one
-            part[18 * k + 6:18 * k + 12] = one
-    part[36] = batch.n
-    part[37] = int((alg == 0).sum())
+            part[18 * k:18 * k + 6] = _ONE6
+            part[18 * k + 6:18 * k + 12] = _ONE6
+    part[72] = n
+    part[73] = n_alg_fail
     return part.view(np.uint8).copy()
 
 
+def vs_partial_from_oracle(batch, threads=1):
+    """The 592-byte mi_vs_partial the HIP library would produce for this shard, computed by the oracle (v1 or v2 batch)."""
+    if isinstance(batch, VS2Batch):
+        _, alg, tot = batch.verify_aggregated(threads)
+        return _partial_pack(list(tot), batch.n, int((alg == 0).sum()))
+    _, alg, tc, tw = batch.verify_aggregated(threads)
+    return _partial_pack([tc, tw], batch.n, int((alg == 0).sum()))
+
+
 def vs_finalize_with_oracle(vk, partials):
-    """Sum the partial accumulators and run the single pairing product: all_ok for the whole batch."""
-    parts = np.ascontiguousarray(partials, dtype=np.uint8).reshape(-1, 304).view(np.uint64)
+    """Sum the partial accumulators and run the single pairing product: all_ok for the whole batch (v1 contexts: the
+    class accumulators are infinity)."""
+    parts = np.ascontiguousarray(partials, dtype=np.uint8).reshape(-1, PARTIAL_BYTES).view(np.uint64)
     tc, tw, fails = u64(12), u64(12), 0
     for p in parts:
         for acc, off in ((tc, 0), (tw, 18)):
             pt = p[off:off + 12] if p[off + 12:off + 18].any() else u64(12)
             acc[:] = g1_add_affine(acc, pt)
-        fails += int(p[37])
+        fails += int(p[73])
     vkb = np.ascontiguousarray(vk).view(np.uint8).reshape(-1)
     h = np.frombuffer(vkb[96:288].tobytes(), dtype=np.uint64).copy()
     tau_h = np.frombuffer(vkb[288:480].tobytes(), dtype=np.uint64).copy()

@@ -590,6 +590,75 @@ def vs_verify_one(tau_h, circuits, proof, r_beta, r_gamma):
     return alg_ok and pairing_product_is_one([(total_c, G2_GEN), (g1_neg(total_w), tau_h)])
 
 
+# ----------------------------------------------------------------------------- VarunaShaped-v2 (rows A5 / A6)
+VS2_PROOF_BYTES, VS2_MAX_BOUNDS = 3184, 2
+VS1_QUERY_OF = [0] * 5 + [1] * 4 + [0] * 6 + [1] * 6  # the hard-wired split of v1 as a table
+
+
+def vs2_parse_proof(b):
+    assert len(b) == VS2_PROOF_BYTES
+    d = vs_parse_proof(b[:VS_PROOF_BYTES])
+    d["raw2"] = bytes(b)
+    d["random_v"] = [_rd_fr(b[2256 + 32 * q:2288 + 32 * q]) for q in range(2)]
+    d["shifted"] = [_rd_g1(b[2320 + 96 * j:2416 + 96 * j]) for j in range(VS_PROOF_COMMS)]
+    return d
+
+
+def vs2_verify_one(tau_h, gamma_g, shift_h, shape, circuits, proof, rs):
+    """shape = {"query_of": [21], "bound_class": [9], "hiding": bool, "n_bounds": int}; rs = (r_beta, r_gamma, r_3).
+    e(total_c, h) e(-total_w, tau h) prod_c e(bound_c, shift_h[c]) == 1 and the public-input identity."""
+    if proof["circuit"] >= len(circuits) or not vs_proof_is_well_formed(proof):
+        return False
+    raw = proof["raw2"]
+    for q in range(2):
+        if int.from_bytes(raw[2256 + 32 * q:2288 + 32 * q], "little") >= R:
+            return False
+    for j in range(VS_PROOF_COMMS):
+        xm = int.from_bytes(raw[2320 + 96 * j:2368 + 96 * j], "little")
+        ym = int.from_bytes(raw[2368 + 96 * j:2416 + 96 * j], "little")
+        if xm >= Q or ym >= Q or ((xm or ym) and not g1_is_on_curve((fq_from_mont(xm), fq_from_mont(ym)))):
+            return False
+    cvk = circuits[proof["circuit"]]
+    zb, zg, xi = vs_challenges(cvk, proof)
+    z = (zb, zg)
+    ev = proof["evals"]
+    zn = pow(zb, VS_INPUTS, R)
+    if zn == 1:
+        return False
+    w = omega(4)
+    xhat = 0
+    for k in range(VS_INPUTS):
+        wk = pow(w, k, R)
+        xhat += proof["inputs"][k] * wk * inv((zb - wk) % R, R)
+    xhat = xhat * (zn - 1) * inv(VS_INPUTS, R) % R
+    alg_ok = ev[0] == (xhat + (zn - 1) * ev[1]) % R
+    total_c, total_w, gs, hs = None, None, 0, 0
+    bound = [None] * VS2_MAX_BOUNDS
+    for p in range(VS_EVALS):
+        q = shape["query_of"][p]
+        cm = proof["comms"][p] if p < VS_PROOF_COMMS else cvk["comms"][p - VS_PROOF_COMMS]
+        coef = rs[q] * pow(xi, p, R) % R
+        total_c = g1_add(total_c, g1_mul(cm, coef))
+        gs = (gs + coef * ev[p]) % R
+    for q in range(2):
+        total_c = g1_add(total_c, g1_mul(proof["w"][q], rs[q] * z[q] % R))
+        total_w = g1_add(total_w, g1_mul(proof["w"][q], rs[q]))
+        if shape["hiding"]:
+            hs = (hs + rs[q] * proof["random_v"][q]) % R
+    total_c = g1_add(total_c, g1_neg(g1_mul(G1_GEN, gs)))
+    if shape["hiding"]:
+        total_c = g1_add(total_c, g1_neg(g1_mul(gamma_g, hs)))
+    for j in range(VS_PROOF_COMMS):
+        c = shape["bound_class"][j]
+        if c < 0 or c >= shape["n_bounds"]:
+            continue
+        rho = rs[2] * pow(xi, VS_EVALS + j, R) % R
+        total_c = g1_add(total_c, g1_neg(g1_mul(proof["shifted"][j], rho)))
+        bound[c] = g1_add(bound[c], g1_mul(proof["comms"][j], rho))
+    pairs = [(total_c, G2_GEN), (g1_neg(total_w), tau_h)] + [(bound[c], shift_h[c]) for c in range(shape["n_bounds"])]
+    return alg_ok and pairing_product_is_one(pairs)
+
+
 # ----------------------------------------------------------------------------- Poseidon sponge over Fq (row A9)
 # Structure as recalled for snarkVM's PoseidonSponge<Fq, RATE = 2, CAPACITY = 1>: width 3, S-box x^17, 8 full +
 # 31 partial rounds.  snarkVM's round constants and MDS matrix are NOT available offline, so the parameters here

@@ -288,9 +288,12 @@ class VarunaShaped:
     """Batch verifier for the synthetic VarunaShaped-v1 proofs; the role of
     VarunaSNARK::verify_batch inside VM::check_transactions."""
 
-    def __init__(self, kzg_vk, circuit_vks, transcript="sha256"):
+    def __init__(self, kzg_vk, circuit_vks, transcript="sha256", shape=None, key_ext=None):
         """transcript: "sha256" (the round-1 stand-in) or "poseidon" (sponge over Fq with the reference's absorb volume,
-        mi_vs_ctx_create_ex(..., MI_VS_FS_POSEIDON)); proofs are bound to their transcript kind."""
+        mi_vs_ctx_create_ex(..., MI_VS_FS_POSEIDON)); proofs are bound to their transcript kind.
+        shape / key_ext: VarunaShaped-v2 (mi_vs_ctx_create_v2): the 32-byte mi_vs_shape (query-set table, degree-bound
+        classes, hiding) and the 480-byte mi_vs_key_ext (gamma_g, shift_h[2]); records are then 3184 bytes (mi_vs_proof2)
+        with three 128-bit randomizers (48 bytes) per proof."""
         vk = np.ascontiguousarray(kzg_vk).view(np.uint8).reshape(-1)
         cv = np.ascontiguousarray(circuit_vks).view(np.uint8).reshape(-1)
         assert vk.size == L.KZG_VK_BYTES and cv.size % L.VS_CIRCUIT_VK_BYTES == 0
@@ -298,8 +301,17 @@ class VarunaShaped:
         self.n_circuits = cv.size // L.VS_CIRCUIT_VK_BYTES
         h = C.c_uint64(0)
         flags = L.VS_FS_POSEIDON if transcript == "poseidon" else 0
-        L.check(L.lib().mi_vs_ctx_create_ex(L.ptr(vk), L.ptr(cv), C.c_size_t(self.n_circuits), C.c_uint32(flags), C.byref(h)),
-                "mi_vs_ctx_create_ex")
+        self.proof_bytes, self.rand_bytes = L.VS_PROOF_BYTES, 32
+        if shape is not None:
+            sh = np.ascontiguousarray(shape).view(np.uint8).reshape(-1)
+            ext = None if key_ext is None else np.ascontiguousarray(key_ext).view(np.uint8).reshape(-1)
+            assert sh.size == L.VS2_SHAPE_BYTES and (ext is None or ext.size == L.VS2_KEY_EXT_BYTES)
+            L.check(L.lib().mi_vs_ctx_create_v2(L.ptr(vk), L.ptr(ext), L.ptr(sh), L.ptr(cv), C.c_size_t(self.n_circuits),
+                                                C.c_uint32(flags), C.byref(h)), "mi_vs_ctx_create_v2")
+            self.proof_bytes, self.rand_bytes = L.VS2_PROOF_BYTES, 48
+        else:
+            L.check(L.lib().mi_vs_ctx_create_ex(L.ptr(vk), L.ptr(cv), C.c_size_t(self.n_circuits), C.c_uint32(flags), C.byref(h)),
+                    "mi_vs_ctx_create_ex")
         self.ctx = h.value
         # accumulation lanes of this context (the library reads the same variable when it creates the context)
         try:
@@ -317,16 +329,16 @@ class VarunaShaped:
         """Returns (all_ok: bool, verdicts: uint8[n])."""
         all_ok = np.zeros(1, dtype=np.uint8)
         if _is_torch_cuda(proofs):
-            n = proofs.numel() * proofs.element_size() // L.VS_PROOF_BYTES
+            n = proofs.numel() * proofs.element_size() // self.proof_bytes
             verdicts = np.zeros(n, dtype=np.uint8)
             L.check(L.lib().mi_vs_verify_batch_device(C.c_uint64(self.ctx), L.dptr(proofs), C.c_size_t(n),
                                                       L.dptr(randomizers128), L.ptr(verdicts), L.ptr(all_ok),
                                                       L.stream_ptr(stream)), "mi_vs_verify_batch_device")
             return bool(all_ok[0]), verdicts
         p = np.ascontiguousarray(proofs).view(np.uint8).reshape(-1)
-        n = p.size // L.VS_PROOF_BYTES
+        n = p.size // self.proof_bytes
         r = np.ascontiguousarray(randomizers128, dtype=np.uint8).reshape(-1)
-        assert r.size == 32 * n
+        assert r.size == self.rand_bytes * n
         verdicts = np.zeros(n, dtype=np.uint8)
         L.check(L.lib().mi_vs_verify_batch(C.c_uint64(self.ctx), L.ptr(p), C.c_size_t(n), L.ptr(r), L.ptr(verdicts),
                                            L.ptr(all_ok)), "mi_vs_verify_batch")
@@ -337,9 +349,9 @@ class VarunaShaped:
         shards, one partial per device, all-gather (RCCL from the library), one pairing product.
         Returns (all_ok, verdicts[n])."""
         p = np.ascontiguousarray(proofs).view(np.uint8).reshape(-1)
-        n = p.size // L.VS_PROOF_BYTES
+        n = p.size // self.proof_bytes
         r = np.ascontiguousarray(randomizers128, dtype=np.uint8).reshape(-1)
-        assert r.size == 32 * n
+        assert r.size == self.rand_bytes * n
         verdicts, all_ok = np.zeros(n, dtype=np.uint8), np.zeros(1, dtype=np.uint8)
         L.check(L.lib().mi_vs_verify_block(C.c_uint64(self.ctx), L.ptr(p), C.c_size_t(n), L.ptr(r), L.ptr(verdicts), L.ptr(all_ok)),
                 "mi_vs_verify_block")
@@ -351,7 +363,7 @@ class VarunaShaped:
         k = len(shards)
         dp = (C.c_void_p * k)(*[L.dptr(p).value for p, _ in shards])
         dr = (C.c_void_p * k)(*[L.dptr(r).value for _, r in shards])
-        cnt = (C.c_size_t * k)(*[p.numel() * p.element_size() // L.VS_PROOF_BYTES for p, _ in shards])
+        cnt = (C.c_size_t * k)(*[p.numel() * p.element_size() // self.proof_bytes for p, _ in shards])
         n = sum(cnt)
         verdicts, all_ok = np.zeros(n, dtype=np.uint8), np.zeros(1, dtype=np.uint8)
         L.check(L.lib().mi_vs_verify_block_device(C.c_uint64(self.ctx), dp, dr, cnt, C.c_int32(k), L.ptr(verdicts), L.ptr(all_ok)),
@@ -359,8 +371,8 @@ class VarunaShaped:
         return bool(all_ok[0]), verdicts
 
     def accumulate(self, proofs_cuda, randomizers_cuda, stream=None):
-        """One shard's accumulator (304 bytes): the unit exchanged between GPUs."""
-        n = proofs_cuda.numel() * proofs_cuda.element_size() // L.VS_PROOF_BYTES
+        """One shard's accumulator (592 bytes): the unit exchanged between GPUs."""
+        n = proofs_cuda.numel() * proofs_cuda.element_size() // self.proof_bytes
         part = np.zeros(L.VS_PARTIAL_BYTES, dtype=np.uint8)
         L.check(L.lib().mi_vs_accumulate_device(C.c_uint64(self.ctx), L.dptr(proofs_cuda), C.c_size_t(n),
                                                 L.dptr(randomizers_cuda), L.ptr(part), L.stream_ptr(stream)),
@@ -369,7 +381,7 @@ class VarunaShaped:
 
     def accumulate_begin(self, proofs_cuda, randomizers_cuda, stream=None):
         """Enqueue one shard's accumulation (derive + both MSMs) without waiting; returns a handle."""
-        n = proofs_cuda.numel() * proofs_cuda.element_size() // L.VS_PROOF_BYTES
+        n = proofs_cuda.numel() * proofs_cuda.element_size() // self.proof_bytes
         h = C.c_uint64(0)
         L.check(L.lib().mi_vs_accumulate_begin(C.c_uint64(self.ctx), L.dptr(proofs_cuda), C.c_size_t(n),
                                                L.dptr(randomizers_cuda), L.stream_ptr(stream), C.byref(h)),
@@ -401,8 +413,8 @@ class VarunaShaped:
         A thin wrapper over the library's native driver (mi_vs_stream_*: csrc/stream.hip).  The caller's thread
         enqueues batch k (derive + both MSMs on one of `acc_depth` stream lanes); `fold_threads` native threads wait
         for accumulations and fold them on the host; one finisher thread takes the partials in batch order,
-        exchanges them (`gather`, optional: maps this rank's (count, 304) partials of `exchange_group` consecutive
-        batches to all ranks' (world, count, 304) -- one collective per group, issued from that one thread) and starts
+        exchanges them (`gather`, optional: maps this rank's (count, 592) partials of `exchange_group` consecutive
+        batches to all ranks' (world, count, 592) -- one collective per group, issued from that one thread) and starts
         the pairing products; up to `depth` (<= 8) products are in flight, each on its own stream.  `batches` yields
         (proofs_cuda, randomizers_cuda).  `comm` (a handle of lib.comm_init_rank) makes the exchange native instead:
         the library's own mi_vs_exchange_rccl (ncclAllGather from the finisher thread, no Python on the data path).
@@ -454,7 +466,7 @@ class VarunaShaped:
 
         try:
             for proofs, rnd in batches:
-                n = proofs.numel() * proofs.element_size() // L.VS_PROOF_BYTES
+                n = proofs.numel() * proofs.element_size() // self.proof_bytes
                 held.append((proofs, rnd))
                 st = lib.mi_vs_stream_submit(sid, L.dptr(proofs), C.c_size_t(n), L.dptr(rnd), L.stream_ptr(None))
                 if st != L.MI_OK:

@@ -17,15 +17,23 @@ struct G1Xyzz;
 struct MsmJob {
     size_t n = 0, groups = 0;  // groups: sums per problem
     int c = 0, nwin = 0;
-    int problems = 1;  // 2: two MSMs sharing one launch sequence (msm_enqueue's split), h holds problems * groups sums
+    int problems = 1;  // up to 4 MSMs sharing one launch sequence (msm_enqueue's split points), h holds problems * groups sums
     bool per_bit = false;
     G1Xyzz *h = nullptr;  // pinned host copy of the window / bit sums
     hipEvent_t done = nullptr;  // recorded after the copy into h
 };
+// split points of a fused launch: points [0, at[0]) are problem 0, [at[0], at[1]) problem 1, ...; 0 = unused
+struct MsmSplits {
+    size_t at[3] = {0, 0, 0};
+    MsmSplits() {}
+    MsmSplits(size_t a, size_t b = 0, size_t c = 0) : at{a, b, c} {}
+    __host__ __device__ uint32_t problem_of(size_t i) const { return (uint32_t)(i >= at[0]) + (uint32_t)(i >= at[1]) + (uint32_t)(i >= at[2]); }
+};
 void msm_enqueue(Context &cx, const G1Affine *d_points, const uint32_t *d_scalars, size_t n, hipStream_t st, int scalar_bits,
-                 int slot, MsmJob *job, int force_c = 0, int pin_parity = 0, size_t split = 0);
-// out_b: the second problem's result when the job was enqueued with a split
-void msm_finish(Context &cx, MsmJob *job, hipStream_t st, mi_g1_jac *out, mi_g1_jac *out_b = nullptr);
+                 int slot, MsmJob *job, int force_c = 0, int pin_parity = 0, MsmSplits split = MsmSplits());
+// out_b .. out_d: the further problems' results when the job was enqueued with split points
+void msm_finish(Context &cx, MsmJob *job, hipStream_t st, mi_g1_jac *out, mi_g1_jac *out_b = nullptr, mi_g1_jac *out_c = nullptr,
+                mi_g1_jac *out_d = nullptr);
 size_t msm_small_limit();  // largest n on the latency-bound small path (the only one that takes a split)
 void msm_device(Context &cx, const G1Affine *d_points, const uint32_t *d_scalars, size_t n, mi_g1_jac *out,
                 hipStream_t st, int scalar_bits = 254, int force_c = 0);
@@ -53,8 +61,10 @@ const PoseidonConsts *poseidon_consts(Context &cx, hipStream_t st);
 int32_t kzg_batch_check_host(Context &cx, const mi_kzg_vk *vk, const mi_g1_affine *gamma_g, const mi_g1_affine *comms,
                              const mi_fr *points, const mi_fr *values, const mi_g1_affine *witnesses, const mi_fr *random_v,
                              size_t n, const uint8_t *rand128, uint8_t *ok_out);
-int32_t vs_ctx_create(Context &cx, const mi_kzg_vk *vk, const mi_vs_circuit_vk *circuits, size_t n_circuits, uint32_t flags,
-                      uint64_t *out);
+int32_t vs_ctx_create(Context &cx, const mi_kzg_vk *vk, const mi_vs_key_ext *ext, const mi_vs_shape *shape,
+                      const mi_vs_circuit_vk *circuits, size_t n_circuits, uint32_t flags, uint64_t *out);
+// record and randomizer strides of a verifier context (v1: 2256 / 32, v2: 3184 / 48); false: no such context
+bool vs_strides(uint64_t id, size_t *proof_bytes, size_t *rand_bytes);
 int32_t vs_ctx_destroy(Context &cx, uint64_t id);
 int32_t vs_accumulate_device(Context &cx, uint64_t id, const void *d_proofs, size_t n, const void *d_rand,
                              mi_vs_partial *out, hipStream_t st);

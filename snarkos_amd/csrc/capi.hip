@@ -734,11 +734,16 @@ int32_t mi_poseidon_fq_hash_many_device(const void *d_inputs, size_t n, size_t m
 // ------------------------------------------------------------ VarunaShaped-v1
 int32_t mi_vs_ctx_create(const mi_kzg_vk *vk, const mi_vs_circuit_vk *circuits, size_t n_circuits, uint64_t *ctx_out) {
     if (!vk || !circuits || !n_circuits || !ctx_out) return MI_ERR_BAD_ARGS;
-    return guarded([&](Context &cx) -> int32_t { return vs_ctx_create(cx, vk, circuits, n_circuits, 0, ctx_out); });
+    return guarded([&](Context &cx) -> int32_t { return vs_ctx_create(cx, vk, nullptr, nullptr, circuits, n_circuits, 0, ctx_out); });
+}
+int32_t mi_vs_ctx_create_v2(const mi_kzg_vk *vk, const mi_vs_key_ext *ext, const mi_vs_shape *shape, const mi_vs_circuit_vk *circuits,
+                            size_t n_circuits, uint32_t flags, uint64_t *ctx_out) {
+    if (!vk || !shape || !circuits || !n_circuits || !ctx_out || (flags & ~(uint32_t)MI_VS_FS_POSEIDON)) return MI_ERR_BAD_ARGS;
+    return guarded([&](Context &cx) -> int32_t { return vs_ctx_create(cx, vk, ext, shape, circuits, n_circuits, flags, ctx_out); });
 }
 int32_t mi_vs_ctx_create_ex(const mi_kzg_vk *vk, const mi_vs_circuit_vk *circuits, size_t n_circuits, uint32_t flags, uint64_t *ctx_out) {
     if (!vk || !circuits || !n_circuits || !ctx_out || (flags & ~(uint32_t)MI_VS_FS_POSEIDON)) return MI_ERR_BAD_ARGS;
-    return guarded([&](Context &cx) -> int32_t { return vs_ctx_create(cx, vk, circuits, n_circuits, flags, ctx_out); });
+    return guarded([&](Context &cx) -> int32_t { return vs_ctx_create(cx, vk, nullptr, nullptr, circuits, n_circuits, flags, ctx_out); });
 }
 int32_t mi_vs_ctx_destroy(uint64_t c) {
     int32_t st = ensure_init();
@@ -753,10 +758,12 @@ int32_t mi_vs_verify_batch(uint64_t c, const mi_vs_proof *proofs, size_t n, cons
                            uint8_t *verdicts, uint8_t *all_ok) {
     if (!proofs || !n || !randomizers128 || !verdicts || !all_ok) return MI_ERR_BAD_ARGS;
     return guarded([&](Context &cx) -> int32_t {
-        void *dp = cx.buf("vs.in_proofs", sizeof(mi_vs_proof) * n);
-        void *dr = cx.buf("vs.in_rand", 32 * n);
-        MI_HIP(hipMemcpyAsync(dp, proofs, sizeof(mi_vs_proof) * n, hipMemcpyHostToDevice, cx.stream));
-        MI_HIP(hipMemcpyAsync(dr, randomizers128, 32 * n, hipMemcpyHostToDevice, cx.stream));
+        size_t pb = 0, rb = 0;
+        if (!vs_strides(c, &pb, &rb)) return MI_ERR_BAD_ARGS;
+        void *dp = cx.buf("vs.in_proofs", pb * n);
+        void *dr = cx.buf("vs.in_rand", rb * n);
+        MI_HIP(hipMemcpyAsync(dp, proofs, pb * n, hipMemcpyHostToDevice, cx.stream));
+        MI_HIP(hipMemcpyAsync(dr, randomizers128, rb * n, hipMemcpyHostToDevice, cx.stream));
         return vs_verify_batch_device(cx, c, dp, n, dr, verdicts, all_ok, cx.stream);
     });
 }
@@ -773,14 +780,16 @@ int32_t mi_vs_verify_block(uint64_t c, const mi_vs_proof *proofs, size_t n, cons
     const int32_t st = ensure_init();
     if (st != MI_OK) return st;
     const int nd = n_contexts();
+    size_t pb = 0, rb = 0;
+    if (!vs_strides(c, &pb, &rb)) return MI_ERR_BAD_ARGS;
     std::vector<const void *> p(nd), r(nd);
     std::vector<size_t> cnt(nd);
     const size_t base = n / nd, rem = n % nd;  // contiguous shards, sizes differ by at most one (sharding.shard_bounds)
     size_t lo = 0;
     for (int d = 0; d < nd; d++) {
         cnt[d] = base + ((size_t)d < rem ? 1 : 0);
-        p[d] = proofs + lo;
-        r[d] = randomizers128 + 32 * lo;
+        p[d] = (const uint8_t *)proofs + pb * lo;
+        r[d] = randomizers128 + rb * lo;
         lo += cnt[d];
     }
     try {

@@ -15,8 +15,8 @@
 // Large path (n > 2^16): chunk map + chunks ordered by length; multi-chunk buckets summed (msm_combine_*);
 //   msm_segments (running sums per L-bucket segment + (gL) fix-up); point_tree_sum per window; the host folds the
 //   nwin window sums (<= 256 doublings) and normalises to z = 1.
-// Small path (n <= 2^16, latency bound; takes an optional `split`: two MSMs as one launch sequence, the second as
-//   the first's extra windows): ONE planning workgroup instead of scans / memsets / chunk kernels, accumulate finds its
+// Small path (n <= 2^16, latency bound; takes optional split points: up to four MSMs as one launch sequence, each
+//   further problem as another set of windows): ONE planning workgroup instead of scans / memsets / chunk kernels, accumulate finds its
 //   bucket by bisection, msm_bit_sums_* forms per-(window, bit) subset sums straight from the chunk partials into
 //   pinned host memory, and the host folds over bit positions (halves of each problem on pool threads).
 // HBM traffic per (point, scalar) pair: 32 B scalar read once, 96 B point read once per window from
@@ -107,13 +107,13 @@ static MsmPlan msm_plan(size_t n, int scalar_bits, int force_c) {
 template <int C, int BITS>
 __global__ void __launch_bounds__(256) msm_digits_kernel(const uint32_t *__restrict__ scalars, size_t n,
                                                          int32_t *__restrict__ digits, uint32_t *__restrict__ ranks,
-                                                         uint32_t *__restrict__ counts_all, size_t split) {
+                                                         uint32_t *__restrict__ counts_all, MsmSplits splits) {
     constexpr int NWIN = (BITS + C - 1) / C;
     constexpr uint32_t B = 1u << (C - 1);
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    // two problems in one launch: points [split, n) use a second set of NWIN windows (buckets NWIN*B ...)
-    const uint32_t pbase = i >= split ? (uint32_t)NWIN * B : 0u;
+    // several problems in one launch: the points past each split point use a further set of NWIN windows
+    const uint32_t pbase = splits.problem_of(i) * (uint32_t)NWIN * B;
     const int lane = threadIdx.x & 63;
     const uint4 *sp = reinterpret_cast<const uint4 *>(scalars + i * 8);
     uint4 lo = sp[0], hi = sp[1];
@@ -242,13 +242,13 @@ __global__ void __launch_bounds__(256) scan_finish_kernel(uint32_t *__restrict__
 __global__ void __launch_bounds__(256) msm_scatter_kernel(const int32_t *__restrict__ digits,
                                                           const uint32_t *__restrict__ ranks, size_t n, int nwin, uint32_t B,
                                                           const uint32_t *__restrict__ offsets, uint32_t *__restrict__ sorted,
-                                                          size_t split) {
+                                                          MsmSplits sp) {
     size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= n * (size_t)nwin) return;
     int32_t d = digits[t];
     if (d == 0) return;
     size_t w = t / n, i = t - w * n;
-    if (i >= split) w += nwin;  // second problem: its own windows
+    w += (size_t)nwin * sp.problem_of(i);  // every problem has its own windows
     uint32_t mag = d < 0 ? (uint32_t)(-d) : (uint32_t)d;
     uint32_t pos = offsets[w * B + (mag - 1)] + ranks[t];
     sorted[pos] = ((uint32_t)i << 1) | (d < 0 ? 1u : 0u);
@@ -698,7 +698,7 @@ __global__ void __launch_bounds__(1024) msm_rank_fixup_kernel(const int32_t *__r
 // ---------------------------------------------------------------- host driver
 template <int C>
 static void launch_digits(const uint32_t *scalars, size_t n, int32_t *digits, uint32_t *ranks, uint32_t *counts,
-                          int scalar_bits, size_t split, hipStream_t st) {
+                          int scalar_bits, MsmSplits split, hipStream_t st) {
     if (scalar_bits > 128)
         hipLaunchKernelGGL((msm_digits_kernel<C, 254>), dim3(cdiv(n, 256)), dim3(256), 0, st, scalars, n, digits, ranks, counts, split);
     else
@@ -736,7 +736,7 @@ struct MsmState {  // per device (Context::mod)
 // Enqueue the whole device pipeline of one MSM on `st` (no host synchronisation); `slot` names the workspace set,
 // so two MSMs with different slots may run on two streams at once.  msm_finish() waits and folds on the host.
 void msm_enqueue(Context &cx, const G1Affine *d_points, const uint32_t *d_scalars, size_t n, hipStream_t st, int scalar_bits,
-                 int slot, MsmJob *job, int force_c, int pin_parity, size_t split) {
+                 int slot, MsmJob *job, int force_c, int pin_parity, MsmSplits split) {
     job->n = n;
     job->groups = 0;
     job->problems = 1;
@@ -752,9 +752,14 @@ void msm_enqueue(Context &cx, const G1Affine *d_points, const uint32_t *d_scalar
     // A small MSM is latency bound (one mixed addition is ~10k instructions; its ~17 dependent launches cost more
     // than their work): it takes short chunks, one fused planning kernel and the log-depth reduction below.
     const bool small = n <= msm_small_limit();
-    const int problems = (split > 0 && split < n) ? 2 : 1;
-    if (problems == 2 && !small) throw HipError{hipErrorInvalidValue, "msm split needs n <= 2^16", __LINE__};
-    if (problems == 1) split = n;
+    int problems = 1;
+    for (int k = 0; k < 3; k++) {
+        if (split.at[k] == 0 || split.at[k] >= n) split.at[k] = n;  // unused: no point lies beyond it
+        else problems = k + 2;
+    }
+    for (int k = 0; k + 1 < problems; k++)
+        if (split.at[k] == n || (k && split.at[k] < split.at[k - 1])) throw HipError{hipErrorInvalidValue, "msm split points", __LINE__};
+    if (problems > 1 && !small) throw HipError{hipErrorInvalidValue, "msm split needs n <= 2^16", __LINE__};
     job->problems = problems;
     cx.prof.begin("msm_total", st, n);
     HostSpan hs_bufs("msm.enqueue_all");
@@ -969,13 +974,14 @@ struct FoldSplit {
     void run_lo() { lo = fold_bits(h, 0, mid); }
     G1Jac result() const { return affine_to_jac(to_affine(add(hi, lo))); }
 };
-void msm_finish(Context &cx, MsmJob *job, hipStream_t st, mi_g1_jac *out, mi_g1_jac *out_b) {
+void msm_finish(Context &cx, MsmJob *job, hipStream_t st, mi_g1_jac *out, mi_g1_jac *out_b, mi_g1_jac *out_c, mi_g1_jac *out_d) {
     (void)cx;
     (void)st;
+    mi_g1_jac *outs[4] = {out, out_b, out_c, out_d};
     G1Jac res = G1Jac{Fq::one(), Fq::one(), Fq::zero()};
     if (job->n == 0) {
-        memcpy(out, &res, sizeof res);
-        if (out_b) memcpy(out_b, &res, sizeof res);
+        for (mi_g1_jac *o : outs)
+            if (o) memcpy(o, &res, sizeof res);
         return;
     }
     {
@@ -984,45 +990,50 @@ void msm_finish(Context &cx, MsmJob *job, hipStream_t st, mi_g1_jac *out, mi_g1_
     }
     HostSpan hs_fold("finish.fold");
     const G1Xyzz *h = job->h;
-    G1Xyzz acc;
     if (job->per_bit) {
-        FoldSplit fa(h, job->groups), fb(h + job->groups, job->problems == 2 ? job->groups : 0);
-        std::future<void> t1 = worker_pool().submit([&]() { fa.run_hi(); });
-        std::future<void> t2, t3;
-        if (job->problems == 2) {
-            t2 = worker_pool().submit([&]() { fb.run_lo(); });
-            t3 = worker_pool().submit([&]() { fb.run_hi(); });
+        // every problem's bit sums fold as two independent halves; all halves of the job run side by side on the pool
+        // (this thread takes the first), then the normalisations (one Fq inversion each) do the same
+        const int np = job->problems;
+        std::vector<FoldSplit> f;
+        f.reserve(4);
+        for (int p = 0; p < np; p++) f.emplace_back(h + (size_t)p * job->groups, job->groups);
+        std::vector<std::future<void>> tasks;
+        for (int p = 0; p < np; p++) {
+            FoldSplit *fp = &f[p];
+            tasks.push_back(worker_pool().submit([fp]() { fp->run_hi(); }));
+            if (p) tasks.push_back(worker_pool().submit([fp]() { fp->run_lo(); }));
         }
         std::exception_ptr err;
         try {
-            fa.run_lo();
+            f[0].run_lo();
         } catch (...) {
             err = std::current_exception();
         }
-        for (std::future<void> *t : {&t1, &t2, &t3})
-            if (t->valid()) {
-                try {
-                    t->get();
-                } catch (...) {
-                    if (!err) err = std::current_exception();
-                }
+        for (auto &t : tasks) {
+            try {
+                t.get();
+            } catch (...) {
+                if (!err) err = std::current_exception();
             }
-        if (err) std::rethrow_exception(err);
-        // normalise (one Fq inversion each) side by side
-        G1Jac res_b = res;
-        std::future<void> tn;
-        if (job->problems == 2 && out_b) tn = worker_pool().submit([&]() { res_b = fb.result(); });
-        res = fa.result();
-        if (tn.valid()) tn.get();
-        memcpy(out, &res, sizeof res);
-        if (job->problems == 2 && out_b) memcpy(out_b, &res_b, sizeof res_b);
-        return;
-    } else {
-        acc = h[job->nwin - 1];
-        for (int w = job->nwin - 2; w >= 0; w--) {
-            for (int k = 0; k < job->c; k++) acc = dbl(acc);
-            acc = add(acc, h[w]);
         }
+        if (err) std::rethrow_exception(err);
+        G1Jac r[4];
+        tasks.clear();
+        for (int p = 1; p < np; p++) {
+            FoldSplit *fp = &f[p];
+            G1Jac *rp = &r[p];
+            if (outs[p]) tasks.push_back(worker_pool().submit([fp, rp]() { *rp = fp->result(); }));
+        }
+        r[0] = f[0].result();
+        for (auto &t : tasks) t.get();
+        for (int p = 0; p < np; p++)
+            if (outs[p]) memcpy(outs[p], &r[p], sizeof r[p]);
+        return;
+    }
+    G1Xyzz acc = h[job->nwin - 1];
+    for (int w = job->nwin - 2; w >= 0; w--) {
+        for (int k = 0; k < job->c; k++) acc = dbl(acc);
+        acc = add(acc, h[w]);
     }
     res = affine_to_jac(to_affine(acc));
     memcpy(out, &res, sizeof res);

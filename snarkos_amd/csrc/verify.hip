@@ -113,6 +113,13 @@ __device__ void sha256_prefixed(uint32_t out[8], const uint32_t prefix[8], const
     for (int i = 0; i < 8; i++) out[i] = st[i];
 }
 
+// polynomial p (0..20: 9 proof commitments then 12 vk commitments) opens at query 0 (beta) or 1 (gamma): the fixed table of v1
+__host__ __device__ __forceinline__ int vs_query_of(int p) {
+    if (p < MI_VS_PROOF_COMMS) return p < 5 ? 0 : 1;
+    return (p - MI_VS_PROOF_COMMS) < 6 ? 0 : 1;
+}
+
+
 // ---------------------------------------------------------------- VarunaShaped-v1 context
 struct VsConsts {
     Fr omega16[MI_VS_INPUTS];  // w_16^k
@@ -120,8 +127,26 @@ struct VsConsts {
     uint32_t tag[8];           // big-endian words of the 32-byte domain tag
     G1Affine g;
     Fq tag_elem;               // the tag as an absorbed Fq element (its 32 bytes as Montgomery limbs)
+    G1Affine gamma_g;          // v2 with hiding
     uint32_t fs_kind;          // 0: SHA-256 transcript, MI_VS_FS_POSEIDON: Poseidon sponge over Fq
-    uint32_t _pad[3];
+    // ---- the shape (VarunaShaped-v2: include/mi355x_snark.h, mi_vs_shape; v1 = the fixed table, nothing bounded or hidden)
+    uint32_t proof_words;      // record stride in 32-bit words: 564 (mi_vs_proof) or 796 (mi_vs_proof2)
+    uint32_t rand_bytes;       // caller randomizers per proof: 32 (two) or 48 (three)
+    uint32_t hiding, n_bounds;
+    uint32_t n_bounded;        // proof polynomials with a degree bound
+    uint32_t per_proof;        // H-side points per proof: 9 commitments + 2 witnesses + n_bounded shifted commitments
+    uint32_t class_count[MI_VS_MAX_BOUNDS];
+    uint8_t query_of[MI_VS_EVALS];
+    int8_t bound_class[MI_VS_PROOF_COMMS];
+    uint8_t _pad[2];
+};
+// where one proof's operands go (device pointers into the lane's workspace)
+struct VsOut {
+    G1Affine *pts1, *pts2, *ptsb[MI_VS_MAX_BOUNDS];
+    uint32_t *sc1, *sc2, *scb[MI_VS_MAX_BOUNDS];
+    Fr *vk_scal, *g_scal, *h_scal;
+    uint8_t *alg_ok;
+    uint32_t *circuit_of;
 };
 #define VS_SLOTS MI_VS_MAX_TICKETS
 #define VS_ACC_DEPTH MI_VS_MAX_OPEN_ACCUMULATIONS  // accumulations (derive + both MSMs) that may be enqueued before the oldest is folded
@@ -143,17 +168,20 @@ struct VsCtx {
     mi_kzg_vk vk;
     std::vector<mi_vs_circuit_vk> circuits;
     G2Prepared h_prep, tauh_prep;  // prepared once on the host (as the reference prepares prepared_h / prepared_beta_h)
+    G2Prepared shift_prep[MI_VS_MAX_BOUNDS];  // v2: the G2 partners of the degree-bound classes (prepared_shift_power)
     VsConsts consts;
 };
 struct VsKeys {  // one device's copy
-    DevBuf circuits, h_prep, tauh_prep, consts;
+    DevBuf circuits, h_prep, tauh_prep, consts, shift_prep[MI_VS_MAX_BOUNDS];
     size_t n_circuits = 0;
     bool fs_poseidon = false;
+    VsConsts shape;  // host copy of what consts holds
     ~VsKeys() {
         circuits.release();
         h_prep.release();
         tauh_prep.release();
         consts.release();
+        for (auto &b : shift_prep) b.release();
     }
 };
 struct VsKeyTable {
@@ -164,8 +192,9 @@ struct VsAcc {  // an accumulation whose kernels are enqueued but whose host fol
     uint64_t handle = 0, ctx = 0;
     size_t n = 0;
     hipStream_t st = nullptr;
-    MsmJob j1, j2;
-    bool fused = false;  // j1 carries both MSMs
+    MsmJob j[4];         // H side, tau-H side, class 0, class 1
+    size_t nb[MI_VS_MAX_BOUNDS] = {0, 0};
+    bool fused = false;  // j[0] carries all MSMs
     bool closing = false;
     uint8_t *h_alg = nullptr;
 };
@@ -252,6 +281,13 @@ static std::shared_ptr<VsCtx> vs_find(uint64_t id) {
     auto it = vs_ctxs().find(id);
     return it == vs_ctxs().end() ? nullptr : it->second;
 }
+bool vs_strides(uint64_t id, size_t *proof_bytes, size_t *rand_bytes) {
+    std::shared_ptr<VsCtx> v = vs_find(id);
+    if (!v) return false;
+    *proof_bytes = (size_t)v->consts.proof_words * 4;
+    *rand_bytes = v->consts.rand_bytes;
+    return true;
+}
 void verify_release_keys() {
     std::lock_guard<std::mutex> lk(g_vs_mu);
     vs_ctxs().clear();
@@ -270,6 +306,9 @@ static VsKeys &vs_keys(Context &cx, const VsCtx &v) {
     MI_HIP(hipMemcpyAsync(k->h_prep.get(sizeof(G2Prepared)), &v.h_prep, sizeof(G2Prepared), hipMemcpyHostToDevice, st));
     MI_HIP(hipMemcpyAsync(k->tauh_prep.get(sizeof(G2Prepared)), &v.tauh_prep, sizeof(G2Prepared), hipMemcpyHostToDevice, st));
     MI_HIP(hipMemcpyAsync(k->consts.get(sizeof(VsConsts)), &v.consts, sizeof(VsConsts), hipMemcpyHostToDevice, st));
+    k->shape = v.consts;
+    for (uint32_t c = 0; c < v.consts.n_bounds; c++)
+        MI_HIP(hipMemcpyAsync(k->shift_prep[c].get(sizeof(G2Prepared)), &v.shift_prep[c], sizeof(G2Prepared), hipMemcpyHostToDevice, st));
     MI_HIP(hipStreamSynchronize(st));  // sources are the master's members: alive, but later users run on other streams
     (void)vs_pipe(cx);                 // all of the device's streams exist before the first launch (creation order)
     (void)pairing_consts(cx, st);      // the Frobenius table, before any pipelined launch
@@ -278,8 +317,12 @@ static VsKeys &vs_keys(Context &cx, const VsCtx &v) {
     return ref;
 }
 
-int32_t vs_ctx_create(Context &cx, const mi_kzg_vk *vk, const mi_vs_circuit_vk *circuits, size_t n_circuits, uint32_t flags,
-                      uint64_t *out) {
+int32_t vs_ctx_create(Context &cx, const mi_kzg_vk *vk, const mi_vs_key_ext *ext, const mi_vs_shape *shape,
+                      const mi_vs_circuit_vk *circuits, size_t n_circuits, uint32_t flags, uint64_t *out) {
+    if (shape) {
+        if (shape->n_bounds > MI_VS_MAX_BOUNDS || shape->hiding > 1 || (shape->query_of[0] & 1) || (shape->query_of[1] & 1)) return MI_ERR_BAD_ARGS;
+        if ((shape->hiding || shape->n_bounds) && !ext) return MI_ERR_BAD_ARGS;
+    }
     std::shared_ptr<VsCtx> v(new VsCtx());
     v->n_circuits = n_circuits;
     v->flags = flags;
@@ -304,6 +347,35 @@ int32_t vs_ctx_create(Context &cx, const mi_kzg_vk *vk, const mi_vs_circuit_vk *
     memcpy(hc.tag_elem.l, TAG, 32);
     hc.fs_kind = flags & MI_VS_FS_POSEIDON;
     memset(hc._pad, 0, sizeof hc._pad);
+    hc.gamma_g = G1Affine::inf();
+    // ---- the shape: v1 = the fixed query table, nothing hidden, nothing bounded, 2256-byte records, two randomizers
+    hc.proof_words = sizeof(mi_vs_proof) / 4;
+    hc.rand_bytes = 32;
+    hc.hiding = hc.n_bounds = hc.n_bounded = 0;
+    hc.class_count[0] = hc.class_count[1] = 0;
+    for (int p = 0; p < MI_VS_EVALS; p++) hc.query_of[p] = (uint8_t)vs_query_of(p);
+    for (int j = 0; j < MI_VS_PROOF_COMMS; j++) hc.bound_class[j] = -1;
+    if (shape) {
+        hc.proof_words = sizeof(mi_vs_proof2) / 4;
+        hc.rand_bytes = 48;
+        hc.hiding = shape->hiding;
+        hc.n_bounds = shape->n_bounds;
+        memcpy(hc.query_of, shape->query_of, sizeof hc.query_of);
+        for (int j = 0; j < MI_VS_PROOF_COMMS; j++) {
+            const int c = shape->bound_class[j];
+            hc.bound_class[j] = (c >= 0 && c < (int)shape->n_bounds) ? (int8_t)c : (int8_t)-1;
+            if (hc.bound_class[j] >= 0) {
+                hc.n_bounded++;
+                hc.class_count[c]++;
+            }
+        }
+        if (shape->hiding) memcpy(&hc.gamma_g, &ext->gamma_g, sizeof hc.gamma_g);
+        for (uint32_t c = 0; c < shape->n_bounds; c++) {
+            memcpy(&qa, &ext->shift_h[c], sizeof qa);
+            g2_prepare_host(v->shift_prep[c], qa);
+        }
+    }
+    hc.per_proof = MI_VS_PROOF_COMMS + 2 + hc.n_bounded;
     {
         std::lock_guard<std::mutex> lk(g_vs_mu);
         v->id = g_vs_next++;
@@ -334,15 +406,6 @@ int32_t vs_ctx_destroy(Context &cx, uint64_t id) {
     }
     return MI_OK;
 }
-
-// polynomial p (0..20: 9 proof commitments then 12 vk commitments) opens at query 0 (beta) or 1 (gamma)
-__host__ __device__ __forceinline__ int vs_query_of(int p) {
-    if (p < MI_VS_PROOF_COMMS) return p < 5 ? 0 : 1;
-    return (p - MI_VS_PROOF_COMMS) < 6 ? 0 : 1;
-}
-
-#define VS_PER_PROOF_POINTS (MI_VS_PROOF_COMMS + 2)
-
 // ---------------------------------------------------------------- K: transcript + Fr work, one lane per proof
 // Writes, for proof i:
 //   pts1[i*11 + k]   = C_k (k < 9), W_beta, W_gamma          sc1[i*11 + k] = r_q xi^k | r_q z_q   (canonical)
@@ -382,20 +445,22 @@ __device__ __attribute__((noinline)) bool vs_point_ok(const uint32_t *__restrict
 // FS = 0: the SHA-256 transcript is walked here; FS = 1: the challenges come from `chal` (n x 3 x 128 bits: z_beta,
 // z_gamma, xi), written by vs_fs_poseidon_kernel
 template <int FS>
-__global__ void __launch_bounds__(128) vs_derive_kernel(const mi_vs_proof *__restrict__ proofs, size_t n,
+__global__ void __launch_bounds__(128) vs_derive_kernel(const void *__restrict__ proofs, size_t n,
                                                         const uint8_t *__restrict__ rand128,
                                                         const mi_vs_circuit_vk *__restrict__ circuits, size_t n_circuits,
-                                                        const VsConsts *__restrict__ kc, G1Affine *__restrict__ pts1,
-                                                        uint32_t *__restrict__ sc1, G1Affine *__restrict__ pts2,
-                                                        uint32_t *__restrict__ sc2, Fr *__restrict__ vk_scal,
-                                                        Fr *__restrict__ g_scal, uint8_t *__restrict__ alg_ok,
-                                                        uint32_t *__restrict__ circuit_of, const uint32_t *__restrict__ chal) {
+                                                        const VsConsts *__restrict__ kc, VsOut o, const uint32_t *__restrict__ chal) {
     __shared__ uint32_t zb_lds[64][4];
     const int lane = threadIdx.x & 63, role = threadIdx.x >> 6;  // role 0: transcript + scalars, role 1: points + check
     const size_t i = (size_t)blockIdx.x * 64 + lane;
     const bool live = i < n;
-    const mi_vs_proof *p = proofs + (live ? i : 0);
-    const uint32_t *pw = reinterpret_cast<const uint32_t *>(p);
+    const uint32_t PW = kc->proof_words, PP = kc->per_proof, RB = kc->rand_bytes, NB = kc->n_bounds;
+    const bool v2 = PW != sizeof(mi_vs_proof) / 4;
+    const uint32_t *pw = reinterpret_cast<const uint32_t *>(proofs) + (live ? i : 0) * (size_t)PW;
+    G1Affine *const pts1 = o.pts1, *const pts2 = o.pts2;
+    uint32_t *const sc1 = o.sc1, *const sc2 = o.sc2, *const circuit_of = o.circuit_of;
+    Fr *const vk_scal = o.vk_scal, *const g_scal = o.g_scal;
+    uint8_t *const alg_ok = o.alg_ok;
+    const uint32_t *extra = pw + sizeof(mi_vs_proof) / 4;  // v2: random_v[2] (16 words), shifted[9] (216 words)
     uint32_t circuit = pw[0];
     if (circuit >= n_circuits) circuit = 0;  // malformed index: still well-defined, proof is rejected below
     const bool bad_circuit = pw[0] >= n_circuits;
@@ -425,20 +490,36 @@ __global__ void __launch_bounds__(128) vs_derive_kernel(const mi_vs_proof *__res
         for (int q = 0; q < 2; q++) well_formed = well_formed && vs_point_ok(evals + 168 + 24 * q);
         for (int k = 0; k < MI_VS_INPUTS; k++) well_formed = well_formed && vs_limbs_below(inputs + 8 * k, FrP::MOD, 8);
         for (int k = 0; k < MI_VS_EVALS; k++) well_formed = well_formed && vs_limbs_below(evals + 8 * k, FrP::MOD, 8);
+        if (v2) {
+            for (int q = 0; q < 2; q++) well_formed = well_formed && vs_limbs_below(extra + 8 * q, FrP::MOD, 8);
+            for (int j = 0; j < MI_VS_PROOF_COMMS; j++) well_formed = well_formed && vs_point_ok(extra + 16 + 24 * j);
+        }
         circuit_of[i] = circuit;
         // ---- points into MSM order, randomizers as the tau-H side's scalars
         const G1Affine *pc = reinterpret_cast<const G1Affine *>(comms);
-        for (int k = 0; k < MI_VS_PROOF_COMMS; k++) copy_g1(pts1 + i * VS_PER_PROOF_POINTS + k, pc + k);
+        for (int k = 0; k < MI_VS_PROOF_COMMS; k++) copy_g1(pts1 + i * PP + k, pc + k);
         const G1Affine *wpt = reinterpret_cast<const G1Affine *>(evals + 168);
 #pragma unroll
         for (int q = 0; q < 2; q++) {
-            copy_g1(pts1 + i * VS_PER_PROOF_POINTS + MI_VS_PROOF_COMMS + q, wpt + q);
+            copy_g1(pts1 + i * PP + MI_VS_PROOF_COMMS + q, wpt + q);
             copy_g1(pts2 + i * 2 + q, wpt + q);
         }
-        const uint32_t *rw = reinterpret_cast<const uint32_t *>(rand128 + 32 * i);
-        uint32_t *o = sc2 + i * 16;
+        if (NB) {  // degree-bounded polynomials: S_j joins the H side, C_j its class's accumulator
+            const G1Affine *sh = reinterpret_cast<const G1Affine *>(extra + 16);
+            uint32_t b = 0, pos[MI_VS_MAX_BOUNDS] = {0, 0};
+            for (int j = 0; j < MI_VS_PROOF_COMMS; j++) {
+                const int c = kc->bound_class[j];
+                if (c < 0 || c >= (int)NB) continue;  // uniform
+                copy_g1(pts1 + i * PP + MI_VS_PROOF_COMMS + 2 + b, sh + j);
+                copy_g1(o.ptsb[c] + i * kc->class_count[c] + pos[c], pc + j);
+                b++;
+                pos[c]++;
+            }
+        }
+        const uint32_t *rw = reinterpret_cast<const uint32_t *>(rand128 + (size_t)RB * i);
+        uint32_t *os = sc2 + i * 16;
 #pragma unroll
-        for (int k = 0; k < 4; k++) { o[k] = rw[k]; o[4 + k] = 0; o[8 + k] = rw[4 + k]; o[12 + k] = 0; }
+        for (int k = 0; k < 4; k++) { os[k] = rw[k]; os[4 + k] = 0; os[8 + k] = rw[4 + k]; os[12 + k] = 0; }
     }
     __syncthreads();
     if (!live) return;
@@ -460,26 +541,46 @@ __global__ void __launch_bounds__(128) vs_derive_kernel(const mi_vs_proof *__res
         Fr z[2] = {fr_from_u128(zw[0]), fr_from_u128(zw[1])};
         Fr xi = fr_from_u128(xw);
         // ---- randomizers
-        const uint32_t *rw = reinterpret_cast<const uint32_t *>(rand128 + 32 * i);
+        const uint32_t *rw = reinterpret_cast<const uint32_t *>(rand128 + (size_t)RB * i);
         uint32_t r0[4] = {rw[0], rw[1], rw[2], rw[3]}, r1[4] = {rw[4], rw[5], rw[6], rw[7]};
         Fr r[2] = {fr_from_u128(r0), fr_from_u128(r1)};
-        // ---- opening-challenge powers, combined values, MSM scalars
+        // ---- opening-challenge powers, combined values, MSM scalars (the query of each polynomial: the shape's table)
         Fr xip = Fr::one(), val[2] = {Fr::zero(), Fr::zero()};
         for (int k = 0; k < MI_VS_EVALS; k++) {
-            int q = vs_query_of(k);
-            Fr s = mul(r[q], xip);
-            if (k < MI_VS_PROOF_COMMS) fr_store(sc1 + (i * VS_PER_PROOF_POINTS + k) * 8, from_mont(s));
+            const int q = kc->query_of[k] & 1;
+            Fr s = mul(q ? r[1] : r[0], xip);
+            if (k < MI_VS_PROOF_COMMS) fr_store(sc1 + (i * PP + k) * 8, from_mont(s));
             else fr_store(vk_scal + i * MI_VS_VK_COMMS + (k - MI_VS_PROOF_COMMS), s);
-            val[q] = add(val[q], mul(xip, fr_load(evals + 8 * k)));
+            const Fr tv = mul(xip, fr_load(evals + 8 * k));
+            if (q) val[1] = add(val[1], tv);
+            else val[0] = add(val[0], tv);
             xip = mul(xip, xi);
         }
-        Fr gs = Fr::zero();
+        if (NB) {  // rho_j = r_3 xi^(21 + j): -rho_j S_j on the H side, +rho_j C_j in the class accumulator
+            uint32_t r2w[4] = {rw[8], rw[9], rw[10], rw[11]};
+            const Fr r3 = fr_from_u128(r2w);
+            uint32_t b = 0, pos[MI_VS_MAX_BOUNDS] = {0, 0};
+            for (int j = 0; j < MI_VS_PROOF_COMMS; j++) {
+                const int c = kc->bound_class[j];
+                if (c >= 0 && c < (int)NB) {  // uniform
+                    const Fr rho = mul(r3, xip);
+                    fr_store(sc1 + (i * PP + MI_VS_PROOF_COMMS + 2 + b) * 8, from_mont(neg(rho)));
+                    fr_store(o.scb[c] + (i * kc->class_count[c] + pos[c]) * 8, from_mont(rho));
+                    b++;
+                    pos[c]++;
+                }
+                xip = mul(xip, xi);
+            }
+        }
+        Fr gs = Fr::zero(), hs = Fr::zero();
 #pragma unroll
         for (int q = 0; q < 2; q++) {
-            fr_store(sc1 + (i * VS_PER_PROOF_POINTS + MI_VS_PROOF_COMMS + q) * 8, from_mont(mul(r[q], z[q])));
+            fr_store(sc1 + (i * PP + MI_VS_PROOF_COMMS + q) * 8, from_mont(mul(r[q], z[q])));
             gs = sub(gs, mul(r[q], val[q]));
+            if (kc->hiding) hs = sub(hs, mul(r[q], fr_load(extra + 8 * q)));  // KZGProof.random_v of query q
         }
         fr_store(g_scal + i, gs);
+        if (kc->hiding) fr_store(o.h_scal + i, hs);
         return;
     }
     // ---- role 1: public-input consistency, inversion-free.  With d_k = z - w^k and prod_k d_k = z^16 - 1:
@@ -555,7 +656,7 @@ __device__ __forceinline__ Fq vs_fs_element(const mi_vs_proof *__restrict__ p, c
 }
 #define VS_FS_BLOCKS 37
 #define VS_FS_ELEMS 73
-__global__ void __launch_bounds__(64) vs_fs_poseidon_kernel(const mi_vs_proof *__restrict__ proofs, size_t n,
+__global__ void __launch_bounds__(64) vs_fs_poseidon_kernel(const void *__restrict__ proofs, size_t n,
                                                              const mi_vs_circuit_vk *__restrict__ circuits, size_t n_circuits,
                                                              const VsConsts *__restrict__ kc, const PoseidonConsts *__restrict__ pc,
                                                              uint32_t *__restrict__ chal) {
@@ -563,7 +664,7 @@ __global__ void __launch_bounds__(64) vs_fs_poseidon_kernel(const mi_vs_proof *_
     __shared__ Fq xt[16][2][3];  // partial rounds: lane l's products mds[i][l] s_l, l = 1, 2
     const int t = threadIdx.x, ps = t >> 2, l = t & 3, lc = l < 3 ? l : 0;
     const size_t i = (size_t)blockIdx.x * 16 + ps;
-    const mi_vs_proof *p = proofs + (i < n ? i : 0);
+    const mi_vs_proof *p = reinterpret_cast<const mi_vs_proof *>(reinterpret_cast<const uint32_t *>(proofs) + (i < n ? i : 0) * (size_t)kc->proof_words);
     uint32_t circuit = reinterpret_cast<const uint32_t *>(p)[0];
     if (circuit >= n_circuits) circuit = 0;
     const uint32_t *digest = reinterpret_cast<const uint32_t *>(circuits[circuit].digest);
@@ -619,10 +720,11 @@ __global__ void __launch_bounds__(64) vs_fs_poseidon_kernel(const mi_vs_proof *_
     }
 }
 
-// one block per merged slot: slot < n_circuits*12 -> sum of vk_scal over the proofs of that circuit;
-// last slot -> sum of g_scal.  Output: canonical scalar at sc1[(n*11 + slot)], point copied alongside.
+// one block per merged slot: slot < n_circuits*12 -> sum of vk_scal over the proofs of that circuit; then the sum of
+// g_scal (G), then -- with hiding -- the sum of h_scal (gamma_g).  Output: canonical scalar at sc1[n * per_proof + slot],
+// point copied alongside.
 __global__ void __launch_bounds__(256) vs_merge_kernel(const Fr *__restrict__ vk_scal, const Fr *__restrict__ g_scal,
-                                                       const uint32_t *__restrict__ circuit_of, size_t n,
+                                                       const Fr *__restrict__ h_scal, const uint32_t *__restrict__ circuit_of, size_t n,
                                                        const mi_vs_circuit_vk *__restrict__ circuits, size_t n_circuits,
                                                        const VsConsts *__restrict__ kc, G1Affine *__restrict__ pts1,
                                                        uint32_t *__restrict__ sc1) {
@@ -635,7 +737,8 @@ __global__ void __launch_bounds__(256) vs_merge_kernel(const Fr *__restrict__ vk
         for (size_t i = t; i < n; i += 256)
             if (circuit_of[i] == c) acc = add(acc, fr_load(vk_scal + i * MI_VS_VK_COMMS + k));
     } else {
-        for (size_t i = t; i < n; i += 256) acc = add(acc, fr_load(g_scal + i));
+        const Fr *src = slot == n_vk_slots ? g_scal : h_scal;
+        for (size_t i = t; i < n; i += 256) acc = add(acc, fr_load(src + i));
     }
     for (int stride = 128; stride >= 1; stride >>= 1) {
         if (t >= stride && t < 2 * stride)
@@ -651,55 +754,69 @@ __global__ void __launch_bounds__(256) vs_merge_kernel(const Fr *__restrict__ vk
         __syncthreads();
     }
     if (t == 0) {
-        const size_t dst = n * VS_PER_PROOF_POINTS + slot;
+        const size_t dst = n * kc->per_proof + slot;
         fr_store(sc1 + dst * 8, from_mont(acc));
         if (slot < n_vk_slots)
             copy_g1(pts1 + dst, reinterpret_cast<const G1Affine *>(circuits[slot / MI_VS_VK_COMMS].comms) + slot % MI_VS_VK_COMMS);
         else
-            copy_g1(pts1 + dst, &kc->g);
+            copy_g1(pts1 + dst, slot == n_vk_slots ? &kc->g : &kc->gamma_g);
     }
 }
 
 // ---------------------------------------------------------------- per-proof fallback (names the bad proofs)
-// lane (i, k): k < 11 own points, 11..22 vk points, 23 G, 24..25 W_q with r_q  ->  term[i][k] = scalar * point
-#define VS_TERMS 26
-__global__ void __launch_bounds__(128) vs_terms_kernel(size_t n, const G1Affine *__restrict__ pts1,
-                                                       const uint32_t *__restrict__ sc1, const uint32_t *__restrict__ sc2,
-                                                       const Fr *__restrict__ vk_scal, const Fr *__restrict__ g_scal,
-                                                       const uint32_t *__restrict__ circuit_of,
-                                                       const mi_vs_circuit_vk *__restrict__ circuits,
+// One lane per (proof, term): term[i][k] = scalar * point.  Terms of a proof, in order (PP = per_proof, H = hiding):
+//   [0, PP)            its own H-side points (commitments, witnesses times z, shifted commitments) with sc1
+//   [PP, PP + 12)      the circuit's commitments with vk_scal
+//   PP + 12            G with g_scal;   PP + 13 (if H): gamma_g with h_scal
+//   next 2             W_q with r_q (the tau-H side, 128-bit scalars)
+//   then               the class accumulators' C_j with rho_j, class 0 first
+struct VsTermsIn {
+    const G1Affine *pts1, *ptsb[MI_VS_MAX_BOUNDS];
+    const uint32_t *sc1, *sc2, *scb[MI_VS_MAX_BOUNDS];
+    const Fr *vk_scal, *g_scal, *h_scal;
+    const uint32_t *circuit_of;
+};
+__host__ __device__ __forceinline__ uint32_t vs_terms_of(uint32_t per_proof, uint32_t hiding, uint32_t n_bounded) {
+    return per_proof + MI_VS_VK_COMMS + 1 + hiding + 2 + n_bounded;
+}
+__global__ void __launch_bounds__(128) vs_terms_kernel(size_t n, VsTermsIn in, const mi_vs_circuit_vk *__restrict__ circuits,
                                                        const VsConsts *__restrict__ kc, G1Xyzz *__restrict__ terms) {
+    const uint32_t PP = kc->per_proof, H = kc->hiding, T = vs_terms_of(PP, H, kc->n_bounded);
     size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= n * VS_TERMS) return;
-    size_t i = t / VS_TERMS;
-    int k = (int)(t % VS_TERMS);
+    if (t >= n * T) return;
+    size_t i = t / T;
+    uint32_t k = (uint32_t)(t % T);
     G1Affine P;
     uint32_t s[8];
     int bits = 253;
-    if (k < VS_PER_PROOF_POINTS) {
-        copy_g1(&P, pts1 + i * VS_PER_PROOF_POINTS + k);
-        Fr v = fr_load(sc1 + (i * VS_PER_PROOF_POINTS + k) * 8);
-#pragma unroll
-        for (int j = 0; j < 8; j++) s[j] = v.l[j];
-    } else if (k < VS_PER_PROOF_POINTS + MI_VS_VK_COMMS) {
-        int kk = k - VS_PER_PROOF_POINTS;
-        copy_g1(&P, reinterpret_cast<const G1Affine *>(circuits[circuit_of[i]].comms) + kk);
-        Fr v = from_mont(fr_load(vk_scal + i * MI_VS_VK_COMMS + kk));
-#pragma unroll
-        for (int j = 0; j < 8; j++) s[j] = v.l[j];
-    } else if (k == VS_PER_PROOF_POINTS + MI_VS_VK_COMMS) {
+    Fr v;
+    if (k < PP) {
+        copy_g1(&P, in.pts1 + i * PP + k);
+        v = fr_load(in.sc1 + (i * PP + k) * 8);
+    } else if (k < PP + MI_VS_VK_COMMS) {
+        const uint32_t kk = k - PP;
+        copy_g1(&P, reinterpret_cast<const G1Affine *>(circuits[in.circuit_of[i]].comms) + kk);
+        v = from_mont(fr_load(in.vk_scal + i * MI_VS_VK_COMMS + kk));
+    } else if (k == PP + MI_VS_VK_COMMS) {
         copy_g1(&P, &kc->g);
-        Fr v = from_mont(fr_load(g_scal + i));
-#pragma unroll
-        for (int j = 0; j < 8; j++) s[j] = v.l[j];
-    } else {
-        int q = k - (VS_PER_PROOF_POINTS + MI_VS_VK_COMMS + 1);
-        copy_g1(&P, pts1 + i * VS_PER_PROOF_POINTS + MI_VS_PROOF_COMMS + q);
-        Fr v = fr_load(sc2 + (i * 2 + q) * 8);
-#pragma unroll
-        for (int j = 0; j < 8; j++) s[j] = v.l[j];
+        v = from_mont(fr_load(in.g_scal + i));
+    } else if (H && k == PP + MI_VS_VK_COMMS + 1) {
+        copy_g1(&P, &kc->gamma_g);
+        v = from_mont(fr_load(in.h_scal + i));
+    } else if (k < PP + MI_VS_VK_COMMS + 1 + H + 2) {
+        const uint32_t q = k - (PP + MI_VS_VK_COMMS + 1 + H);
+        copy_g1(&P, in.pts1 + i * PP + MI_VS_PROOF_COMMS + q);
+        v = fr_load(in.sc2 + (i * 2 + q) * 8);
         bits = 128;
+    } else {
+        uint32_t e = k - (PP + MI_VS_VK_COMMS + 1 + H + 2);
+        const uint32_t c = e < kc->class_count[0] ? 0u : 1u;
+        if (c) e -= kc->class_count[0];
+        copy_g1(&P, in.ptsb[c] + i * kc->class_count[c] + e);
+        v = fr_load(in.scb[c] + (i * kc->class_count[c] + e) * 8);
     }
+#pragma unroll
+    for (int j = 0; j < 8; j++) s[j] = v.l[j];
     G1Xyzz acc = G1Xyzz::inf();
     for (int b = bits - 1; b >= 0; b--) {
         acc = dbl(acc);
@@ -711,88 +828,103 @@ __global__ void __launch_bounds__(128) vs_terms_kernel(size_t n, const G1Affine 
     }
     store_xyzz(&terms[t], acc);
 }
-// block i (192 lanes): total_c_i = sum of terms 0..23, total_w_i = terms 24 + 25 (lanes 0 and 1), then the
-// workgroup-cooperative pairing product; verdict
-__global__ void __launch_bounds__(PW_THREADS) vs_per_proof_pairing_kernel(size_t n, const G1Xyzz *__restrict__ terms,
-                                                                          const G2Prepared *__restrict__ h,
-                                                                          const G2Prepared *__restrict__ tauh,
+// block i (192 lanes): the proof's accumulators from its terms (one lane each), then the workgroup-cooperative pairing
+// product over 2 + n_bounds pairs; verdict
+struct VsG2Keys {
+    const G2Prepared *q[MI_MAX_PAIRS];  // h, tau h, shift_h[0], shift_h[1]
+};
+__global__ void __launch_bounds__(PW_THREADS) vs_per_proof_pairing_kernel(size_t n, const G1Xyzz *__restrict__ terms, VsG2Keys keys,
+                                                                          const VsConsts *__restrict__ kc,
                                                                           const PairingConsts *__restrict__ pc,
                                                                           const uint8_t *__restrict__ alg_ok,
                                                                           uint8_t *__restrict__ verdicts) {
     extern __shared__ uint4 pw_lds[];  // PW_LDS_BYTES
     LShared &S = *(LShared *)pw_lds;
-    __shared__ G1Affine ps[2];
-    __shared__ const G2Prepared *qs[2];
+    __shared__ G1Affine ps[MI_MAX_PAIRS];
+    __shared__ const G2Prepared *qs[MI_MAX_PAIRS];
     __shared__ Fq12 result;
     const size_t i = blockIdx.x;
-    if (threadIdx.x == 0) {
-        G1Xyzz tc = G1Xyzz::inf();
-        for (int k = 0; k < 24; k++) tc = add(tc, load_xyzz(&terms[i * VS_TERMS + k]));
-        ps[0] = to_affine(tc);
-        qs[0] = h;
-        qs[1] = tauh;
-    } else if (threadIdx.x == 64) {
-        G1Xyzz tw = add(load_xyzz(&terms[i * VS_TERMS + 24]), load_xyzz(&terms[i * VS_TERMS + 25]));
-        ps[1] = neg(to_affine(tw));
+    const uint32_t PP = kc->per_proof, H = kc->hiding, T = vs_terms_of(PP, H, kc->n_bounded);
+    const uint32_t n_c = PP + MI_VS_VK_COMMS + 1 + H;  // terms of total_c, then 2 of total_w, then the classes'
+    const int tid = threadIdx.x, acc_id = tid >> 6;      // one wave's first lane per accumulator (waves 0..2), class 1 on lane 1
+    const G1Xyzz *tp = terms + i * T;
+    if ((tid & 63) == 0 || tid == 1) {
+        const int which = tid == 1 ? 3 : acc_id;
+        uint32_t lo, hi;
+        if (which == 0) { lo = 0; hi = n_c; }
+        else if (which == 1) { lo = n_c; hi = n_c + 2; }
+        else if (which == 2) { lo = n_c + 2; hi = n_c + 2 + kc->class_count[0]; }
+        else { lo = n_c + 2 + kc->class_count[0]; hi = T; }
+        if (which < 2 + (int)kc->n_bounds) {
+            G1Xyzz a = G1Xyzz::inf();
+            for (uint32_t k = lo; k < hi; k++) a = add(a, load_xyzz(&tp[k]));
+            const G1Affine pa = to_affine(a);
+            ps[which] = which == 1 ? neg(pa) : pa;
+            qs[which] = keys.q[which];
+        }
     }
     __syncthreads();
-    pw_pairing_product(S, ps, qs, 2, pc, &result);
+    pw_pairing_product(S, ps, qs, 2 + (int)kc->n_bounds, pc, &result);
     if (threadIdx.x == 0) verdicts[i] = (result.is_one() && alg_ok[i]) ? 1 : 0;
 }
 
 // ---------------------------------------------------------------- host drivers
 struct VsWork {
-    G1Affine *pts1, *pts2;
-    uint32_t *sc1, *sc2, *circuit_of;
-    Fr *vk_scal, *g_scal;
-    uint8_t *alg_ok;
-    size_t n1, n2;
+    VsOut o;
+    size_t n1, n2, nb[MI_VS_MAX_BOUNDS];  // points of the H side, the tau-H side, the class accumulators
 };
 
 static VsWork vs_run_derive(Context &cx, VsKeys &v, const void *d_proofs, size_t n, const void *d_rand, hipStream_t st,
                             int lane) {
     VsWork w;
-    w.n1 = n * VS_PER_PROOF_POINTS + v.n_circuits * MI_VS_VK_COMMS + 1;
+    const VsConsts &hc = v.shape;  // host copy of the device constants
+    w.n1 = n * hc.per_proof + v.n_circuits * MI_VS_VK_COMMS + 1 + hc.hiding;
     w.n2 = n * 2;
+    for (int c = 0; c < MI_VS_MAX_BOUNDS; c++) w.nb[c] = c < (int)hc.n_bounds ? n * hc.class_count[c] : 0;
+    const size_t total = w.n1 + w.n2 + w.nb[0] + w.nb[1];
     // every operand array exists once per lane: several batches are in flight on different streams
     char nm[32];
     auto W = [&](const char *name) {
         snprintf(nm, sizeof nm, "vs%d.%s", lane, name);
         return nm;
     };
-    // one array for both MSMs' operands (H side first, tau-H side behind it): they run as ONE launch sequence
-    w.pts1 = (G1Affine *)cx.buf(W("pts"), sizeof(G1Affine) * (w.n1 + w.n2));
-    w.sc1 = (uint32_t *)cx.buf(W("sc"), 32 * (w.n1 + w.n2));
-    w.pts2 = w.pts1 + w.n1;
-    w.sc2 = w.sc1 + 8 * w.n1;
-    w.vk_scal = (Fr *)cx.buf(W("vk_scal"), sizeof(Fr) * n * MI_VS_VK_COMMS);
-    w.g_scal = (Fr *)cx.buf(W("g_scal"), sizeof(Fr) * n);
-    w.alg_ok = (uint8_t *)cx.buf(W("alg_ok"), n);
-    w.circuit_of = (uint32_t *)cx.buf(W("circuit_of"), 4 * n);
+    // one array for all MSMs' operands (H side, tau-H side, then the class accumulators): they run as ONE launch
+    // sequence when they fit the small-MSM path
+    VsOut &o = w.o;
+    o.pts1 = (G1Affine *)cx.buf(W("pts"), sizeof(G1Affine) * total);
+    o.sc1 = (uint32_t *)cx.buf(W("sc"), 32 * total);
+    o.pts2 = o.pts1 + w.n1;
+    o.sc2 = o.sc1 + 8 * w.n1;
+    o.ptsb[0] = o.pts2 + w.n2;
+    o.scb[0] = o.sc2 + 8 * w.n2;
+    o.ptsb[1] = o.ptsb[0] + w.nb[0];
+    o.scb[1] = o.scb[0] + 8 * w.nb[0];
+    o.vk_scal = (Fr *)cx.buf(W("vk_scal"), sizeof(Fr) * n * MI_VS_VK_COMMS);
+    o.g_scal = (Fr *)cx.buf(W("g_scal"), sizeof(Fr) * 2 * n);
+    o.h_scal = o.g_scal + n;
+    o.alg_ok = (uint8_t *)cx.buf(W("alg_ok"), n);
+    o.circuit_of = (uint32_t *)cx.buf(W("circuit_of"), 4 * n);
+    const uint32_t *chal = nullptr;
     if (v.fs_poseidon) {
-        uint32_t *chal = (uint32_t *)cx.buf(W("chal"), 48 * n);
+        uint32_t *ch = (uint32_t *)cx.buf(W("chal"), 48 * n);
         const PoseidonConsts *pc = poseidon_consts(cx, st);
         cx.prof.begin("vs_fs_poseidon", st, n);
-        hipLaunchKernelGGL(vs_fs_poseidon_kernel, dim3(cdiv(n, 16)), dim3(64), 0, st, (const mi_vs_proof *)d_proofs, n,
-                           (const mi_vs_circuit_vk *)v.circuits.p, v.n_circuits, (const VsConsts *)v.consts.p, pc, chal);
+        hipLaunchKernelGGL(vs_fs_poseidon_kernel, dim3(cdiv(n, 16)), dim3(64), 0, st, d_proofs, n,
+                           (const mi_vs_circuit_vk *)v.circuits.p, v.n_circuits, (const VsConsts *)v.consts.p, pc, ch);
         cx.prof.end("vs_fs_poseidon", st);
-        cx.prof.begin("vs_derive", st, n);
-        hipLaunchKernelGGL(vs_derive_kernel<1>, dim3(cdiv(n, 64)), dim3(128), 0, st, (const mi_vs_proof *)d_proofs, n,
-                           (const uint8_t *)d_rand, (const mi_vs_circuit_vk *)v.circuits.p, v.n_circuits,
-                           (const VsConsts *)v.consts.p, w.pts1, w.sc1, w.pts2, w.sc2, w.vk_scal, w.g_scal, w.alg_ok, w.circuit_of,
-                           (const uint32_t *)chal);
-        cx.prof.end("vs_derive", st);
-    } else {
-        cx.prof.begin("vs_derive", st, n);
-        hipLaunchKernelGGL(vs_derive_kernel<0>, dim3(cdiv(n, 64)), dim3(128), 0, st, (const mi_vs_proof *)d_proofs, n,
-                           (const uint8_t *)d_rand, (const mi_vs_circuit_vk *)v.circuits.p, v.n_circuits,
-                           (const VsConsts *)v.consts.p, w.pts1, w.sc1, w.pts2, w.sc2, w.vk_scal, w.g_scal, w.alg_ok, w.circuit_of,
-                           (const uint32_t *)nullptr);
-        cx.prof.end("vs_derive", st);
+        chal = ch;
     }
-    hipLaunchKernelGGL(vs_merge_kernel, dim3((unsigned)(v.n_circuits * MI_VS_VK_COMMS + 1)), dim3(256), 0, st, w.vk_scal,
-                       w.g_scal, w.circuit_of, n, (const mi_vs_circuit_vk *)v.circuits.p, v.n_circuits,
-                       (const VsConsts *)v.consts.p, w.pts1, w.sc1);
+    cx.prof.begin("vs_derive", st, n);
+    if (v.fs_poseidon)
+        hipLaunchKernelGGL(vs_derive_kernel<1>, dim3(cdiv(n, 64)), dim3(128), 0, st, d_proofs, n, (const uint8_t *)d_rand,
+                           (const mi_vs_circuit_vk *)v.circuits.p, v.n_circuits, (const VsConsts *)v.consts.p, o, chal);
+    else
+        hipLaunchKernelGGL(vs_derive_kernel<0>, dim3(cdiv(n, 64)), dim3(128), 0, st, d_proofs, n, (const uint8_t *)d_rand,
+                           (const mi_vs_circuit_vk *)v.circuits.p, v.n_circuits, (const VsConsts *)v.consts.p, o, chal);
+    cx.prof.end("vs_derive", st);
+    hipLaunchKernelGGL(vs_merge_kernel, dim3((unsigned)(v.n_circuits * MI_VS_VK_COMMS + 1 + hc.hiding)), dim3(256), 0, st, o.vk_scal,
+                       o.g_scal, o.h_scal, o.circuit_of, n, (const mi_vs_circuit_vk *)v.circuits.p, v.n_circuits,
+                       (const VsConsts *)v.consts.p, o.pts1, o.sc1);
     MI_HIP(hipGetLastError());
     return w;
 }
@@ -813,6 +945,23 @@ static inline uint64_t vs_make_id(uint64_t seq, int dev_index, int unit) { retur
 static void vs_release_lane(Context &cx, VsAcc &a) {
     a.open = a.closing = false;
     cx.lane_cv.notify_all();
+}
+
+// All MSMs of one accumulation on the lane's stream: the H side (253-bit scalars), the tau-H side (the 128-bit
+// randomizers) and, with degree bounds, one accumulator per class.  When everything fits the small-MSM path they share
+// ONE launch sequence: each further problem is another set of windows (msm_enqueue's split points).
+static bool vs_enqueue_msms(Context &cx, const VsWork &w, hipStream_t st, int lane, MsmJob j[4], int force_c) {
+    const size_t total = w.n1 + w.n2 + w.nb[0] + w.nb[1];
+    if (total <= msm_small_limit()) {
+        const size_t s0 = w.n1, s1 = w.nb[0] ? s0 + w.n2 : 0, s2 = w.nb[1] ? s1 + w.nb[0] : 0;
+        msm_enqueue(cx, w.o.pts1, w.o.sc1, total, st, 254, 8 + 4 * lane, &j[0], force_c, lane, MsmSplits(s0, s1, s2));
+        return true;
+    }
+    msm_enqueue(cx, w.o.pts2, w.o.sc2, w.n2, st, 128, 8 + 4 * lane + 1, &j[1], 0, lane);
+    for (int c = 0; c < MI_VS_MAX_BOUNDS; c++)
+        if (w.nb[c]) msm_enqueue(cx, w.o.ptsb[c], w.o.scb[c], w.nb[c], st, 254, 8 + 4 * lane + 2 + c, &j[2 + c], 0, lane);
+    msm_enqueue(cx, w.o.pts1, w.o.sc1, w.n1, st, 254, 8 + 4 * lane, &j[0], 0, lane);
+    return false;
 }
 
 // accumulate one shard: partial sums + algebraic failures (+ optional per-proof alg flags to host)
@@ -851,13 +1000,8 @@ static int32_t vs_accumulate_begin_impl(Context &cx, const VsCtx &vc, const void
             char nm[32];
             snprintf(nm, sizeof nm, "vs.alg_pin%d", p);
             (void)cx.pin_named(nm, n);
-            MsmJob j1, j2;
-            if (w.n1 + w.n2 <= msm_small_limit()) {
-                msm_enqueue(cx, w.pts1, w.sc1, w.n1 + w.n2, sp, 254, 4 + 2 * p, &j1, 0, p, w.n1);
-            } else {
-                msm_enqueue(cx, w.pts2, w.sc2, w.n2, sp, 128, 4 + 2 * p + 1, &j2, 0, p);
-                msm_enqueue(cx, w.pts1, w.sc1, w.n1, sp, 254, 4 + 2 * p, &j1, 0, p);
-            }
+            MsmJob jj[4];
+            (void)vs_enqueue_msms(cx, w, sp, p, jj, 0);
         }
         for (int p = 0; p < pp.lanes; p++)
             if (p != par && !pp.acc[p].open) MI_HIP(hipStreamSynchronize(pp.acc_st[p]));
@@ -882,20 +1026,13 @@ static int32_t vs_accumulate_begin_impl(Context &cx, const VsCtx &vc, const void
     a.h_alg = (uint8_t *)cx.pin_named(nm, n);
     {
         HostSpan hs("begin.alg_copy");
-        MI_HIP(hipMemcpyAsync(a.h_alg, w.alg_ok, n, hipMemcpyDeviceToHost, sa));  // ahead of the MSMs: their done-event covers it
+        MI_HIP(hipMemcpyAsync(a.h_alg, w.o.alg_ok, n, hipMemcpyDeviceToHost, sa));  // ahead of the MSMs: their done-event covers it
     }
     HostSpan hs_msm("begin.msm_enqueue");
-    // both MSMs (H side: 11n + 12 circuits + 1 points; tau-H side: 2n points, 128-bit scalars) share one launch
-    // sequence: the second is the first's extra set of windows (msm_enqueue's split)
-    if (w.n1 + w.n2 <= msm_small_limit()) {
-        static const int vs_c = getenv("MI_SNARK_VS_C") ? atoi(getenv("MI_SNARK_VS_C")) : 0;  // window width override (experiments)
-        msm_enqueue(cx, w.pts1, w.sc1, w.n1 + w.n2, sa, 254, 4 + 2 * par, &a.j1, vs_c, par, w.n1);
-        a.fused = true;
-    } else {
-        msm_enqueue(cx, w.pts2, w.sc2, w.n2, sa, 128, 4 + 2 * par + 1, &a.j2, 0, par);
-        msm_enqueue(cx, w.pts1, w.sc1, w.n1, sa, 254, 4 + 2 * par, &a.j1, 0, par);
-        a.fused = false;
-    }
+    static const int vs_c = getenv("MI_SNARK_VS_C") ? atoi(getenv("MI_SNARK_VS_C")) : 0;  // window width override (experiments)
+    a.fused = vs_enqueue_msms(cx, w, sa, par, a.j, vs_c);
+    a.nb[0] = w.nb[0];
+    a.nb[1] = w.nb[1];
     a.n = n;
     a.st = sa;
     a.handle = hd;
@@ -916,11 +1053,21 @@ static int32_t vs_accumulate_end_impl(Context &cx, uint64_t handle, mi_vs_partia
     uint64_t fails = 0;
     try {
         Unlocked unlocked;
+        const G1Jac inf = G1Jac{Fq::one(), Fq::one(), Fq::zero()};
+        memcpy(&out->bound[0], &inf, sizeof inf);
+        memcpy(&out->bound[1], &inf, sizeof inf);
         if (a.fused) {
-            msm_finish(cx, &a.j1, a.st, &out->total_c, &out->total_w);
+            msm_finish(cx, &a.j[0], a.st, &out->total_c, &out->total_w, a.nb[0] ? &out->bound[0] : nullptr,
+                       a.nb[1] ? &out->bound[a.nb[0] ? 1 : 0] : nullptr);
+            if (a.nb[1] && !a.nb[0]) {  // only class 1 in use: it was the third problem
+                out->bound[1] = out->bound[0];
+                memcpy(&out->bound[0], &inf, sizeof inf);
+            }
         } else {
-            msm_finish(cx, &a.j2, a.st, &out->total_w);
-            msm_finish(cx, &a.j1, a.st, &out->total_c);
+            msm_finish(cx, &a.j[1], a.st, &out->total_w);
+            for (int c = 0; c < MI_VS_MAX_BOUNDS; c++)
+                if (a.nb[c]) msm_finish(cx, &a.j[2 + c], a.st, &out->bound[c]);
+            msm_finish(cx, &a.j[0], a.st, &out->total_c);
         }
         for (size_t i = 0; i < a.n; i++) fails += a.h_alg[i] ? 0 : 1;
     } catch (...) {
@@ -953,30 +1100,41 @@ int32_t vs_accumulate_device(Context &cx, uint64_t id, const void *d_proofs, siz
     return vs_accumulate_end_impl(cx, hd, out);
 }
 
-// sum the shards' partials on the host: the two points of the pairing check and the count of algebraic failures
-static void vs_sum_partials(const mi_vs_partial *parts, size_t np, G1Affine ps[2], uint64_t *fails) {
-    G1Xyzz tc = G1Xyzz::inf(), tw = G1Xyzz::inf();
+// sum the shards' partials on the host: the points of the pairing check (total_c, -total_w, the class accumulators) and
+// the count of algebraic failures
+static void vs_sum_partials(const mi_vs_partial *parts, size_t np, G1Affine ps[MI_MAX_PAIRS], uint64_t *fails) {
+    G1Xyzz t[MI_MAX_PAIRS] = {G1Xyzz::inf(), G1Xyzz::inf(), G1Xyzz::inf(), G1Xyzz::inf()};
     uint64_t f = 0;
     for (size_t k = 0; k < np; k++) {
-        tc = add_mixed(tc, host_jac_to_affine_normalised(parts[k].total_c));
-        tw = add_mixed(tw, host_jac_to_affine_normalised(parts[k].total_w));
+        t[0] = add_mixed(t[0], host_jac_to_affine_normalised(parts[k].total_c));
+        t[1] = add_mixed(t[1], host_jac_to_affine_normalised(parts[k].total_w));
+        for (int c = 0; c < MI_VS_MAX_BOUNDS; c++) t[2 + c] = add_mixed(t[2 + c], host_jac_to_affine_normalised(parts[k].bound[c]));
         f += parts[k].n_alg_fail;
     }
-    ps[0] = to_affine(tc);
-    ps[1] = neg(to_affine(tw));
+    for (int k = 0; k < MI_MAX_PAIRS; k++) ps[k] = to_affine(t[k]);
+    ps[1] = neg(ps[1]);
     *fails = f;
+}
+// the G2 side: h, tau h and the degree-bound classes' partners; returns the number of pairs
+static int vs_g2_keys(VsKeys &v, const G2Prepared *qs[MI_MAX_PAIRS]) {
+    qs[0] = (const G2Prepared *)v.h_prep.p;
+    qs[1] = (const G2Prepared *)v.tauh_prep.p;
+    for (uint32_t c = 0; c < v.shape.n_bounds; c++) qs[2 + c] = (const G2Prepared *)v.shift_prep[c].p;
+    for (uint32_t c = v.shape.n_bounds; c < MI_VS_MAX_BOUNDS; c++) qs[2 + c] = nullptr;
+    return 2 + (int)v.shape.n_bounds;
 }
 
 int32_t vs_finalize(Context &cx, uint64_t id, const mi_vs_partial *parts, size_t np, uint8_t *all_ok, hipStream_t st) {
     std::shared_ptr<VsCtx> vc = vs_find(id);
     if (!vc) return MI_ERR_BAD_ARGS;
     VsKeys &v = vs_keys(cx, *vc);
-    G1Affine ps[2];
+    G1Affine ps[MI_MAX_PAIRS];
     uint64_t fails = 0;
     vs_sum_partials(parts, np, ps, &fails);
-    const G2Prepared *qs[2] = {(const G2Prepared *)v.h_prep.p, (const G2Prepared *)v.tauh_prep.p};
+    const G2Prepared *qs[MI_MAX_PAIRS];
+    const int K = vs_g2_keys(v, qs);
     Fq12 f;
-    pairing_product_prepared(cx, ps, qs, 2, &f, st);
+    pairing_product_prepared(cx, ps, qs, K, &f, st);
     *all_ok = (f.is_one() && fails == 0) ? 1 : 0;
     return MI_OK;
 }
@@ -1007,11 +1165,12 @@ int32_t vs_finalize_async(Context &cx, uint64_t id, const mi_vs_partial *parts, 
     const uint64_t tk = vs_make_id(pp.next_ticket++, cx.index, slot);
     VsSlot &sl = pp.slots[slot];
     HostSpan hs("finalize_async");
-    G1Affine ps[2];
+    G1Affine ps[MI_MAX_PAIRS];
     uint64_t fails = 0;
     vs_sum_partials(parts, np, ps, &fails);
-    const G2Prepared *qs[2] = {(const G2Prepared *)v.h_prep.p, (const G2Prepared *)v.tauh_prep.p};
-    pairing_launch(cx, ps, qs, 2, sl.h_out, sl.stream);  // the kernel stores its result in pinned host memory
+    const G2Prepared *qs[MI_MAX_PAIRS];
+    const int K = vs_g2_keys(v, qs);
+    pairing_launch(cx, ps, qs, K, sl.h_out, sl.stream);  // the kernel stores its result in pinned host memory
     MI_HIP(hipEventRecord(sl.done, sl.stream));
     sl.ticket = tk;
     sl.busy = true;
@@ -1031,16 +1190,24 @@ int32_t vs_finalize_wait(Context &cx, uint64_t id, uint64_t ticket, uint8_t *all
 // workspaces (the lane is still held by the caller)
 static void vs_identify(Context &cx, VsKeys &v, const VsWork &w, size_t n, int lane, hipStream_t st, uint8_t *verdicts) {
     char nm[32];
+    const uint32_t T = vs_terms_of(v.shape.per_proof, v.shape.hiding, v.shape.n_bounded);
     snprintf(nm, sizeof nm, "vs%d.terms", lane);
-    G1Xyzz *terms = (G1Xyzz *)cx.buf(nm, sizeof(G1Xyzz) * n * VS_TERMS);
+    G1Xyzz *terms = (G1Xyzz *)cx.buf(nm, sizeof(G1Xyzz) * n * T);
     snprintf(nm, sizeof nm, "vs%d.verdicts", lane);
     uint8_t *d_verdicts = (uint8_t *)cx.buf(nm, n);
-    hipLaunchKernelGGL(vs_terms_kernel, dim3(cdiv(n * VS_TERMS, 128)), dim3(128), 0, st, n, w.pts1, w.sc1, w.sc2, w.vk_scal,
-                       w.g_scal, w.circuit_of, (const mi_vs_circuit_vk *)v.circuits.p, (const VsConsts *)v.consts.p, terms);
+    VsTermsIn in;
+    in.pts1 = w.o.pts1; in.sc1 = w.o.sc1; in.sc2 = w.o.sc2;
+    for (int c = 0; c < MI_VS_MAX_BOUNDS; c++) { in.ptsb[c] = w.o.ptsb[c]; in.scb[c] = w.o.scb[c]; }
+    in.vk_scal = w.o.vk_scal; in.g_scal = w.o.g_scal; in.h_scal = w.o.h_scal; in.circuit_of = w.o.circuit_of;
+    hipLaunchKernelGGL(vs_terms_kernel, dim3(cdiv(n * T, 128)), dim3(128), 0, st, n, in, (const mi_vs_circuit_vk *)v.circuits.p,
+                       (const VsConsts *)v.consts.p, terms);
+    VsG2Keys keys;
+    const G2Prepared *qs[MI_MAX_PAIRS];
+    (void)vs_g2_keys(v, qs);
+    for (int k = 0; k < MI_MAX_PAIRS; k++) keys.q[k] = qs[k];
     cx.raise_lds_limit((const void *)vs_per_proof_pairing_kernel, (int)PW_LDS_BYTES);
-    hipLaunchKernelGGL(vs_per_proof_pairing_kernel, dim3((unsigned)n), dim3(PW_THREADS), PW_LDS_BYTES, st, n, terms,
-                       (const G2Prepared *)v.h_prep.p, (const G2Prepared *)v.tauh_prep.p, pairing_consts(cx, st), w.alg_ok,
-                       d_verdicts);
+    hipLaunchKernelGGL(vs_per_proof_pairing_kernel, dim3((unsigned)n), dim3(PW_THREADS), PW_LDS_BYTES, st, n, terms, keys,
+                       (const VsConsts *)v.consts.p, pairing_consts(cx, st), w.o.alg_ok, d_verdicts);
     MI_HIP(hipGetLastError());
     snprintf(nm, sizeof nm, "vs.verdict_pin%d", lane);
     uint8_t *h = (uint8_t *)cx.pin_named(nm, n);
@@ -1141,10 +1308,11 @@ int32_t vs_verify_block(uint64_t id, const void *const *proofs, const void *cons
             const void *dp = j.proofs, *dr = j.rand;
             hipStream_t st = cx.stream;
             if (!device_ptrs) {
-                void *p = cx.buf("blk.in_proofs", sizeof(mi_vs_proof) * j.n);
-                void *r = cx.buf("blk.in_rand", 32 * j.n);
-                MI_HIP(hipMemcpyAsync(p, j.proofs, sizeof(mi_vs_proof) * j.n, hipMemcpyHostToDevice, st));
-                MI_HIP(hipMemcpyAsync(r, j.rand, 32 * j.n, hipMemcpyHostToDevice, st));
+                const size_t pb = (size_t)vc->consts.proof_words * 4, rb = vc->consts.rand_bytes;
+                void *p = cx.buf("blk.in_proofs", pb * j.n);
+                void *r = cx.buf("blk.in_rand", rb * j.n);
+                MI_HIP(hipMemcpyAsync(p, j.proofs, pb * j.n, hipMemcpyHostToDevice, st));
+                MI_HIP(hipMemcpyAsync(r, j.rand, rb * j.n, hipMemcpyHostToDevice, st));
                 dp = p;
                 dr = r;
             }

@@ -26,11 +26,14 @@ FQ12_U64 = 72
 KZG_VK_BYTES = 480
 VS_PROOF_BYTES = 2256
 VS_CIRCUIT_VK_BYTES = 1184
-VS_PARTIAL_BYTES = 304
+VS_PARTIAL_BYTES = 592
 VS_MAX_OPEN_ACCUMULATIONS = 14  # compile-time cap; a context has MI_SNARK_VS_LANES (default 12) lanes
 VS_DEFAULT_LANES = 12
 VS_MAX_TICKETS = 8
 VS_FS_POSEIDON = 1  # mi_vs_ctx_create_ex flag: Poseidon Fiat-Shamir transcript
+VS2_PROOF_BYTES = 3184  # mi_vs_proof2
+VS2_KEY_EXT_BYTES = 480
+VS2_SHAPE_BYTES = 32
 
 # every symbol include/mi355x_snark.h declares
 EXPORTS = [
@@ -41,7 +44,7 @@ EXPORTS = [
     "mi_ntt_divide_by_vanishing_on_coset", "mi_ntt_divide_by_vanishing_on_coset_device",
     "mi_pairing_product_is_one", "mi_pairing", "mi_kzg_batch_check", "mi_kzg_batch_check_hiding",
     "mi_poseidon_fq_hash_many", "mi_poseidon_fq_hash_many_device",
-    "mi_vs_ctx_create", "mi_vs_ctx_create_ex", "mi_vs_ctx_destroy", "mi_vs_verify_batch", "mi_vs_verify_batch_device",
+    "mi_vs_ctx_create", "mi_vs_ctx_create_ex", "mi_vs_ctx_create_v2", "mi_vs_ctx_destroy", "mi_vs_verify_batch", "mi_vs_verify_batch_device",
     "mi_vs_accumulate_device", "mi_vs_accumulate_begin", "mi_vs_accumulate_end", "mi_vs_finalize", "mi_vs_finalize_async", "mi_vs_finalize_wait",
     "mi_vs_verify_block", "mi_vs_verify_block_device",
     "mi_vs_stream_open", "mi_vs_stream_submit", "mi_vs_stream_finish", "mi_vs_stream_next", "mi_vs_stream_close",

@@ -1,7 +1,7 @@
 """Multi-GPU sharding of one block-validation batch.
 
 Proofs are independent until the final accumulator, so a batch of N proofs is cut into contiguous shards,
-one per rank (one process per GPU).  Each rank folds its shard into a 304-byte `mi_vs_partial`
+one per rank (one process per GPU).  Each rank folds its shard into a 592-byte `mi_vs_partial`
 (two G1 accumulators + counts); the only exchange is an all-gather of those partials (RCCL over xGMI on the
 GPU box, gloo in the CPU tests), after which any rank adds the partials and runs the single pairing product.
 RCCL has no elliptic-curve reduction operator, hence gather + local add instead of a reduce.
@@ -11,7 +11,7 @@ product passes the HIP library's entry points, the CPU tests pass the oracle's.
 """
 import numpy as np
 
-PARTIAL_BYTES = 304
+PARTIAL_BYTES = 592
 PROOF_BYTES = 2256
 G1_JAC_BYTES = 144
 
@@ -40,7 +40,7 @@ def gather_bytes(blob, nbytes, dist=None, device=None):
 
 
 def gather_partials(partial, dist=None, device=None):
-    """All-gather one 304-byte partial per rank -> (world, 304) uint8 array on every rank."""
+    """All-gather one 592-byte partial per rank -> (world, 592) uint8 array on every rank."""
     return gather_bytes(np.ascontiguousarray(partial, dtype=np.uint8), PARTIAL_BYTES, dist, device)
 
 
@@ -67,8 +67,8 @@ def verify_sharded(proofs, randomizers, accumulate, finalize, dist=None, device=
     """Verify one batch across the ranks of `dist`.
 
     proofs / randomizers: the whole batch (every rank holds it; rank r works on shard r), or with
-    pre_sharded=True this rank's shard only.  accumulate(proofs_shard, randomizers_shard) -> 304-byte partial;
-    finalize((world, 304) partials) -> bool.  Returns all_ok (identical on every rank).
+    pre_sharded=True this rank's shard only.  accumulate(proofs_shard, randomizers_shard) -> 592-byte partial;
+    finalize((world, 592) partials) -> bool.  Returns all_ok (identical on every rank).
     """
     world = dist.get_world_size() if dist is not None and dist.is_initialized() else 1
     rank = dist.get_rank() if world > 1 else 0

@@ -32,7 +32,7 @@ def test_struct_sizes_match_header():
     assert L.KZG_VK_BYTES == 96 + 2 * 192
     assert L.VS_CIRCUIT_VK_BYTES == 12 * 96 + 32
     assert L.VS_PROOF_BYTES == 16 + 16 * 32 + 9 * 96 + 21 * 32 + 2 * 96
-    assert L.VS_PARTIAL_BYTES == 2 * 144 + 16
+    assert L.VS_PARTIAL_BYTES == 4 * 144 + 16 and L.VS2_PROOF_BYTES == L.VS_PROOF_BYTES + 2 * 32 + 9 * 96
 
 
 def test_error_strings_and_bad_args():

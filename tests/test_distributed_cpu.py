@@ -1,4 +1,4 @@
-"""CPU tier: the N > 1 path (contiguous shards, all-gather of 304-byte partials, one finalize) with
+"""CPU tier: the N > 1 path (contiguous shards, all-gather of 592-byte partials, one finalize) with
 world_size 2 and 3 over gloo.  The oracle stands in for the HIP accumulate/finalize entry points; the
 sharding protocol object (snarkos_amd/sharding.py) is the one bench.py uses over RCCL."""
 import os

@@ -106,9 +106,9 @@ def test_pipelined_stream_matches_batchwise(orc, mi):
         def gather(parts):
             seen.append(parts.shape)
             return parts[None]
-        assert list(v.verify_stream(iter(seq), gather)) == want and seen == [(1, 304)] * 7
+        assert list(v.verify_stream(iter(seq), gather)) == want and seen == [(1, 592)] * 7
         del seen[:]
-        assert list(v.verify_stream(iter(seq), gather, exchange_group=3)) == want and seen == [(3, 304), (3, 304), (1, 304)]
+        assert list(v.verify_stream(iter(seq), gather, exchange_group=3)) == want and seen == [(3, 592), (3, 592), (1, 592)]
 
         def broken(parts):
             raise ValueError("exchange failed")
@@ -209,7 +209,7 @@ def test_proof_with_points_at_infinity(orc, mi):
 
 def test_block_of_8192_proofs_as_eight_shards(orc, mi):
     """BASELINE configs[4] at full size on one GPU: the 8192-proof block is eight 1024-proof shards (the committed
-    fixture under eight different randomizer sets); each shard is accumulated as a rank would, the eight 304-byte
+    fixture under eight different randomizer sets); each shard is accumulated as a rank would, the eight 592-byte
     partials are finalised with ONE pairing product.  Properties: all-valid block accepts; one corrupted proof in
     one shard makes the block reject; the shard partials add up to the single-shot accumulator of the oracle."""
     import torch
@@ -341,8 +341,8 @@ def test_native_stream_driver_api(orc, mi):
 
         def two(_u, mine, count, out, cap):  # rank-major: [this rank's count partials][the other rank's count partials]
             calls.append(count)
-            o = np.ctypeslib.as_array(out, shape=(2 * count, 304))
-            o[:count] = np.ctypeslib.as_array(mine, shape=(count, 304))
+            o = np.ctypeslib.as_array(out, shape=(2 * count, 592))
+            o[:count] = np.ctypeslib.as_array(mine, shape=(count, 592))
             o[count:] = other
             return 2
         assert run(L.VS_EXCHANGE_FN(two), [(pa, ra)] * 5) == [True] * 5 and calls == [1] * 5

@@ -1,0 +1,195 @@
+"""-m gpu: VarunaShaped-v2 (query-set table, hiding gamma_g / random_v, degree-bound classes: 2 + n_bounds pairs, three
+randomizers per proof) through the same mi_vs_* entry points, against the CPU oracle (oracle/orc_algo.c vs2_*, itself
+checked against oracle/pyref.py vs2_verify_one in tests/test_oracle_golden.py)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+P2 = 3184
+
+
+def _ctx(mi, b, transcript="sha256"):
+    return mi.VarunaShaped(b.vk, b.circuits, transcript=transcript, shape=b.shape, key_ext=b.ext)
+
+
+def _partial_points(whole):
+    from helpers import jac_affine
+    part = np.frombuffer(np.ascontiguousarray(whole).tobytes(), dtype=np.uint64)
+    return np.stack([jac_affine(part[18 * k:18 * k + 18]) for k in range(4)]), int(part[72]), int(part[73])
+
+
+def test_valid_batch_and_partial_bit_exact(orc, mi):
+    import torch
+    b = orc.VS2Batch(0x20B1, 72, 5, 0)
+    v = _ctx(mi, b)
+    try:
+        ok, verdicts = v.verify_batch(b.proofs, b.randomizers)
+        assert ok and verdicts.all() and (b.verify_cpu(8) == verdicts).all()
+        proofs = torch.from_numpy(b.proofs).cuda(); rnd = torch.from_numpy(b.randomizers).cuda()
+        whole = v.accumulate(proofs, rnd)
+        ok_o, alg, tot = b.verify_aggregated(8)
+        pts, n, fails = _partial_points(whole)
+        assert ok_o and n == b.n and fails == 0
+        assert (pts == tot).all()
+        assert tot[2].any() and tot[3].any()  # both degree-bound classes carry weight
+        assert (np.frombuffer(whole.tobytes(), dtype=np.uint8) == orc.vs_partial_from_oracle(b, 8)).all()
+        assert v.finalize([whole])
+        # shards: three ragged pieces sum to the same verdict
+        cuts = [0, 17, 18, 72]
+        parts = [v.accumulate(proofs[cuts[i] * P2:cuts[i + 1] * P2].contiguous(), rnd[cuts[i] * 48:cuts[i + 1] * 48].contiguous())
+                 for i in range(3)]
+        assert v.finalize(parts)
+    finally:
+        v.close()
+
+
+def test_corrupted_batch_names_the_bad_proofs(orc, mi):
+    b = orc.VS2Batch(0x20B2, 80, 4, 200)
+    assert 0 < b.expected.sum() < b.n
+    v = _ctx(mi, b)
+    try:
+        ok, verdicts = v.verify_batch(b.proofs, b.randomizers)
+        assert not ok and (verdicts == b.expected).all() and (verdicts == b.verify_cpu(8)).all()
+    finally:
+        v.close()
+
+
+@pytest.mark.parametrize("field", ["random_v", "shifted", "commitment_of_bounded", "evaluation"])
+def test_each_new_proof_field_is_bound(orc, mi, field):
+    """flipping one bit in random_v, a shifted commitment, a degree-bounded commitment or an evaluation turns exactly
+    that proof invalid"""
+    b = orc.VS2Batch(0x20B3, 24, 3, 0)
+    off = {"random_v": 2256 + 5, "shifted": 2256 + 64 + 96 * 6 + 3, "commitment_of_bounded": 16 + 512 + 96 * 7 + 2,
+           "evaluation": 16 + 512 + 864 + 32 * 13}[field]
+    bad = b.proofs.copy()
+    bad[11 * P2 + off] ^= 1
+    v = _ctx(mi, b)
+    try:
+        ok, verdicts = v.verify_batch(bad, b.randomizers)
+        want = np.ones(24, dtype=np.uint8); want[11] = 0
+        cpu = orc.VS2Batch.wrap(b.vk, b.ext, b.shape, b.circuits, bad, b.randomizers).verify_cpu(8)
+        assert (cpu == want).all()
+        assert not ok and (verdicts == want).all()
+        if field == "shifted":
+            # polynomial 1 has no degree bound in the default shape: its shifted slot is validated (a point of the curve)
+            # but enters no sum -- another valid point there changes nothing, an off-curve one is malformed
+            same = b.proofs.copy()
+            o1, o6 = 11 * P2 + 2256 + 64 + 96 * 1, 11 * P2 + 2256 + 64 + 96 * 6
+            same[o1:o1 + 96] = b.proofs[o6:o6 + 96]
+            ok, verdicts = v.verify_batch(same, b.randomizers)
+            assert ok and verdicts.all()
+            same[o1 + 3] ^= 1
+            ok, verdicts = v.verify_batch(same, b.randomizers)
+            cpu = orc.VS2Batch.wrap(b.vk, b.ext, b.shape, b.circuits, same, b.randomizers).verify_cpu(8)
+            assert not ok and (verdicts == want).all() and (cpu == want).all()
+    finally:
+        v.close()
+
+
+@pytest.mark.parametrize("hiding,n_bounds,bound_class", [
+    (False, 0, [-1] * 9),                              # the v1 relation in v2 records
+    (True, 0, [-1] * 9),                               # hiding only
+    (False, 1, [-1, -1, 0, -1, -1, -1, -1, -1, 0]),    # one class, K = 3
+    (True, 2, [1, -1, -1, 0, -1, 1, -1, 0, 0]),        # K = 4, classes of unequal size
+])
+def test_shapes(orc, mi, hiding, n_bounds, bound_class):
+    import torch
+    q = [0, 0, 1, 0, 1, 1, 0, 1, 0] + [1, 0] * 6
+    shape = orc.vs2_shape(q, bound_class, hiding, n_bounds)
+    b = orc.VS2Batch(0x20B4 + n_bounds, 40, 3, 128, shape=shape)
+    assert 0 < b.expected.sum() < b.n
+    v = _ctx(mi, b)
+    try:
+        ok, verdicts = v.verify_batch(b.proofs, b.randomizers)
+        assert not ok and (verdicts == b.expected).all()
+        good = orc.VS2Batch(0x20B9, 40, 3, 0, shape=shape)
+        v2 = _ctx(mi, good)
+        try:
+            whole = v2.accumulate(torch.from_numpy(good.proofs).cuda(), torch.from_numpy(good.randomizers).cuda())
+            assert (np.frombuffer(whole.tobytes(), dtype=np.uint8) == orc.vs_partial_from_oracle(good, 8)).all()
+            assert v2.finalize([whole])
+            pts, _, _ = _partial_points(whole)
+            for c in range(2):
+                assert pts[2 + c].any() == (c < n_bounds)
+        finally:
+            v2.close()
+    finally:
+        v.close()
+
+
+def test_v1_shape_in_v2_records_equals_v1(orc, mi):
+    """the v1 relation (fixed query table, no hiding, no bounds) through mi_vs_ctx_create_v2 gives the partial the v1
+    context gives on the same proofs (total_c, total_w; the third randomizer is unused)"""
+    import torch
+    b1 = orc.VSBatch(0x20B5, 32, 3, 0)
+    shape = orc.vs2_shape(None, [-1] * 9, False, 0)
+    rec = np.zeros((32, P2), dtype=np.uint8)
+    rec[:, :2256] = b1.proofs.reshape(32, 2256)
+    rnd = np.zeros((32, 48), dtype=np.uint8)
+    rnd[:, :32] = b1.randomizers.reshape(32, 32)
+    rnd[:, 32:] = 7
+    v1 = mi.VarunaShaped(b1.vk, b1.circuits)
+    v2 = mi.VarunaShaped(b1.vk, b1.circuits, shape=shape)
+    try:
+        a = v1.accumulate(torch.from_numpy(b1.proofs).cuda(), torch.from_numpy(b1.randomizers).cuda())
+        c = v2.accumulate(torch.from_numpy(rec.reshape(-1)).cuda(), torch.from_numpy(rnd.reshape(-1)).cuda())
+        assert (np.asarray(a) == np.asarray(c)).all()
+        assert v2.finalize([c])
+    finally:
+        v1.close(); v2.close()
+
+
+def test_poseidon_transcript_with_v2(orc, mi):
+    b = orc.VS2Batch(0x20B6, 36, 3, 150, transcript=orc.FS_POSEIDON)
+    assert 0 < b.expected.sum() < b.n
+    v = _ctx(mi, b, "poseidon")
+    try:
+        ok, verdicts = v.verify_batch(b.proofs, b.randomizers)
+        assert not ok and (verdicts == b.expected).all()
+    finally:
+        v.close()
+        orc.lib().orc_vs_set_transcript(orc.FS_SHA256)
+
+
+def test_stream_and_block(orc, mi):
+    """the pipelined stream and the in-library block path take v2 records"""
+    import torch
+    good = orc.VS2Batch(0x20B7, 48, 3, 0)
+    v = _ctx(mi, good)
+    try:
+        gp = torch.from_numpy(good.proofs).cuda(); gr = torch.from_numpy(good.randomizers).cuda()
+        bad_np = good.proofs.copy(); bad_np[9 * P2 + 2256 + 64 + 96 * 8] ^= 1
+        bp = torch.from_numpy(bad_np).cuda()
+        seq = [(gp, gr), (bp, gr), (gp, gr), (gp, gr), (bp, gr), (gp, gr)]
+        want = [True, False, True, True, False, True]
+        assert list(v.verify_stream(iter(seq))) == want
+        ok, verdicts = v.verify_block(bad_np, good.randomizers)
+        w = np.ones(48, dtype=np.uint8); w[9] = 0
+        assert not ok and (verdicts == w).all()
+        ok, verdicts = v.verify_block(good.proofs, good.randomizers)
+        assert ok and verdicts.all()
+    finally:
+        v.close()
+
+
+def test_full_size_batch_1024_v2(orc, mi):
+    """configs[3]'s size with the v2 shape: the committed fixture (tests/golden/vs2_batch_1024.npz, oracle/gen_vs_fixture.py),
+    valid then ~1 % corrupted, verdict vector against the oracle"""
+    import os
+    d = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "vs2_batch_1024.npz"))
+    v = mi.VarunaShaped(d["vk"], d["circuits"], shape=d["shape"], key_ext=d["ext"])
+    try:
+        ok, verdicts = v.verify_batch(d["proofs"], d["randomizers"])
+        assert ok and verdicts.all()
+        bad = d["proofs"].copy()
+        idx = np.arange(3, 1024, 97)
+        for k, i in enumerate(idx):
+            bad[i * P2 + (2256 + 64 + 96 * 5 + 1, 2256 + 9, 16 + 512 + 864 + 32 * 4)[k % 3]] ^= 1
+        ok, verdicts = v.verify_batch(bad, d["randomizers"])
+        want = np.ones(1024, dtype=np.uint8); want[idx] = 0
+        assert not ok and (verdicts == want).all()
+        cpu = orc.VS2Batch.wrap(d["vk"], d["ext"], d["shape"], d["circuits"], bad, d["randomizers"]).verify_cpu(16)
+        assert (cpu == want).all()
+    finally:
+        v.close()

@@ -86,7 +86,7 @@ def test_struct_layouts_match_the_python_loader_and_the_header():
     from snarkos_amd import lib as L
     _, structs, _, _ = G.parse_header()
     defines = dict(G.parse_header()[0])
-    size = {"uint64_t": 8, "uint32_t": 4, "uint8_t": 1}
+    size = {"uint64_t": 8, "uint32_t": 4, "uint8_t": 1, "int8_t": 1}
     for name, fields in structs:  # declaration order: members are defined before use; all members are 8-byte multiples or u8/u32 tails
         total = 0
         for _, ty, arr in fields:

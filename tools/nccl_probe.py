@@ -18,13 +18,13 @@ d = np.load(os.path.join(ROOT, "tests", "golden", "vs_batch_1024.npz"))
 v = A.VarunaShaped(d["vk"], d["circuits"])
 p = torch.from_numpy(d["proofs"]).cuda(); r = torch.from_numpy(d["randomizers"]).cuda()
 gdev = dev if backend == "nccl" else None
-def gather(part):  # (count, 304) -> (world = 1, count, 304), through a real collective
+def gather(part):  # (count, 592) -> (world = 1, count, 592), through a real collective
     torch.cuda.set_device(0)
     mine = torch.from_numpy(np.ascontiguousarray(part).reshape(-1).copy())
     mine = mine.to(gdev) if gdev is not None else mine
     out = torch.empty_like(mine)
     dist.all_gather_into_tensor(out, mine)
-    return out.cpu().numpy().reshape(1, -1, 304)
+    return out.cpu().numpy().reshape(1, -1, 592)
 GROUP = int(os.environ.get("PROBE_GROUP", "1"))
 for g in (None, gather):
     list(v.verify_stream(((p, r) for _ in range(10)), g, exchange_group=GROUP))
