@@ -576,6 +576,34 @@ def extras(dev, verifier, proofs, rnd):
         vp.close()
     except FileNotFoundError:
         pass
+    # --- VarunaShaped-v2: the query-set table, hiding and two degree-bound classes (4 pairs, 4 fused MSMs, 3184-byte records)
+    try:
+        d2 = np.load(os.path.join(ROOT, "tests", "golden", "vs2_batch_1024.npz"))
+        v2 = A.VarunaShaped(d2["vk"], d2["circuits"], shape=d2["shape"], key_ext=d2["ext"])
+        p2, r2 = torch.from_numpy(d2["proofs"]).to(dev), torch.from_numpy(d2["randomizers"]).to(dev)
+        ok, _ = v2.verify_batch(p2, r2)
+        assert ok
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(5):
+            ok, _ = v2.verify_batch(p2, r2)
+        torch.cuda.synchronize()
+        lat = (time.perf_counter() - t0) / 5
+        nb = 200
+        list(v2.verify_stream(((p2, r2) for _ in range(20))))
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        oks = list(v2.verify_stream(((p2, r2) for _ in range(nb))))
+        torch.cuda.synchronize()
+        dts = time.perf_counter() - t0
+        assert all(oks)
+        ex["batch_1024_v2_shape"] = {
+            "latency_ms_one_batch_unpipelined": 1e3 * lat, "streamed_proofs_per_s": 1024 * nb / dts,
+            "streamed_ms_per_batch": 1e3 * dts / nb, "pairs_in_product": 4, "msm_points_per_proof": 9 + 2 + 4 + 4,
+            "note": "hiding (gamma_g, random_v), degree-bound classes {5,6} and {7,8}, SHA-256 transcript"}
+        v2.close()
+    except FileNotFoundError:
+        pass
     # --- the same 1024-proof batch with 1 % corrupted proofs: aggregate check fails, fallback names them
     bad = proofs.copy()
     idx = np.arange(5, 1024, 101)  # 11 proofs

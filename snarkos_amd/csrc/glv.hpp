@@ -1,0 +1,173 @@
+// Scalar multiplication of ONE point by ONE scalar on a lane (the per-proof fallback of the batch verifier and
+// mi_g1_mul_many_device): the MSM machinery shares its doublings over thousands of points, a lone product cannot, and
+// its latency is its doubling chain.  Two levers cut that chain and the work beside it:
+//   * GLV: phi(x, y) = (beta x, y) is multiplication by lambda = x^2 - 1 on G1 (lambda^2 + lambda + 1 = r), so
+//     s P = s1 P + s2 phi(P) with s1, s2 < 2^127: two half-length chains that run on two lanes;
+//   * signed fixed windows of W bits: lanes of a wave run in lockstep, so a data-dependent addition (double-and-add,
+//     NAF) costs every lane an addition per bit whatever its own digit; with fixed windows every lane adds once per
+//     W doublings.  The table {P, 2P, .., 2^(W-1) P} lives in global memory (192 B per entry and lane, too large for
+//     registers or LDS at the occupancy wanted), read once per window.
+// Reference: snarkvm_curves' `ProjectiveCurve::mul` / `mul_bits` double-and-add (snarkVM 1.0.0 @ dea322b, curves/src/
+// templates/short_weierstrass_jacobian/projective.rs, un-vendored) and bls12_377::g1's GLV
+// parameters; constants here are derived in tools/gen_constants.py.
+#pragma once
+#include "curve.hpp"
+
+namespace mi {
+
+MI_HD Fq glv_beta() {
+    Fq b;
+#pragma unroll
+    for (int i = 0; i < 6; i++) {
+        b.l[2 * i] = (uint32_t)MI_GLV_BETA[i];
+        b.l[2 * i + 1] = (uint32_t)(MI_GLV_BETA[i] >> 32);
+    }
+    return b;
+}
+
+// s (canonical, < r) = s1 + lambda s2 with 0 <= s1 < lambda and 0 <= s2 <= lambda + 1 (both below 2^127)
+MI_HD void glv_split(const uint32_t (&s)[8], uint32_t (&s1)[4], uint32_t (&s2)[4]) {
+    const uint32_t LAM[4] = {(uint32_t)MI_GLV_LAMBDA[0], (uint32_t)(MI_GLV_LAMBDA[0] >> 32), (uint32_t)MI_GLV_LAMBDA[1],
+                             (uint32_t)(MI_GLV_LAMBDA[1] >> 32)};
+    const uint32_t MU[5] = {(uint32_t)MI_GLV_MU[0], (uint32_t)(MI_GLV_MU[0] >> 32), (uint32_t)MI_GLV_MU[1],
+                            (uint32_t)(MI_GLV_MU[1] >> 32), (uint32_t)MI_GLV_MU[2]};
+    // qhat = floor(s mu / 2^256), mu = floor(2^256 / lambda): the quotient or one less
+    uint32_t prod[13];
+#pragma unroll
+    for (int i = 0; i < 13; i++) prod[i] = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        uint32_t carry = 0;
+#pragma unroll
+        for (int j = 0; j < 5; j++) {
+            const uint64_t t = (uint64_t)s[i] * MU[j] + prod[i + j] + carry;
+            prod[i + j] = (uint32_t)t;
+            carry = (uint32_t)(t >> 32);
+        }
+        prod[i + 5] = carry;
+    }
+    uint32_t q[4] = {prod[8], prod[9], prod[10], prod[11]};
+    // rem = s - qhat lambda, below 2 lambda < 2^128: five limbs carry it
+    uint32_t t5[5] = {0, 0, 0, 0, 0};
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        uint32_t carry = 0;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            if (i + j < 5) {
+                const uint64_t t = (uint64_t)q[i] * LAM[j] + t5[i + j] + carry;
+                t5[i + j] = (uint32_t)t;
+                carry = (uint32_t)(t >> 32);
+            }
+        }
+        if (i + 4 < 5) t5[i + 4] = carry;
+    }
+    uint32_t rem[5];
+    {
+        uint32_t borrow = 0;
+#pragma unroll
+        for (int i = 0; i < 5; i++) {
+            const uint64_t d = (uint64_t)s[i] - t5[i] - borrow;
+            rem[i] = (uint32_t)d;
+            borrow = (uint32_t)(d >> 63);
+        }
+    }
+#pragma unroll
+    for (int round = 0; round < 2; round++) {
+        // rem >= lambda ?
+        uint32_t d[5], borrow = 0;
+#pragma unroll
+        for (int i = 0; i < 5; i++) {
+            const uint64_t t = (uint64_t)rem[i] - (i < 4 ? LAM[i] : 0u) - borrow;
+            d[i] = (uint32_t)t;
+            borrow = (uint32_t)(t >> 63);
+        }
+        const uint32_t ge = 1u - borrow;
+        uint32_t c = ge;
+#pragma unroll
+        for (int i = 0; i < 5; i++) rem[i] = ge ? d[i] : rem[i];
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const uint64_t t = (uint64_t)q[i] + c;
+            q[i] = (uint32_t)t;
+            c = (uint32_t)(t >> 32);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; i++) { s1[i] = rem[i]; s2[i] = q[i]; }
+}
+
+// Signed digits of a value below 2^128 in windows of W bits, packed as nibbles (digit + 8), low window first.
+// W = 3: digits -3..4, 43 windows (the top one holds bits 126..128: at most 3 + carry = 4, no carry out);
+// W = 4: digits -8..7, 33 windows (the top one holds the last carry only).
+template <int W>
+struct GlvDigits {
+    static constexpr int NW = (128 + W) / W;          // 43 (W = 3), 33 (W = 4)
+    static constexpr int WORDS = (NW + 7) / 8;
+    uint32_t w[WORDS];
+    MI_HD void recode(const uint32_t (&v)[4]) {
+#pragma unroll
+        for (int i = 0; i < WORDS; i++) w[i] = 0;
+        uint32_t carry = 0;
+#pragma unroll
+        for (int i = 0; i < NW; i++) {
+            const int bit = W * i, word = bit >> 5, off = bit & 31;
+            uint32_t raw = word < 4 ? v[word] >> off : 0u;
+            if (off + W > 32 && word + 1 < 4) raw |= v[word + 1] << (32 - off);
+            raw = (raw & ((1u << W) - 1)) + carry;
+            carry = raw > (W == 4 ? 7u : (1u << (W - 1))) ? 1u : 0u;
+            const uint32_t nib = raw + 8u - (carry << W);  // digit + 8
+            w[i >> 3] |= nib << (4 * (i & 7));
+        }
+    }
+    // digit of window i (dynamic i, no register indexing)
+    MI_HD int digit(int i) const {
+        uint32_t word = 0;
+#pragma unroll
+        for (int j = 0; j < WORDS; j++) word = (i >> 3) == j ? w[j] : word;
+        return (int)((word >> (4 * (i & 7))) & 15u) - 8;
+    }
+};
+
+// table[e] = (e + 1) P for e < 2^(W-1), in this lane's slice of global memory; P not infinity
+template <int W>
+__device__ __forceinline__ void glv_build_table(G1Xyzz *tab, const G1Affine &P) {
+    G1Xyzz one = G1Xyzz{P.x, P.y, Fq::one(), Fq::one()};
+    store_xyzz(&tab[0], one);
+    G1Xyzz two = dbl_affine(P);
+    store_xyzz(&tab[1], two);
+    G1Xyzz three = add_mixed(two, P);
+    store_xyzz(&tab[2], three);
+    G1Xyzz four = dbl(two);
+    store_xyzz(&tab[3], four);
+    if constexpr (W == 4) {
+        store_xyzz(&tab[4], add_mixed(four, P));
+        G1Xyzz six = dbl(three);
+        store_xyzz(&tab[5], six);
+        store_xyzz(&tab[6], add_mixed(six, P));
+        store_xyzz(&tab[7], dbl(four));
+    }
+}
+
+// v P from the table of P's multiples, v < 2^128: NW windows, W doublings and one addition each
+template <int W>
+__device__ __forceinline__ G1Xyzz glv_chain(const G1Xyzz *tab, const uint32_t (&v)[4]) {
+    GlvDigits<W> dg;
+    dg.recode(v);
+    G1Xyzz acc = G1Xyzz::inf();
+    for (int i = GlvDigits<W>::NW - 1; i >= 0; i--) {
+        if (i != GlvDigits<W>::NW - 1) {
+#pragma unroll 1
+            for (int k = 0; k < W; k++) acc = dbl(acc);
+        }
+        const int d = dg.digit(i);
+        if (d != 0) {
+            G1Xyzz t = load_xyzz(&tab[(d < 0 ? -d : d) - 1]);
+            if (d < 0) t.y = neg(t.y);
+            acc = add(acc, t);
+        }
+    }
+    return acc;
+}
+
+}  // namespace mi

@@ -16,6 +16,7 @@
 #include "api.hpp"
 #include "tower.hpp"
 #include "pairing_wg.hpp"
+#include "glv.hpp"
 
 namespace mi {
 
@@ -764,12 +765,23 @@ __global__ void __launch_bounds__(256) vs_merge_kernel(const Fr *__restrict__ vk
 }
 
 // ---------------------------------------------------------------- per-proof fallback (names the bad proofs)
-// One lane per (proof, term): term[i][k] = scalar * point.  Terms of a proof, in order (PP = per_proof, H = hiding):
+// A batch whose aggregate check failed is taken apart on the device, without a host round trip between the steps:
+//   1. vs_terms_kernel    every term scalar * point of every proof (glv.hpp: two half-length chains per 253-bit scalar,
+//                         signed fixed windows; one lane per chain, ~1.8 k Fq products deep)
+//   2. vs_sums_kernel     the proof's accumulators (total_c, -total_w, the classes') from its terms, affine
+//   3. vs_check_kernel    group testing: the pairing product of VS_GROUP proofs' summed accumulators (the randomizers
+//                         are already in the terms, so a group passes only if all its proofs do), then
+//   4. vs_check_kernel    one pairing product per proof, for the proofs of failing groups only (the other blocks
+//                         exit at once).
+// Terms of a proof, in order (PP = per_proof, H = hiding):
 //   [0, PP)            its own H-side points (commitments, witnesses times z, shifted commitments) with sc1
 //   [PP, PP + 12)      the circuit's commitments with vk_scal
 //   PP + 12            G with g_scal;   PP + 13 (if H): gamma_g with h_scal
-//   next 2             W_q with r_q (the tau-H side, 128-bit scalars)
+//   next 2             W_q with r_q (the tau-H side, 128-bit scalars: one chain each)
 //   then               the class accumulators' C_j with rho_j, class 0 first
+// and its chains: 2 per term (s1 P, s2 phi(P)) except the two 128-bit ones.
+#define VS_GLV_W 3
+#define VS_GROUP 4
 struct VsTermsIn {
     const G1Affine *pts1, *ptsb[MI_VS_MAX_BOUNDS];
     const uint32_t *sc1, *sc2, *scb[MI_VS_MAX_BOUNDS];
@@ -779,16 +791,23 @@ struct VsTermsIn {
 __host__ __device__ __forceinline__ uint32_t vs_terms_of(uint32_t per_proof, uint32_t hiding, uint32_t n_bounded) {
     return per_proof + MI_VS_VK_COMMS + 1 + hiding + 2 + n_bounded;
 }
-__global__ void __launch_bounds__(128) vs_terms_kernel(size_t n, VsTermsIn in, const mi_vs_circuit_vk *__restrict__ circuits,
-                                                       const VsConsts *__restrict__ kc, G1Xyzz *__restrict__ terms) {
-    const uint32_t PP = kc->per_proof, H = kc->hiding, T = vs_terms_of(PP, H, kc->n_bounded);
+__host__ __device__ __forceinline__ uint32_t vs_chains_of(uint32_t per_proof, uint32_t hiding, uint32_t n_bounded) {
+    return 2 * vs_terms_of(per_proof, hiding, n_bounded) - 2;
+}
+__global__ void __launch_bounds__(256) vs_terms_kernel(size_t n, VsTermsIn in, const mi_vs_circuit_vk *__restrict__ circuits,
+                                                      const VsConsts *__restrict__ kc, G1Xyzz *__restrict__ tables,
+                                                      G1Xyzz *__restrict__ terms) {
+    const uint32_t PP = kc->per_proof, H = kc->hiding, CH = vs_chains_of(PP, H, kc->n_bounded);
+    const uint32_t n_c = PP + MI_VS_VK_COMMS + 1 + H;
     size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= n * T) return;
-    size_t i = t / T;
-    uint32_t k = (uint32_t)(t % T);
+    if (t >= n * CH) return;
+    const size_t i = t / CH;
+    const uint32_t c2 = (uint32_t)(t % CH);
+    uint32_t k, half;
+    if (c2 < 2 * n_c) { k = c2 >> 1; half = c2 & 1; }
+    else if (c2 < 2 * n_c + 2) { k = n_c + (c2 - 2 * n_c); half = 2; }  // 128-bit scalar, one chain
+    else { k = n_c + 2 + ((c2 - 2 * n_c - 2) >> 1); half = c2 & 1; }
     G1Affine P;
-    uint32_t s[8];
-    int bits = 253;
     Fr v;
     if (k < PP) {
         copy_g1(&P, in.pts1 + i * PP + k);
@@ -803,69 +822,128 @@ __global__ void __launch_bounds__(128) vs_terms_kernel(size_t n, VsTermsIn in, c
     } else if (H && k == PP + MI_VS_VK_COMMS + 1) {
         copy_g1(&P, &kc->gamma_g);
         v = from_mont(fr_load(in.h_scal + i));
-    } else if (k < PP + MI_VS_VK_COMMS + 1 + H + 2) {
-        const uint32_t q = k - (PP + MI_VS_VK_COMMS + 1 + H);
+    } else if (k < n_c + 2) {
+        const uint32_t q = k - n_c;
         copy_g1(&P, in.pts1 + i * PP + MI_VS_PROOF_COMMS + q);
         v = fr_load(in.sc2 + (i * 2 + q) * 8);
-        bits = 128;
     } else {
-        uint32_t e = k - (PP + MI_VS_VK_COMMS + 1 + H + 2);
+        uint32_t e = k - (n_c + 2);
         const uint32_t c = e < kc->class_count[0] ? 0u : 1u;
         if (c) e -= kc->class_count[0];
         copy_g1(&P, in.ptsb[c] + i * kc->class_count[c] + e);
         v = fr_load(in.scb[c] + (i * kc->class_count[c] + e) * 8);
     }
+    uint32_t sv[4];
+    if (half == 2) {
 #pragma unroll
-    for (int j = 0; j < 8; j++) s[j] = v.l[j];
+        for (int j = 0; j < 4; j++) sv[j] = v.l[j];
+    } else {
+        uint32_t s8[8], s1[4], s2[4];
+#pragma unroll
+        for (int j = 0; j < 8; j++) s8[j] = v.l[j];
+        glv_split(s8, s1, s2);
+#pragma unroll
+        for (int j = 0; j < 4; j++) sv[j] = half ? s2[j] : s1[j];
+        if (half) P.x = mulq(P.x, glv_beta());  // phi(P); (0, 0) stays (0, 0)
+    }
     G1Xyzz acc = G1Xyzz::inf();
-    for (int b = bits - 1; b >= 0; b--) {
-        acc = dbl(acc);
-        // select the scalar bit without dynamic register indexing
-        uint32_t word = 0;
-#pragma unroll
-        for (int j = 0; j < 8; j++) word = (b >> 5) == j ? s[j] : word;
-        if ((word >> (b & 31)) & 1u) acc = add_mixed(acc, P);
+    if (!P.is_inf() && (sv[0] | sv[1] | sv[2] | sv[3])) {
+        G1Xyzz *tab = tables + t * (1u << (VS_GLV_W - 1));
+        glv_build_table<VS_GLV_W>(tab, P);
+        acc = glv_chain<VS_GLV_W>(tab, sv);
     }
     store_xyzz(&terms[t], acc);
 }
-// block i (192 lanes): the proof's accumulators from its terms (one lane each), then the workgroup-cooperative pairing
-// product over 2 + n_bounds pairs; verdict
+
+// block i (128 lanes): segmented tree sums of the proof's chains in LDS -> ps[i][4] affine (total_c, -total_w, class 0,
+// class 1; unused ones infinity)
+#define VS_SUM_LANES 128
+__global__ void __launch_bounds__(VS_SUM_LANES) vs_sums_kernel(size_t n, const G1Xyzz *__restrict__ terms,
+                                                               const VsConsts *__restrict__ kc, G1Affine *__restrict__ ps) {
+    __shared__ G1Xyzz sh[VS_SUM_LANES];
+    const size_t i = blockIdx.x;
+    const uint32_t PP = kc->per_proof, H = kc->hiding, CH = vs_chains_of(PP, H, kc->n_bounded);
+    const uint32_t n_c = PP + MI_VS_VK_COMMS + 1 + H;
+    const uint32_t lo1 = 2 * n_c, lo2 = lo1 + 2, lo3 = lo2 + 2 * kc->class_count[0];
+    const uint32_t l = threadIdx.x;
+    uint32_t seg, lo, hi;
+    if (l < lo1) { seg = 0; lo = 0; hi = lo1; }
+    else if (l < lo2) { seg = 1; lo = lo1; hi = lo2; }
+    else if (l < lo3) { seg = 2; lo = lo2; hi = lo3; }
+    else { seg = 3; lo = lo3; hi = CH; }
+    const bool live = l < CH;
+    G1Xyzz mine = live ? load_xyzz(&terms[i * CH + l]) : G1Xyzz::inf();
+    store_xyzz(&sh[l], mine);
+    const uint32_t pos = l - lo;
+    for (uint32_t stride = 1; stride < VS_SUM_LANES; stride <<= 1) {
+        __syncthreads();
+        const bool act = live && (pos & (2 * stride - 1)) == 0 && l + stride < hi;
+        if (act) mine = add(mine, load_xyzz(&sh[l + stride]));
+        __syncthreads();
+        if (act) store_xyzz(&sh[l], mine);
+    }
+    if (live && pos == 0) {
+        G1Affine pa = to_affine(mine);
+        if (seg == 1) pa = neg(pa);
+        copy_g1(&ps[i * MI_MAX_PAIRS + seg], &pa);
+    }
+    if (l < MI_MAX_PAIRS) {  // segments of no chain at all (contexts without that class)
+        const uint32_t slo[4] = {0, lo1, lo2, lo3}, shi[4] = {lo1, lo2, lo3, CH};
+        if (slo[l] >= shi[l]) {
+            G1Affine z = G1Affine::inf();
+            copy_g1(&ps[i * MI_MAX_PAIRS + l], &z);
+        }
+    }
+}
+
+// block b (192 lanes): the workgroup-cooperative pairing product over the summed accumulators of proofs [b g, (b+1) g).
+// g > 1: out[b] = group passes (and none of its proofs failed the algebraic checks); g = 1: out[b] = verdict of proof b,
+// blocks whose group (of pg proofs, parent_ok) passed write it without computing.
 struct VsG2Keys {
     const G2Prepared *q[MI_MAX_PAIRS];  // h, tau h, shift_h[0], shift_h[1]
 };
-__global__ void __launch_bounds__(PW_THREADS) vs_per_proof_pairing_kernel(size_t n, const G1Xyzz *__restrict__ terms, VsG2Keys keys,
-                                                                          const VsConsts *__restrict__ kc,
-                                                                          const PairingConsts *__restrict__ pc,
-                                                                          const uint8_t *__restrict__ alg_ok,
-                                                                          uint8_t *__restrict__ verdicts) {
+__global__ void __launch_bounds__(PW_THREADS) vs_check_kernel(size_t n, uint32_t g, const G1Affine *__restrict__ sums, VsG2Keys keys,
+                                                              const VsConsts *__restrict__ kc, const PairingConsts *__restrict__ pc,
+                                                              const uint8_t *__restrict__ alg_ok, const uint8_t *__restrict__ parent_ok,
+                                                              uint32_t pg, uint8_t *__restrict__ out) {
     extern __shared__ uint4 pw_lds[];  // PW_LDS_BYTES
     LShared &S = *(LShared *)pw_lds;
     __shared__ G1Affine ps[MI_MAX_PAIRS];
     __shared__ const G2Prepared *qs[MI_MAX_PAIRS];
     __shared__ Fq12 result;
-    const size_t i = blockIdx.x;
-    const uint32_t PP = kc->per_proof, H = kc->hiding, T = vs_terms_of(PP, H, kc->n_bounded);
-    const uint32_t n_c = PP + MI_VS_VK_COMMS + 1 + H;  // terms of total_c, then 2 of total_w, then the classes'
-    const int tid = threadIdx.x, acc_id = tid >> 6;      // one wave's first lane per accumulator (waves 0..2), class 1 on lane 1
-    const G1Xyzz *tp = terms + i * T;
-    if ((tid & 63) == 0 || tid == 1) {
-        const int which = tid == 1 ? 3 : acc_id;
-        uint32_t lo, hi;
-        if (which == 0) { lo = 0; hi = n_c; }
-        else if (which == 1) { lo = n_c; hi = n_c + 2; }
-        else if (which == 2) { lo = n_c + 2; hi = n_c + 2 + kc->class_count[0]; }
-        else { lo = n_c + 2 + kc->class_count[0]; hi = T; }
-        if (which < 2 + (int)kc->n_bounds) {
-            G1Xyzz a = G1Xyzz::inf();
-            for (uint32_t k = lo; k < hi; k++) a = add(a, load_xyzz(&tp[k]));
-            const G1Affine pa = to_affine(a);
-            ps[which] = which == 1 ? neg(pa) : pa;
+    const size_t b = blockIdx.x, first = b * g, last = first + g < n ? first + g : n;
+    const int K = 2 + (int)kc->n_bounds, tid = threadIdx.x;
+    bool alg = true;
+    for (size_t i = first; i < last; i++) alg = alg && alg_ok[i];
+    if (parent_ok && parent_ok[first / pg]) {  // uniform: the group's product was one, nothing to name in it
+        if (tid == 0) out[b] = alg ? 1 : 0;
+        return;
+    }
+    if (!alg) {  // uniform: a malformed / algebraically failing proof decides without a pairing
+        if (tid == 0) out[b] = 0;
+        return;
+    }
+    if ((tid & 63) == 0 || tid == 1) {  // one lane per accumulator, on different waves where there are three
+        const int which = tid == 1 ? 3 : (tid >> 6);
+        if (which < K) {
+            G1Affine pa;
+            copy_g1(&pa, &sums[first * MI_MAX_PAIRS + which]);
+            if (last - first > 1) {
+                G1Xyzz a = G1Xyzz::from_affine(pa);
+                for (size_t i = first + 1; i < last; i++) {
+                    G1Affine t;
+                    copy_g1(&t, &sums[i * MI_MAX_PAIRS + which]);
+                    a = add_mixed(a, t);
+                }
+                pa = to_affine(a);
+            }
+            ps[which] = pa;
             qs[which] = keys.q[which];
         }
     }
     __syncthreads();
-    pw_pairing_product(S, ps, qs, 2 + (int)kc->n_bounds, pc, &result);
-    if (threadIdx.x == 0) verdicts[i] = (result.is_one() && alg_ok[i]) ? 1 : 0;
+    pw_pairing_product(S, ps, qs, K, pc, &result);
+    if (tid == 0) out[b] = result.is_one() ? 1 : 0;
 }
 
 // ---------------------------------------------------------------- host drivers
@@ -1186,29 +1264,49 @@ int32_t vs_finalize_wait(Context &cx, uint64_t id, uint64_t ticket, uint8_t *all
     return vs_slot_wait(sl, all_ok);
 }
 
-// name the invalid proofs of a batch whose aggregate check failed: every proof on its own, on the lane's stream and
-// workspaces (the lane is still held by the caller)
+// name the invalid proofs of a batch whose aggregate check failed: terms, sums, group products, per-proof products, all
+// on the lane's stream and workspaces (the lane is still held by the caller); one wait at the end
 static void vs_identify(Context &cx, VsKeys &v, const VsWork &w, size_t n, int lane, hipStream_t st, uint8_t *verdicts) {
     char nm[32];
-    const uint32_t T = vs_terms_of(v.shape.per_proof, v.shape.hiding, v.shape.n_bounded);
+    const uint32_t CH = vs_chains_of(v.shape.per_proof, v.shape.hiding, v.shape.n_bounded);
+    const size_t n_groups = cdiv(n, VS_GROUP);
     snprintf(nm, sizeof nm, "vs%d.terms", lane);
-    G1Xyzz *terms = (G1Xyzz *)cx.buf(nm, sizeof(G1Xyzz) * n * T);
+    G1Xyzz *terms = (G1Xyzz *)cx.buf(nm, sizeof(G1Xyzz) * n * CH);
+    snprintf(nm, sizeof nm, "vs%d.tables", lane);
+    G1Xyzz *tables = (G1Xyzz *)cx.buf(nm, sizeof(G1Xyzz) * n * CH * (1u << (VS_GLV_W - 1)));
+    snprintf(nm, sizeof nm, "vs%d.sums", lane);
+    G1Affine *sums = (G1Affine *)cx.buf(nm, sizeof(G1Affine) * n * MI_MAX_PAIRS);
     snprintf(nm, sizeof nm, "vs%d.verdicts", lane);
-    uint8_t *d_verdicts = (uint8_t *)cx.buf(nm, n);
+    uint8_t *d_verdicts = (uint8_t *)cx.buf(nm, n + n_groups);
+    uint8_t *d_group_ok = d_verdicts + n;
     VsTermsIn in;
     in.pts1 = w.o.pts1; in.sc1 = w.o.sc1; in.sc2 = w.o.sc2;
     for (int c = 0; c < MI_VS_MAX_BOUNDS; c++) { in.ptsb[c] = w.o.ptsb[c]; in.scb[c] = w.o.scb[c]; }
     in.vk_scal = w.o.vk_scal; in.g_scal = w.o.g_scal; in.h_scal = w.o.h_scal; in.circuit_of = w.o.circuit_of;
-    hipLaunchKernelGGL(vs_terms_kernel, dim3(cdiv(n * T, 128)), dim3(128), 0, st, n, in, (const mi_vs_circuit_vk *)v.circuits.p,
-                       (const VsConsts *)v.consts.p, terms);
+    const VsConsts *kc = (const VsConsts *)v.consts.p;
+    cx.prof.begin("vs_terms", st, n);
+    hipLaunchKernelGGL(vs_terms_kernel, dim3(cdiv(n * CH, 256)), dim3(256), 0, st, n, in, (const mi_vs_circuit_vk *)v.circuits.p, kc,
+                       tables, terms);
+    cx.prof.end("vs_terms", st);
+    if (CH > VS_SUM_LANES) throw std::runtime_error("vs_identify: shape has more chains per proof than vs_sums_kernel lanes");
+    cx.prof.begin("vs_sums", st, n);
+    hipLaunchKernelGGL(vs_sums_kernel, dim3((unsigned)n), dim3(VS_SUM_LANES), 0, st, n, terms, kc, sums);
+    cx.prof.end("vs_sums", st);
     VsG2Keys keys;
     const G2Prepared *qs[MI_MAX_PAIRS];
     (void)vs_g2_keys(v, qs);
     for (int k = 0; k < MI_MAX_PAIRS; k++) keys.q[k] = qs[k];
-    cx.raise_lds_limit((const void *)vs_per_proof_pairing_kernel, (int)PW_LDS_BYTES);
-    hipLaunchKernelGGL(vs_per_proof_pairing_kernel, dim3((unsigned)n), dim3(PW_THREADS), PW_LDS_BYTES, st, n, terms, keys,
-                       (const VsConsts *)v.consts.p, pairing_consts(cx, st), w.o.alg_ok, d_verdicts);
+    cx.raise_lds_limit((const void *)vs_check_kernel, (int)PW_LDS_BYTES);
+    const PairingConsts *pc = pairing_consts(cx, st);
+    cx.prof.begin("vs_groups", st, n);
+    hipLaunchKernelGGL(vs_check_kernel, dim3((unsigned)n_groups), dim3(PW_THREADS), PW_LDS_BYTES, st, n, (uint32_t)VS_GROUP, sums, keys,
+                       kc, pc, w.o.alg_ok, (const uint8_t *)nullptr, 1u, d_group_ok);
+    cx.prof.end("vs_groups", st);
+    cx.prof.begin("vs_per_proof", st, n);
+    hipLaunchKernelGGL(vs_check_kernel, dim3((unsigned)n), dim3(PW_THREADS), PW_LDS_BYTES, st, n, 1u, sums, keys, kc, pc, w.o.alg_ok,
+                       (const uint8_t *)d_group_ok, (uint32_t)VS_GROUP, d_verdicts);
     MI_HIP(hipGetLastError());
+    cx.prof.end("vs_per_proof", st);
     snprintf(nm, sizeof nm, "vs.verdict_pin%d", lane);
     uint8_t *h = (uint8_t *)cx.pin_named(nm, n);
     MI_HIP(hipMemcpyAsync(h, d_verdicts, n, hipMemcpyDeviceToHost, st));

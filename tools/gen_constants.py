@@ -65,6 +65,57 @@ TWIST_B = (0, (-pow(5, -1, Q)) % Q)
 assert (TWIST_B[1] * (-5) % Q) == 1  # (b1 u) * u = -5 b1 = 1
 
 
+# GLV endomorphism on G1 (y^2 = x^3 + 1): phi(x, y) = (beta x, y) acts as multiplication by lambda = x^2 - 1 on the
+# order-r subgroup (lambda^2 + lambda + 1 = r); beta is the cube root of unity in Fq that matches this lambda, found
+# by comparing lambda G with (beta Gx, Gy).  GLV_MU = floor(2^256 / lambda) for the Barrett quotient s div lambda.
+LAMBDA = X * X - 1
+assert (LAMBDA * LAMBDA + LAMBDA + 1) == R
+
+
+def _ec_add(p1, p2):
+    if p1 is None:
+        return p2
+    if p2 is None:
+        return p1
+    (x1, y1), (x2, y2) = p1, p2
+    if x1 == x2:
+        if (y1 + y2) % Q == 0:
+            return None
+        l = 3 * x1 * x1 * pow(2 * y1, -1, Q) % Q
+    else:
+        l = (y2 - y1) * pow(x2 - x1, -1, Q) % Q
+    x3 = (l * l - x1 - x2) % Q
+    return (x3, (l * (x1 - x3) - y1) % Q)
+
+
+def _ec_mul(k, p):
+    acc = None
+    while k:
+        if k & 1:
+            acc = _ec_add(acc, p)
+        p = _ec_add(p, p)
+        k >>= 1
+    return acc
+
+
+def _glv_beta():
+    g = 2
+    while pow(g, (Q - 1) // 3, Q) == 1:
+        g += 1
+    b = pow(g, (Q - 1) // 3, Q)
+    lam_g = _ec_mul(LAMBDA, (G1X, G1Y))
+    for cand in (b, b * b % Q):
+        if lam_g == (cand * G1X % Q, G1Y):
+            return cand
+    raise AssertionError("no cube root of unity matches lambda")
+
+
+BETA = _glv_beta()
+assert pow(BETA, 3, Q) == 1 and BETA != 1
+GLV_MU = (1 << 256) // LAMBDA
+assert LAMBDA.bit_length() == 127 and GLV_MU.bit_length() <= 160
+
+
 # Poseidon over Fq: width 3, x^17, 8 full + 31 partial rounds; constants generated here
 # (SHA-256 counter stream, Cauchy MDS) because snarkVM's are not available offline.
 import hashlib  # noqa: E402
@@ -117,6 +168,10 @@ def emit(prefix, static_kw):
     a("%s uint64_t %sG2_GEN_X[2][6] = {%s, %s};" % (static_kw, prefix, fq(G2X[0]), fq(G2X[1])))
     a("%s uint64_t %sG2_GEN_Y[2][6] = {%s, %s};" % (static_kw, prefix, fq(G2Y[0]), fq(G2Y[1])))
     a("%s uint64_t %sTWIST_B[2][6] = {%s, %s};" % (static_kw, prefix, fq(TWIST_B[0]), fq(TWIST_B[1])))
+    a("/* GLV: phi(x, y) = (beta x, y) = lambda (x, y) on G1; lambda = x^2 - 1 (127 bits); MU = floor(2^256 / lambda) */")
+    a("%s uint64_t %sGLV_BETA[6] = %s; /* Montgomery */" % (static_kw, prefix, fq(BETA)))
+    a("%s uint64_t %sGLV_LAMBDA[2] = %s;" % (static_kw, prefix, arr(LAMBDA, 2)))
+    a("%s uint64_t %sGLV_MU[3] = %s;" % (static_kw, prefix, arr(GLV_MU, 3)))
     a("/* FROB[e-1][k] = gamma_e^k (Montgomery): multiply the Fq coefficient of w^k, k = i + 2j + 6b for c_i.c_j.c_b */")
     a("%s uint64_t %sFROB[3][12][6] = {" % (static_kw, prefix))
     for e in range(3):
