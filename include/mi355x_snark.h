@@ -193,6 +193,12 @@ int32_t mi_vs_verify_batch(uint64_t ctx, const mi_vs_proof *proofs, size_t n, co
 /* device-pointer form (proofs and randomizers already in HBM) */
 int32_t mi_vs_verify_batch_device(uint64_t ctx, const void *d_proofs, size_t n, const void *d_randomizers128,
                                   uint8_t *verdicts, uint8_t *all_ok, void *stream);
+/* the verdict vector of a batch already known to fail (all_ok = 0 from mi_vs_finalize* or mi_vs_stream_next, which keep
+ * no per-proof state): re-derives the scalars and names the invalid proofs without the aggregate MSMs and product.
+ * The fallback, here and inside mi_vs_verify_batch*: every term scalar * point (GLV half-length chains), the proofs'
+ * accumulators, one pairing product per group of 4 proofs, then per proof inside failing groups; all on the device. */
+int32_t mi_vs_identify_device(uint64_t ctx, const void *d_proofs, size_t n, const void *d_randomizers128, uint8_t *verdicts,
+                              void *stream);
 /* one block-validation batch over ALL devices of the process (SURVEY.md 8e inside one process): contiguous shards, one
  * host thread per device (stage, derive, both MSMs, fold), the 592-byte partials all-gathered over RCCL (grouped
  * ncclAllGather over an in-process communicator; added on the host when RCCL is unavailable or MI_SNARK_EXCHANGE=host),

@@ -406,7 +406,17 @@ class VarunaShaped:
         L.check(L.lib().mi_vs_finalize_wait(C.c_uint64(self.ctx), C.c_uint64(ticket), L.ptr(ok)), "mi_vs_finalize_wait")
         return bool(ok[0])
 
-    def verify_stream(self, batches, gather=None, depth=8, acc_depth=12, fold_threads=3, exchange_group=1, comm=None):
+    def identify(self, proofs_cuda, randomizers_cuda, stream=None):
+        """The verdict vector of a batch already known to fail (mi_vs_identify_device): what verify_batch would return,
+        without its aggregate pass."""
+        n = proofs_cuda.numel() * proofs_cuda.element_size() // self.proof_bytes
+        verdicts = np.zeros(n, dtype=np.uint8)
+        L.check(L.lib().mi_vs_identify_device(C.c_uint64(self.ctx), L.dptr(proofs_cuda), C.c_size_t(n), L.dptr(randomizers_cuda),
+                                              L.ptr(verdicts), L.stream_ptr(stream)), "mi_vs_identify_device")
+        return verdicts
+
+    def verify_stream(self, batches, gather=None, depth=8, acc_depth=12, fold_threads=3, exchange_group=1, comm=None,
+                      verdicts=False):
         """Pipelined verification of a stream of batches (chunks of a block, or mempool traffic): yields all_ok per
         batch, in order.
 
@@ -419,6 +429,9 @@ class VarunaShaped:
         (proofs_cuda, randomizers_cuda).  `comm` (a handle of lib.comm_init_rank) makes the exchange native instead:
         the library's own mi_vs_exchange_rccl (ncclAllGather from the finisher thread, no Python on the data path).
         Submitted tensors are kept alive until their verdict has been yielded.
+        verdicts=True yields (all_ok, verdict vector or None) instead: a failing batch's vector comes from
+        mi_vs_identify_device on the still-held tensors (single-rank streams: with an exchange, all_ok covers every
+        rank's shard and each rank names the invalid proofs of its own).
         """
         lib = L.lib()
         keep = {}
@@ -454,9 +467,13 @@ class VarunaShaped:
             while True:
                 st = lib.mi_vs_stream_next(sid, 1 if block else 0, C.byref(ok))
                 if st == L.MI_OK:
-                    if held:
-                        held.pop(0)
-                    yield bool(ok.value)
+                    mine = held.pop(0) if held else None
+                    if not verdicts:
+                        yield bool(ok.value)
+                    elif ok.value or mine is None:
+                        yield bool(ok.value), None
+                    else:
+                        yield False, self.identify(mine[0], mine[1])
                 elif st == L.MI_ERR_AGAIN or st == L.MI_ERR_DONE:
                     return
                 else:

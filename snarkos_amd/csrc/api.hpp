@@ -74,6 +74,8 @@ int32_t vs_accumulate_end(Context &cx, uint64_t id, uint64_t handle, mi_vs_parti
 int32_t vs_finalize(Context &cx, uint64_t id, const mi_vs_partial *parts, size_t np, uint8_t *all_ok, hipStream_t st);
 int32_t vs_finalize_async(Context &cx, uint64_t id, const mi_vs_partial *parts, size_t np, uint64_t *ticket);
 int32_t vs_finalize_wait(Context &cx, uint64_t id, uint64_t ticket, uint8_t *all_ok);
+int32_t vs_identify_device(Context &cx, uint64_t id, const void *d_proofs, size_t n, const void *d_rand, uint8_t *verdicts,
+                           hipStream_t st);
 int32_t vs_verify_batch_device(Context &cx, uint64_t id, const void *d_proofs, size_t n, const void *d_rand,
                                uint8_t *verdicts, uint8_t *all_ok, hipStream_t st);
 void verify_release_keys();

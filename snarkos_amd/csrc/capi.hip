@@ -117,7 +117,7 @@ __global__ void __launch_bounds__(256) dbg_fq_mul_throughput_kernel(Fq *out, uin
 
 // ------------------------------------------------------------ Poseidon sponge over Fq, one lane per sponge
 __device__ __forceinline__ Fq pow17(const Fq &x) {
-    Fq x2 = mul(x, x), x4 = mul(x2, x2), x8 = mul(x4, x4), x16 = mul(x8, x8);
+    Fq x2 = sqr(x), x4 = sqr(x2), x8 = sqr(x4), x16 = sqr(x8);
     return mul(x16, x);
 }
 __device__ __attribute__((noinline)) void poseidon_permute(Fq st[3], const PoseidonConsts *__restrict__ pc) {
@@ -772,6 +772,13 @@ int32_t mi_vs_verify_batch_device(uint64_t c, const void *d_proofs, size_t n, co
     if (!d_proofs || !n || !d_randomizers128 || !verdicts || !all_ok) return MI_ERR_BAD_ARGS;
     return guarded_ptr(d_proofs, [&](Context &cx) -> int32_t {
         return vs_verify_batch_device(cx, c, d_proofs, n, d_randomizers128, verdicts, all_ok, (hipStream_t)stream);
+    });
+}
+int32_t mi_vs_identify_device(uint64_t c, const void *d_proofs, size_t n, const void *d_randomizers128, uint8_t *verdicts,
+                              void *stream) {
+    if (!d_proofs || !n || !d_randomizers128 || !verdicts) return MI_ERR_BAD_ARGS;
+    return guarded_ptr(d_proofs, [&](Context &cx) -> int32_t {
+        return vs_identify_device(cx, c, d_proofs, n, d_randomizers128, verdicts, (hipStream_t)stream);
     });
 }
 int32_t mi_vs_verify_block(uint64_t c, const mi_vs_proof *proofs, size_t n, const uint8_t *randomizers128, uint8_t *verdicts,

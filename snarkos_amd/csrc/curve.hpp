@@ -42,7 +42,7 @@ MI_HD Fq fm(const Fq &a, const Fq &b) {
 }
 template <bool I>
 MI_HD Fq fs(const Fq &a) {
-    if constexpr (I) return mul(a, a);
+    if constexpr (I) return sqr(a);
     else return sqrq(a);
 }
 

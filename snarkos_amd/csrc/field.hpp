@@ -278,9 +278,15 @@ MI_HD Fp<FqP> mul_nr(const Fp<FqP> &a, const Fp<FqP> &b) {
 #endif
 }
 
+// a^2: the device has a dedicated squaring (n (n + 1) / 2 limb products for the square, the same reduction: ~0.78 of a
+// product's instructions); the value is the product's, bit for bit
 template <class P>
 MI_HD Fp<P> sqr(const Fp<P> &a) {
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(MI_MUL32)
+    return sqr_comba_gen<P>(a);
+#else
     return mul(a, a);
+#endif
 }
 
 template <class P>
@@ -346,7 +352,7 @@ using Fr = Fp<FrP>;
 #endif
 // operands by value: 24 + 12 VGPRs travel in registers (by reference they would go through scratch memory)
 inline MI_NI Fq mulq(Fq a, Fq b) { return mul(a, b); }
-inline MI_NI Fq sqrq(Fq a) { return mul(a, a); }
+inline MI_NI Fq sqrq(Fq a) { return sqr(a); }
 // Inverse by the binary extended Euclid algorithm (shifts and subtractions only: ~10x fewer instructions
 // than the Fermat power on one lane).  Input and output in Montgomery form; inv(0) = 0.
 template <class P>

@@ -5,8 +5,11 @@
 //     s P = s1 P + s2 phi(P) with s1, s2 < 2^127: two half-length chains that run on two lanes;
 //   * signed fixed windows of W bits: lanes of a wave run in lockstep, so a data-dependent addition (double-and-add,
 //     NAF) costs every lane an addition per bit whatever its own digit; with fixed windows every lane adds once per
-//     W doublings.  The table {P, 2P, .., 2^(W-1) P} lives in global memory (192 B per entry and lane, too large for
-//     registers or LDS at the occupancy wanted), read once per window.
+//     W doublings.  The table {P, 2P, .., 2^(W-1) P} is made affine with one shared inversion (every addition of the
+//     chain is then a mixed one) and lives in global memory (96 B per entry and lane: too large for registers or
+//     LDS at the occupancy wanted), read once per window;
+//   * the accumulator is Jacobian: a chain is mostly doublings, 2M + 5S there against 6M + 3S in XYZZ, with the
+//     dedicated squaring of field.hpp.
 // Reference: snarkvm_curves' `ProjectiveCurve::mul` / `mul_bits` double-and-add (snarkVM 1.0.0 @ dea322b, curves/src/
 // templates/short_weierstrass_jacobian/projective.rs, un-vendored) and bls12_377::g1's GLV
 // parameters; constants here are derived in tools/gen_constants.py.
@@ -129,45 +132,112 @@ struct GlvDigits {
     }
 };
 
-// table[e] = (e + 1) P for e < 2^(W-1), in this lane's slice of global memory; P not infinity
-template <int W>
-__device__ __forceinline__ void glv_build_table(G1Xyzz *tab, const G1Affine &P) {
-    G1Xyzz one = G1Xyzz{P.x, P.y, Fq::one(), Fq::one()};
-    store_xyzz(&tab[0], one);
-    G1Xyzz two = dbl_affine(P);
-    store_xyzz(&tab[1], two);
-    G1Xyzz three = add_mixed(two, P);
-    store_xyzz(&tab[2], three);
-    G1Xyzz four = dbl(two);
-    store_xyzz(&tab[3], four);
-    if constexpr (W == 4) {
-        store_xyzz(&tab[4], add_mixed(four, P));
-        G1Xyzz six = dbl(three);
-        store_xyzz(&tab[5], six);
-        store_xyzz(&tab[6], add_mixed(six, P));
-        store_xyzz(&tab[7], dbl(four));
-    }
+// ---- the chain's own group law: Jacobian doubling is 2M + 5S against 6M + 3S in XYZZ, and a chain is mostly doublings
+// 2 (X, Y, Z), a = 0 (EFD dbl-2009-l); Z = 0 stays Z = 0
+MI_HD G1Jac glv_dbl(const G1Jac &p) {
+    const Fq a = sqrq(p.x), b = sqrq(p.y), c = sqrq(b);
+    Fq d = sub(sub(sqrq(add(p.x, b)), a), c);
+    d = dbl(d);
+    const Fq e = add(dbl(a), a), f = sqrq(e);
+    G1Jac r;
+    r.x = sub(f, dbl(d));
+    r.y = sub(mulq(e, sub(d, r.x)), dbl(dbl(dbl(c))));
+    r.z = dbl(mulq(p.y, p.z));
+    return r;
 }
-
-// v P from the table of P's multiples, v < 2^128: NW windows, W doublings and one addition each
-template <int W>
-__device__ __forceinline__ G1Xyzz glv_chain(const G1Xyzz *tab, const uint32_t (&v)[4]) {
+// (X, Y, Z) + affine q, q not infinity (EFD madd-2007-bl: 7M + 4S), all special cases handled
+MI_HD G1Jac glv_add_mixed(const G1Jac &p, const G1Affine &q) {
+    if (p.z.is_zero()) return G1Jac{q.x, q.y, Fq::one()};
+    const Fq z1z1 = sqrq(p.z), u2 = mulq(q.x, z1z1), s2 = mulq(mulq(q.y, p.z), z1z1);
+    const Fq h = sub(u2, p.x), rr = sub(s2, p.y);
+    if (h.is_zero()) {
+        if (rr.is_zero()) return glv_dbl(p);
+        return G1Jac{Fq::one(), Fq::one(), Fq::zero()};
+    }
+    const Fq hh = sqrq(h), i = dbl(dbl(hh)), j = mulq(h, i), r2 = dbl(rr), v = mulq(p.x, i);
+    G1Jac r;
+    r.x = sub(sub(sqrq(r2), j), dbl(v));
+    r.y = sub(mulq(r2, sub(v, r.x)), dbl(mulq(p.y, j)));
+    r.z = sub(sub(sqrq(add(p.z, h)), z1z1), hh);
+    return r;
+}
+MI_HD G1Xyzz glv_to_xyzz(const G1Jac &p) {
+    if (p.z.is_zero()) return G1Xyzz::inf();
+    const Fq zz = sqrq(p.z);
+    return G1Xyzz{p.x, p.y, zz, mulq(zz, p.z)};
+}
+// v P from a table of P's multiples (T::get(e, negate) = +-(e + 1) P, affine), v < 2^128: NW windows, W doublings and
+// one mixed addition each
+template <int W, class T>
+MI_HD G1Xyzz glv_chain(const T &tab, const uint32_t (&v)[4]) {
     GlvDigits<W> dg;
     dg.recode(v);
-    G1Xyzz acc = G1Xyzz::inf();
+    G1Jac acc = G1Jac{Fq::one(), Fq::one(), Fq::zero()};
     for (int i = GlvDigits<W>::NW - 1; i >= 0; i--) {
         if (i != GlvDigits<W>::NW - 1) {
 #pragma unroll 1
-            for (int k = 0; k < W; k++) acc = dbl(acc);
+            for (int k = 0; k < W; k++) acc = glv_dbl(acc);
         }
         const int d = dg.digit(i);
         if (d != 0) {
-            G1Xyzz t = load_xyzz(&tab[(d < 0 ? -d : d) - 1]);
-            if (d < 0) t.y = neg(t.y);
-            acc = add(acc, t);
+            const G1Affine t = tab.get((uint32_t)((d < 0 ? -d : d) - 1), d < 0);
+            if (!t.is_inf()) acc = glv_add_mixed(acc, t);
         }
     }
-    return acc;
+    return glv_to_xyzz(acc);
 }
+
+#if defined(__HIPCC__)
+__device__ __forceinline__ void glv_store_affine(G1Affine *dst, const G1Affine &a) {
+    uint4 *o = reinterpret_cast<uint4 *>(dst);
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        o[k] = make_uint4(a.x.l[4 * k], a.x.l[4 * k + 1], a.x.l[4 * k + 2], a.x.l[4 * k + 3]);
+        o[3 + k] = make_uint4(a.y.l[4 * k], a.y.l[4 * k + 1], a.y.l[4 * k + 2], a.y.l[4 * k + 3]);
+    }
+}
+
+// table[e] = (e + 1) P for e < 2^(W-1), AFFINE (one shared inversion: every addition of the chain is then a mixed one),
+// in this lane's slice of global memory; P not infinity.  An entry that is the point at infinity (P of small order)
+// is stored as (0, 0).
+template <int W>
+__device__ __forceinline__ void glv_build_table(G1Affine *tab, const G1Affine &P) {
+    constexpr int E = 1 << (W - 1);
+    glv_store_affine(&tab[0], P);
+    G1Xyzz m[E];  // m[e] = (e + 1) P; m[0] unused
+    m[1] = dbl_affine(P);
+    m[2] = add_mixed(m[1], P);
+    m[3] = dbl(m[1]);
+    if constexpr (W == 4) {
+        m[4] = add_mixed(m[3], P);
+        m[5] = dbl(m[2]);
+        m[6] = add_mixed(m[5], P);
+        m[7] = dbl(m[3]);
+    }
+    // 1 / (zz zzz) of every entry from one inversion (Montgomery's trick); an infinite entry enters as 1
+    Fq w[E], pre[E];
+    Fq run = Fq::one();
+#pragma unroll
+    for (int e = 1; e < E; e++) {
+        w[e] = m[e].is_inf() ? Fq::one() : mulq(m[e].zz, m[e].zzz);
+        pre[e] = run;
+        run = mulq(run, w[e]);
+    }
+    Fq inv = invq(run);
+#pragma unroll
+    for (int e = E - 1; e >= 1; e--) {
+        const Fq iw = mulq(inv, pre[e]);  // 1 / w[e]
+        inv = mulq(inv, w[e]);
+        G1Affine a = G1Affine::inf();
+        if (!m[e].is_inf()) a = G1Affine{mulq(m[e].x, mulq(iw, m[e].zzz)), mulq(m[e].y, mulq(iw, m[e].zz))};
+        glv_store_affine(&tab[e], a);
+    }
+}
+
+struct GlvGlobalTable {
+    const G1Affine *tab;
+    __device__ __forceinline__ G1Affine get(uint32_t e, bool negate) const { return load_point(tab, (e << 1) | (negate ? 1u : 0u)); }
+};
+#endif
 
 }  // namespace mi

@@ -440,7 +440,7 @@ __device__ __attribute__((noinline)) bool vs_point_ok(const uint32_t *__restrict
     }
     if (!vs_limbs_below(x.l, FqP::MOD, 12) || !vs_limbs_below(y.l, FqP::MOD, 12)) return false;
     if (!any) return true;
-    return mulq(y, y) == add(mulq(mulq(x, x), x), Fq::one());
+    return sqrq(y) == add(mulq(sqrq(x), x), Fq::one());
 }
 
 // FS = 0: the SHA-256 transcript is walked here; FS = 1: the challenges come from `chal` (n x 3 x 128 bits: z_beta,
@@ -795,7 +795,7 @@ __host__ __device__ __forceinline__ uint32_t vs_chains_of(uint32_t per_proof, ui
     return 2 * vs_terms_of(per_proof, hiding, n_bounded) - 2;
 }
 __global__ void __launch_bounds__(256) vs_terms_kernel(size_t n, VsTermsIn in, const mi_vs_circuit_vk *__restrict__ circuits,
-                                                      const VsConsts *__restrict__ kc, G1Xyzz *__restrict__ tables,
+                                                      const VsConsts *__restrict__ kc, G1Affine *__restrict__ tables,
                                                       G1Xyzz *__restrict__ terms) {
     const uint32_t PP = kc->per_proof, H = kc->hiding, CH = vs_chains_of(PP, H, kc->n_bounded);
     const uint32_t n_c = PP + MI_VS_VK_COMMS + 1 + H;
@@ -848,102 +848,136 @@ __global__ void __launch_bounds__(256) vs_terms_kernel(size_t n, VsTermsIn in, c
     }
     G1Xyzz acc = G1Xyzz::inf();
     if (!P.is_inf() && (sv[0] | sv[1] | sv[2] | sv[3])) {
-        G1Xyzz *tab = tables + t * (1u << (VS_GLV_W - 1));
+        G1Affine *tab = tables + t * (1u << (VS_GLV_W - 1));
         glv_build_table<VS_GLV_W>(tab, P);
-        acc = glv_chain<VS_GLV_W>(tab, sv);
+        acc = glv_chain<VS_GLV_W>(GlvGlobalTable{tab}, sv);
     }
     store_xyzz(&terms[t], acc);
 }
 
-// block i (128 lanes): segmented tree sums of the proof's chains in LDS -> ps[i][4] affine (total_c, -total_w, class 0,
-// class 1; unused ones infinity)
-#define VS_SUM_LANES 128
-__global__ void __launch_bounds__(VS_SUM_LANES) vs_sums_kernel(size_t n, const G1Xyzz *__restrict__ terms,
-                                                               const VsConsts *__restrict__ kc, G1Affine *__restrict__ ps) {
-    __shared__ G1Xyzz sh[VS_SUM_LANES];
-    const size_t i = blockIdx.x;
+// block b (VS_GROUP proofs, LP = 64 or 128 lanes each: one wave per SIMD at 1024 proofs, so the sums run at a lone
+// wave's latency): segmented tree sums of every proof's chains in LDS -> ps[i][4] affine (total_c, -total_w, class 0,
+// class 1; unused ones infinity) and the same accumulators summed over the group -> gs[b][4].  The group's sums sit on
+// the lanes next to the first proof's segment heads, so that all inversions of a wave are one lockstep call.
+template <uint32_t LP>
+__global__ void __launch_bounds__(VS_GROUP * LP) vs_sums_kernel(size_t n, const G1Xyzz *__restrict__ terms,
+                                                                const VsConsts *__restrict__ kc, G1Affine *__restrict__ ps,
+                                                                G1Affine *__restrict__ gs) {
+    extern __shared__ uint4 sums_lds[];  // VS_GROUP * LP G1Xyzz
+    G1Xyzz *sh = reinterpret_cast<G1Xyzz *>(sums_lds);
+    const uint32_t pl = threadIdx.x / LP, l = threadIdx.x % LP;
+    const size_t first = (size_t)blockIdx.x * VS_GROUP, i = first + pl;
     const uint32_t PP = kc->per_proof, H = kc->hiding, CH = vs_chains_of(PP, H, kc->n_bounded);
     const uint32_t n_c = PP + MI_VS_VK_COMMS + 1 + H;
     const uint32_t lo1 = 2 * n_c, lo2 = lo1 + 2, lo3 = lo2 + 2 * kc->class_count[0];
-    const uint32_t l = threadIdx.x;
     uint32_t seg, lo, hi;
     if (l < lo1) { seg = 0; lo = 0; hi = lo1; }
     else if (l < lo2) { seg = 1; lo = lo1; hi = lo2; }
     else if (l < lo3) { seg = 2; lo = lo2; hi = lo3; }
     else { seg = 3; lo = lo3; hi = CH; }
-    const bool live = l < CH;
+    const bool live = i < n && l < CH;
     G1Xyzz mine = live ? load_xyzz(&terms[i * CH + l]) : G1Xyzz::inf();
-    store_xyzz(&sh[l], mine);
+    store_xyzz(&sh[threadIdx.x], mine);
     const uint32_t pos = l - lo;
-    for (uint32_t stride = 1; stride < VS_SUM_LANES; stride <<= 1) {
+#pragma unroll 1
+    for (uint32_t stride = 1; stride < LP; stride <<= 1) {
         __syncthreads();
         const bool act = live && (pos & (2 * stride - 1)) == 0 && l + stride < hi;
-        if (act) mine = add(mine, load_xyzz(&sh[l + stride]));
+        if (act) mine = add(load_xyzz(&sh[threadIdx.x]), load_xyzz(&sh[threadIdx.x + stride]));
         __syncthreads();
-        if (act) store_xyzz(&sh[l], mine);
+        if (act) store_xyzz(&sh[threadIdx.x], mine);
     }
-    if (live && pos == 0) {
+    __syncthreads();
+    mine = load_xyzz(&sh[threadIdx.x]);
+    if (pl == 0 && live && pos == 0) {  // the group's sum of this accumulator, parked on the neighbouring lane's slot
+        G1Xyzz g = mine;
+        for (uint32_t p = 1; p < VS_GROUP; p++)
+            if (first + p < n) g = add(g, load_xyzz(&sh[p * LP + l]));
+        store_xyzz(&sh[threadIdx.x + 1], g);
+    }
+    __syncthreads();
+    const bool head = live && pos == 0, ghead = pl == 0 && live && pos == 1;
+    if (head || ghead) {
+        if (ghead) mine = load_xyzz(&sh[threadIdx.x]);
         G1Affine pa = to_affine(mine);
         if (seg == 1) pa = neg(pa);
-        copy_g1(&ps[i * MI_MAX_PAIRS + seg], &pa);
+        copy_g1(head ? &ps[i * MI_MAX_PAIRS + seg] : &gs[(size_t)blockIdx.x * MI_MAX_PAIRS + seg], &pa);
     }
-    if (l < MI_MAX_PAIRS) {  // segments of no chain at all (contexts without that class)
+    if (l < MI_MAX_PAIRS && i < n) {  // segments of no chain at all (contexts without that class)
         const uint32_t slo[4] = {0, lo1, lo2, lo3}, shi[4] = {lo1, lo2, lo3, CH};
         if (slo[l] >= shi[l]) {
             G1Affine z = G1Affine::inf();
             copy_g1(&ps[i * MI_MAX_PAIRS + l], &z);
+            if (pl == 0) copy_g1(&gs[(size_t)blockIdx.x * MI_MAX_PAIRS + l], &z);
         }
     }
 }
 
-// block b (192 lanes): the workgroup-cooperative pairing product over the summed accumulators of proofs [b g, (b+1) g).
-// g > 1: out[b] = group passes (and none of its proofs failed the algebraic checks); g = 1: out[b] = verdict of proof b,
-// blocks whose group (of pg proofs, parent_ok) passed write it without computing.
+// The pairing products of the fallback, workgroup-cooperative (192 lanes), over 2 + n_bounds pairs.
 struct VsG2Keys {
     const G2Prepared *q[MI_MAX_PAIRS];  // h, tau h, shift_h[0], shift_h[1]
 };
-__global__ void __launch_bounds__(PW_THREADS) vs_check_kernel(size_t n, uint32_t g, const G1Affine *__restrict__ sums, VsG2Keys keys,
-                                                              const VsConsts *__restrict__ kc, const PairingConsts *__restrict__ pc,
-                                                              const uint8_t *__restrict__ alg_ok, const uint8_t *__restrict__ parent_ok,
-                                                              uint32_t pg, uint8_t *__restrict__ out) {
+// block b: group b's summed accumulators.  A group whose product is one has only valid proofs (verdicts written here);
+// otherwise, or when a member failed the algebraic checks (its points may be anything, so the sum says nothing), the
+// members that are still undecided go on the list of proofs to check one by one.
+__global__ void __launch_bounds__(PW_THREADS) vs_group_check_kernel(size_t n, const G1Affine *__restrict__ gs, VsG2Keys keys,
+                                                                    const VsConsts *__restrict__ kc,
+                                                                    const PairingConsts *__restrict__ pc,
+                                                                    const uint8_t *__restrict__ alg_ok, uint8_t *__restrict__ verdicts,
+                                                                    uint32_t *__restrict__ todo, uint32_t *__restrict__ todo_count) {
     extern __shared__ uint4 pw_lds[];  // PW_LDS_BYTES
     LShared &S = *(LShared *)pw_lds;
     __shared__ G1Affine ps[MI_MAX_PAIRS];
     __shared__ const G2Prepared *qs[MI_MAX_PAIRS];
     __shared__ Fq12 result;
-    const size_t b = blockIdx.x, first = b * g, last = first + g < n ? first + g : n;
+    const size_t b = blockIdx.x, first = b * VS_GROUP, last = first + VS_GROUP < n ? first + VS_GROUP : n;
     const int K = 2 + (int)kc->n_bounds, tid = threadIdx.x;
     bool alg = true;
     for (size_t i = first; i < last; i++) alg = alg && alg_ok[i];
-    if (parent_ok && parent_ok[first / pg]) {  // uniform: the group's product was one, nothing to name in it
-        if (tid == 0) out[b] = alg ? 1 : 0;
-        return;
-    }
-    if (!alg) {  // uniform: a malformed / algebraically failing proof decides without a pairing
-        if (tid == 0) out[b] = 0;
-        return;
-    }
-    if ((tid & 63) == 0 || tid == 1) {  // one lane per accumulator, on different waves where there are three
-        const int which = tid == 1 ? 3 : (tid >> 6);
-        if (which < K) {
-            G1Affine pa;
-            copy_g1(&pa, &sums[first * MI_MAX_PAIRS + which]);
-            if (last - first > 1) {
-                G1Xyzz a = G1Xyzz::from_affine(pa);
-                for (size_t i = first + 1; i < last; i++) {
-                    G1Affine t;
-                    copy_g1(&t, &sums[i * MI_MAX_PAIRS + which]);
-                    a = add_mixed(a, t);
-                }
-                pa = to_affine(a);
-            }
-            ps[which] = pa;
-            qs[which] = keys.q[which];
+    bool ok = false;
+    if (alg) {  // uniform
+        if (tid < K) {
+            copy_g1(&ps[tid], &gs[b * MI_MAX_PAIRS + tid]);
+            qs[tid] = keys.q[tid];
         }
+        __syncthreads();
+        pw_pairing_product(S, ps, qs, K, pc, &result);
+        __syncthreads();
+        ok = result.is_one();
     }
-    __syncthreads();
-    pw_pairing_product(S, ps, qs, K, pc, &result);
-    if (tid == 0) out[b] = result.is_one() ? 1 : 0;
+    if (tid < (int)(last - first)) {
+        const size_t i = first + tid;
+        if (ok) verdicts[i] = 1;
+        else if (!alg_ok[i]) verdicts[i] = 0;
+        else todo[atomicAdd(todo_count, 1u)] = (uint32_t)i;
+    }
+}
+// a fixed grid walks the list: launching one block per proof would spend ~1 us of dispatch per block, most of them to
+// find nothing to do
+__global__ void __launch_bounds__(PW_THREADS) vs_proof_check_kernel(const G1Affine *__restrict__ sums, VsG2Keys keys,
+                                                                    const VsConsts *__restrict__ kc,
+                                                                    const PairingConsts *__restrict__ pc, uint8_t *__restrict__ verdicts,
+                                                                    const uint32_t *__restrict__ todo,
+                                                                    const uint32_t *__restrict__ todo_count) {
+    extern __shared__ uint4 pw_lds[];  // PW_LDS_BYTES
+    LShared &S = *(LShared *)pw_lds;
+    __shared__ G1Affine ps[MI_MAX_PAIRS];
+    __shared__ const G2Prepared *qs[MI_MAX_PAIRS];
+    __shared__ Fq12 result;
+    const int K = 2 + (int)kc->n_bounds, tid = threadIdx.x;
+    const uint32_t count = *todo_count;
+    for (uint32_t idx = blockIdx.x; idx < count; idx += gridDim.x) {  // uniform
+        const size_t i = todo[idx];
+        if (tid < K) {
+            copy_g1(&ps[tid], &sums[i * MI_MAX_PAIRS + tid]);
+            qs[tid] = keys.q[tid];
+        }
+        __syncthreads();
+        pw_pairing_product(S, ps, qs, K, pc, &result);
+        __syncthreads();
+        if (tid == 0) verdicts[i] = result.is_one() ? 1 : 0;
+        __syncthreads();
+    }
 }
 
 // ---------------------------------------------------------------- host drivers
@@ -1048,8 +1082,9 @@ static bool vs_enqueue_msms(Context &cx, const VsWork &w, hipStream_t st, int la
 // pinned result buffers, so the next batches' kernels run while batch k is folded.  When every lane is taken the call
 // WAITS for one (the device lock is released meanwhile): a synchronous verify beside a saturated stream is late, not
 // refused.
+// msm = false: derive only (the caller wants the lane's workspaces for the per-proof fallback, not the aggregate)
 static int32_t vs_accumulate_begin_impl(Context &cx, const VsCtx &vc, const void *d_proofs, size_t n, const void *d_rand,
-                                        hipStream_t st, uint64_t *handle, VsWork *work_out) {
+                                        hipStream_t st, uint64_t *handle, VsWork *work_out, bool msm = true) {
     VsKeys &v = vs_keys(cx, vc);
     VsPipe &pp = vs_pipe(cx);
     int par = -1;
@@ -1102,13 +1137,15 @@ static int32_t vs_accumulate_begin_impl(Context &cx, const VsCtx &vc, const void
     char nm[32];
     snprintf(nm, sizeof nm, "vs.alg_pin%d", par);
     a.h_alg = (uint8_t *)cx.pin_named(nm, n);
-    {
-        HostSpan hs("begin.alg_copy");
-        MI_HIP(hipMemcpyAsync(a.h_alg, w.o.alg_ok, n, hipMemcpyDeviceToHost, sa));  // ahead of the MSMs: their done-event covers it
+    if (msm) {
+        {
+            HostSpan hs("begin.alg_copy");
+            MI_HIP(hipMemcpyAsync(a.h_alg, w.o.alg_ok, n, hipMemcpyDeviceToHost, sa));  // ahead of the MSMs: their done-event covers it
+        }
+        HostSpan hs_msm("begin.msm_enqueue");
+        static const int vs_c = getenv("MI_SNARK_VS_C") ? atoi(getenv("MI_SNARK_VS_C")) : 0;  // window width override (experiments)
+        a.fused = vs_enqueue_msms(cx, w, sa, par, a.j, vs_c);
     }
-    HostSpan hs_msm("begin.msm_enqueue");
-    static const int vs_c = getenv("MI_SNARK_VS_C") ? atoi(getenv("MI_SNARK_VS_C")) : 0;  // window width override (experiments)
-    a.fused = vs_enqueue_msms(cx, w, sa, par, a.j, vs_c);
     a.nb[0] = w.nb[0];
     a.nb[1] = w.nb[1];
     a.n = n;
@@ -1273,38 +1310,51 @@ static void vs_identify(Context &cx, VsKeys &v, const VsWork &w, size_t n, int l
     snprintf(nm, sizeof nm, "vs%d.terms", lane);
     G1Xyzz *terms = (G1Xyzz *)cx.buf(nm, sizeof(G1Xyzz) * n * CH);
     snprintf(nm, sizeof nm, "vs%d.tables", lane);
-    G1Xyzz *tables = (G1Xyzz *)cx.buf(nm, sizeof(G1Xyzz) * n * CH * (1u << (VS_GLV_W - 1)));
+    G1Affine *tables = (G1Affine *)cx.buf(nm, sizeof(G1Affine) * n * CH * (1u << (VS_GLV_W - 1)));
     snprintf(nm, sizeof nm, "vs%d.sums", lane);
-    G1Affine *sums = (G1Affine *)cx.buf(nm, sizeof(G1Affine) * n * MI_MAX_PAIRS);
+    G1Affine *sums = (G1Affine *)cx.buf(nm, sizeof(G1Affine) * (n + n_groups) * MI_MAX_PAIRS);
+    G1Affine *gsums = sums + n * MI_MAX_PAIRS;
     snprintf(nm, sizeof nm, "vs%d.verdicts", lane);
-    uint8_t *d_verdicts = (uint8_t *)cx.buf(nm, n + n_groups);
-    uint8_t *d_group_ok = d_verdicts + n;
+    const size_t todo_off = (n + 15) / 16 * 16;
+    uint8_t *d_verdicts = (uint8_t *)cx.buf(nm, todo_off + 4 * (n + 1));
+    uint32_t *d_todo = (uint32_t *)(d_verdicts + todo_off), *d_count = d_todo + n;
     VsTermsIn in;
     in.pts1 = w.o.pts1; in.sc1 = w.o.sc1; in.sc2 = w.o.sc2;
     for (int c = 0; c < MI_VS_MAX_BOUNDS; c++) { in.ptsb[c] = w.o.ptsb[c]; in.scb[c] = w.o.scb[c]; }
     in.vk_scal = w.o.vk_scal; in.g_scal = w.o.g_scal; in.h_scal = w.o.h_scal; in.circuit_of = w.o.circuit_of;
     const VsConsts *kc = (const VsConsts *)v.consts.p;
+    MI_HIP(hipMemsetAsync(d_count, 0, 4, st));
     cx.prof.begin("vs_terms", st, n);
     hipLaunchKernelGGL(vs_terms_kernel, dim3(cdiv(n * CH, 256)), dim3(256), 0, st, n, in, (const mi_vs_circuit_vk *)v.circuits.p, kc,
                        tables, terms);
     cx.prof.end("vs_terms", st);
-    if (CH > VS_SUM_LANES) throw std::runtime_error("vs_identify: shape has more chains per proof than vs_sums_kernel lanes");
+    if (CH > 128) throw std::runtime_error("vs_identify: shape has more chains per proof than vs_sums_kernel lanes");
+    const uint32_t LP = CH <= 64 ? 64 : 128;
+    const size_t sums_lds = sizeof(G1Xyzz) * VS_GROUP * LP;
     cx.prof.begin("vs_sums", st, n);
-    hipLaunchKernelGGL(vs_sums_kernel, dim3((unsigned)n), dim3(VS_SUM_LANES), 0, st, n, terms, kc, sums);
+    if (LP == 64) {
+        cx.raise_lds_limit((const void *)vs_sums_kernel<64>, (int)sums_lds);
+        hipLaunchKernelGGL(vs_sums_kernel<64>, dim3((unsigned)n_groups), dim3(VS_GROUP * 64), sums_lds, st, n, terms, kc, sums, gsums);
+    } else {
+        cx.raise_lds_limit((const void *)vs_sums_kernel<128>, (int)sums_lds);
+        hipLaunchKernelGGL(vs_sums_kernel<128>, dim3((unsigned)n_groups), dim3(VS_GROUP * 128), sums_lds, st, n, terms, kc, sums, gsums);
+    }
     cx.prof.end("vs_sums", st);
     VsG2Keys keys;
     const G2Prepared *qs[MI_MAX_PAIRS];
     (void)vs_g2_keys(v, qs);
     for (int k = 0; k < MI_MAX_PAIRS; k++) keys.q[k] = qs[k];
-    cx.raise_lds_limit((const void *)vs_check_kernel, (int)PW_LDS_BYTES);
+    cx.raise_lds_limit((const void *)vs_group_check_kernel, (int)PW_LDS_BYTES);
+    cx.raise_lds_limit((const void *)vs_proof_check_kernel, (int)PW_LDS_BYTES);
     const PairingConsts *pc = pairing_consts(cx, st);
     cx.prof.begin("vs_groups", st, n);
-    hipLaunchKernelGGL(vs_check_kernel, dim3((unsigned)n_groups), dim3(PW_THREADS), PW_LDS_BYTES, st, n, (uint32_t)VS_GROUP, sums, keys,
-                       kc, pc, w.o.alg_ok, (const uint8_t *)nullptr, 1u, d_group_ok);
+    hipLaunchKernelGGL(vs_group_check_kernel, dim3((unsigned)n_groups), dim3(PW_THREADS), PW_LDS_BYTES, st, n, gsums, keys, kc, pc,
+                       w.o.alg_ok, d_verdicts, d_todo, d_count);
     cx.prof.end("vs_groups", st);
     cx.prof.begin("vs_per_proof", st, n);
-    hipLaunchKernelGGL(vs_check_kernel, dim3((unsigned)n), dim3(PW_THREADS), PW_LDS_BYTES, st, n, 1u, sums, keys, kc, pc, w.o.alg_ok,
-                       (const uint8_t *)d_group_ok, (uint32_t)VS_GROUP, d_verdicts);
+    const unsigned grid = (unsigned)std::min<size_t>(n, (size_t)cx.n_cus);
+    hipLaunchKernelGGL(vs_proof_check_kernel, dim3(grid), dim3(PW_THREADS), PW_LDS_BYTES, st, sums, keys, kc, pc, d_verdicts,
+                       (const uint32_t *)d_todo, (const uint32_t *)d_count);
     MI_HIP(hipGetLastError());
     cx.prof.end("vs_per_proof", st);
     snprintf(nm, sizeof nm, "vs.verdict_pin%d", lane);
@@ -1342,6 +1392,28 @@ int32_t vs_verify_batch_device(Context &cx, uint64_t id, const void *d_proofs, s
     }
     vs_release_lane(cx, a);
     return s;
+}
+
+// the verdict vector of a batch KNOWN to fail (a streamed batch whose all_ok came back 0: the stream keeps no per-proof
+// state): derive and the per-proof fallback, without the aggregate MSMs and product
+int32_t vs_identify_device(Context &cx, uint64_t id, const void *d_proofs, size_t n, const void *d_rand, uint8_t *verdicts,
+                           hipStream_t st) {
+    std::shared_ptr<VsCtx> vc = vs_find(id);
+    if (!vc) return MI_ERR_BAD_ARGS;
+    if (n == 0) return MI_OK;
+    VsWork w;
+    uint64_t hd;
+    const int32_t s = vs_accumulate_begin_impl(cx, *vc, d_proofs, n, d_rand, st, &hd, &w, false);
+    if (s != MI_OK) return s;
+    VsAcc &a = vs_pipe(cx).acc[hd & 0xff];
+    try {
+        vs_identify(cx, vs_keys(cx, *vc), w, n, (int)(hd & 0xff), a.st, verdicts);
+    } catch (...) {
+        vs_release_lane(cx, a);
+        throw;
+    }
+    vs_release_lane(cx, a);
+    return MI_OK;
 }
 
 // ---------------------------------------------------------------- one block over all devices of the process

@@ -3,6 +3,7 @@
 // Test infrastructure: compiled by tests/test_host_arith.py into tests/hostlib/libhostcheck.so.
 #include <string.h>
 #include "../../snarkos_amd/csrc/tower.hpp"
+#include "../../snarkos_amd/csrc/glv.hpp"
 
 using namespace mi;
 
@@ -12,6 +13,32 @@ static Fq fq_from64(const uint64_t *l) {
     return r;
 }
 
+// the fallback's scalar multiplication (glv.hpp) on the host: split, signed windows, Jacobian chain; the table is built
+// one entry at a time here (the device shares one inversion over it)
+template <int W>
+static G1Affine glv_mul_host(const G1Affine &p, const uint32_t *k8) {
+    struct Tab {
+        G1Affine t[8];
+        G1Affine get(uint32_t e, bool negate) const { return negate ? neg(t[e]) : t[e]; }
+    };
+    uint32_t s[8], s1[4], s2[4];
+    for (int i = 0; i < 8; i++) s[i] = k8[i];
+    glv_split(s, s1, s2);
+    G1Xyzz sum = G1Xyzz::inf();
+    for (int half = 0; half < 2; half++) {
+        G1Affine q = p;
+        if (half) q.x = mul(q.x, glv_beta());
+        if (q.is_inf()) continue;
+        Tab tab;
+        G1Xyzz m = G1Xyzz::from_affine(q);
+        for (int e = 0; e < (1 << (W - 1)); e++) {
+            tab.t[e] = to_affine(m);
+            m = add_mixed(m, q);
+        }
+        sum = add(sum, glv_chain<W>(tab, half ? s2 : s1));
+    }
+    return to_affine(sum);
+}
 extern "C" {
 void hc_fq_mul(const Fq *a, const Fq *b, Fq *o) { *o = mul(*a, *b); }
 void hc_fq_mul32(const Fq *a, const Fq *b, Fq *o) { *o = mul32(*a, *b); }
@@ -43,6 +70,19 @@ void hc_pairing_product(const G1Affine *ps, const G2Affine *qs, int n, Fq12 *out
         for (int k = 0; k < 12; k++) pc.frob[e][k] = fq_from64(MI_FROB[e][k]);
     *out = final_exponentiation(miller_product(ps, qp, n), pc);
 }
+void hc_glv_split(const uint32_t *s8, uint32_t *s1, uint32_t *s2) {
+    uint32_t s[8], a[4], b[4];
+    for (int i = 0; i < 8; i++) s[i] = s8[i];
+    glv_split(s, a, b);
+    for (int i = 0; i < 4; i++) { s1[i] = a[i]; s2[i] = b[i]; }
+}
+void hc_glv_digits(int w, const uint32_t *v4, int *out) {  // out[NW]
+    uint32_t v[4] = {v4[0], v4[1], v4[2], v4[3]};
+    if (w == 3) { GlvDigits<3> d; d.recode(v); for (int i = 0; i < GlvDigits<3>::NW; i++) out[i] = d.digit(i); }
+    else { GlvDigits<4> d; d.recode(v); for (int i = 0; i < GlvDigits<4>::NW; i++) out[i] = d.digit(i); }
+}
+void hc_glv_mul(int w, const G1Affine *p, const uint32_t *k8, G1Affine *o) { *o = w == 3 ? glv_mul_host<3>(*p, k8) : glv_mul_host<4>(*p, k8); }
+void hc_fq_sqr(const Fq *a, Fq *o) { *o = sqr(*a); }
 int hc_constants_ok() {
     // the 32-bit limb tables in field.hpp must equal the generated 64-bit constants
     for (int i = 0; i < 6; i++) {

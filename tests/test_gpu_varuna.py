@@ -100,6 +100,13 @@ def test_pipelined_stream_matches_batchwise(orc, mi):
         assert list(v.verify_stream(iter(seq))) == want
         assert [v.verify_batch(p, r)[0] for p, r in seq] == want
         assert list(v.verify_stream(iter([]))) == []
+        # verdict vectors from the stream: a failing batch is taken apart (mi_vs_identify_device), the others yield None
+        got = list(v.verify_stream(iter(seq), verdicts=True))
+        w7 = np.ones(48, dtype=np.uint8); w7[7] = 0
+        assert [g[0] for g in got] == want
+        for (ok, vec), exp in zip(got, want):
+            assert (vec is None) if exp else (vec == w7).all()
+        assert (v.identify(bp, gr) == w7).all() and v.identify(gp, gr).all()
         # the exchange hook of the Python wrapper (identity 'all-gather' of one rank), single batches and groups of three
         seen = []
 

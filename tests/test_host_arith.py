@@ -121,6 +121,40 @@ def test_g1_group_law(hc, orc):
     assert (out == orc.g1_mul(a[6], orc.limbs_to_int(k))).all()
 
 
+def test_glv_scalar_multiplication(hc, orc):
+    """glv.hpp, the per-proof fallback's scalar multiplication: s = s1 + lambda s2 with both halves below 2^127, signed
+    window digits that recompose the value, and the whole chain (endomorphism, Jacobian doubling / mixed addition)
+    against the oracle's double-and-add -- edge scalars included"""
+    import random
+    lam = P.X * P.X - 1
+    assert (lam * lam + lam + 1) == P.R
+    rnd = random.Random(11)
+    edge = [0, 1, 2, lam - 1, lam, lam + 1, 2 * lam, P.R - 1, P.R - 2, (1 << 128) - 1, 1 << 127, (1 << 252) + 12345, lam * lam, lam * (lam + 1)]
+    scalars = edge + [rnd.randrange(P.R) for _ in range(300)]
+    s1, s2 = np.zeros(4, dtype=np.uint32), np.zeros(4, dtype=np.uint32)
+    for s in scalars:
+        s8 = np.frombuffer(orc.int_to_limbs(s, 4).tobytes(), dtype=np.uint32).copy()
+        hc.hc_glv_split(_p(s8), _p(s1), _p(s2))
+        a, b = orc.limbs_to_int(s1.view(np.uint64)), orc.limbs_to_int(s2.view(np.uint64))
+        assert a + lam * b == s and a < lam and b < (1 << 127), hex(s)
+    for w, nw in ((3, 43), (4, 33)):
+        digs = np.zeros(nw, dtype=np.int32)
+        for v in [0, 1, (1 << 128) - 1, (1 << 127) - 1, 1 << 127, int("4" * 32, 16), int("c" * 32, 16)] + [rnd.getrandbits(128) for _ in range(200)]:
+            v4 = np.frombuffer(orc.int_to_limbs(v, 2).tobytes(), dtype=np.uint32).copy()
+            hc.hc_glv_digits(C.c_int(w), _p(v4), _p(digs))
+            assert sum(int(d) << (w * i) for i, d in enumerate(digs)) == v
+            assert all(-(1 << (w - 1)) <= d <= (1 << (w - 1)) for d in digs)
+    pts = rng_points(21, 6)
+    pts[5] = 0
+    out = np.zeros(12, dtype=np.uint64)
+    for i, s in enumerate(edge + [rnd.randrange(P.R) for _ in range(10)]):
+        s8 = np.frombuffer(orc.int_to_limbs(s, 4).tobytes(), dtype=np.uint32).copy()
+        pt = np.ascontiguousarray(pts[i % 6])
+        for w in (3, 4):
+            hc.hc_glv_mul(C.c_int(w), _p(pt), _p(s8), _p(out))
+            assert (out == orc.g1_mul(pt, s)).all(), (i, w)
+
+
 def test_fq12_and_pairing(hc, orc):
     g, h = orc.g1_generator(), orc.g2_generator()
     p = orc.g1_mul(g, 0xABCDEF12345); q = orc.g2_mul(h, 0x13579BDF)

@@ -69,17 +69,97 @@ def gen(name, params, n, lanes, reduce=True):
     return "\n".join(o)
 
 
+def gen_sqr(params, n):
+    """a^2 R^-1: the cross products a_i a_j (i < j) are taken once against the doubled operand a2 = 2a (2a < 2^(32 n):
+    both moduli leave at least 3 spare bits), the squares a_i^2 once: n (n + 1) / 2 limb products instead of n^2; the
+    reduction half (m_i p_j) is the product's.
+    Limb j of 2a is (a_j << 1) | (a_(j-1) >> 31): the bit that comes in from below belongs to the products with a_(j-1),
+    and a_i times it is what the pair (i, j - 1) lost when a_(j-1) << 1 dropped its top bit -- except for i = j - 1,
+    where no such pair exists (the square a_i^2 is taken once, not doubled): those neighbours use b2_j = a_j << 1."""
+    o = []
+    a = o.append
+    a("template <>")
+    a("__device__ __forceinline__ Fp<%s> sqr_comba_gen<%s>(const Fp<%s> &a) {" % (params, params, params))
+    a("    uint32_t m[%d], r[%d], a2[%d], b2[%d];" % (n, n, n, n))
+    a("    a2[0] = a.l[0] << 1; b2[0] = a2[0];")
+    for j in range(1, n):
+        a("    a2[%d] = __builtin_amdgcn_alignbit(a.l[%d], a.l[%d], 31); b2[%d] = a.l[%d] << 1;" % (j, j, j - 1, j, j))
+    a("    uint64_t acc = 0;")
+    a("    uint32_t ovf = 0;")
+    for k in range(2 * n - 1):
+        for kind in ("aa", "mp"):
+            ins = []
+            if kind == "aa":
+                for i in range(n):
+                    j = k - i
+                    if i < j < n:
+                        ins.append('"v"(a.l[%d]), "v"(%s[%d])' % (i, "b2" if j == i + 1 else "a2", j))
+                if k % 2 == 0 and k // 2 < n:
+                    ins.append('"v"(a.l[%d]), "v"(a.l[%d])' % (k // 2, k // 2))
+            else:
+                for i in range(n):
+                    j = k - i
+                    if 1 <= j < n and i < k:
+                        ins.append('"v"(m[%d]), "s"(%s::MOD[%d])' % (i, params, j))
+            if not ins:
+                continue
+            lines = []
+            for idx in range(len(ins)):
+                x = 2 + 2 * idx
+                lines.append("v_mad_u64_u32 %%0, vcc, %%%d, %%%d, %%0" % (x, x + 1))
+                lines.append("v_addc_co_u32 %1, vcc, 0, %1, vcc")
+            a('    asm("%s"' % "\\n\\t".join(lines))
+            a('        : "+&v"(acc), "+&v"(ovf)')
+            a("        : %s" % ", ".join(ins))
+            a('        : "vcc");')
+        if k < n:
+            a("    { const uint32_t lo = (uint32_t)acc, hi = (uint32_t)(acc >> 32); m[%d] = 0u - lo;" % k)
+            a("      acc = ((uint64_t)ovf << 32) + (uint64_t)hi + (uint64_t)(lo != 0); ovf = 0; }")
+        else:
+            a("    { r[%d] = (uint32_t)acc; acc = ((uint64_t)ovf << 32) | (acc >> 32); ovf = 0; }" % (k - n))
+    a("    r[%d] = (uint32_t)acc;" % (n - 1))
+    a("    Fp<%s> out;" % params)
+    for i in range(n):
+        a("    out.l[%d] = r[%d];" % (i, i))
+    a("    reduce_once(out);")
+    a("    return out;")
+    a("}")
+    return "\n".join(o)
+
+
+def sqr_columns_model(a, n):
+    """the integer the squaring's product half accumulates, column by column, exactly as gen_sqr emits it
+    (tests/test_comba_model.py checks it equals a * a)"""
+    al = [(a >> (32 * i)) & 0xFFFFFFFF for i in range(n)]
+    a2 = [((al[j] << 1) | (al[j - 1] >> 31 if j else 0)) & 0xFFFFFFFF for j in range(n)]
+    b2 = [(al[j] << 1) & 0xFFFFFFFF for j in range(n)]
+    tot = 0
+    for k in range(2 * n - 1):
+        col = 0
+        for i in range(n):
+            j = k - i
+            if i < j < n:
+                col += al[i] * (b2[j] if j == i + 1 else a2[j])
+        if k % 2 == 0 and k // 2 < n:
+            col += al[k // 2] ** 2
+        tot += col << (32 * k)
+    return tot
+
+
 def main():
     parts = ["// GENERATED by tools/gen_comba.py -- do not edit.",
              "// Product-scanning (Comba) Montgomery products for gfx950, see field.hpp.",
              "#pragma once",
              "namespace mi {",
              "template <class P, int LANES> __device__ __forceinline__ Fp<P> mul_comba_gen(const Fp<P> &a, const Fp<P> &b);",
-             "template <class P> __device__ __forceinline__ Fp<P> mul_comba_nr_gen(const Fp<P> &a, const Fp<P> &b);"]
+             "template <class P> __device__ __forceinline__ Fp<P> mul_comba_nr_gen(const Fp<P> &a, const Fp<P> &b);",
+             "template <class P> __device__ __forceinline__ Fp<P> sqr_comba_gen(const Fp<P> &a);"]
     for lanes in (1, 2):
         parts.append(gen("Fq", "FqP", 12, lanes))
         parts.append(gen("Fr", "FrP", 8, lanes))
     parts.append(gen("Fq", "FqP", 12, 1, reduce=False))
+    parts.append(gen_sqr("FqP", 12))
+    parts.append(gen_sqr("FrP", 8))
     parts.append("}  // namespace mi")
     open(OUT, "w").write("\n".join(parts) + "\n")
     print("wrote", OUT)
