@@ -621,6 +621,26 @@ def extras(dev, verifier, proofs, rnd):
     want[idx] = 0
     ex["batch_1pct_corrupted"] = {"proofs_per_s": 1024 / dt, "ms": 1e3 * dt, "all_ok": ok,
                                   "verdicts_correct": bool((verdicts == want).all()), "n_bad": int(len(idx))}
+    # the same fallback with one invalid proof and with every proof invalid (group testing: 1 and 256 failing groups),
+    # and the verdict vector of a failed STREAMED batch (mi_vs_identify_device: no aggregate pass)
+    for name, which in (("one_bad", np.array([517])), ("all_bad", np.arange(1024))):
+        b2 = proofs.copy()
+        for i in which:
+            b2[i * L.VS_PROOF_BYTES + ev_off + 32 * 7] ^= 1
+        d_b2 = torch.from_numpy(b2).to(dev)
+        verifier.verify_batch(d_b2, d_rnd)
+        t0 = time.perf_counter()
+        ok2, v2 = verifier.verify_batch(d_b2, d_rnd)
+        dt2 = time.perf_counter() - t0
+        w2 = np.ones(1024, dtype=np.uint8)
+        w2[which] = 0
+        ex["batch_1pct_corrupted"]["ms_" + name] = 1e3 * dt2
+        ex["batch_1pct_corrupted"]["verdicts_correct"] &= bool((v2 == w2).all()) and not ok2
+    verifier.identify(d_bad, d_rnd)
+    t0 = time.perf_counter()
+    v3 = verifier.identify(d_bad, d_rnd)
+    ex["batch_1pct_corrupted"]["ms_identify_only"] = 1e3 * (time.perf_counter() - t0)
+    ex["batch_1pct_corrupted"]["verdicts_correct"] &= bool((v3 == want).all())
     return ex
 
 

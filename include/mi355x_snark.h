@@ -253,6 +253,11 @@ int32_t mi_vs_stream_finish(uint64_t stream);
 /* next verdict in submission order.  block = 0: MI_ERR_AGAIN if it is not ready yet; after the last verdict of a
  * finished stream: MI_ERR_DONE.  A failure inside the pipeline is reported here (status of the failing call). */
 int32_t mi_vs_stream_next(uint64_t stream, int32_t block, uint8_t *all_ok);
+/* the same with the batch's verdict vector: *n_out = its size; verdicts[0..n) = 1 when all_ok, otherwise the invalid
+ * proofs of THIS rank's shard are named by mi_vs_identify_device on the submitted buffers, which therefore must stay
+ * valid until their verdict has been taken.  capacity < n: MI_ERR_BAD_ARGS (the verdict is consumed). */
+int32_t mi_vs_stream_next_verdicts(uint64_t stream, int32_t block, uint8_t *all_ok, uint8_t *verdicts, size_t capacity,
+                                   size_t *n_out);
 int32_t mi_vs_stream_close(uint64_t stream); /* finishes, drains and joins the threads */
 
 /* ---- the exchange itself, native: RCCL called from the library (librccl is dlopen'ed on first use) ----

@@ -429,9 +429,9 @@ class VarunaShaped:
         (proofs_cuda, randomizers_cuda).  `comm` (a handle of lib.comm_init_rank) makes the exchange native instead:
         the library's own mi_vs_exchange_rccl (ncclAllGather from the finisher thread, no Python on the data path).
         Submitted tensors are kept alive until their verdict has been yielded.
-        verdicts=True yields (all_ok, verdict vector or None) instead: a failing batch's vector comes from
-        mi_vs_identify_device on the still-held tensors (single-rank streams: with an exchange, all_ok covers every
-        rank's shard and each rank names the invalid proofs of its own).
+        verdicts=True yields (all_ok, verdict vector or None) instead (mi_vs_stream_next_verdicts): a failing batch is
+        taken apart on the device from the still-held tensors; with an exchange, all_ok covers every rank's shard and
+        each rank names the invalid proofs of its own.
         """
         lib = L.lib()
         keep = {}
@@ -465,15 +465,19 @@ class VarunaShaped:
 
         def drain(block):
             while True:
-                st = lib.mi_vs_stream_next(sid, 1 if block else 0, C.byref(ok))
+                if verdicts:
+                    cap = max([p.numel() * p.element_size() // self.proof_bytes for p, _ in held] or [1])
+                    vec, n_out = np.zeros(cap, dtype=np.uint8), C.c_size_t(0)
+                    st = lib.mi_vs_stream_next_verdicts(sid, 1 if block else 0, C.byref(ok), L.ptr(vec), C.c_size_t(cap), C.byref(n_out))
+                else:
+                    st = lib.mi_vs_stream_next(sid, 1 if block else 0, C.byref(ok))
                 if st == L.MI_OK:
-                    mine = held.pop(0) if held else None
+                    if held:
+                        held.pop(0)
                     if not verdicts:
                         yield bool(ok.value)
-                    elif ok.value or mine is None:
-                        yield bool(ok.value), None
                     else:
-                        yield False, self.identify(mine[0], mine[1])
+                        yield bool(ok.value), (None if ok.value else vec[:n_out.value].copy())
                 elif st == L.MI_ERR_AGAIN or st == L.MI_ERR_DONE:
                     return
                 else:

@@ -6,6 +6,7 @@
 // them on the host (mi_vs_accumulate_end), one finisher exchanges partials (multi-GPU callback), starts the pairing
 // products (mi_vs_finalize_async, up to `products` in flight) and publishes verdicts in submission order.  The entry
 // points drop the library lock around their waits and folds, so the stages overlap.  Pure host code: no kernels here.
+#include <string.h>
 #include <condition_variable>
 #include <deque>
 #include <map>
@@ -28,6 +29,8 @@ struct Stream {
     std::deque<std::pair<uint64_t, uint64_t>> to_fold;  // (sequence number, accumulate handle), submission order
     std::map<uint64_t, mi_vs_partial> folded;           // sequence number -> this rank's partial
     std::deque<int32_t> results;                        // 0 / 1 verdicts, or a negative status
+    struct Sub { const void *proofs; size_t n; const void *rand; };
+    std::deque<Sub> pending;                            // submitted batches whose verdict has not been taken, oldest first
     uint64_t submitted = 0, open = 0;                   // batches submitted; accumulations begun and not yet folded
     bool finished = false;                              // no more submissions
     bool finisher_done = false;
@@ -192,6 +195,7 @@ int32_t mi_vs_stream_submit(uint64_t stream, const void *d_proofs, size_t n, con
         return st;
     }
     s->to_fold.emplace_back(s->submitted++, h);
+    s->pending.push_back(Stream::Sub{d_proofs, n, d_randomizers128});
     s->cv.notify_all();
     return MI_OK;
 }
@@ -205,22 +209,43 @@ int32_t mi_vs_stream_finish(uint64_t stream) {
     return MI_OK;
 }
 
-int32_t mi_vs_stream_next(uint64_t stream, int32_t block, uint8_t *all_ok) {
+int32_t mi_vs_stream_next_verdicts(uint64_t stream, int32_t block, uint8_t *all_ok, uint8_t *verdicts, size_t capacity,
+                                   size_t *n_out) {
     auto s = find(stream);
     if (!s || !all_ok) return MI_ERR_BAD_ARGS;
-    std::unique_lock<std::mutex> lk(s->mu);
-    for (;;) {
-        if (!s->results.empty()) {
-            const int32_t v = s->results.front();
-            s->results.pop_front();
-            if (v < 0) return v;
-            *all_ok = (uint8_t)v;
-            return MI_OK;
+    Stream::Sub sub{nullptr, 0, nullptr};
+    {
+        std::unique_lock<std::mutex> lk(s->mu);
+        for (;;) {
+            if (!s->results.empty()) {
+                const int32_t v = s->results.front();
+                s->results.pop_front();
+                if (!s->pending.empty()) {
+                    sub = s->pending.front();
+                    s->pending.pop_front();
+                }
+                if (v < 0) return v;
+                *all_ok = (uint8_t)v;
+                break;
+            }
+            if (s->finisher_done) return s->error != MI_OK ? s->error : MI_ERR_DONE;
+            if (!block) return MI_ERR_AGAIN;
+            s->cv.wait(lk);
         }
-        if (s->finisher_done) return s->error != MI_OK ? s->error : MI_ERR_DONE;
-        if (!block) return MI_ERR_AGAIN;
-        s->cv.wait(lk);
     }
+    if (n_out) *n_out = sub.n;
+    if (!verdicts) return MI_OK;
+    if (capacity < sub.n) return MI_ERR_BAD_ARGS;
+    if (*all_ok) {
+        memset(verdicts, 1, sub.n);
+        return MI_OK;
+    }
+    // the stream keeps no per-proof state: the failed batch is taken apart from its (still resident) inputs
+    return mi_vs_identify_device(s->ctx, sub.proofs, sub.n, sub.rand, verdicts, nullptr);
+}
+
+int32_t mi_vs_stream_next(uint64_t stream, int32_t block, uint8_t *all_ok) {
+    return mi_vs_stream_next_verdicts(stream, block, all_ok, nullptr, 0, nullptr);
 }
 
 int32_t mi_vs_stream_close(uint64_t stream) {

@@ -47,7 +47,7 @@ EXPORTS = [
     "mi_vs_ctx_create", "mi_vs_ctx_create_ex", "mi_vs_ctx_create_v2", "mi_vs_ctx_destroy", "mi_vs_verify_batch", "mi_vs_verify_batch_device", "mi_vs_identify_device",
     "mi_vs_accumulate_device", "mi_vs_accumulate_begin", "mi_vs_accumulate_end", "mi_vs_finalize", "mi_vs_finalize_async", "mi_vs_finalize_wait",
     "mi_vs_verify_block", "mi_vs_verify_block_device",
-    "mi_vs_stream_open", "mi_vs_stream_submit", "mi_vs_stream_finish", "mi_vs_stream_next", "mi_vs_stream_close",
+    "mi_vs_stream_open", "mi_vs_stream_submit", "mi_vs_stream_finish", "mi_vs_stream_next", "mi_vs_stream_next_verdicts", "mi_vs_stream_close",
     "mi_comm_unique_id", "mi_comm_init_rank", "mi_comm_init_local", "mi_comm_world", "mi_comm_destroy", "mi_comm_all_gather",
     "mi_vs_exchange_rccl",
     "mi_dbg_fq_mul", "mi_dbg_fr_mul", "mi_dbg_g1_add", "mi_dbg_fq_mul_throughput", "mi_dbg_gen_points_device",
@@ -91,6 +91,8 @@ def lib():
         l.mi_vs_stream_open.argtypes = [C.c_uint64, C.c_int32, C.c_int32, C.c_int32, VS_EXCHANGE_FN, C.c_void_p, C.c_int32, C.POINTER(C.c_uint64)]
         l.mi_vs_stream_submit.argtypes = [C.c_uint64, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
         l.mi_vs_stream_next.argtypes = [C.c_uint64, C.c_int32, C.POINTER(C.c_uint8)]
+        l.mi_vs_stream_next_verdicts.argtypes = [C.c_uint64, C.c_int32, C.POINTER(C.c_uint8), C.c_void_p, C.c_size_t,
+                                                 C.POINTER(C.c_size_t)]
         l.mi_vs_stream_finish.argtypes = [C.c_uint64]
         l.mi_vs_stream_close.argtypes = [C.c_uint64]
         l.mi_error_string.argtypes = [C.c_int32]

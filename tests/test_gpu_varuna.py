@@ -434,3 +434,32 @@ def test_malformed_proofs_are_rejected(orc, mi, transcript):
         assert not ok and (verdicts == want).all()
     finally:
         v.close()
+
+
+@pytest.mark.parametrize("n_bad", [1, 11, 1024])
+def test_reject_path_group_testing(orc, mi, n_bad):
+    """the fallback (terms, sums, groups of 4, per proof) on the full-size batch with 1, 11 and ALL proofs invalid:
+    verdict vector exact against the oracle, through verify_batch and through the stream's verdict call"""
+    import torch
+    vk, circuits, proofs, rnd = _fixture()
+    bad = proofs.copy()
+    idx = np.arange(1024) if n_bad == 1024 else (np.array([517]) if n_bad == 1 else np.arange(5, 1024, 101))
+    for k, i in enumerate(idx):  # evaluations, a commitment coordinate (off the curve: malformed), a witness
+        off = (16 + 512 + 864 + 32 * (k % 21), 16 + 512 + 96 * (k % 9) + 7, 16 + 512 + 864 + 672 + 96 * (k % 2) + 50)[k % 3]
+        bad[i * 2256 + off] ^= 1 << (k % 8)
+    want = np.ones(1024, dtype=np.uint8); want[idx] = 0
+    cpu = orc.VSArrays(vk, circuits, bad, rnd).verify_cpu(16)
+    assert (cpu == want).all()
+    v = mi.VarunaShaped(vk, circuits)
+    try:
+        ok, verdicts = v.verify_batch(bad, rnd)
+        assert not ok and (verdicts == want).all()
+        db, dg, dr = torch.from_numpy(bad).cuda(), torch.from_numpy(proofs).cuda(), torch.from_numpy(rnd).cuda()
+        got = list(v.verify_stream(iter([(dg, dr), (db, dr), (dg, dr)]), verdicts=True))
+        assert [g[0] for g in got] == [True, False, True] and got[0][1] is None and (got[1][1] == want).all()
+        # ragged sizes: a tail group of fewer than four proofs, a batch smaller than a group
+        for cut in (1023, 1022, 1021, 3, 1):
+            ok, verdicts = v.verify_batch(bad[:cut * 2256], rnd[:cut * 32])
+            assert ok == bool(want[:cut].all()) and (verdicts == want[:cut]).all(), cut
+    finally:
+        v.close()
