@@ -7,7 +7,10 @@
 using namespace mi;
 
 template <int MODE>
-__global__ void __launch_bounds__(PW_THREADS) rounds_kernel(int n, Fq *out) {
+#ifndef RB_THREADS
+#define RB_THREADS PW_THREADS
+#endif
+__global__ void __launch_bounds__(RB_THREADS) rounds_kernel(int n, Fq *out) {
     extern __shared__ uint4 pw_lds[];
     LShared &S = *(LShared *)pw_lds;
     const int t = threadIdx.x;
@@ -43,7 +46,7 @@ __global__ void __launch_bounds__(PW_THREADS) rounds_kernel(int n, Fq *out) {
             pb_round_impl<true, true>(S, alt, cur->c, cur, fc.d0, fc.d1, fc.d2, fc.d3, prof);
             LPB *sw = cur; cur = alt; alt = sw;
         }
-        if (t < 8) ((uint64_t *)out)[16 + t] = prof[t];
+        if (t < 8) ((uint64_t *)out)[80 + t] = prof[t];  // behind the 12 result coefficients (576 B)
         if (t < 12) out[t] = lds_load(&cur->c[t]);
         return;
     }
@@ -69,6 +72,7 @@ __global__ void __launch_bounds__(PW_THREADS) rounds_kernel(int n, Fq *out) {
 int main() {
     Fq *d;
     hipMalloc(&d, sizeof(Fq) * 12 + 1024);
+    hipMemset(d, 0, sizeof(Fq) * 12 + 1024);
     hipEvent_t e0, e1;
     hipEventCreate(&e0); hipEventCreate(&e1);
     const char *names[5] = {"dense round, in place (2 barriers)", "dense round, ping-pong (1 barrier)", "Fq inversion on one lane",
@@ -82,11 +86,11 @@ int main() {
         const int N = mode == 2 ? 50 : 2000;
         for (int rep = 0; rep < 2; rep++) {
             hipEventRecord(e0, 0);
-            if (mode == 0) hipLaunchKernelGGL(rounds_kernel<0>, dim3(1), dim3(PW_THREADS), PW_LDS_BYTES, 0, N, d);
-            else if (mode == 1) hipLaunchKernelGGL(rounds_kernel<1>, dim3(1), dim3(PW_THREADS), PW_LDS_BYTES, 0, N, d);
-            else if (mode == 2) hipLaunchKernelGGL(rounds_kernel<2>, dim3(1), dim3(PW_THREADS), PW_LDS_BYTES, 0, N, d);
-            else if (mode == 3) hipLaunchKernelGGL(rounds_kernel<3>, dim3(1), dim3(PW_THREADS), PW_LDS_BYTES, 0, N, d);
-            else hipLaunchKernelGGL(rounds_kernel<4>, dim3(1), dim3(PW_THREADS), PW_LDS_BYTES, 0, N, d);
+            if (mode == 0) hipLaunchKernelGGL(rounds_kernel<0>, dim3(1), dim3(RB_THREADS), PW_LDS_BYTES, 0, N, d);
+            else if (mode == 1) hipLaunchKernelGGL(rounds_kernel<1>, dim3(1), dim3(RB_THREADS), PW_LDS_BYTES, 0, N, d);
+            else if (mode == 2) hipLaunchKernelGGL(rounds_kernel<2>, dim3(1), dim3(RB_THREADS), PW_LDS_BYTES, 0, N, d);
+            else if (mode == 3) hipLaunchKernelGGL(rounds_kernel<3>, dim3(1), dim3(RB_THREADS), PW_LDS_BYTES, 0, N, d);
+            else hipLaunchKernelGGL(rounds_kernel<4>, dim3(1), dim3(RB_THREADS), PW_LDS_BYTES, 0, N, d);
             hipEventRecord(e1, 0);
             hipEventSynchronize(e1);
             float ms = 0;
@@ -94,7 +98,7 @@ int main() {
             if (rep) printf("%s: %.3f us each\n", names[mode], ms * 1e3 / N);
             if (rep && mode == 3) {
                 uint64_t h[8];
-                hipMemcpy(h, (char *)d + 16 * 8, sizeof h, hipMemcpyDeviceToHost);
+                hipMemcpy(h, (char *)d + 80 * 8, sizeof h, hipMemcpyDeviceToHost);
                 const char *st[7] = {"loads", "product", "quad reduction", "fold", "row reduction", "Barrett + twin", "stores + barrier"};
                 for (int k = 0; k < 7; k++) printf("    %-18s %7.1f ticks per round\n", st[k], (double)h[k] / N);
             }
