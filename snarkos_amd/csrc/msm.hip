@@ -28,6 +28,7 @@
 #include <map>
 #include <thread>
 #include "api.hpp"
+#include "field28.hpp"
 
 namespace mi {
 
@@ -381,7 +382,7 @@ __global__ void __launch_bounds__(256) msm_len_scatter_kernel(const uint32_t *__
     if (live) order[lh[T + 1 + bin] + rank] = (uint32_t)t;
 }
 
-__global__ void __launch_bounds__(128) msm_accumulate_kernel(const G1Affine *__restrict__ points,
+__global__ void __launch_bounds__(128, 2) msm_accumulate_kernel(const G1Affine *__restrict__ points,
                                                              const uint32_t *__restrict__ sorted,
                                                              const uint32_t *__restrict__ offsets,
                                                              const uint32_t *__restrict__ chunk_off,
@@ -408,15 +409,36 @@ __global__ void __launch_bounds__(128) msm_accumulate_kernel(const G1Affine *__r
     uint32_t k = offsets[b] + ((uint32_t)t - chunk_off[b]) * T;
     uint32_t end = offsets[b + 1];
     if (end - k > T) end = k + T;
-    G1Xyzz acc = G1Xyzz::inf();
-    G1Affine nxt = load_point(points, sorted[k]);
+    // The chunk's sum in the reduced-radix arithmetic of field28.hpp (one v_mad_i64_i32 per limb product, carry-free
+    // additions): the accumulator lives in 28-bit limbs from the first point to the last, the gathered points are
+    // re-read 8 bits higher (no arithmetic), the result goes back to the library's form once per chunk.
+    G1Xyzz28 acc;
+    bool have = false;
+    uint32_t e_nxt = sorted[k];
+    G1Affine nxt = load_point(points, e_nxt & ~1u);
     while (k < end) {
-        G1Affine cur = nxt;
+        const G1Affine cur = nxt;
+        const uint32_t e_cur = e_nxt;
         k++;
-        if (k < end) nxt = load_point(points, sorted[k]);  // issue the next gather before the add
-        acc = add_mixed<true>(acc, cur);
+        if (k < end) {  // issue the next gather before the add
+            e_nxt = sorted[k];
+            nxt = load_point(points, e_nxt & ~1u);
+        }
+        if (cur.is_inf()) continue;
+        const Fq28 qx = load28(cur.x);
+        Fq28 qy = load28(cur.y);
+        if (e_cur & 1u) qy = neg28(qy);
+        if (!have) {
+            const Fq28 one = f28_one();
+            acc = G1Xyzz28{mul28(qx, one), mul28(qy, one), one, one};
+            have = true;
+            continue;
+        }
+        have = add_mixed28(acc, qx, qy);
     }
-    store_xyzz(&chunk_partial[t], acc);
+    G1Xyzz out = G1Xyzz::inf();
+    if (have) out = xyzz28_store(acc);
+    store_xyzz(&chunk_partial[t], out);
 }
 // Buckets cut into more than one chunk ("heavy": the top window, skewed scalars): sum their chunk partials into
 // buckets[b].  Up to SERIAL_MAX chunks one LANE walks them (a realistic top window is cut into 4-8 chunks per bucket);

@@ -216,3 +216,33 @@ def test_msm_full_range_scalars_large_path(orc, mi, log_n):
     got = jac_affine(mi.VariableBase.msm(bases, scalars))
     want = orc.msm_pippenger(bases, scalars, threads=16)
     assert (got == want).all()
+
+
+@pytest.mark.parametrize("n", [64, 3000, 1 << 17])
+def test_msm_degenerate_additions_in_the_accumulation(orc, mi, n):
+    """the bucket accumulation's own degenerate branches (reduced-radix arithmetic, field28.hpp add_mixed28): many
+    copies of ONE point (every bucket addition after the first two is P + kP, the second is a doubling), runs of P, -P
+    with equal scalars (sums that pass through infinity inside a chunk), and both mixed into random data; small and
+    large path"""
+    import pyref
+    base = rng_points(31, 4)
+    negb = base.copy()
+    for i in range(4):
+        negb[i, 6:] = orc.fq_from_int((-orc.fq_to_int(base[i, 6:])) % pyref.Q)
+    sc = rng_scalars(32, 8)
+    bases, scalars = rng_points(33, n), rng_scalars(34, n)
+    bases[: n // 4] = base[0]                      # one point, random scalars
+    scalars[n // 4: n // 2] = sc[0]                # random points, one scalar
+    q = n // 2
+    for j in range(q, q + (n // 8)):               # P, -P, P, -P ... with one scalar: same buckets, alternating
+        bases[j] = base[1] if (j & 1) == 0 else negb[1]
+        scalars[j] = sc[1]
+    for j in range(q + n // 8, q + n // 4):        # P, P, -P, -P ...
+        bases[j] = base[2] if ((j >> 1) & 1) == 0 else negb[2]
+        scalars[j] = sc[2]
+    got = jac_affine(mi.VariableBase.msm(bases, scalars))
+    assert (got == orc.msm_pippenger(bases, scalars, threads=8)).all()
+    # only the cancelling part: the whole MSM is the point at infinity
+    m = (n // 8) & ~1
+    got = jac_affine(mi.VariableBase.msm(bases[q:q + m], scalars[q:q + m]))
+    assert not got.any()

@@ -127,6 +127,61 @@ def gen_sqr(params, n):
     return "\n".join(o)
 
 
+OUT28 = os.path.join(os.path.dirname(OUT), "f28_gen.hpp")
+
+
+def gen_mul28(square):
+    """Montgomery product / squaring on 14 signed 28-bit limbs (field28.hpp; arithmetic and bounds: tools/model_f28.py):
+    ONE v_mad_i64_i32 per limb product, the column's carry is an arithmetic shift of the 64-bit accumulator."""
+    n, w = 14, 28
+    o = []
+    a = o.append
+    if square:
+        a("__device__ __forceinline__ Fq28 sqr28_gen(const Fq28 &a) {")
+        a("    int32_t a2[14];")
+        for j in range(1, n):
+            a("    a2[%d] = a.l[%d] * 2;" % (j, j))
+    else:
+        a("__device__ __forceinline__ Fq28 mul28_gen(const Fq28 &a, const Fq28 &b) {")
+    a("    constexpr uint32_t MASK = (1u << 28) - 1u;")
+    a("    int32_t m[14];")
+    a("    Fq28 r;")
+    a("    int64_t acc = 0;")
+    for k in range(2 * n - 1):
+        ab, mp = [], []
+        for i in range(n):
+            j = k - i
+            if not 0 <= j < n:
+                continue
+            if not square:
+                ab.append('"v"(a.l[%d]), "v"(b.l[%d])' % (i, j))
+            elif i < j:
+                ab.append('"v"(a.l[%d]), "v"(a2[%d])' % (i, j))
+            elif i == j:
+                ab.append('"v"(a.l[%d]), "v"(a.l[%d])' % (i, i))
+        for i in range(min(k, n)):
+            j = k - i
+            if 1 <= j < n:
+                mp.append('"v"(m[%d]), "s"(F28C.mod[%d])' % (i, j))
+        for ins in (ab, mp):
+            if not ins:
+                continue
+            assert len(ins) <= 14
+            lines = ["v_mad_i64_i32 %%0, vcc, %%%d, %%%d, %%0" % (1 + 2 * x, 2 + 2 * x) for x in range(len(ins))]
+            a('    asm("%s"' % "\\n\\t".join(lines))
+            a('        : "+&v"(acc)')
+            a("        : %s" % ", ".join(ins))
+            a('        : "vcc");')
+        if k < n:
+            a("    { const uint32_t lo = (uint32_t)acc & MASK; m[%d] = (int32_t)((0u - lo) & MASK); acc = (acc + m[%d]) >> 28; }" % (k, k))
+        else:
+            a("    { r.l[%d] = (int32_t)((uint32_t)acc & MASK); acc >>= 28; }" % (k - n))
+    a("    r.l[13] = (int32_t)acc;")
+    a("    return r;")
+    a("}")
+    return "\n".join(o)
+
+
 def sqr_columns_model(a, n):
     """the integer the squaring's product half accumulates, column by column, exactly as gen_sqr emits it
     (tests/test_comba_model.py checks it equals a * a)"""
@@ -163,6 +218,11 @@ def main():
     parts.append("}  // namespace mi")
     open(OUT, "w").write("\n".join(parts) + "\n")
     print("wrote", OUT)
+    parts28 = ["// GENERATED by tools/gen_comba.py -- do not edit.",
+               "// Montgomery product and squaring on 14 signed 28-bit limbs for gfx950, see field28.hpp.",
+               "#pragma once", "namespace mi {", gen_mul28(False), gen_mul28(True), "}  // namespace mi"]
+    open(OUT28, "w").write("\n".join(parts28) + "\n")
+    print("wrote", OUT28)
 
 
 if __name__ == "__main__":

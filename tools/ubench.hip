@@ -4,6 +4,7 @@
 #include <stdio.h>
 #include <type_traits>
 #include "../snarkos_amd/csrc/field.hpp"
+#include "../snarkos_amd/csrc/field28.hpp"
 using namespace mi;
 
 #define CHECK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); return 1; } } while (0)
@@ -86,6 +87,20 @@ __global__ void __launch_bounds__(256) fmul_kernel(F *out, int iters) {
     out[i] = add(a, b);
 }
 
+// the reduced-radix product (field28.hpp): same loop shape as fmul_kernel
+template <int V>
+__global__ void __launch_bounds__(256) fmul28_kernel(Fq *out, int iters) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    Fq a0 = Fq::one(), b0 = Fq::r2();
+    a0.l[0] += (uint32_t)i;
+    Fq28 a = load28(a0), b = load28(b0);
+    for (int k = 0; k < iters; k++) {
+        if (V == 0) { a = mul28(a, b); b = mul28(b, a); }
+        else { a = sqr28(a); b = sqr28(sub28(b, a)); }
+    }
+    out[i] = store28(sub28(a, b));
+}
+
 template <class K, class... A>
 static double time_kernel(K k, dim3 g, dim3 b, A... args) {
     hipEvent_t e0, e1;
@@ -139,6 +154,13 @@ int main() {
         for (int v = 0; v < 3; v++)
             printf("waves/SIMD=%d %s  Fq mul %.2f Gmul/s (%.0f ns per mul per wave)   Fr mul %.2f Gmul/s\n", wps, vn[v],
                    400.0 * blocks * 256 / tq[v] / 1e9, tq[v] / 400 * 1e9, 400.0 * blocks * 256 / tr[v] / 1e9);
+    }
+    for (int wps = 1; wps <= 8; wps *= 2) {
+        int blocks = 256 * wps;
+        const double tm = time_kernel(fmul28_kernel<0>, dim3(blocks), dim3(256), (Fq *)d, 200);
+        const double ts = time_kernel(fmul28_kernel<1>, dim3(blocks), dim3(256), (Fq *)d, 200);
+        printf("waves/SIMD=%d  28-bit limbs: Fq mul %.2f Gmul/s (%.0f ns per mul per wave)   sqr %.2f G/s\n", wps,
+               400.0 * blocks * 256 / tm / 1e9, tm / 400 * 1e9, 400.0 * blocks * 256 / ts / 1e9);
     }
     hipFree(d);
     return 0;
