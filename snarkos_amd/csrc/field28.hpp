@@ -212,5 +212,45 @@ __device__ __forceinline__ bool add_mixed28(G1Xyzz28 &acc, const Fq28 &qx, const
     return true;
 }
 
+// ---- Jacobian doubling and mixed addition for the fallback's scalar-multiplication chains (glv.hpp), limb bounds as in
+// tools/model_f28.py jac_dbl / jac_madd: X, Y normalised, Z with limbs below 2^29
+struct G1Jac28 {
+    Fq28 x, y, z;
+};
+__device__ __forceinline__ Fq28 scale28(const Fq28 &a, int32_t k) {
+    Fq28 r;
+#pragma unroll
+    for (int i = 0; i < 14; i++) r.l[i] = a.l[i] * k;
+    return r;
+}
+// 2 (X, Y, Z), a = 0 (EFD dbl-2009-l: 2M + 5S)
+__device__ __forceinline__ G1Jac28 jac_dbl28(const G1Jac28 &p) {
+    const Fq28 a = sqr28(p.x), b = sqr28(p.y), c = sqr28(b);
+    const Fq28 d = normalise28(dbl28(sub28(sub28(sqr28(add28(p.x, b)), a), c)));
+    const Fq28 e = normalise28(add28(dbl28(a), a));
+    G1Jac28 r;
+    r.x = normalise28(sub28(sqr28(e), dbl28(d)));
+    r.y = normalise28(sub28(mul28(e, sub28(d, r.x)), scale28(c, 8)));
+    r.z = dbl28(mul28(p.y, p.z));
+    return r;
+}
+// (X, Y, Z) + affine (qx, qy) as loaded (EFD madd-2007-bl: 7M + 4S); the accumulator is not infinity.
+// Returns 0: done; 1: the sum is the point at infinity; 2: same point (the caller doubles the affine point instead)
+__device__ __forceinline__ int jac_add_mixed28(G1Jac28 &p, const Fq28 &qx, const Fq28 &qy) {
+    const Fq28 z1z1 = sqr28(p.z);
+    const Fq28 h = sub28(mul28(qx, z1z1), p.x);
+    const Fq28 rr = sub28(mul28(mul28(qy, p.z), z1z1), p.y);  // r / 2
+    if (maybe_zero28(h, 8)) {
+        if (store28(h).is_zero()) return store28(rr).is_zero() ? 2 : 1;
+    }
+    const Fq28 hh = sqr28(h), i4 = scale28(hh, 4);
+    const Fq28 j = mul28(h, i4), v = mul28(p.x, i4);
+    const Fq28 x3 = normalise28(sub28(sub28(scale28(sqr28(rr), 4), j), dbl28(v)));
+    p.y = normalise28(dbl28(sub28(mul28(rr, sub28(v, x3)), mul28(p.y, j))));
+    p.z = normalise28(sub28(sub28(sqr28(normalise28(add28(p.z, h))), z1z1), hh));
+    p.x = x3;
+    return 0;
+}
+
 }  // namespace mi
 #endif

@@ -188,6 +188,9 @@ MI_HD G1Xyzz glv_chain(const T &tab, const uint32_t (&v)[4]) {
 }
 
 #if defined(__HIPCC__)
+}  // namespace mi
+#include "field28.hpp"
+namespace mi {
 __device__ __forceinline__ void glv_store_affine(G1Affine *dst, const G1Affine &a) {
     uint4 *o = reinterpret_cast<uint4 *>(dst);
 #pragma unroll
@@ -232,6 +235,44 @@ __device__ __forceinline__ void glv_build_table(G1Affine *tab, const G1Affine &P
         if (!m[e].is_inf()) a = G1Affine{mulq(m[e].x, mulq(iw, m[e].zzz)), mulq(m[e].y, mulq(iw, m[e].zz))};
         glv_store_affine(&tab[e], a);
     }
+}
+
+// The device's chain: the same windows over the same affine table, with the accumulator in the reduced-radix arithmetic
+// of field28.hpp (one instruction per limb product, carry-free additions); table entries are read as they are stored
+// (canonical, 32-bit limbs) and enter 8 bits higher.
+template <int W>
+__device__ __forceinline__ G1Xyzz glv_chain28(const G1Affine *tab, const uint32_t (&v)[4]) {
+    GlvDigits<W> dg;
+    dg.recode(v);
+    G1Jac28 acc;
+    bool have = false;
+    for (int i = GlvDigits<W>::NW - 1; i >= 0; i--) {
+        if (have) {
+#pragma unroll 1
+            for (int k = 0; k < W; k++) acc = jac_dbl28(acc);
+        }
+        const int d = dg.digit(i);
+        if (d != 0) {
+            const G1Affine t = load_point(tab, (uint32_t)(((d < 0 ? -d : d) - 1) << 1));
+            if (!t.is_inf()) {
+                const Fq28 qx = load28(t.x);
+                Fq28 qy = load28(t.y);
+                if (d < 0) qy = neg28(qy);
+                const Fq28 one = f28_one();
+                int st = 2;  // an empty accumulator takes the point itself (as a doubling of nothing: same code path)
+                if (have) st = jac_add_mixed28(acc, qx, qy);
+                if (st == 1) have = false;
+                if (st == 2) {
+                    acc = G1Jac28{mul28(qx, one), mul28(qy, one), one};
+                    if (have) acc = jac_dbl28(acc);  // the accumulator was this very point
+                    have = true;
+                }
+            }
+        }
+    }
+    if (!have) return G1Xyzz::inf();
+    const Fq28 zz = sqr28(acc.z);
+    return G1Xyzz{store28(acc.x), store28(acc.y), store28(zz), store28(mul28(zz, acc.z))};
 }
 
 struct GlvGlobalTable {

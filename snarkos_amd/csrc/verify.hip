@@ -850,7 +850,7 @@ __global__ void __launch_bounds__(256) vs_terms_kernel(size_t n, VsTermsIn in, c
     if (!P.is_inf() && (sv[0] | sv[1] | sv[2] | sv[3])) {
         G1Affine *tab = tables + t * (1u << (VS_GLV_W - 1));
         glv_build_table<VS_GLV_W>(tab, P);
-        acc = glv_chain<VS_GLV_W>(GlvGlobalTable{tab}, sv);
+        acc = glv_chain28<VS_GLV_W>(tab, sv);
     }
     store_xyzz(&terms[t], acc);
 }

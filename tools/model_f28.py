@@ -203,6 +203,60 @@ def madd(acc, pt, stats):
     return (x3, y3, zz3, zzz3)
 
 
+# ---------------------------------------------------------------------------------------------------------------
+# the Jacobian doubling and mixed addition of the fallback's scalar-multiplication chains (glv.hpp) in this arithmetic
+def mul_fits(la, lb):
+    """a column of 14 products of limbs below la, lb plus the reduction's 13 products and the carry stays in 64 bits"""
+    return 14 * la * lb + 13 * (1 << 56) + (1 << 37) < (1 << 63)
+
+
+def lim(a, bound):
+    assert limb_mag(a[:13]) < bound, (limb_mag(a[:13]).bit_length(), bound.bit_length())
+    return a
+
+
+def jac_dbl(P, stats):
+    """(X, Y, Z) -> 2 (X, Y, Z), a = 0 (dbl-2009-l); X, Y normalised (limbs < 2^28), Z with limbs < 2^29"""
+    X, Y, Z = P
+    lim(X, 1 << 28), lim(Y, 1 << 28), lim(Z, 1 << 29)
+    A, B = sqr(X, stats), sqr(Y, stats)
+    C = sqr(B, stats)
+    assert mul_fits(1 << 29, 1 << 29)
+    t = sqr(lim(add(X, B), 1 << 29), stats)
+    D = normalise(dbl(sub(sub(t, A), C)))          # limbs of the difference below 3 2^28, doubled below 2^31
+    E = normalise(add(dbl(A), A))                  # 3 A
+    F = sqr(E, stats)
+    X3 = normalise(sub(F, dbl(D)))
+    assert mul_fits(1 << 28, 1 << 30)
+    Y3 = normalise(sub(mul(E, lim(sub(D, X3), 1 << 30), stats), lim([8 * c for c in C], 1 << 31)))
+    Z3 = dbl(mul(Y, Z, stats))
+    return (X3, Y3, Z3)
+
+
+def jac_madd(P, pt, stats):
+    """(X, Y, Z) + affine (x2, y2) (madd-2007-bl), x2, y2 as loaded; None for the degenerate cases"""
+    X1, Y1, Z1 = P
+    x2, y2 = pt
+    lim(X1, 1 << 28), lim(Y1, 1 << 28), lim(Z1, 1 << 29), lim(x2, 1 << 28), lim(y2, 1 << 28)
+    z1z1 = sqr(Z1, stats)
+    u2 = mul(x2, z1z1, stats)
+    s2 = mul(mul(y2, Z1, stats), z1z1, stats)
+    H = lim(sub(u2, X1), 1 << 29)
+    if is_zero_mod_q(H, 8):
+        return None
+    rr = lim(sub(s2, Y1), 1 << 29)                  # r / 2
+    HH = sqr(H, stats)
+    I = [4 * x for x in HH]                         # limbs below 2^30
+    assert mul_fits(1 << 29, 1 << 30)
+    J = mul(H, lim(I, 1 << 30), stats)
+    V = mul(X1, I, stats)
+    X3 = normalise(sub(sub([4 * x for x in sqr(rr, stats)], J), dbl(V)))
+    Y3 = normalise(dbl(sub(mul(rr, lim(sub(V, X3), 1 << 29), stats), mul(Y1, J, stats))))
+    Z3 = sub(sub(sqr(normalise(add(Z1, H)), stats), z1z1), HH)  # (the sum's limbs reach 2^30: carried before the squaring)
+    # Z3 feeds the next doubling, which wants limbs below 2^29
+    return (X3, Y3, normalise(Z3))
+
+
 def self_test(n=60, seed=3):
     rnd = random.Random(seed)
     stats = {}
@@ -281,6 +335,28 @@ def self_test(n=60, seed=3):
         xa = store32(acc[0]) * from_mont * pow(zz, -1, Q) % Q
         ya = store32(acc[1]) * from_mont * pow(zzz, -1, Q) % Q
         assert (xa, ya) == accp
+    # a Jacobian double-and-add chain against the affine group law
+    def aff_dbl(p1):
+        x1, y1 = p1
+        lam = 3 * x1 * x1 * pow(2 * y1, -1, Q) % Q
+        x3 = (lam * lam - 2 * x1) % Q
+        return (x3, (lam * (x1 - x3) - y1) % Q)
+
+    base = pts[3]
+    b28 = (load32(base[0] * R32 % Q), load32(base[1] * R32 % Q))
+    J0 = (mul(b28[0], ONE), mul(b28[1], ONE), ONE)
+    ref = base
+    scalar = 0b110101101110010111
+    for bit in bin(scalar)[3:]:
+        J0 = jac_dbl(J0, stats)
+        ref = aff_dbl(ref)
+        if bit == "1":
+            J0 = jac_madd(J0, b28, stats)
+            ref = aff_add(ref, base)
+        z = store32(J0[2]) * from_mont % Q
+        assert (store32(J0[0]) * from_mont * pow(z * z, -1, Q) % Q, store32(J0[1]) * from_mont * pow(z * z * z, -1, Q) % Q) == ref
+    assert jac_madd((mul(b28[0], ONE), mul(b28[1], ONE), ONE), b28, stats) is None
+    mul([(1 << 29) - 1] * 13 + [1 << 21], [-((1 << 30) - 1)] * 13 + [1 << 21], stats)
     # the degenerate cases are flagged
     p0 = pts[0]
     l0 = (load32(p0[0] * R32 % Q), load32(p0[1] * R32 % Q))
