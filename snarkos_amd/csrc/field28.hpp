@@ -212,6 +212,58 @@ __device__ __forceinline__ bool add_mixed28(G1Xyzz28 &acc, const Fq28 &qx, const
     return true;
 }
 
+// ---- full XYZZ addition for reductions of partial sums (tools/model_f28.py xyzz_add / xyzz_dbl): operands with limbs
+// below 2^28 -- normalised x, y and product outputs zz, zzz, or coordinates as loaded
+__device__ __forceinline__ G1Xyzz28 xyzz28_from(const G1Xyzz &a) { return G1Xyzz28{load28(a.x), load28(a.y), load28(a.zz), load28(a.zzz)}; }
+// 2 a (dbl-2008-s-1, a = 0); cold
+__device__ __forceinline__ G1Xyzz28 xyzz_dbl28(const G1Xyzz28 &a) {
+    const Fq28 u = dbl28(a.y), v = sqr28(u), w = mul28(u, v), s = mul28(a.x, v), xx = sqr28(a.x);
+    const Fq28 m = normalise28(add28(dbl28(xx), xx));
+    const Fq28 x3 = sub28(sqr28(m), dbl28(s));
+    const Fq28 y3 = sub28(mul28(m, sub28(s, x3)), mul28(w, a.y));
+    return G1Xyzz28{normalise28(x3), normalise28(y3), mul28(v, a.zz), mul28(w, a.zzz)};
+}
+// a += b, neither infinity (add-2008-s: 12M + 2S).  Returns false when the sum is the point at infinity (a untouched).
+__device__ __forceinline__ bool xyzz_add28(G1Xyzz28 &a, const G1Xyzz28 &b) {
+    const Fq28 u1 = mul28(a.x, b.zz), s1 = mul28(a.y, b.zzz);
+    const Fq28 p = sub28(mul28(b.x, a.zz), u1);
+    if (maybe_zero28(p, 8)) {
+        if (store28(p).is_zero()) {
+            if (!store28(sub28(mul28(b.y, a.zzz), s1)).is_zero()) return false;
+            a = xyzz_dbl28(a);
+            return true;
+        }
+    }
+    const Fq28 r = sub28(mul28(b.y, a.zzz), s1);
+    const Fq28 pp = sqr28(p), ppp = mul28(p, pp), qq = mul28(u1, pp);
+    a.zz = mul28(mul28(a.zz, b.zz), pp);
+    a.zzz = mul28(mul28(a.zzz, b.zzz), ppp);
+    const Fq28 x3 = sub28(sub28(sqr28(r), ppp), dbl28(qq));
+    a.y = normalise28(sub28(mul28(r, sub28(qq, x3)), mul28(s1, ppp)));
+    a.x = normalise28(x3);
+    return true;
+}
+// the same with either side possibly infinity (a flag each)
+__device__ __forceinline__ void xyzz_acc28(G1Xyzz28 &a, bool &have_a, const G1Xyzz28 &b, bool have_b) {
+    if (!have_b) return;
+    if (!have_a) {
+        a = b;
+        have_a = true;
+        return;
+    }
+    have_a = xyzz_add28(a, b);
+}
+
+__device__ __forceinline__ Fq28 shfl_down28(const Fq28 &a, int delta) {
+    Fq28 r;
+#pragma unroll
+    for (int k = 0; k < 14; k++) r.l[k] = __shfl_down(a.l[k], delta, 64);
+    return r;
+}
+__device__ __forceinline__ G1Xyzz28 xyzz28_shfl_down(const G1Xyzz28 &a, int delta) {
+    return G1Xyzz28{shfl_down28(a.x, delta), shfl_down28(a.y, delta), shfl_down28(a.zz, delta), shfl_down28(a.zzz, delta)};
+}
+
 // ---- Jacobian doubling and mixed addition for the fallback's scalar-multiplication chains (glv.hpp), limb bounds as in
 // tools/model_f28.py jac_dbl / jac_madd: X, Y normalised, Z with limbs below 2^29
 struct G1Jac28 {

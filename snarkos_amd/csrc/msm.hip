@@ -560,7 +560,10 @@ __global__ void __launch_bounds__(64) msm_bit_sums_queue_kernel(const G1Xyzz *__
     const int lane = threadIdx.x;
     const uint32_t g = blockIdx.x, w = g / (uint32_t)c, bit = g - w * (uint32_t)c;
     const uint32_t lo = chunk_off[(size_t)w * B], hi = chunk_off[(size_t)(w + 1) * B];
-    G1Xyzz acc = G1Xyzz::inf();
+    // sums in the reduced-radix arithmetic of field28.hpp from the first partial to the last shuffle level; one
+    // conversion back per group
+    G1Xyzz28 acc;
+    bool have = false;
     uint32_t head = 0, tail = 0;  // wave-uniform
     for (uint32_t base = lo; base < hi; base += 64) {
         const uint32_t e = base + lane;
@@ -572,17 +575,22 @@ __global__ void __launch_bounds__(64) msm_bit_sums_queue_kernel(const G1Xyzz *__
         if (tail - head >= 64) {
             const uint32_t q = queue[(head + lane) & 127u];
             head += 64;
-            acc = add<true>(acc, load_xyzz(&chunk_partial[q]));
+            const G1Xyzz v = load_xyzz(&chunk_partial[q]);
+            xyzz_acc28(acc, have, xyzz28_from(v), !v.is_inf());
         }
         __syncthreads();
     }
-    if ((uint32_t)lane < tail - head) acc = add<true>(acc, load_xyzz(&chunk_partial[queue[(head + lane) & 127u]]));
+    if ((uint32_t)lane < tail - head) {
+        const G1Xyzz v = load_xyzz(&chunk_partial[queue[(head + lane) & 127u]]);
+        xyzz_acc28(acc, have, xyzz28_from(v), !v.is_inf());
+    }
 #pragma unroll 1
     for (int stride = 32; stride >= 1; stride >>= 1) {
-        G1Xyzz other = xyzz_shfl_down(acc, stride);
-        if (lane < stride) acc = add<true>(acc, other);
+        const G1Xyzz28 other = xyzz28_shfl_down(acc, stride);
+        const bool have_other = __shfl_down((int)have, stride, 64) != 0;
+        if (lane < stride) xyzz_acc28(acc, have, other, have_other);
     }
-    if (lane == 0) store_xyzz(&out[g], acc);
+    if (lane == 0) store_xyzz(&out[g], have ? xyzz28_store(acc) : G1Xyzz::inf());
 }
 
 template <int LPG>  // lanes per group: 64 (one group per wave) or 32 (two: half the tree work, twice the walk)

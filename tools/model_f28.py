@@ -203,6 +203,45 @@ def madd(acc, pt, stats):
     return (x3, y3, zz3, zzz3)
 
 
+def xyzz_add(A, B, stats):
+    """full XYZZ addition (add-2008-s); operands: x, y with limbs below 2^28 (normalised or loaded), zz, zzz product
+    outputs or loaded; None for the degenerate cases"""
+    x1, y1, zz1, zzz1 = A
+    x2, y2, zz2, zzz2 = B
+    for t in A + B:
+        lim(t, 1 << 28)
+    u1, u2 = mul(x1, zz2, stats), mul(x2, zz1, stats)
+    s1, s2 = mul(y1, zzz2, stats), mul(y2, zzz1, stats)
+    p, r = lim(sub(u2, u1), 1 << 28), lim(sub(s2, s1), 1 << 28)
+    if is_zero_mod_q(p, 8):
+        return None
+    pp = sqr(p, stats)
+    ppp = mul(p, pp, stats)
+    qq = mul(u1, pp, stats)
+    x3 = sub(sub(sqr(r, stats), ppp), dbl(qq))
+    assert mul_fits(1 << 28, 1 << 31)
+    y3 = sub(mul(r, lim(sub(qq, x3), 1 << 31), stats), mul(s1, ppp, stats))
+    zz3 = mul(mul(zz1, zz2, stats), pp, stats)
+    zzz3 = mul(mul(zzz1, zzz2, stats), ppp, stats)
+    return (normalise(x3), normalise(y3), zz3, zzz3)
+
+
+def xyzz_dbl(A, stats):
+    """2 (X, Y, ZZ, ZZZ), a = 0 (dbl-2008-s-1)"""
+    x, y, zz, zzz = A
+    for t in A:
+        lim(t, 1 << 28)
+    u = dbl(y)
+    v = sqr(u, stats)
+    w = mul(u, v, stats)
+    s_ = mul(x, v, stats)
+    xx = sqr(x, stats)
+    m = normalise(add(dbl(xx), xx))
+    x3 = sub(sqr(m, stats), dbl(s_))
+    y3 = sub(mul(m, lim(sub(s_, x3), 1 << 31), stats), mul(w, y, stats))
+    return (normalise(x3), normalise(y3), mul(v, zz, stats), mul(w, zzz, stats))
+
+
 # ---------------------------------------------------------------------------------------------------------------
 # the Jacobian doubling and mixed addition of the fallback's scalar-multiplication chains (glv.hpp) in this arithmetic
 def mul_fits(la, lb):
@@ -335,6 +374,26 @@ def self_test(n=60, seed=3):
         xa = store32(acc[0]) * from_mont * pow(zz, -1, Q) % Q
         ya = store32(acc[1]) * from_mont * pow(zzz, -1, Q) % Q
         assert (xa, ya) == accp
+    # full XYZZ additions and doublings: a small tree of sums against the affine group law
+    def to_aff(A):
+        zz, zzz = store32(A[2]) * from_mont % Q, store32(A[3]) * from_mont % Q
+        return (store32(A[0]) * from_mont * pow(zz, -1, Q) % Q, store32(A[1]) * from_mont * pow(zzz, -1, Q) % Q)
+
+    def lift(pt):
+        return (load32(pt[0] * R32 % Q), load32(pt[1] * R32 % Q), load32(R32 % Q), load32(R32 % Q))
+
+    s01 = xyzz_add(lift(pts[0]), lift(pts[1]), stats)
+    s23 = xyzz_add(lift(pts[2]), lift(pts[3]), stats)
+    assert to_aff(s01) == aff_add(pts[0], pts[1])
+    s0123 = xyzz_add(s01, s23, stats)
+    assert to_aff(s0123) == aff_add(aff_add(pts[0], pts[1]), aff_add(pts[2], pts[3]))
+    assert xyzz_add(s01, s01, stats) is None and xyzz_add(s01, lift(aff_add(pts[0], pts[1])), stats) is None
+    d = xyzz_dbl(s0123, stats)
+    s_aff = to_aff(s0123)
+    lam = 3 * s_aff[0] * s_aff[0] * pow(2 * s_aff[1], -1, Q) % Q
+    dx = (lam * lam - 2 * s_aff[0]) % Q
+    assert to_aff(d) == (dx, (lam * (s_aff[0] - dx) - s_aff[1]) % Q)
+    assert to_aff(xyzz_dbl(lift(pts[4]), stats))[0] == (pow(3 * pts[4][0] ** 2 * pow(2 * pts[4][1], -1, Q), 2, Q) - 2 * pts[4][0]) % Q
     # a Jacobian double-and-add chain against the affine group law
     def aff_dbl(p1):
         x1, y1 = p1
