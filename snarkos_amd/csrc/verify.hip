@@ -635,6 +635,12 @@ __device__ __forceinline__ Fq fq_sel(bool c, const Fq &a, const Fq &b) {
     for (int k = 0; k < 12; k++) r.l[k] = c ? a.l[k] : b.l[k];
     return r;
 }
+__device__ __forceinline__ Fq28 f28_sel(bool c, const Fq28 &a, const Fq28 &b) {
+    Fq28 r;
+#pragma unroll
+    for (int k = 0; k < 14; k++) r.l[k] = c ? a.l[k] : b.l[k];
+    return r;
+}
 __device__ __forceinline__ Fq vs_fs_element(const mi_vs_proof *__restrict__ p, const uint32_t *__restrict__ digest,
                                             const VsConsts *__restrict__ kc, int e) {
     // element e of the transcript: a run of 16 / 32 / 48 bytes of the proof taken as Montgomery limbs (zero-extended)
@@ -661,8 +667,11 @@ __global__ void __launch_bounds__(64) vs_fs_poseidon_kernel(const void *__restri
                                                              const mi_vs_circuit_vk *__restrict__ circuits, size_t n_circuits,
                                                              const VsConsts *__restrict__ kc, const PoseidonConsts *__restrict__ pc,
                                                              uint32_t *__restrict__ chal) {
-    __shared__ Fq xs[16][3];     // the state of each proof (full rounds), or lane 0's new element in slot 0 (partial)
-    __shared__ Fq xt[16][2][3];  // partial rounds: lane l's products mds[i][l] s_l, l = 1, 2
+    // The permutation runs in the reduced-radix arithmetic of field28.hpp (14 signed 28-bit limbs: one instruction per
+    // limb product, a dedicated squaring for the S-box chain, carry-free additions): the state never leaves it between
+    // the first absorb and the last squeeze; constants and absorbed elements enter as they are stored.
+    __shared__ Fq28 xs[16][3];     // the state of each proof (full rounds), or lane 0's new element in slot 0 (partial)
+    __shared__ Fq28 xt[16][2][3];  // partial rounds: lane l's products mds[i][l] s_l, l = 1, 2
     const int t = threadIdx.x, ps = t >> 2, l = t & 3, lc = l < 3 ? l : 0;
     const size_t i = (size_t)blockIdx.x * 16 + ps;
     const mi_vs_proof *p = reinterpret_cast<const mi_vs_proof *>(reinterpret_cast<const uint32_t *>(proofs) + (i < n ? i : 0) * (size_t)kc->proof_words);
@@ -670,36 +679,38 @@ __global__ void __launch_bounds__(64) vs_fs_poseidon_kernel(const void *__restri
     if (circuit >= n_circuits) circuit = 0;
     const uint32_t *digest = reinterpret_cast<const uint32_t *>(circuits[circuit].digest);
     // this lane's constants: its MDS column (partial rounds), its row (full rounds)
-    Fq mcol[3], mrow[3];
+    Fq28 mcol[3], mrow[3];
 #pragma unroll
     for (int k = 0; k < 3; k++) {
-        mcol[k] = pc->mds[k][lc];
-        mrow[k] = pc->mds[lc][k];
+        mcol[k] = load28(pc->mds[k][lc]);
+        mrow[k] = load28(pc->mds[lc][k]);
     }
-    Fq s = Fq::zero();
+    Fq28 s;
+#pragma unroll
+    for (int k = 0; k < 14; k++) s.l[k] = 0;
     for (int b = 0; b < VS_FS_BLOCKS; b++) {
         // ---- absorb: lane 1 takes element 2b, lane 2 element 2b + 1 (the last block holds one)
         const int e = 2 * b + (l == 2 ? 1 : 0);
-        if ((l == 1 || l == 2) && e < VS_FS_ELEMS) s = add(s, vs_fs_element(p, digest, kc, e));
+        if ((l == 1 || l == 2) && e < VS_FS_ELEMS) s = add28(s, load28(vs_fs_element(p, digest, kc, e)));
         // ---- permutation
         for (int r = 0; r < MI_POSEIDON_ROUNDS; r++) {
-            s = add(s, pc->ark[r][lc]);
+            s = normalise28(add28(s, load28(pc->ark[r][lc])));
             const bool full = r < MI_POSEIDON_FULL_HALF || r >= MI_POSEIDON_FULL_HALF + MI_POSEIDON_PARTIAL;  // uniform
             if (full) {
-                const Fq x2 = mul(s, s), x4 = mul(x2, x2), x8 = mul(x4, x4), x16 = mul(x8, x8);
-                s = mul(x16, s);
+                const Fq28 x2 = sqr28(s), x4 = sqr28(x2), x8 = sqr28(x4), x16 = sqr28(x8);
+                s = mul28(x16, s);
                 if (l < 3) xs[ps][l] = s;
                 __syncthreads();
-                const Fq a0 = xs[ps][0], a1 = xs[ps][1], a2 = xs[ps][2];
-                s = add(add(mul(mrow[0], a0), mul(mrow[1], a1)), mul(mrow[2], a2));
+                const Fq28 a0 = xs[ps][0], a1 = xs[ps][1], a2 = xs[ps][2];
+                s = add28(add28(mul28(mrow[0], a0), mul28(mrow[1], a1)), mul28(mrow[2], a2));
                 __syncthreads();
             } else {
                 const bool sb = l == 0;  // the S-box lane; lanes 1, 2 run their MDS column beside it
-                const Fq x2 = mul(fq_sel(sb, s, mcol[0]), s);
-                const Fq x4 = mul(fq_sel(sb, x2, mcol[1]), fq_sel(sb, x2, s));
-                const Fq x8 = mul(fq_sel(sb, x4, mcol[2]), fq_sel(sb, x4, s));
-                const Fq x16 = mul(x8, x8);   // lanes 1, 2: idle slots (results unused)
-                const Fq x17 = mul(x16, s);
+                const Fq28 x2 = mul28(f28_sel(sb, s, mcol[0]), s);
+                const Fq28 x4 = mul28(f28_sel(sb, x2, mcol[1]), f28_sel(sb, x2, s));
+                const Fq28 x8 = mul28(f28_sel(sb, x4, mcol[2]), f28_sel(sb, x4, s));
+                const Fq28 x16 = sqr28(x8);   // lanes 1, 2: idle slots (results unused)
+                const Fq28 x17 = mul28(x16, s);
                 if (l == 0) xs[ps][0] = x17;
                 if (l == 1 || l == 2) {
                     xt[ps][l - 1][0] = x2;
@@ -707,14 +718,14 @@ __global__ void __launch_bounds__(64) vs_fs_poseidon_kernel(const void *__restri
                     xt[ps][l - 1][2] = x8;
                 }
                 __syncthreads();
-                const Fq s0 = xs[ps][0];
-                s = add(add(mul(mrow[0], s0), xt[ps][0][lc]), xt[ps][1][lc]);
+                const Fq28 s0 = xs[ps][0];
+                s = add28(add28(mul28(mrow[0], s0), xt[ps][0][lc]), xt[ps][1][lc]);
                 __syncthreads();
             }
         }
         // ---- squeeze: the low 128 bits of the canonical value of the first rate element
         if ((b == 21 || b == 25 || b == VS_FS_BLOCKS - 1) && l == 1 && i < n) {
-            const Fq c = from_mont(s);
+            const Fq c = from_mont(store28(s));
             const int which = b == 21 ? 0 : (b == 25 ? 1 : 2);
             reinterpret_cast<uint4 *>(chal)[3 * i + which] = make_uint4(c.l[0], c.l[1], c.l[2], c.l[3]);
         }
