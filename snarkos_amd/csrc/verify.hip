@@ -874,8 +874,10 @@ template <uint32_t LP>
 __global__ void __launch_bounds__(VS_GROUP * LP) vs_sums_kernel(size_t n, const G1Xyzz *__restrict__ terms,
                                                                 const VsConsts *__restrict__ kc, G1Affine *__restrict__ ps,
                                                                 G1Affine *__restrict__ gs) {
-    extern __shared__ uint4 sums_lds[];  // VS_GROUP * LP G1Xyzz
-    G1Xyzz *sh = reinterpret_cast<G1Xyzz *>(sums_lds);
+    // sums in the reduced-radix arithmetic of field28.hpp (224 B per point in LDS, plus a flag: infinity)
+    extern __shared__ uint4 sums_lds[];  // VS_GROUP * LP G1Xyzz28, then VS_GROUP * LP flags
+    G1Xyzz28 *sh = reinterpret_cast<G1Xyzz28 *>(sums_lds);
+    uint32_t *shf = reinterpret_cast<uint32_t *>(sh + VS_GROUP * LP);
     const uint32_t pl = threadIdx.x / LP, l = threadIdx.x % LP;
     const size_t first = (size_t)blockIdx.x * VS_GROUP, i = first + pl;
     const uint32_t PP = kc->per_proof, H = kc->hiding, CH = vs_chains_of(PP, H, kc->n_bounded);
@@ -887,30 +889,45 @@ __global__ void __launch_bounds__(VS_GROUP * LP) vs_sums_kernel(size_t n, const 
     else if (l < lo3) { seg = 2; lo = lo2; hi = lo3; }
     else { seg = 3; lo = lo3; hi = CH; }
     const bool live = i < n && l < CH;
-    G1Xyzz mine = live ? load_xyzz(&terms[i * CH + l]) : G1Xyzz::inf();
-    store_xyzz(&sh[threadIdx.x], mine);
+    G1Xyzz28 mine;
+    bool have = false;
+    if (live) {
+        const G1Xyzz v = load_xyzz(&terms[i * CH + l]);
+        have = !v.is_inf();
+        mine = xyzz28_from(v);
+    }
+    sh[threadIdx.x] = mine;
+    shf[threadIdx.x] = have ? 1u : 0u;
     const uint32_t pos = l - lo;
 #pragma unroll 1
     for (uint32_t stride = 1; stride < LP; stride <<= 1) {
         __syncthreads();
         const bool act = live && (pos & (2 * stride - 1)) == 0 && l + stride < hi;
-        if (act) mine = add(load_xyzz(&sh[threadIdx.x]), load_xyzz(&sh[threadIdx.x + stride]));
+        if (act) xyzz_acc28(mine, have, sh[threadIdx.x + stride], shf[threadIdx.x + stride] != 0);
         __syncthreads();
-        if (act) store_xyzz(&sh[threadIdx.x], mine);
+        if (act) {
+            sh[threadIdx.x] = mine;
+            shf[threadIdx.x] = have ? 1u : 0u;
+        }
     }
     __syncthreads();
-    mine = load_xyzz(&sh[threadIdx.x]);
     if (pl == 0 && live && pos == 0) {  // the group's sum of this accumulator, parked on the neighbouring lane's slot
-        G1Xyzz g = mine;
+        G1Xyzz28 g = mine;
+        bool hg = have;
         for (uint32_t p = 1; p < VS_GROUP; p++)
-            if (first + p < n) g = add(g, load_xyzz(&sh[p * LP + l]));
-        store_xyzz(&sh[threadIdx.x + 1], g);
+            if (first + p < n) xyzz_acc28(g, hg, sh[p * LP + l], shf[p * LP + l] != 0);
+        sh[threadIdx.x + 1] = g;
+        shf[threadIdx.x + 1] = hg ? 1u : 0u;
     }
     __syncthreads();
     const bool head = live && pos == 0, ghead = pl == 0 && live && pos == 1;
     if (head || ghead) {
-        if (ghead) mine = load_xyzz(&sh[threadIdx.x]);
-        G1Affine pa = to_affine(mine);
+        if (ghead) {
+            mine = sh[threadIdx.x];
+            have = shf[threadIdx.x] != 0;
+        }
+        G1Affine pa = G1Affine::inf();
+        if (have) pa = to_affine(xyzz28_store(mine));
         if (seg == 1) pa = neg(pa);
         copy_g1(head ? &ps[i * MI_MAX_PAIRS + seg] : &gs[(size_t)blockIdx.x * MI_MAX_PAIRS + seg], &pa);
     }
@@ -1341,7 +1358,7 @@ static void vs_identify(Context &cx, VsKeys &v, const VsWork &w, size_t n, int l
     cx.prof.end("vs_terms", st);
     if (CH > 128) throw std::runtime_error("vs_identify: shape has more chains per proof than vs_sums_kernel lanes");
     const uint32_t LP = CH <= 64 ? 64 : 128;
-    const size_t sums_lds = sizeof(G1Xyzz) * VS_GROUP * LP;
+    const size_t sums_lds = (sizeof(G1Xyzz28) + 4) * VS_GROUP * LP;
     cx.prof.begin("vs_sums", st, n);
     if (LP == 64) {
         cx.raise_lds_limit((const void *)vs_sums_kernel<64>, (int)sums_lds);
