@@ -454,9 +454,13 @@ __global__ void __launch_bounds__(64) msm_combine_serial_kernel(const G1Xyzz *__
         const uint32_t b = heavy_list[h];
         const uint32_t lo = chunk_off[b], hi = chunk_off[b + 1];
         if (hi - lo > MSM_HEAVY_SERIAL_MAX) continue;
-        G1Xyzz acc = load_xyzz(&chunk_partial[lo]);
-        for (uint32_t e = lo + 1; e < hi; e++) acc = xyzz_add_ni(acc, load_xyzz(&chunk_partial[e]));
-        store_xyzz(&buckets[b], acc);
+        G1Xyzz28 acc;
+        bool have = false;
+        for (uint32_t e = lo; e < hi; e++) {
+            const G1Xyzz v = load_xyzz(&chunk_partial[e]);
+            xyzz_acc28(acc, have, xyzz28_from(v), !v.is_inf());
+        }
+        store_xyzz(&buckets[b], have ? xyzz28_store(acc) : G1Xyzz::inf());
     }
 }
 __global__ void __launch_bounds__(256) msm_combine_heavy_kernel(const G1Xyzz *__restrict__ chunk_partial,
@@ -464,22 +468,30 @@ __global__ void __launch_bounds__(256) msm_combine_heavy_kernel(const G1Xyzz *__
                                                                 const uint32_t *__restrict__ heavy_list,
                                                                 const uint32_t *__restrict__ heavy_count,
                                                                 G1Xyzz *__restrict__ buckets) {
-    __shared__ G1Xyzz lds[128];
+    __shared__ G1Xyzz28 lds[128];
+    __shared__ uint32_t ldsf[128];
     const int t = threadIdx.x;
     const uint32_t nheavy = *heavy_count;
     for (uint32_t h = blockIdx.x; h < nheavy; h += gridDim.x) {
         const uint32_t b = heavy_list[h];
         const uint32_t lo = chunk_off[b], hi = chunk_off[b + 1];
         if (hi - lo <= MSM_HEAVY_SERIAL_MAX) continue;  // block-uniform
-        G1Xyzz acc = G1Xyzz::inf();
-        for (uint32_t i = lo + t; i < hi; i += 256) acc = xyzz_add_ni(acc, load_xyzz(&chunk_partial[i]));
+        G1Xyzz28 acc;
+        bool have = false;
+        for (uint32_t i = lo + t; i < hi; i += 256) {
+            const G1Xyzz v = load_xyzz(&chunk_partial[i]);
+            xyzz_acc28(acc, have, xyzz28_from(v), !v.is_inf());
+        }
         for (int stride = 128; stride >= 1; stride >>= 1) {
-            if (t >= stride && t < 2 * stride) store_xyzz(&lds[t - stride], acc);
+            if (t >= stride && t < 2 * stride) {
+                lds[t - stride] = acc;
+                ldsf[t - stride] = have ? 1u : 0u;
+            }
             __syncthreads();
-            if (t < stride) acc = xyzz_add_ni(acc, load_xyzz(&lds[t]));
+            if (t < stride) xyzz_acc28(acc, have, lds[t], ldsf[t] != 0);
             __syncthreads();
         }
-        if (t == 0) store_xyzz(&buckets[b], acc);
+        if (t == 0) store_xyzz(&buckets[b], have ? xyzz28_store(acc) : G1Xyzz::inf());
     }
 }
 
@@ -495,7 +507,9 @@ __global__ void __launch_bounds__(128) msm_segments_kernel(const G1Xyzz *__restr
     size_t w = t / G;
     uint32_t g = (uint32_t)(t - w * G);
     const size_t b0 = w * B + (size_t)g * L;
-    G1Xyzz run = G1Xyzz::inf(), wsum = G1Xyzz::inf();
+    // running sums and the (g L) * run fix-up in the reduced-radix arithmetic of field28.hpp; one conversion back per segment
+    G1Xyzz28 run, wsum;
+    bool have_run = false, have_w = false;
     for (int j = (int)L - 1; j >= 0; j--) {
         // the bucket's value is its single chunk partial (no separate combine pass); buckets cut into more chunks
         // (heavy = 1) were summed by the heavy kernel
@@ -503,39 +517,48 @@ __global__ void __launch_bounds__(128) msm_segments_kernel(const G1Xyzz *__restr
         G1Xyzz v = G1Xyzz::inf();
         if (hi - lo > heavy) v = load_xyzz(&heavy_buckets[b0 + j]);
         else if (lo < hi) v = load_xyzz(&chunk_partial[lo]);
-        run = add(run, v);
-        wsum = add(wsum, run);
+        xyzz_acc28(run, have_run, xyzz28_from(v), !v.is_inf());
+        xyzz_acc28(wsum, have_w, run, have_run);
     }
-    // + (g*L) * run  (double-and-add on the XYZZ point)
+    // + (g*L) * run  (double-and-add)
     uint32_t k = g * L;
-    if (k != 0 && !run.is_inf()) {
-        G1Xyzz acc = G1Xyzz::inf();
+    if (k != 0 && have_run) {
+        G1Xyzz28 acc;
+        bool have_acc = false;
         for (int b = 31 - __clz(k); b >= 0; b--) {
-            acc = dbl(acc);
-            if ((k >> b) & 1u) acc = add(acc, run);
+            if (have_acc) acc = xyzz_dbl28(acc);
+            if ((k >> b) & 1u) xyzz_acc28(acc, have_acc, run, true);
         }
-        wsum = add(wsum, acc);
+        xyzz_acc28(wsum, have_w, acc, have_acc);
     }
-    store_xyzz(&partials[t], wsum);
+    store_xyzz(&partials[t], have_w ? xyzz28_store(wsum) : G1Xyzz::inf());
 }
 
 // ---------------------------------------------------------------- K6: per-group tree sum through LDS
 // in[group][m] -> out[group][gridDim.x]; block (x, group) sums a strided slice, then an LDS tree.
 __global__ void __launch_bounds__(256) point_tree_sum_kernel(const G1Xyzz *__restrict__ in, size_t m,
                                                              G1Xyzz *__restrict__ out) {
-    __shared__ G1Xyzz lds[128];  // 24 KiB: the upper half of the live lanes parks its sum here each level
+    __shared__ G1Xyzz28 lds[128];  // 28 KiB: the upper half of the live lanes parks its sum here each level
+    __shared__ uint32_t ldsf[128];
     const size_t group = blockIdx.y;
     const G1Xyzz *src = in + group * m;
-    G1Xyzz acc = G1Xyzz::inf();
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < m; i += (size_t)gridDim.x * 256) acc = xyzz_add_ni(acc, load_xyzz(&src[i]));
+    G1Xyzz28 acc;
+    bool have = false;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < m; i += (size_t)gridDim.x * 256) {
+        const G1Xyzz v = load_xyzz(&src[i]);
+        xyzz_acc28(acc, have, xyzz28_from(v), !v.is_inf());
+    }
     const int t = threadIdx.x;
     for (int stride = 128; stride >= 1; stride >>= 1) {
-        if (t >= stride && t < 2 * stride) store_xyzz(&lds[t - stride], acc);
+        if (t >= stride && t < 2 * stride) {
+            lds[t - stride] = acc;
+            ldsf[t - stride] = have ? 1u : 0u;
+        }
         __syncthreads();
-        if (t < stride) acc = xyzz_add_ni(acc, load_xyzz(&lds[t]));
+        if (t < stride) xyzz_acc28(acc, have, lds[t], ldsf[t] != 0);
         __syncthreads();
     }
-    if (t == 0) store_xyzz(&out[group * gridDim.x + blockIdx.x], acc);
+    if (t == 0) store_xyzz(&out[group * gridDim.x + blockIdx.x], have ? xyzz28_store(acc) : G1Xyzz::inf());
 }
 
 // ---------------------------------------------------------------- small-MSM reduction: per-bit subset sums
