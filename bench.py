@@ -488,10 +488,12 @@ def extras(dev, verifier, proofs, rnd):
     ex["msm_2^20"] = {"points_per_s": n / dt, "ms": 1e3 * dt, "accumulate_kernel_ms": ms / launches,
                       "gpu_pipeline_ms": ms_t / l_t,
                       "roofline_frac_hbm": 128.0 * n / dt / 1e9 / HBM_PEAK_GBPS,
-                      # integer-ALU view of the dominant kernel: 10 Fq products per mixed addition, one addition per
-                      # (point, window) digit, against the product rate measured in a tight loop (tools/ubench: 56.6 G/s)
+                      # integer-ALU view of the dominant kernel: 8 Fq products + 2 squarings per mixed addition, one
+                      # addition per (point, window) digit, against the rates measured in a tight loop for the reduced-radix
+                      # arithmetic the kernel uses (tools/ubench, 8 waves/SIMD: 79.9 G products/s, 96.7 G squarings/s)
                       "accumulate_fq_products_per_s": 10.0 * units_adds(n, 16) / (ms / launches * 1e-3),
-                      "accumulate_frac_of_measured_alu_peak": 10.0 * units_adds(n, 16) / (ms / launches * 1e-3) / 56.6e9,
+                      "accumulate_frac_of_measured_alu_peak": units_adds(n, 16) * (8.0 / 79.9e9 + 2.0 / 96.7e9) / (ms / launches * 1e-3),
+                      "accumulate_vs_32bit_limb_product_rate": 10.0 * units_adds(n, 16) / (ms / launches * 1e-3) / 56.6e9,
                       "result_is_infinity": bool(not res[12:].any())}
     # --- 8f row 3: KZG10::commit of a 2^20-coefficient polynomial (Montgomery coefficients resident, powers resident):
     # coefficient conversion + the same MSM
