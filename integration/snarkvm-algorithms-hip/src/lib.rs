@@ -126,6 +126,24 @@ impl BatchVerifier {
         check(unsafe { mi_vs_verify_block(self.0, proofs.as_ptr(), proofs.len(), randomizers128.as_ptr(), verdicts.as_mut_ptr(), &mut all_ok) })?;
         Ok((all_ok != 0, verdicts))
     }
+    /// VarunaShaped-v2 (query-set table, hiding, degree-bound classes): records are `mi_vs_proof2`, three 128-bit
+    /// randomizers per proof; every other method takes them through the same entry points (pointer casts).
+    pub fn new_v2(vk: &mi_kzg_vk, ext: Option<&mi_vs_key_ext>, shape: &mi_vs_shape, circuits: &[mi_vs_circuit_vk], poseidon: bool)
+                  -> Result<Self, Status> {
+        let mut h = 0u64;
+        let e = ext.map_or(std::ptr::null(), |x| x as *const mi_vs_key_ext);
+        let flags = if poseidon { MI_VS_FS_POSEIDON } else { 0 };
+        check(unsafe { mi_vs_ctx_create_v2(vk, e, shape, circuits.as_ptr(), circuits.len(), flags, &mut h) })?;
+        Ok(Self(h))
+    }
+    /// The verdict vector of a chunk already known to fail (a streamed chunk whose `all_ok` came back false), from
+    /// its device-resident inputs: no aggregate pass.
+    pub unsafe fn identify(&self, d_proofs: *const c_void, n: usize, d_randomizers128: *const c_void, hip_stream: *mut c_void)
+                           -> Result<Vec<u8>, Status> {
+        let mut verdicts = vec![0u8; n];
+        check(mi_vs_identify_device(self.0, d_proofs, n, d_randomizers128, verdicts.as_mut_ptr(), hip_stream))?;
+        Ok(verdicts)
+    }
     /// Streamed chunks (mempool admission, block sync): `exchange` = None on one GPU, or
     /// `Some(ffi::mi_vs_exchange_rccl)` with `user` = a communicator of `mi_comm_init_rank` when one process per GPU
     /// verifies one block together.
@@ -158,6 +176,20 @@ impl VerifyStream {
         let mut ok = 0u8;
         match unsafe { mi_vs_stream_next(self.0, block as i32, &mut ok) } {
             MI_OK => Ok(Some(ok != 0)),
+            MI_ERR_AGAIN | MI_ERR_DONE => Ok(None),
+            st => Err(st),
+        }
+    }
+    /// The same with the chunk's verdict vector (all ones when `all_ok`; otherwise the invalid proofs of this rank's
+    /// shard named on the device from the submitted, still resident buffers).  `capacity` >= the largest chunk.
+    pub fn next_verdicts(&self, block: bool, capacity: usize) -> Result<Option<(bool, Vec<u8>)>, Status> {
+        let (mut ok, mut n) = (0u8, 0usize);
+        let mut verdicts = vec![0u8; capacity];
+        match unsafe { mi_vs_stream_next_verdicts(self.0, block as i32, &mut ok, verdicts.as_mut_ptr(), capacity, &mut n) } {
+            MI_OK => {
+                verdicts.truncate(n);
+                Ok(Some((ok != 0, verdicts)))
+            }
             MI_ERR_AGAIN | MI_ERR_DONE => Ok(None),
             st => Err(st),
         }
