@@ -132,7 +132,7 @@ impl BatchVerifier {
                   -> Result<Self, Status> {
         let mut h = 0u64;
         let e = ext.map_or(std::ptr::null(), |x| x as *const mi_vs_key_ext);
-        let flags = if poseidon { MI_VS_FS_POSEIDON } else { 0 };
+        let flags: u32 = if poseidon { MI_VS_FS_POSEIDON as u32 } else { 0 };
         check(unsafe { mi_vs_ctx_create_v2(vk, e, shape, circuits.as_ptr(), circuits.len(), flags, &mut h) })?;
         Ok(Self(h))
     }
