@@ -222,7 +222,7 @@ def main():
         "unit": "proofs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": 1e3 * dt / args.steps, "steady_state_ms_per_step": steady,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "u32-limb Montgomery (Fq 12x32, Fr 8x32)", "data": "synthetic",
+        "dtype": "integer limbs, Montgomery (Fq 12x32-bit, and 14 signed 28-bit limbs in the MSM / transcript kernels; Fr 8x32-bit)", "data": "synthetic",
         "config": {"workload": "configs[3]: batch verify of 1024 synthetic VarunaShaped-v1 proofs per GPU "
                                "(KZG open + pairing check); N GPUs = one %d-proof block sharded, partials all-gathered over RCCL" % (world * PROOFS_PER_GPU),
                    "proofs_per_gpu": PROOFS_PER_GPU, "circuits": 8, "all_valid": True, "parallelism": "shard%d" % world,
@@ -339,7 +339,7 @@ def single_process(args):
     assert ok and verdicts.all()
     out = {"metric": "varuna_proofs_verified_per_sec", "value": n_dev * PROOFS_PER_GPU * args.steps / dt, "unit": "proofs/s",
            "n_gpus": n_dev, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
-           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u32-limb Montgomery (Fq 12x32, Fr 8x32)",
+           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "integer limbs, Montgomery (Fq 12x32-bit, and 14 signed 28-bit limbs in the MSM / transcript kernels; Fr 8x32-bit)",
            "data": "synthetic",
            "config": {"workload": "configs[4] shape in ONE process: a %d-proof block per step, mi_vs_verify_block_device over %d "
                                   "device(s): one host thread and one 1024-proof shard per device, partials all-gathered (RCCL from the "
