@@ -288,6 +288,10 @@ int32_t mi_poseidon_fq_hash_many_device(const void *d_inputs, size_t n, size_t m
 int32_t mi_dbg_fq_mul(const mi_fq *a, const mi_fq *b, mi_fq *out, size_t n);
 int32_t mi_dbg_fr_mul(const mi_fr *a, const mi_fr *b, mi_fr *out, size_t n);
 int32_t mi_dbg_g1_add(const mi_g1_affine *a, const mi_g1_affine *b, mi_g1_affine *out, size_t n);
+/* the reduced-radix arithmetic of the MSM / transcript kernels (csrc/field28.hpp) through its conversions: out[i] = a[i] b[i]
+ * R^-1 for even i, 4 a[i] b[i] R^-1 (via squarings and lazy additions) for odd i; out[i] = a[i] + b[i] through its group law */
+int32_t mi_dbg_fq_mul28(const mi_fq *a, const mi_fq *b, mi_fq *out, size_t n);
+int32_t mi_dbg_g1_add28(const mi_g1_affine *a, const mi_g1_affine *b, mi_g1_affine *out, size_t n);
 int32_t mi_dbg_fq_mul_throughput(size_t n_threads, uint32_t iters, double *gmul_per_s);
 /* synthetic inputs made on the device: out[i] = k_i * G with k_i = splitmix64(seed + i) (distinct, in-subgroup) */
 int32_t mi_dbg_gen_points_device(uint64_t seed, size_t n, void *d_out, void *stream);

@@ -4,6 +4,7 @@
 #include <new>
 #include <vector>
 #include "api.hpp"
+#include "field28.hpp"
 #include "tower.hpp"
 
 extern "C" int mi_host_cpu_ok(void);  // cpu_probe.cpp (built without the x86-64-v3 / ADX flags)
@@ -79,6 +80,48 @@ __global__ void dbg_fr_mul_kernel(const Fr *a, const Fr *b, Fr *out, size_t n) {
 __global__ void dbg_g1_add_kernel(const G1Affine *a, const G1Affine *b, G1Affine *out, size_t n) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) out[i] = to_affine(add_mixed(G1Xyzz::from_affine(a[i]), b[i]));
+}
+// the reduced-radix arithmetic (field28.hpp) through its load / store conversions
+__global__ void dbg_fq_mul28_kernel(const Fq *a, const Fq *b, Fq *out, size_t n) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const Fq28 x = load28(a[i]), y = load28(b[i]);
+    // even lanes: a * b; odd lanes: the same value through squarings and lazy additions: ((a + b)^2 - (a - b)^2) / 4
+    // = a b, with the division folded into the comparison by the caller (the kernel returns 4 a b there)
+    if ((i & 1) == 0) out[i] = store28(mul28(x, y));
+    else out[i] = store28(sub28(sqr28(normalise28(add28(x, y))), sqr28(sub28(x, y))));
+}
+__global__ void dbg_g1_add28_kernel(const G1Affine *a, const G1Affine *b, G1Affine *out, size_t n) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    // mixed additions on 28-bit limbs: out = a + b + b (every branch of add_mixed28 and xyzz_add28: doubling, opposite
+    // points, infinity on either side)
+    G1Affine r = G1Affine::inf();
+    G1Xyzz28 acc;
+    bool have = false;
+    const G1Affine pa = a[i], pb = b[i];
+    const Fq28 one = f28_one();
+    if (!pa.is_inf()) {
+        acc = G1Xyzz28{mul28(load28(pa.x), one), mul28(load28(pa.y), one), one, one};
+        have = true;
+    }
+    if (!pb.is_inf()) {
+        const Fq28 qx = load28(pb.x), qy = load28(pb.y);
+        for (int rep = 0; rep < 2; rep++) {
+            if (!have) {
+                acc = G1Xyzz28{mul28(qx, one), mul28(qy, one), one, one};
+                have = true;
+            } else {
+                have = add_mixed28(acc, qx, qy);
+            }
+        }
+        // and once through the full addition: + (-b)
+        G1Xyzz28 nb{mul28(qx, one), neg28(mul28(qy, one)), one, one};
+        nb.y = normalise28(nb.y);
+        xyzz_acc28(acc, have, nb, true);
+    }
+    if (have) r = to_affine(xyzz28_store(acc));
+    out[i] = r;  // a + b
 }
 __device__ __forceinline__ uint64_t splitmix64(uint64_t x) {
     x += 0x9E3779B97F4A7C15ull;
@@ -865,6 +908,12 @@ int32_t mi_dbg_fr_mul(const mi_fr *a, const mi_fr *b, mi_fr *out, size_t n) {
 }
 int32_t mi_dbg_g1_add(const mi_g1_affine *a, const mi_g1_affine *b, mi_g1_affine *out, size_t n) {
     return dbg_binary((const G1Affine *)a, (const G1Affine *)b, (G1Affine *)out, n, dbg_g1_add_kernel);
+}
+int32_t mi_dbg_fq_mul28(const mi_fq *a, const mi_fq *b, mi_fq *out, size_t n) {
+    return dbg_binary((const Fq *)a, (const Fq *)b, (Fq *)out, n, dbg_fq_mul28_kernel);
+}
+int32_t mi_dbg_g1_add28(const mi_g1_affine *a, const mi_g1_affine *b, mi_g1_affine *out, size_t n) {
+    return dbg_binary((const G1Affine *)a, (const G1Affine *)b, (G1Affine *)out, n, dbg_g1_add28_kernel);
 }
 int32_t mi_dbg_fq_mul_throughput(size_t n_threads, uint32_t iters, double *gmul_per_s) {
     if (!gmul_per_s || !n_threads) return MI_ERR_BAD_ARGS;

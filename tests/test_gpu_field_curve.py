@@ -148,3 +148,47 @@ def test_device_entry_points_on_two_streams_from_two_threads(orc, mi):
     for t in threads:
         t.join()
     assert not errors, errors
+
+
+def test_reduced_radix_field_arithmetic_bit_exact(orc, mi):
+    """field28.hpp (14 signed 28-bit limbs) through its conversions: products, squarings and lazy additions against the
+    oracle's Montgomery product; edge operands: 0, 1, q - 1, the Montgomery one, all-ones limb patterns below q"""
+    import pyref
+    from snarkos_amd import lib as L
+    n = 4096
+    a = rng_points(41, n // 2).reshape(-1, 6).copy()
+    b = rng_points(42, n // 2).reshape(-1, 6).copy()
+    q = pyref.Q
+    edge = [0, 1, q - 1, q - 2, (1 << 384) % q, (1 << 376) - 1, int("f" * 7 + "0" * 7, 16) << 300, (1 << 28) - 1, 1 << 28, (1 << 56) + 5]
+    k = 0
+    for x in edge:
+        for y in edge:
+            a[k] = orc.int_to_limbs(x % q, 6); b[k] = orc.int_to_limbs(y % q, 6)
+            a[k + 1] = a[k]; b[k + 1] = b[k]       # the same pair on an odd lane
+            k += 2
+    out = np.zeros_like(a)
+    L.check(L.lib().mi_dbg_fq_mul28(L.ptr(a), L.ptr(b), L.ptr(out), C.c_size_t(n)), "mi_dbg_fq_mul28")
+    rinv = pow(1 << 384, -1, q)
+    for i in range(n):
+        x, y = orc.limbs_to_int(a[i]), orc.limbs_to_int(b[i])
+        want = x * y * rinv % q
+        if i & 1:
+            want = 4 * want % q
+        assert orc.limbs_to_int(out[i]) == want, i
+
+
+def test_reduced_radix_group_law_all_cases(orc, mi):
+    """add_mixed28 / xyzz_add28 / their degenerate branches: out = a + b computed as ((a + b) + b) - b"""
+    from snarkos_amd import lib as L
+    n = 256
+    a, b = rng_points(51, n), rng_points(52, n)
+    b[0] = a[0]                                        # doubling inside the mixed addition
+    b[1] = a[1]; b[1, 6:] = neg_y(orc, a[1, 6:])       # a + b = O, then O + b, then b - b = O
+    a[2] = 0
+    b[3] = 0
+    a[4] = 0; b[4] = 0
+    out = np.zeros_like(a)
+    L.check(L.lib().mi_dbg_g1_add28(L.ptr(a), L.ptr(b), L.ptr(out), C.c_size_t(n)), "mi_dbg_g1_add28")
+    for i in range(n):
+        want = orc.g1_add_affine(a[i], b[i])
+        assert (out[i] == want).all(), i
