@@ -663,17 +663,18 @@ __device__ __forceinline__ Fq vs_fs_element(const mi_vs_proof *__restrict__ p, c
 }
 #define VS_FS_BLOCKS 37
 #define VS_FS_ELEMS 73
-__global__ void __launch_bounds__(64) vs_fs_poseidon_kernel(const void *__restrict__ proofs, size_t n,
+#define VS_FS_PROOFS_PER_BLOCK 64
+__global__ void __launch_bounds__(4 * VS_FS_PROOFS_PER_BLOCK) vs_fs_poseidon_kernel(const void *__restrict__ proofs, size_t n,
                                                              const mi_vs_circuit_vk *__restrict__ circuits, size_t n_circuits,
                                                              const VsConsts *__restrict__ kc, const PoseidonConsts *__restrict__ pc,
                                                              uint32_t *__restrict__ chal) {
     // The permutation runs in the reduced-radix arithmetic of field28.hpp (14 signed 28-bit limbs: one instruction per
     // limb product, a dedicated squaring for the S-box chain, carry-free additions): the state never leaves it between
     // the first absorb and the last squeeze; constants and absorbed elements enter as they are stored.
-    __shared__ Fq28 xs[16][3];     // the state of each proof (full rounds), or lane 0's new element in slot 0 (partial)
-    __shared__ Fq28 xt[16][2][3];  // partial rounds: lane l's products mds[i][l] s_l, l = 1, 2
+    __shared__ Fq28 xs[VS_FS_PROOFS_PER_BLOCK][3];     // the state of each proof (full rounds), or lane 0's new element in slot 0 (partial)
+    __shared__ Fq28 xt[VS_FS_PROOFS_PER_BLOCK][2][3];  // partial rounds: lane l's products mds[i][l] s_l, l = 1, 2
     const int t = threadIdx.x, ps = t >> 2, l = t & 3, lc = l < 3 ? l : 0;
-    const size_t i = (size_t)blockIdx.x * 16 + ps;
+    const size_t i = (size_t)blockIdx.x * VS_FS_PROOFS_PER_BLOCK + ps;
     const mi_vs_proof *p = reinterpret_cast<const mi_vs_proof *>(reinterpret_cast<const uint32_t *>(proofs) + (i < n ? i : 0) * (size_t)kc->proof_words);
     uint32_t circuit = reinterpret_cast<const uint32_t *>(p)[0];
     if (circuit >= n_circuits) circuit = 0;
@@ -1049,7 +1050,12 @@ static VsWork vs_run_derive(Context &cx, VsKeys &v, const void *d_proofs, size_t
         uint32_t *ch = (uint32_t *)cx.buf(W("chal"), 48 * n);
         const PoseidonConsts *pc = poseidon_consts(cx, st);
         cx.prof.begin("vs_fs_poseidon", st, n);
-        hipLaunchKernelGGL(vs_fs_poseidon_kernel, dim3(cdiv(n, 16)), dim3(64), 0, st, d_proofs, n,
+        // 64 proofs (4 waves, one per SIMD) per block, and a block asks for more than half a CU's LDS: the transcript
+        // kernels of the batches in flight then never share a CU.  Their loop body (~70 KB of unrolled products) is
+        // larger than the instruction cache; waves of different batches on one CU sit at different places in it and
+        // fetch against each other (4 concurrent kernels each ran 2.2x slower before).
+        static const size_t fs_pad = getenv("MI_SNARK_FS_LDS_PAD") ? (size_t)atoi(getenv("MI_SNARK_FS_LDS_PAD")) : 50 * 1024;
+        hipLaunchKernelGGL(vs_fs_poseidon_kernel, dim3(cdiv(n, VS_FS_PROOFS_PER_BLOCK)), dim3(4 * VS_FS_PROOFS_PER_BLOCK), fs_pad, st, d_proofs, n,
                            (const mi_vs_circuit_vk *)v.circuits.p, v.n_circuits, (const VsConsts *)v.consts.p, pc, ch);
         cx.prof.end("vs_fs_poseidon", st);
         chal = ch;
