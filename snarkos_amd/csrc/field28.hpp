@@ -72,6 +72,8 @@ static_assert(F28C.mod[0] == 1, "q = 1 mod 2^28: the Montgomery factor of a colu
 #include "f28_gen.hpp"
 namespace mi {
 
+// (always inlined: an out-of-line copy shared by a kernel's ten call sites was measured on the streamed verifier --
+// 4.9 M against 5.9 M proofs/s: the operands' 28 registers each way cost more than the smaller loop saves)
 __device__ __forceinline__ Fq28 mul28(const Fq28 &a, const Fq28 &b) { return mul28_gen(a, b); }
 __device__ __forceinline__ Fq28 sqr28(const Fq28 &a) { return sqr28_gen(a); }
 
