@@ -152,7 +152,9 @@ typedef struct {
     mi_g1_affine w[2];
 } mi_vs_proof; /* 2256 B */
 /* ---- VarunaShaped-v2: the shape of SonicKZG10::check_combinations on top of v1 ----
- *   - the query set is a table (which of the two query points each polynomial opens at);
+ *   - the query set is a table (which of the two query points each polynomial opens at), and so are the linear
+ *     combinations' coefficients (lc_kind: plain challenge powers, or powers times vanishing-polynomial values at the
+ *     challenges);
  *   - hiding: commitments carry rho gamma_g, the proof carries random_v per query (kzg10::VerifierKey.gamma_g,
  *     KZGProof.random_v);
  *   - degree bounds: proof polynomial j of class c comes with a shifted commitment, and e(C_j, shift_h[c]) = e(S_j, h) is
@@ -161,13 +163,18 @@ typedef struct {
  *   - records are mi_vs_proof2, 3184 B, and THREE 128-bit randomizers per proof (48 B).
  * A context made by mi_vs_ctx_create_v2 takes such records through every mi_vs_* entry point (proof pointers are then
  * pointers to mi_vs_proof2; the host-pointer prototypes keep their v1 pointer type, cast).  Not in the shape (stated
- * in DESIGN.md): linear combinations with challenge-dependent coefficients, per-circuit batch sizes above one. */
+ * in DESIGN.md): per-circuit batch sizes above one. */
 #define MI_VS_MAX_BOUNDS 2
 typedef struct {
     uint8_t query_of[MI_VS_EVALS];         /* 0: the beta query, 1: the gamma query; polynomials 0 and 1 open at beta */
     int8_t bound_class[MI_VS_PROOF_COMMS]; /* degree-bound class of each proof polynomial, -1: none */
     uint8_t hiding, n_bounds;
-} mi_vs_shape; /* 32 B */
+    /* linear-combination table: polynomial p's coefficient xi^p is further multiplied by (z_beta^16 - 1)^(bit 0) and
+     * (z_gamma^16 - 1)^(bit 1) -- challenge-dependent coefficients, as Varuna's lincheck combinations carry
+     * v_H(alpha) v_H(beta)-style factors; polynomials 0 and 1 (the public-input identity) take the plain power */
+    uint8_t lc_kind[MI_VS_EVALS];
+    uint8_t pad[3];
+} mi_vs_shape; /* 56 B */
 typedef struct { mi_g1_affine gamma_g; mi_g2_affine shift_h[MI_VS_MAX_BOUNDS]; } mi_vs_key_ext; /* 480 B */
 typedef struct { mi_vs_proof base; mi_fr random_v[2]; mi_g1_affine shifted[MI_VS_PROOF_COMMS]; } mi_vs_proof2; /* 3184 B */
 /* one shard's accumulator (592 B); bound[c] is infinity for contexts without that class */

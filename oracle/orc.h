@@ -165,7 +165,12 @@ typedef struct {
     uint8_t query_of[ORC_VS_EVALS];          /* 0: the beta query, 1: the gamma query */
     int8_t bound_class[ORC_VS_PROOF_COMMS];  /* degree-bound class of each proof polynomial, -1: none */
     uint8_t hiding, n_bounds;
-} orc_vs_shape; /* 32 B */
+    /* linear-combination coefficient of each polynomial: its xi-power is further multiplied by
+     * (z_beta^16 - 1)^(bit 0) (z_gamma^16 - 1)^(bit 1) -- challenge-dependent coefficients as in Varuna's lincheck
+     * combinations (v_H(alpha) v_H(beta) ...); polynomials 0 and 1 take the plain power */
+    uint8_t lc_kind[ORC_VS_EVALS];
+    uint8_t pad[3];
+} orc_vs_shape; /* 56 B */
 typedef struct { orc_g1_affine gamma_g; orc_g2_affine shift_h[ORC_VS_MAX_BOUNDS]; } orc_vs_key_ext; /* 480 B */
 typedef struct { orc_vs_proof base; orc_fr random_v[2]; orc_g1_affine shifted[ORC_VS_PROOF_COMMS]; } orc_vs_proof2; /* 3184 B */
 void orc_vs2_generate(uint64_t seed, size_t n, size_t n_circuits, uint32_t corrupt_per_1024, const orc_vs_shape *shape,

@@ -795,6 +795,21 @@ void orc_vs_generate(uint64_t seed, size_t n, size_t n_circuits, uint32_t corrup
  * Three 128-bit caller randomizers per proof (r_beta, r_gamma, r_3).  The transcript (either kind) runs over the v1 part
  * of the record.  Toy SRS as in v1: tau, gamma and the shift factors s_c (standing for tau^(D - d_c)) are known to the
  * generator only. */
+/* kap[kind] = (z_beta^16 - 1)^(kind & 1) (z_gamma^16 - 1)^(kind >> 1): the challenge-dependent factors of the shape's
+ * linear-combination table */
+static void vs2_lc_factors(fr_t kap[4], const fr_t z[2]) {
+    fr_t v[2], one;
+    fr_one(&one);
+    for (int q = 0; q < 2; q++) {
+        v[q] = z[q];
+        for (int k = 0; k < 4; k++) fr_mul(&v[q], &v[q], &v[q]);
+        fr_sub(&v[q], &v[q], &one);
+    }
+    kap[0] = one;
+    kap[1] = v[0];
+    kap[2] = v[1];
+    fr_mul(&kap[3], &v[0], &v[1]);
+}
 static void vs2_derive(vs_fr_work *o, fr_t rho[ORC_VS_PROOF_COMMS], fr_t *h_scalar, const orc_vs_shape *sh,
                        const orc_vs_circuit_vk *cvk, const orc_vs_proof2 *p2, const uint8_t *rand3x16) {
     const orc_vs_proof *p = &p2->base;
@@ -804,10 +819,14 @@ static void vs2_derive(vs_fr_work *o, fr_t rho[ORC_VS_PROOF_COMMS], fr_t *h_scal
     fr_one(&xip);
     fr_zero(&val[0]);
     fr_zero(&val[1]);
+    fr_t kap[4];
+    vs2_lc_factors(kap, z);
     for (int k = 0; k < ORC_VS_EVALS; k++) {
         const int q = sh->query_of[k] & 1;
-        fr_mul(&o->poly_scalar[k], &r[q], &xip);
-        fr_mul(&t, &xip, S(&p->evals[k]));
+        fr_t coef;
+        fr_mul(&coef, &xip, &kap[sh->lc_kind[k] & 3]);
+        fr_mul(&o->poly_scalar[k], &r[q], &coef);
+        fr_mul(&t, &coef, S(&p->evals[k]));
         fr_add(&val[q], &val[q], &t);
         fr_mul(&xip, &xip, &xi);
     }
@@ -1037,14 +1056,18 @@ void orc_vs2_generate(uint64_t seed, size_t n, size_t n_circuits, uint32_t corru
         orc_vs_challenges(cvk, p, (orc_fr *)&z[0], (orc_fr *)&z[1], (orc_fr *)&xi);
         fr_one(&xip);
         for (int q = 0; q < 2; q++) { fr_zero(&num[q]); fr_zero(&rv[q]); }
+        fr_t kap[4];
+        vs2_lc_factors(kap, z);
         for (int k = 0; k < ORC_VS_EVALS; k++) {
             const int q = sh->query_of[k] & 1;
             const fr_t *at_tau = k < ORC_VS_PROOF_COMMS ? &ptau[i * PC + k] : &ctau[p->circuit * ORC_VS_VK_COMMS + (k - ORC_VS_PROOF_COMMS)];
+            fr_t coef;
+            fr_mul(&coef, &xip, &kap[sh->lc_kind[k] & 3]);
             fr_sub(&t, at_tau, S(&p->evals[k]));
-            fr_mul(&t, &t, &xip);
+            fr_mul(&t, &t, &coef);
             fr_add(&num[q], &num[q], &t);
             if (k < ORC_VS_PROOF_COMMS) {
-                fr_mul(&t, &xip, &prho[i * PC + k]);
+                fr_mul(&t, &coef, &prho[i * PC + k]);
                 fr_add(&rv[q], &rv[q], &t);
             }
             fr_mul(&xip, &xip, &xi);

@@ -329,19 +329,23 @@ class VSBatch:
         return fr_to_ints(zb)[0], fr_to_ints(zg)[0], fr_to_ints(xi)[0]
 
 
-VS2_PROOF_BYTES, VS2_KEY_EXT_BYTES, VS2_SHAPE_BYTES, VS2_RAND_BYTES = 3184, 480, 32, 48
+VS2_PROOF_BYTES, VS2_KEY_EXT_BYTES, VS2_SHAPE_BYTES, VS2_RAND_BYTES = 3184, 480, 56, 48
 VS1_QUERY_OF = [0] * 5 + [1] * 4 + [0] * 6 + [1] * 6
 
 
-def vs2_shape(query_of=None, bound_class=None, hiding=True, n_bounds=2):
-    """32-byte mi_vs_shape / orc_vs_shape: query table, degree-bound classes, hiding flag"""
+def vs2_shape(query_of=None, bound_class=None, hiding=True, n_bounds=2, lc_kind=None):
+    """56-byte mi_vs_shape / orc_vs_shape: query table, degree-bound classes, hiding flag, linear-combination kinds
+    (0: xi^p; bit 0: times z_beta^16 - 1; bit 1: times z_gamma^16 - 1)"""
     q = list(query_of if query_of is not None else VS1_QUERY_OF)
     bc = list(bound_class if bound_class is not None else [-1, -1, -1, -1, -1, 0, 0, 1, 1])
+    lc = list(lc_kind if lc_kind is not None else [0] * 21)
     assert len(q) == 21 and len(bc) == 9 and q[0] == 0 and q[1] == 0, "p_0 and p_1 open at the beta query (public-input identity)"
-    out = np.zeros(32, dtype=np.uint8)
+    assert len(lc) == 21 and lc[0] == 0 and lc[1] == 0 and all(0 <= x <= 3 for x in lc)
+    out = np.zeros(VS2_SHAPE_BYTES, dtype=np.uint8)
     out[:21] = q
     out[21:30] = np.array(bc, dtype=np.int8).view(np.uint8)
     out[30], out[31] = int(bool(hiding)), n_bounds
+    out[32:53] = lc
     return out
 
 

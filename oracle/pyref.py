@@ -637,7 +637,9 @@ def vs2_verify_one(tau_h, gamma_g, shift_h, shape, circuits, proof, rs):
     for p in range(VS_EVALS):
         q = shape["query_of"][p]
         cm = proof["comms"][p] if p < VS_PROOF_COMMS else cvk["comms"][p - VS_PROOF_COMMS]
-        coef = rs[q] * pow(xi, p, R) % R
+        kind = shape.get("lc_kind", [0] * VS_EVALS)[p]
+        kap = pow((pow(zb, 16, R) - 1) % R, kind & 1, R) * pow((pow(zg, 16, R) - 1) % R, (kind >> 1) & 1, R) % R
+        coef = rs[q] * pow(xi, p, R) * kap % R
         total_c = g1_add(total_c, g1_mul(cm, coef))
         gs = (gs + coef * ev[p]) % R
     for q in range(2):

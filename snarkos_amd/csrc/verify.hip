@@ -138,6 +138,7 @@ struct VsConsts {
     uint32_t per_proof;        // H-side points per proof: 9 commitments + 2 witnesses + n_bounded shifted commitments
     uint32_t class_count[MI_VS_MAX_BOUNDS];
     uint8_t query_of[MI_VS_EVALS];
+    uint8_t lc_kind[MI_VS_EVALS];  // v2: bit 0: times z_beta^16 - 1, bit 1: times z_gamma^16 - 1
     int8_t bound_class[MI_VS_PROOF_COMMS];
     uint8_t _pad[2];
 };
@@ -322,6 +323,9 @@ int32_t vs_ctx_create(Context &cx, const mi_kzg_vk *vk, const mi_vs_key_ext *ext
                       const mi_vs_circuit_vk *circuits, size_t n_circuits, uint32_t flags, uint64_t *out) {
     if (shape) {
         if (shape->n_bounds > MI_VS_MAX_BOUNDS || shape->hiding > 1 || (shape->query_of[0] & 1) || (shape->query_of[1] & 1)) return MI_ERR_BAD_ARGS;
+        if (shape->lc_kind[0] || shape->lc_kind[1]) return MI_ERR_BAD_ARGS;  // the public-input identity reads p_0, p_1 as they are
+        for (int p = 0; p < MI_VS_EVALS; p++)
+            if (shape->lc_kind[p] > 3) return MI_ERR_BAD_ARGS;
         if ((shape->hiding || shape->n_bounds) && !ext) return MI_ERR_BAD_ARGS;
     }
     std::shared_ptr<VsCtx> v(new VsCtx());
@@ -362,6 +366,7 @@ int32_t vs_ctx_create(Context &cx, const mi_kzg_vk *vk, const mi_vs_key_ext *ext
         hc.hiding = shape->hiding;
         hc.n_bounds = shape->n_bounds;
         memcpy(hc.query_of, shape->query_of, sizeof hc.query_of);
+        memcpy(hc.lc_kind, shape->lc_kind, sizeof hc.lc_kind);
         for (int j = 0; j < MI_VS_PROOF_COMMS; j++) {
             const int c = shape->bound_class[j];
             hc.bound_class[j] = (c >= 0 && c < (int)shape->n_bounds) ? (int8_t)c : (int8_t)-1;
@@ -547,12 +552,23 @@ __global__ void __launch_bounds__(128) vs_derive_kernel(const void *__restrict__
         Fr r[2] = {fr_from_u128(r0), fr_from_u128(r1)};
         // ---- opening-challenge powers, combined values, MSM scalars (the query of each polynomial: the shape's table)
         Fr xip = Fr::one(), val[2] = {Fr::zero(), Fr::zero()};
+        // the linear-combination table's challenge-dependent factors (v2): kap[kind] = (z_beta^16 - 1)^(kind & 1)
+        // (z_gamma^16 - 1)^(kind >> 1)
+        Fr kap1 = z[0], kap2 = z[1];
+#pragma unroll
+        for (int k = 0; k < 4; k++) { kap1 = sqr(kap1); kap2 = sqr(kap2); }
+        kap1 = sub(kap1, Fr::one());
+        kap2 = sub(kap2, Fr::one());
+        const Fr kap3 = mul(kap1, kap2);
         for (int k = 0; k < MI_VS_EVALS; k++) {
             const int q = kc->query_of[k] & 1;
-            Fr s = mul(q ? r[1] : r[0], xip);
+            const uint32_t kind = kc->lc_kind[k] & 3u;  // uniform
+            Fr coef = xip;
+            if (kind) coef = mul(xip, kind == 1 ? kap1 : (kind == 2 ? kap2 : kap3));
+            Fr s = mul(q ? r[1] : r[0], coef);
             if (k < MI_VS_PROOF_COMMS) fr_store(sc1 + (i * PP + k) * 8, from_mont(s));
             else fr_store(vk_scal + i * MI_VS_VK_COMMS + (k - MI_VS_PROOF_COMMS), s);
-            const Fr tv = mul(xip, fr_load(evals + 8 * k));
+            const Fr tv = mul(coef, fr_load(evals + 8 * k));
             if (q) val[1] = add(val[1], tv);
             else val[0] = add(val[0], tv);
             xip = mul(xip, xi);

@@ -33,7 +33,7 @@ VS_MAX_TICKETS = 8
 VS_FS_POSEIDON = 1  # mi_vs_ctx_create_ex flag: Poseidon Fiat-Shamir transcript
 VS2_PROOF_BYTES = 3184  # mi_vs_proof2
 VS2_KEY_EXT_BYTES = 480
-VS2_SHAPE_BYTES = 32
+VS2_SHAPE_BYTES = 56
 
 # every symbol include/mi355x_snark.h declares
 EXPORTS = [

@@ -87,16 +87,18 @@ def test_each_new_proof_field_is_bound(orc, mi, field):
         v.close()
 
 
-@pytest.mark.parametrize("hiding,n_bounds,bound_class", [
-    (False, 0, [-1] * 9),                              # the v1 relation in v2 records
-    (True, 0, [-1] * 9),                               # hiding only
-    (False, 1, [-1, -1, 0, -1, -1, -1, -1, -1, 0]),    # one class, K = 3
-    (True, 2, [1, -1, -1, 0, -1, 1, -1, 0, 0]),        # K = 4, classes of unequal size
+@pytest.mark.parametrize("hiding,n_bounds,bound_class,lc", [
+    (False, 0, [-1] * 9, None),                              # the v1 relation in v2 records
+    (True, 0, [-1] * 9, None),                               # hiding only
+    (False, 1, [-1, -1, 0, -1, -1, -1, -1, -1, 0], None),    # one class, K = 3
+    (True, 2, [1, -1, -1, 0, -1, 1, -1, 0, 0], None),        # K = 4, classes of unequal size
+    (True, 2, [1, -1, -1, 0, -1, 1, -1, 0, 0], [0, 0, 1, 2, 3, 0, 1, 3, 2] + [3, 1, 0, 2] * 3),  # + challenge-dependent LC coefficients
+    (False, 0, [-1] * 9, [0, 0] + [3] * 19),                 # every other polynomial times both vanishing values
 ])
-def test_shapes(orc, mi, hiding, n_bounds, bound_class):
+def test_shapes(orc, mi, hiding, n_bounds, bound_class, lc):
     import torch
     q = [0, 0, 1, 0, 1, 1, 0, 1, 0] + [1, 0] * 6
-    shape = orc.vs2_shape(q, bound_class, hiding, n_bounds)
+    shape = orc.vs2_shape(q, bound_class, hiding, n_bounds, lc_kind=lc)
     b = orc.VS2Batch(0x20B4 + n_bounds, 40, 3, 128, shape=shape)
     assert 0 < b.expected.sum() < b.n
     v = _ctx(mi, b)
