@@ -47,7 +47,7 @@ void pairing_product_prepared(Context &cx, const G1Affine *ps, const G2Prepared 
                               hipStream_t st);
 void pairing_product_host_args(Context &cx, const G1Affine *ps, const G2Affine *qs, size_t n, Fq12 *out_host,
                                hipStream_t st);
-void pairing_launch(Context &cx, const G1Affine *ps, const G2Prepared *const *d_qs, size_t n, Fq12 *d_out, hipStream_t st);
+void pairing_launch(Context &cx, const G1Affine *ps, const G2Prepared *const *d_qs, size_t n, Fq12 *d_out, hipStream_t st, int unit);
 const PairingConsts *pairing_consts(Context &cx, hipStream_t st);
 
 // capi.hip: Poseidon over Fq (width 3, x^17, 4 + 31 + 4 rounds), constants resident per device

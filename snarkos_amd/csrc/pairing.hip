@@ -1,4 +1,6 @@
 // Pairing product on the device: kernel + host drivers.  Device/host arithmetic lives in tower.hpp.
+#include <stdio.h>
+#include <stdlib.h>
 #include <vector>
 #include "api.hpp"
 #include "tower.hpp"
@@ -12,12 +14,24 @@ struct PairingArgs {
     int n;
 };
 
-// one workgroup of 192 lanes per pairing product (pairing_wg.hpp)
+// one workgroup of 192 lanes per pairing product (pairing_wg.hpp); merged: the Miller factors of pairing_lines_kernel
 __global__ void __launch_bounds__(PW_THREADS) pairing_product_kernel(PairingArgs args, const PairingConsts *__restrict__ pc,
-                                                                     Fq12 *out) {
+                                                                     Fq12 *out, const Fq *merged) {
     extern __shared__ uint4 pw_lds[];  // PW_LDS_BYTES
     LShared &S = *(LShared *)pw_lds;
-    pw_pairing_product(S, args.p, args.q, args.n, pc, out);
+    pw_pairing_product(S, args.p, args.q, args.n, pc, out, merged);
+}
+// first launch of the two-launch form: workgroup (g, couple) computes the couple's merged Miller factor of steps
+// 3g .. 3g + 2 (pw_miller_group) into merged[couple][g][12]
+__global__ void __launch_bounds__(PW_THREADS) pairing_lines_kernel(PairingArgs args, const PairingConsts *__restrict__ pc, Fq *merged) {
+    extern __shared__ uint4 pw_lds[];  // PW_LDS_BYTES
+    LShared &S = *(LShared *)pw_lds;
+    __shared__ const G2Prepared *live_q[MI_MAX_PAIRS];
+    __shared__ int live_n_s;
+    const int live_n = pw_live_pairs(S, args.p, args.q, args.n, live_q, &live_n_s, pc);
+    const int couple = blockIdx.y, p0 = 2 * couple;
+    if (p0 >= live_n) return;  // uniform
+    pw_miller_group(S, live_q, p0, live_n - p0 >= 2 ? 2 : 1, blockIdx.x, merged + ((size_t)couple * PW_MILLER_GROUPS + blockIdx.x) * 12);
 }
 
 struct PairingState {  // per device (Context::mod)
@@ -63,15 +77,31 @@ const PairingConsts *pairing_consts(Context &cx, hipStream_t st) {
 
 // product over prepared (device-resident) G2 points; P's are host values passed as kernel arguments
 // enqueue one pairing product on `st`; the result lands in d_out (device)
-void pairing_launch(Context &cx, const G1Affine *ps, const G2Prepared *const *d_qs, size_t n, Fq12 *d_out, hipStream_t st) {
+// unit < 0: a product somebody waits for (one batch on its own, a block, mi_pairing*): the two-launch form -- 21
+// workgroups per couple prepare the merged Miller factors, the product kernel is 48 rounds (159 for two couples)
+// shorter: 0.87 -> 0.76 ms.  unit >= 0: a product slot of the streamed verifier, where eight products are in flight
+// and nobody waits for one of them: the one-launch form (the extra workgroups of the other form cost the stream a
+// quarter of its throughput, measured).  MI_SNARK_PAIRING_LAUNCHES=1 / 2 forces either.
+void pairing_launch(Context &cx, const G1Affine *ps, const G2Prepared *const *d_qs, size_t n, Fq12 *d_out, hipStream_t st, int unit) {
     PairingArgs a;
     memset(&a, 0, sizeof a);
     a.n = (int)n;
     for (size_t i = 0; i < n; i++) { a.p[i] = ps[i]; a.q[i] = d_qs[i]; }
     const PairingConsts *pc = pairing_consts(cx, st);
+    static const int force = getenv("MI_SNARK_PAIRING_LAUNCHES") ? atoi(getenv("MI_SNARK_PAIRING_LAUNCHES")) : 0;
+    const bool two_launches = force ? force == 2 : unit < 0;
+    const int couples = (int)((n + 1) / 2);
+    Fq *merged = nullptr;
     cx.prof.begin("pairing", st, n);
     cx.raise_lds_limit((const void *)pairing_product_kernel, (int)PW_LDS_BYTES);
-    hipLaunchKernelGGL(pairing_product_kernel, dim3(1), dim3(PW_THREADS), PW_LDS_BYTES, st, a, pc, d_out);
+    if (two_launches && n > 0) {
+        char nm[32];
+        snprintf(nm, sizeof nm, "pairing.m%d", unit < 0 ? 99 : unit);
+        merged = (Fq *)cx.buf(nm, sizeof(Fq) * 12 * PW_MILLER_GROUPS * (MI_MAX_PAIRS / 2));
+        cx.raise_lds_limit((const void *)pairing_lines_kernel, (int)PW_LDS_BYTES);
+        hipLaunchKernelGGL(pairing_lines_kernel, dim3(PW_MILLER_GROUPS, couples), dim3(PW_THREADS), PW_LDS_BYTES, st, a, pc, merged);
+    }
+    hipLaunchKernelGGL(pairing_product_kernel, dim3(1), dim3(PW_THREADS), PW_LDS_BYTES, st, a, pc, d_out, (const Fq *)merged);
     cx.prof.end("pairing", st);
     MI_HIP(hipGetLastError());
 }
@@ -79,7 +109,7 @@ void pairing_launch(Context &cx, const G1Affine *ps, const G2Prepared *const *d_
 void pairing_product_prepared(Context &cx, const G1Affine *ps, const G2Prepared *const *d_qs, size_t n, Fq12 *out_host,
                                      hipStream_t st) {
     Fq12 *d_out = (Fq12 *)cx.buf("pairing.out", sizeof(Fq12));
-    pairing_launch(cx, ps, d_qs, n, d_out, st);
+    pairing_launch(cx, ps, d_qs, n, d_out, st, -1);
     Fq12 *h = (Fq12 *)cx.pin(sizeof(Fq12));
     MI_HIP(hipMemcpyAsync(h, d_out, sizeof(Fq12), hipMemcpyDeviceToHost, st));
     MI_HIP(hipStreamSynchronize(st));

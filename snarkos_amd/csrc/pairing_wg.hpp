@@ -345,18 +345,17 @@ __device__ const uint8_t PW_LL_TABLE[12][4] = {
 };
 #undef PW_LL
 
-// Miller loop of one COUPLE of live pairs (p0, p0 + 1) -- every KZG / verifier check is one couple -- into S.f.
-// Up front: all line coefficients at their P (552 values, three per lane), then the 69 line products l_1 l_2
-// (828 coefficients: up to four Montgomery products each, a lane per coefficient).  The loop itself is two rounds per
-// doubling step -- f^2, then (l_1 l_2) f -- and one more per addition step.  A single pair (np = 1) runs as a couple
-// whose second line is the constant 1.  Products over more pairs multiply the couples' values (pw_pairing_product).
-__device__ __attribute__((noinline)) void pw_miller2(LShared &S, const G2Prepared *const *qs, int p0, int np) {
+// The lines of one COUPLE of live pairs (p0, p0 + 1) for the line indices [lo, lo + count): every line's coefficients at
+// its P (four per line and pair, a lane each), then the line products l_1 l_2 (twelve coefficients per line: up to four
+// Montgomery products each, a lane per coefficient) into S.lprod[0 .. count).  A single pair (np = 1) runs as a couple
+// whose second line is the constant 1.
+__device__ __forceinline__ void pw_line_products(LShared &S, const G2Prepared *const *qs, int p0, int np, int lo, int count) {
     const int t = threadIdx.x;
-    for (int item = t; item < MI_MILLER_LINES * 8; item += PW_THREADS) {
+    for (int item = t; item < count * 8; item += PW_THREADS) {
         const int idx = item >> 3, p = (item >> 2) & 1, role = item & 3;
         Fq v = Fq::zero();
         if (p < np) {
-            const Line *ln = &qs[p0 + p]->lines[idx];
+            const Line *ln = &qs[p0 + p]->lines[lo + idx];
             if (role == 0) v = mul(ln->c1.c0, lds_load(&S.px[p0 + p]));       // w^1
             else if (role == 1) v = ln->c3.c0;                                 // w^3
             else if (role == 2) v = mul(ln->c1.c1, lds_load(&S.px[p0 + p]));  // w^7
@@ -367,7 +366,7 @@ __device__ __attribute__((noinline)) void pw_miller2(LShared &S, const G2Prepare
     if (t == 12) lds_store(&S.one, Fq::one());
     __syncthreads();
     const LFq *y1 = &S.py[p0], *y2 = np == 2 ? &S.py[p0 + 1] : &S.one;
-    for (int item = t; item < MI_MILLER_LINES * 12; item += PW_THREADS) {
+    for (int item = t; item < count * 12; item += PW_THREADS) {
         const int idx = item / 12, k = item - 12 * idx;
         Fq acc = Fq::zero();
 #pragma unroll 1
@@ -380,6 +379,13 @@ __device__ __attribute__((noinline)) void pw_miller2(LShared &S, const G2Prepare
         }
         lds_store(&S.lprod[idx][k], acc);
     }
+    __syncthreads();
+}
+
+// Miller loop of one couple into S.f: all line products up front, then two rounds per doubling step -- f^2, then
+// (l_1 l_2) f -- and one more per addition step.  Products over more pairs multiply the couples' values.
+__device__ __attribute__((noinline)) void pw_miller2(LShared &S, const G2Prepared *const *qs, int p0, int np) {
+    pw_line_products(S, qs, p0, np, 0, MI_MILLER_LINES);
     pb_set_one(&S.f);
     __syncthreads();
     int idx = 0;
@@ -392,6 +398,73 @@ __device__ __attribute__((noinline)) void pw_miller2(LShared &S, const G2Prepare
         if ((MI_BLS_X >> i) & 1) {
             pb_round_impl<true>(S, alt, S.lprod[idx], cur, fc.d0, fc.d1, fc.d2, fc.d3);  // the addition step's lines
             idx++;
+            LPB *sw = cur; cur = alt; alt = sw;
+        }
+    }
+    if (cur != &S.f) pb_copy(S, &S.f, cur);
+}
+
+// ---- the Miller loop in two launches (pairing.hip): f_(i+1) = f_i^2 X_i with X_i the step's line product (times the
+// addition step's where x has a bit), so three steps are f^8 (X_a^4 X_b^2 X_c).  The merged factors M_g = X_a^4 X_b^2 X_c
+// do not depend on f: a first launch computes the 21 of every couple on 21 workgroups side by side, the product
+// kernel then runs 3 squarings + one multiplication per couple and group: 84 rounds instead of 132 for one couple,
+// 105 instead of 264 for two.
+#define PW_MILLER_GROUPS 21
+static_assert(3 * PW_MILLER_GROUPS == 63, "63 doubling steps in triples");
+// workgroup (g, couple): M_g of the couple (p0, p0 + 1) -> out[12] (plain coefficients in [0, 2q))
+__device__ __forceinline__ void pw_miller_group(LShared &S, const G2Prepared *const *qs, int p0, int np, int g, Fq *out) {
+    // line indices of the group's steps: step s (bit 62 - s of x) has its doubling line at s + (addition steps before s)
+    int lo = 0;
+    for (int s = 0; s < 3 * g; s++) lo += 1 + (int)((MI_BLS_X >> (62 - s)) & 1);
+    int count = 0, nadd[3];
+    for (int k = 0; k < 3; k++) {
+        nadd[k] = (int)((MI_BLS_X >> (62 - (3 * g + k))) & 1);
+        count += 1 + nadd[k];
+    }
+    pw_line_products(S, qs, p0, np, lo, count);
+    const int t = threadIdx.x;
+    const PwFold fc = pw_fold_consts(S);
+    // acc = X_a; then twice: acc = acc^2 X_next.  X_k = lprod[dbl] (* lprod[add]); products keep the running value as
+    // operand B (a PB with its twin) and the line product as operand A (plain)
+    LPB *cur = &S.f, *alt = &S.g;
+    int idx = 0;
+    if (t < 12) pb_put(cur, t, lds_load(&S.lprod[0][t]));
+    __syncthreads();
+    idx = 1;
+    if (nadd[0]) {
+        pb_round_impl<true>(S, alt, S.lprod[idx], cur, fc.d0, fc.d1, fc.d2, fc.d3);
+        idx++;
+        LPB *sw = cur; cur = alt; alt = sw;
+    }
+    for (int k = 1; k < 3; k++) {
+        pb_round_impl<true>(S, alt, cur->c, cur, fc.d0, fc.d1, fc.d2, fc.d3);        // alt = cur^2
+        pb_round_impl<true>(S, cur, S.lprod[idx], alt, fc.d0, fc.d1, fc.d2, fc.d3);  // cur = X_k alt
+        idx++;
+        if (nadd[k]) {
+            pb_round_impl<true>(S, alt, S.lprod[idx], cur, fc.d0, fc.d1, fc.d2, fc.d3);
+            idx++;
+            LPB *sw = cur; cur = alt; alt = sw;
+        }
+    }
+    if (t < 12) out[t] = lds_load(&cur->c[t]);
+}
+// S.f = the Miller value of `couples` couples from their merged factors m[couple][group][12] (global memory)
+__device__ __attribute__((noinline)) void pw_miller_merged(LShared &S, const Fq *m, int couples) {
+    const int t = threadIdx.x;
+    for (int item = t; item < couples * PW_MILLER_GROUPS * 12; item += PW_THREADS) lds_store(&S.lprod[item / 12][item % 12], m[item]);
+    pb_set_one(&S.f);
+    __syncthreads();
+    LPB *cur = &S.f, *alt = &S.g;
+    const PwFold fc = pw_fold_consts(S);
+    for (int g = 0; g < PW_MILLER_GROUPS; g++) {
+        if (g) {  // f = 1 before the first group
+            for (int k = 0; k < 3; k++) {
+                pb_round_impl<true>(S, alt, cur->c, cur, fc.d0, fc.d1, fc.d2, fc.d3);
+                LPB *sw = cur; cur = alt; alt = sw;
+            }
+        }
+        for (int c = 0; c < couples; c++) {
+            pb_round_impl<true>(S, alt, S.lprod[c * PW_MILLER_GROUPS + g], cur, fc.d0, fc.d1, fc.d2, fc.d3);
             LPB *sw = cur; cur = alt; alt = sw;
         }
     }
@@ -427,11 +500,10 @@ __device__ __attribute__((noinline)) void pw_final_exp(LShared &S, const Pairing
     pb_mul(S, &S.f, &S.d, &S.x);
 }
 
-// full product over the pairs whose P is not infinity and whose Q is not infinity; result (tower order) to out
-__device__ __forceinline__ void pw_pairing_product(LShared &S, const G1Affine *ps, const G2Prepared *const *qs, int n,
-                                                   const PairingConsts *pc, Fq12 *out) {
-    __shared__ const G2Prepared *live_q[MI_MAX_PAIRS];
-    __shared__ int live_n;
+// the pairs whose P is not infinity and whose Q is not infinity, packed to the front: S.px / S.py and live_q; returns
+// their number in every lane
+__device__ __forceinline__ int pw_live_pairs(LShared &S, const G1Affine *ps, const G2Prepared *const *qs, int n,
+                                              const G2Prepared **live_q, int *live_n, const PairingConsts *pc) {
     const int t = threadIdx.x;
     if (t == 0) {
         int m = 0;
@@ -442,18 +514,31 @@ __device__ __forceinline__ void pw_pairing_product(LShared &S, const G1Affine *p
             lds_store(&S.py[m], ps[p].y);
             m++;
         }
-        live_n = m;
+        *live_n = m;
     }
     if (t >= 64 && t < 64 + 25) lds_store(&S.dtab[t - 64], pc->dtab[t - 64]);
     __syncthreads();
+    return *live_n;
+}
+// full product over the live pairs; result (tower order) to out.  merged: the couples' merged Miller factors from
+// pw_miller_group (the two-launch form), or null: everything in this workgroup.
+__device__ __forceinline__ void pw_pairing_product(LShared &S, const G1Affine *ps, const G2Prepared *const *qs, int n,
+                                                   const PairingConsts *pc, Fq12 *out, const Fq *merged = nullptr) {
+    __shared__ const G2Prepared *live_q[MI_MAX_PAIRS];
+    __shared__ int live_n_s;
+    const int t = threadIdx.x;
+    const int live_n = pw_live_pairs(S, ps, qs, n, live_q, &live_n_s, pc);
     if (live_n == 0) {
         pb_set_one(&S.f);
         __syncthreads();
-    }
-    for (int c = 0; c < live_n; c += 2) {
-        if (c > 0) pb_copy(S, &S.b, &S.f);  // the couples before this one
-        pw_miller2(S, live_q, c, live_n - c >= 2 ? 2 : 1);
-        if (c > 0) pb_mul(S, &S.f, &S.f, &S.b);
+    } else if (merged) {
+        pw_miller_merged(S, merged, (live_n + 1) / 2);
+    } else {
+        for (int c = 0; c < live_n; c += 2) {
+            if (c > 0) pb_copy(S, &S.b, &S.f);  // the couples before this one
+            pw_miller2(S, live_q, c, live_n - c >= 2 ? 2 : 1);
+            if (c > 0) pb_mul(S, &S.f, &S.f, &S.b);
+        }
     }
     pw_final_exp(S, pc);
     if (t < 12) {

@@ -1335,7 +1335,7 @@ int32_t vs_finalize_async(Context &cx, uint64_t id, const mi_vs_partial *parts, 
     vs_sum_partials(parts, np, ps, &fails);
     const G2Prepared *qs[MI_MAX_PAIRS];
     const int K = vs_g2_keys(v, qs);
-    pairing_launch(cx, ps, qs, K, sl.h_out, sl.stream);  // the kernel stores its result in pinned host memory
+    pairing_launch(cx, ps, qs, K, sl.h_out, sl.stream, slot);  // the kernel stores its result in pinned host memory
     MI_HIP(hipEventRecord(sl.done, sl.stream));
     sl.ticket = tk;
     sl.busy = true;
