@@ -42,7 +42,8 @@ def newest(pattern):
 for pat, out in (("stats/*/*_kernel_stats.csv", "%s_rocprofv3_kernel_stats.csv" % tag), ("bench.json", "%s_bench.json" % tag),
                  ("stats_bench.json", "%s_bench_under_rocprofv3.json" % tag),
                  ("msm20_stats/*/*_kernel_stats.csv", "%s_msm20_kernel_stats.csv" % tag),
-                 ("ntt22_stats/*/*_kernel_stats.csv", "%s_ntt22_kernel_stats.csv" % tag)):
+                 ("ntt22_stats/*/*_kernel_stats.csv", "%s_ntt22_kernel_stats.csv" % tag),
+                 ("batch_stats/*/*_kernel_stats.csv", "%s_one_batch_kernel_stats.csv" % tag)):
     f = newest(pat)
     if f:
         shutil.copy(f, os.path.join(dst, out))

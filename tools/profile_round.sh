@@ -14,6 +14,7 @@ B="--steps 20 --warmup 5 --no-extra --no-cpu-baseline"
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 $R/bench.py $B > $OUT/stats_bench.json 2> $OUT/stats.err || exit 2
 timeout -k 10 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 $R/bench.py --steps 3 --warmup 1 --no-extra --no-cpu-baseline > /dev/null 2> $OUT/pmc_fetch.err || exit 3
 timeout -k 10 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python3 $R/bench.py --steps 3 --warmup 1 --no-extra --no-cpu-baseline > /dev/null 2> $OUT/pmc_write.err || exit 4
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/batch_stats -- python3 $R/tools/batch_one.py > $OUT/batch.log 2>&1 || exit 8
 for W in "msm20 $R/tools/msm_one.py 20" "ntt22 $R/tools/ntt_one.py 22"; do
   set -- $W
   timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/$1_stats -- python3 $2 $3 > $OUT/$1.log 2>&1 || exit 5
