@@ -160,10 +160,12 @@ typedef struct {
  *   - degree bounds: proof polynomial j of class c comes with a shifted commitment, and e(C_j, shift_h[c]) = e(S_j, h) is
  *     folded into the product with rho_j = r_3 xi^(21 + j): 2 + n_bounds pairs
  *     (total_c - sum rho_j S_j, h), (-total_w, tau h), (sum_{j in c} rho_j C_j, shift_h[c]);
- *   - records are mi_vs_proof2, 3184 B, and THREE 128-bit randomizers per proof (48 B).
+ *   - per-circuit batch sizes: with max_instances > 1 a proof carries 1 .. max_instances instances of its circuit;
+ *   - records are mi_vs_proof2, 3184 B (mi_vs_proof3, 5504 B, with instances), and THREE 128-bit randomizers per
+ *     proof (48 B).
  * A context made by mi_vs_ctx_create_v2 takes such records through every mi_vs_* entry point (proof pointers are then
  * pointers to mi_vs_proof2; the host-pointer prototypes keep their v1 pointer type, cast).  Not in the shape (stated
- * in DESIGN.md): per-circuit batch sizes above one. */
+ * in DESIGN.md): coefficients that need a field inversion of a challenge. */
 #define MI_VS_MAX_BOUNDS 2
 typedef struct {
     uint8_t query_of[MI_VS_EVALS];         /* 0: the beta query, 1: the gamma query; polynomials 0 and 1 open at beta */
@@ -173,10 +175,26 @@ typedef struct {
      * (z_gamma^16 - 1)^(bit 1) -- challenge-dependent coefficients, as Varuna's lincheck combinations carry
      * v_H(alpha) v_H(beta)-style factors; polynomials 0 and 1 (the public-input identity) take the plain power */
     uint8_t lc_kind[MI_VS_EVALS];
-    uint8_t pad[3];
+    /* per-circuit batch size (Varuna's batch_sizes): a proof covers 1 .. max_instances instances of its circuit.
+     * 0 / 1: one, records are mi_vs_proof2; more: records are mi_vs_proof3 */
+    uint8_t max_instances;
+    uint8_t pad[2];
 } mi_vs_shape; /* 56 B */
 typedef struct { mi_g1_affine gamma_g; mi_g2_affine shift_h[MI_VS_MAX_BOUNDS]; } mi_vs_key_ext; /* 480 B */
 typedef struct { mi_vs_proof base; mi_fr random_v[2]; mi_g1_affine shifted[MI_VS_PROOF_COMMS]; } mi_vs_proof2; /* 3184 B */
+/* a further instance of the proof's circuit: its public inputs, two commitments A_j, B_j (the analogues of C_0, C_1)
+ * and their evaluations a_j, b_j at the beta query: a_j = x_hat_j(z_beta) + (z_beta^16 - 1) b_j, and the two
+ * polynomials join the beta combination with xi^(30 + 2 (j - 1)), xi^(31 + 2 (j - 1)).  The transcript chains every
+ * further instance in after C_1 (inputs, commitments) and after the evaluations (its two). */
+#define MI_VS_MAX_INSTANCES 4
+#define MI_VS_EXTRA_INSTANCES 3 /* MI_VS_MAX_INSTANCES - 1 */
+typedef struct { mi_fr inputs[MI_VS_INPUTS]; mi_g1_affine comms[2]; mi_fr evals[2]; } mi_vs_instance; /* 768 B */
+typedef struct {
+    mi_vs_proof2 base2;
+    uint32_t n_instances; /* 1 .. the shape's max_instances; anything else: the proof is invalid */
+    uint32_t pad[3];
+    mi_vs_instance extra[MI_VS_EXTRA_INSTANCES];
+} mi_vs_proof3; /* 5504 B */
 /* one shard's accumulator (592 B); bound[c] is infinity for contexts without that class */
 typedef struct { mi_g1_jac total_c, total_w, bound[MI_VS_MAX_BOUNDS]; uint64_t n_proofs, n_alg_fail; } mi_vs_partial;
 

@@ -169,10 +169,30 @@ typedef struct {
      * (z_beta^16 - 1)^(bit 0) (z_gamma^16 - 1)^(bit 1) -- challenge-dependent coefficients as in Varuna's lincheck
      * combinations (v_H(alpha) v_H(beta) ...); polynomials 0 and 1 take the plain power */
     uint8_t lc_kind[ORC_VS_EVALS];
-    uint8_t pad[3];
+    /* per-circuit batch size: a proof covers 1 .. max_instances instances of its circuit (0 / 1: one; records are then
+     * orc_vs_proof2); with more, records are orc_vs_proof3 */
+    uint8_t max_instances;
+    uint8_t pad[2];
 } orc_vs_shape; /* 56 B */
 typedef struct { orc_g1_affine gamma_g; orc_g2_affine shift_h[ORC_VS_MAX_BOUNDS]; } orc_vs_key_ext; /* 480 B */
 typedef struct { orc_vs_proof base; orc_fr random_v[2]; orc_g1_affine shifted[ORC_VS_PROOF_COMMS]; } orc_vs_proof2; /* 3184 B */
+/* a further instance of the proof's circuit: its public inputs, two commitments (the analogues of C_0, C_1), their
+ * evaluations at the beta query; a_j = x_hat_j(z_beta) + (z_beta^16 - 1) b_j, and the two polynomials join the beta
+ * combination with xi^(30 + 2 (j - 1)), xi^(31 + 2 (j - 1)) */
+#define ORC_VS_MAX_INSTANCES 4
+typedef struct { orc_fr inputs[ORC_VS_INPUTS]; orc_g1_affine comms[2]; orc_fr evals[2]; } orc_vs_instance; /* 768 B */
+typedef struct { orc_vs_proof2 base2; uint32_t n_instances; uint32_t pad[3]; orc_vs_instance extra[ORC_VS_MAX_INSTANCES - 1]; } orc_vs_proof3; /* 5504 B */
+/* the same three entry points over records of the shape's kind (orc_vs_proof2 when max_instances <= 1, else
+ * orc_vs_proof3), given as bytes */
+void orc_vs3_generate(uint64_t seed, size_t n, size_t n_circuits, uint32_t corrupt_per_1024, const orc_vs_shape *shape,
+                      orc_kzg_vk *vk, orc_vs_key_ext *ext, orc_vs_circuit_vk *circuits, void *records,
+                      uint8_t *randomizers /* n x 48 */, uint8_t *expected);
+void orc_vs3_verify_batch_cpu(const orc_kzg_vk *vk, const orc_vs_key_ext *ext, const orc_vs_shape *shape,
+                              const orc_vs_circuit_vk *circuits, const void *records, size_t n,
+                              const uint8_t *randomizers, uint8_t *verdicts, int threads);
+int orc_vs3_verify_aggregated(const orc_kzg_vk *vk, const orc_vs_key_ext *ext, const orc_vs_shape *shape,
+                              const orc_vs_circuit_vk *circuits, const void *records, size_t n,
+                              const uint8_t *randomizers, uint8_t *alg_ok, orc_g1_affine totals[4], int threads);
 void orc_vs2_generate(uint64_t seed, size_t n, size_t n_circuits, uint32_t corrupt_per_1024, const orc_vs_shape *shape,
                       orc_kzg_vk *vk, orc_vs_key_ext *ext, orc_vs_circuit_vk *circuits, orc_vs_proof2 *proofs,
                       uint8_t *randomizers /* n x 48 */, uint8_t *expected);

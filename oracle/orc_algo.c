@@ -384,31 +384,47 @@ static void fs_embed(fq_t *r, const void *b, size_t n) {
     memset(r, 0, sizeof *r);
     memcpy(r, b, n);
 }
-/* the e-th of the 73 absorbed elements (oracle/pyref.py: vs_fs_elements) */
-static void fs_element(fq_t *r, const orc_vs_circuit_vk *cvk, const orc_vs_proof *p, int e) {
+/* the e-th of the 73 + 38 m1 absorbed elements (oracle/pyref.py: vs_fs_elements); m1 further instances (768-byte
+ * records: 16 inputs, two commitments, two evaluations) sit after C_1 (36 elements each) and at the end (2 each) */
+static void fs_element(fq_t *r, const orc_vs_circuit_vk *cvk, const orc_vs_proof *p, const uint8_t *extra, int m1, int e) {
     const uint8_t *comms = (const uint8_t *)p->comms;
-    if (e == 0) fs_embed(r, VS_TAG, 32);
-    else if (e == 1) fs_embed(r, cvk->digest, 32);
-    else if (e < 34) fs_embed(r, (const uint8_t *)&p->inputs[(e - 2) >> 1] + 16 * ((e - 2) & 1), 16);
-    else if (e < 52) fs_embed(r, comms + 48 * (e - 34), 48);
-    else fs_embed(r, &p->evals[e - 52], 32);
+    if (e == 0) { fs_embed(r, VS_TAG, 32); return; }
+    if (e == 1) { fs_embed(r, cvk->digest, 32); return; }
+    if (e < 34) { fs_embed(r, (const uint8_t *)&p->inputs[(e - 2) >> 1] + 16 * ((e - 2) & 1), 16); return; }
+    if (e < 38) { fs_embed(r, comms + 48 * (e - 34), 48); return; }
+    e -= 38;
+    if (e < 36 * m1) {
+        const uint8_t *x = extra + 768 * (e / 36);
+        const int k = e % 36;
+        if (k < 32) fs_embed(r, x + 32 * (k >> 1) + 16 * (k & 1), 16);
+        else fs_embed(r, x + 512 + 48 * (k - 32), 48);
+        return;
+    }
+    e -= 36 * m1;
+    if (e < 14) { fs_embed(r, comms + 48 * (4 + e), 48); return; }
+    e -= 14;
+    if (e < 21) { fs_embed(r, &p->evals[e], 32); return; }
+    e -= 21;
+    fs_embed(r, extra + 768 * (e >> 1) + 704 + 32 * (e & 1), 32);
 }
-static void vs_challenges_poseidon(const orc_vs_circuit_vk *cvk, const orc_vs_proof *p, fr_t *z_beta, fr_t *z_gamma, fr_t *xi) {
+static void vs_challenges_poseidon(const orc_vs_circuit_vk *cvk, const orc_vs_proof *p, const uint8_t *extra, int m1, fr_t *z_beta,
+                                   fr_t *z_gamma, fr_t *xi) {
     orc_fq st[3];
     memset(st, 0, sizeof st);
-    for (int b = 0; b < 37; b++) {
+    const int n_el = 73 + 38 * m1, n_blocks = 37 + 19 * m1, b_beta = 21 + 18 * m1, b_gamma = 25 + 18 * m1;
+    for (int b = 0; b < n_blocks; b++) {
         fq_t e;
-        fs_element(&e, cvk, p, 2 * b);
+        fs_element(&e, cvk, p, extra, m1, 2 * b);
         fq_add((fq_t *)&st[1], (fq_t *)&st[1], &e);
-        if (2 * b + 1 < 73) {
-            fs_element(&e, cvk, p, 2 * b + 1);
+        if (2 * b + 1 < n_el) {
+            fs_element(&e, cvk, p, extra, m1, 2 * b + 1);
             fq_add((fq_t *)&st[2], (fq_t *)&st[2], &e);
         }
         orc_poseidon_permute(st);
-        if (b == 21 || b == 25 || b == 36) {
+        if (b == b_beta || b == b_gamma || b == n_blocks - 1) {
             uint64_t c[6];
             fq_to_canonical(c, (const fq_t *)&st[1]);
-            fr_from_u128le(b == 21 ? z_beta : (b == 25 ? z_gamma : xi), (const uint8_t *)c); /* low 128 bits */
+            fr_from_u128le(b == b_beta ? z_beta : (b == b_gamma ? z_gamma : xi), (const uint8_t *)c); /* low 128 bits */
         }
     }
 }
@@ -435,10 +451,18 @@ int orc_vs_proof_is_well_formed(const orc_vs_proof *p) {
     return 1;
 }
 
+/* the transcript with m1 further instances (extra: m1 x 768 bytes): each is chained in after C_1 (inputs and
+ * commitments) and after the evaluations (its two) */
+static void vs_challenges_ex(const orc_vs_circuit_vk *cvk, const orc_vs_proof *p, const uint8_t *extra, int m1, orc_fr *z_beta,
+                             orc_fr *z_gamma, orc_fr *xi);
 void orc_vs_challenges(const orc_vs_circuit_vk *cvk, const orc_vs_proof *p, orc_fr *z_beta, orc_fr *z_gamma,
                        orc_fr *xi) {
+    vs_challenges_ex(cvk, p, NULL, 0, z_beta, z_gamma, xi);
+}
+static void vs_challenges_ex(const orc_vs_circuit_vk *cvk, const orc_vs_proof *p, const uint8_t *extra, int m1, orc_fr *z_beta,
+                             orc_fr *z_gamma, orc_fr *xi) {
     if (g_vs_fs_kind) {
-        vs_challenges_poseidon(cvk, p, S(z_beta), S(z_gamma), S(xi));
+        vs_challenges_poseidon(cvk, p, extra, m1, S(z_beta), S(z_gamma), S(xi));
         return;
     }
     uint8_t buf[32 + 21 * 32 + 64], h[32];
@@ -448,6 +472,11 @@ void orc_vs_challenges(const orc_vs_circuit_vk *cvk, const orc_vs_proof *p, orc_
     memcpy(buf + o, p->inputs, sizeof p->inputs); o += sizeof p->inputs;
     memcpy(buf + o, &p->comms[0], 2 * 96); o += 2 * 96;
     orc_sha256(h, buf, o);
+    for (int j = 0; j < m1; j++) {
+        memcpy(buf, h, 32);
+        memcpy(buf + 32, extra + 768 * j, 704);
+        orc_sha256(h, buf, 32 + 704);
+    }
     o = 0;
     memcpy(buf, h, 32); o = 32;
     memcpy(buf + o, &p->comms[2], 3 * 96); o += 3 * 96;
@@ -460,6 +489,11 @@ void orc_vs_challenges(const orc_vs_circuit_vk *cvk, const orc_vs_proof *p, orc_
     memcpy(buf, h, 32); o = 32;
     memcpy(buf + o, p->evals, sizeof p->evals); o += sizeof p->evals;
     orc_sha256(h, buf, o);
+    for (int j = 0; j < m1; j++) {
+        memcpy(buf, h, 32);
+        memcpy(buf + 32, extra + 768 * j + 704, 64);
+        orc_sha256(h, buf, 32 + 64);
+    }
     fr_from_u128le(S(xi), h);
 }
 
@@ -810,11 +844,13 @@ static void vs2_lc_factors(fr_t kap[4], const fr_t z[2]) {
     kap[2] = v[1];
     fr_mul(&kap[3], &v[0], &v[1]);
 }
+/* inst / m1: the further instances of a proof with instances (their scalars r_beta xi^(30 + 2j + c) go to ex_scalar) */
 static void vs2_derive(vs_fr_work *o, fr_t rho[ORC_VS_PROOF_COMMS], fr_t *h_scalar, const orc_vs_shape *sh,
-                       const orc_vs_circuit_vk *cvk, const orc_vs_proof2 *p2, const uint8_t *rand3x16) {
+                       const orc_vs_circuit_vk *cvk, const orc_vs_proof2 *p2, const uint8_t *rand3x16,
+                       const orc_vs_instance *inst, int m1, fr_t ex_scalar[][2]) {
     const orc_vs_proof *p = &p2->base;
     fr_t z[2], xi, r[3], xip, val[2], t, xhat, znm1;
-    orc_vs_challenges(cvk, p, (orc_fr *)&z[0], (orc_fr *)&z[1], (orc_fr *)&xi);
+    vs_challenges_ex(cvk, p, (const uint8_t *)inst, m1, (orc_fr *)&z[0], (orc_fr *)&z[1], (orc_fr *)&xi);
     for (int k = 0; k < 3; k++) fr_from_u128le(&r[k], rand3x16 + 16 * k);
     fr_one(&xip);
     fr_zero(&val[0]);
@@ -834,6 +870,13 @@ static void vs2_derive(vs_fr_work *o, fr_t rho[ORC_VS_PROOF_COMMS], fr_t *h_scal
         fr_mul(&rho[j], &r[2], &xip);
         fr_mul(&xip, &xip, &xi);
     }
+    for (int j = 0; j < m1; j++)      /* xip = xi^(30 + 2j + c): the further instances' polynomials, beta query */
+        for (int c = 0; c < 2; c++) {
+            fr_mul(&ex_scalar[j][c], &r[0], &xip);
+            fr_mul(&t, &xip, S(&inst[j].evals[c]));
+            fr_add(&val[0], &val[0], &t);
+            fr_mul(&xip, &xip, &xi);
+        }
     fr_zero(&o->g_scalar);
     fr_zero(h_scalar);
     for (int q = 0; q < 2; q++) {
@@ -854,21 +897,55 @@ static void vs2_derive(vs_fr_work *o, fr_t rho[ORC_VS_PROOF_COMMS], fr_t *h_scal
         wf = limbs_lt((const uint64_t *)&pt->x, ORC_FQ_MODULUS, 6) && limbs_lt((const uint64_t *)&pt->y, ORC_FQ_MODULUS, 6) &&
              orc_g1_is_on_curve(pt);
     }
+    for (int j = 0; j < m1 && wf; j++) {
+        for (int k = 0; k < ORC_VS_INPUTS && wf; k++) wf = limbs_lt((const uint64_t *)&inst[j].inputs[k], ORC_FR_MODULUS, 4);
+        for (int k = 0; k < 2 && wf; k++) wf = limbs_lt((const uint64_t *)&inst[j].evals[k], ORC_FR_MODULUS, 4);
+        for (int c = 0; c < 2 && wf; c++) {
+            const orc_g1_affine *pt = &inst[j].comms[c];
+            wf = limbs_lt((const uint64_t *)&pt->x, ORC_FQ_MODULUS, 6) && limbs_lt((const uint64_t *)&pt->y, ORC_FQ_MODULUS, 6) &&
+                 orc_g1_is_on_curve(pt);
+        }
+    }
     if (wf && vs_input_eval(&xhat, &znm1, (const fr_t *)p->inputs, &z[0])) {
         fr_mul(&t, &znm1, S(&p->evals[1]));
         fr_add(&t, &t, &xhat);
         o->alg_ok = fr_eq(&t, S(&p->evals[0]));
+        for (int j = 0; j < m1 && o->alg_ok; j++) { /* every instance's own public-input identity */
+            vs_input_eval(&xhat, &znm1, (const fr_t *)inst[j].inputs, &z[0]);
+            fr_mul(&t, &znm1, S(&inst[j].evals[1]));
+            fr_add(&t, &t, &xhat);
+            o->alg_ok = fr_eq(&t, S(&inst[j].evals[0]));
+        }
     }
+}
+/* the record of proof i under the shape: orc_vs_proof2, or orc_vs_proof3 when the shape carries instances; *m1 = its
+ * further instances (0 when the count is out of range: the proof is then rejected by vs3_count_ok) */
+static size_t vs3_stride(const orc_vs_shape *sh) { return sh->max_instances > 1 ? sizeof(orc_vs_proof3) : sizeof(orc_vs_proof2); }
+static const orc_vs_proof2 *vs3_record(const orc_vs_shape *sh, const void *records, size_t i, const orc_vs_instance **inst, int *m1,
+                                        int *count_ok) {
+    const uint8_t *rec = (const uint8_t *)records + vs3_stride(sh) * i;
+    *inst = NULL;
+    *m1 = 0;
+    *count_ok = 1;
+    if (sh->max_instances > 1) {
+        const orc_vs_proof3 *p3 = (const orc_vs_proof3 *)rec;
+        *count_ok = p3->n_instances >= 1 && p3->n_instances <= sh->max_instances && p3->n_instances <= ORC_VS_MAX_INSTANCES;
+        if (*count_ok) {
+            *m1 = (int)p3->n_instances - 1;
+            *inst = p3->extra;
+        }
+    }
+    return (const orc_vs_proof2 *)rec;
 }
 /* the four accumulators of one proof (Jacobian) */
 static void vs2_accumulate_one(orc_g1_jac acc[4], int *alg_ok, const orc_kzg_vk *vk, const orc_vs_key_ext *ext,
                                const orc_vs_shape *sh, const orc_vs_circuit_vk *circuits, const orc_vs_proof2 *p2,
-                               const uint8_t *rand3x16) {
+                               const uint8_t *rand3x16, const orc_vs_instance *inst, int m1) {
     const orc_vs_proof *p = &p2->base;
     const orc_vs_circuit_vk *cvk = &circuits[p->circuit];
     vs_fr_work fw;
-    fr_t rho[ORC_VS_PROOF_COMMS], hs, t;
-    vs2_derive(&fw, rho, &hs, sh, cvk, p2, rand3x16);
+    fr_t rho[ORC_VS_PROOF_COMMS], hs, t, exs[ORC_VS_MAX_INSTANCES][2];
+    vs2_derive(&fw, rho, &hs, sh, cvk, p2, rand3x16, inst, m1, exs);
     orc_g1_jac tj;
     for (int k = 0; k < 4; k++) g1_set_inf(&acc[k]);
     for (int k = 0; k < ORC_VS_EVALS; k++) {
@@ -876,6 +953,11 @@ static void vs2_accumulate_one(orc_g1_jac acc[4], int *alg_ok, const orc_kzg_vk 
         g1_mul_fr(&tj, c, &fw.poly_scalar[k]);
         orc_g1_add(&acc[0], &acc[0], &tj);
     }
+    for (int j = 0; j < m1; j++)
+        for (int c = 0; c < 2; c++) {
+            g1_mul_fr(&tj, &inst[j].comms[c], &exs[j][c]);
+            orc_g1_add(&acc[0], &acc[0], &tj);
+        }
     for (int q = 0; q < 2; q++) {
         g1_mul_fr(&tj, &p->w[q], &fw.w_scalar_c[q]);
         orc_g1_add(&acc[0], &acc[0], &tj);
@@ -905,8 +987,8 @@ static int vs2_product_is_one(const orc_g1_jac acc[4], const orc_g2_prepared *co
     orc_g1_neg_affine(&ps[1], &ps[1]); /* infinity is (0, 0) and stays so */
     return orc_pairing_product_is_one(ps, preps, (size_t)(2 + n_bounds)) == 1;
 }
-void orc_vs2_verify_batch_cpu(const orc_kzg_vk *vk, const orc_vs_key_ext *ext, const orc_vs_shape *sh,
-                              const orc_vs_circuit_vk *circuits, const orc_vs_proof2 *proofs, size_t n,
+void orc_vs3_verify_batch_cpu(const orc_kzg_vk *vk, const orc_vs_key_ext *ext, const orc_vs_shape *sh,
+                              const orc_vs_circuit_vk *circuits, const void *records, size_t n,
                               const uint8_t *randomizers /* n x 48 */, uint8_t *verdicts, int threads) {
     orc_g2_prepared *pr = (orc_g2_prepared *)malloc(sizeof(orc_g2_prepared) * 4);
     orc_g2_prepare(&pr[0], &vk->h);
@@ -917,16 +999,25 @@ void orc_vs2_verify_batch_cpu(const orc_kzg_vk *vk, const orc_vs_key_ext *ext, c
 #pragma omp parallel for schedule(dynamic, 4) num_threads(threads)
     for (size_t i = 0; i < n; i++) {
         orc_g1_jac acc[4];
-        int alg;
-        vs2_accumulate_one(acc, &alg, vk, ext, sh, circuits, &proofs[i], randomizers + 48 * i);
-        verdicts[i] = (uint8_t)(alg && vs2_product_is_one(acc, preps, sh->n_bounds));
+        int alg, m1, count_ok;
+        const orc_vs_instance *inst;
+        const orc_vs_proof2 *p2 = vs3_record(sh, records, i, &inst, &m1, &count_ok);
+        vs2_accumulate_one(acc, &alg, vk, ext, sh, circuits, p2, randomizers + 48 * i, inst, m1);
+        verdicts[i] = (uint8_t)(alg && count_ok && vs2_product_is_one(acc, preps, sh->n_bounds));
     }
     free(pr);
 }
-/* the aggregated form: per-proof accumulators summed (the group result is what the library's RLC MSMs produce);
- * totals[0..3] = total_c, total_w, bound[0], bound[1] as affine points ((0,0) = infinity) */
-int orc_vs2_verify_aggregated(const orc_kzg_vk *vk, const orc_vs_key_ext *ext, const orc_vs_shape *sh,
+void orc_vs2_verify_batch_cpu(const orc_kzg_vk *vk, const orc_vs_key_ext *ext, const orc_vs_shape *sh,
                               const orc_vs_circuit_vk *circuits, const orc_vs_proof2 *proofs, size_t n,
+                              const uint8_t *randomizers, uint8_t *verdicts, int threads) {
+    orc_vs3_verify_batch_cpu(vk, ext, sh, circuits, proofs, n, randomizers, verdicts, threads);
+}
+/* the aggregated form: per-proof accumulators summed (the group result is what the library's RLC MSMs produce);
+ * totals[0..3] = total_c, total_w, bound[0], bound[1] as affine points ((0,0) = infinity).  A proof whose instance
+ * count is out of range counts as algebraically failed and contributes its first instance only (what the library's
+ * derive kernel does: the further instances' scalars are zero). */
+int orc_vs3_verify_aggregated(const orc_kzg_vk *vk, const orc_vs_key_ext *ext, const orc_vs_shape *sh,
+                              const orc_vs_circuit_vk *circuits, const void *records, size_t n,
                               const uint8_t *randomizers, uint8_t *alg_ok, orc_g1_affine totals[4], int threads) {
     if (threads < 1) threads = 1;
     orc_g1_jac *part = (orc_g1_jac *)malloc(sizeof(orc_g1_jac) * 4 * (size_t)threads);
@@ -937,9 +1028,11 @@ int orc_vs2_verify_aggregated(const orc_kzg_vk *vk, const orc_vs_key_ext *ext, c
 #pragma omp for schedule(dynamic, 8)
         for (size_t i = 0; i < n; i++) {
             orc_g1_jac acc[4];
-            int alg;
-            vs2_accumulate_one(acc, &alg, vk, ext, sh, circuits, &proofs[i], randomizers + 48 * i);
-            alg_ok[i] = (uint8_t)alg;
+            int alg, m1, count_ok;
+            const orc_vs_instance *inst;
+            const orc_vs_proof2 *p2 = vs3_record(sh, records, i, &inst, &m1, &count_ok);
+            vs2_accumulate_one(acc, &alg, vk, ext, sh, circuits, p2, randomizers + 48 * i, inst, m1);
+            alg_ok[i] = (uint8_t)(alg && count_ok);
             for (int k = 0; k < 4; k++) orc_g1_add(&part[4 * tid + k], &part[4 * tid + k], &acc[k]);
         }
     }
@@ -961,9 +1054,19 @@ int orc_vs2_verify_aggregated(const orc_kzg_vk *vk, const orc_vs_key_ext *ext, c
     for (int k = 0; k < 4; k++) orc_g1_to_affine(&totals[k], &tot[k]); /* (0, 0) for infinity */
     return ok && all_alg;
 }
-void orc_vs2_generate(uint64_t seed, size_t n, size_t n_circuits, uint32_t corrupt_per_1024, const orc_vs_shape *sh,
-                      orc_kzg_vk *vk, orc_vs_key_ext *ext, orc_vs_circuit_vk *circuits, orc_vs_proof2 *proofs,
+int orc_vs2_verify_aggregated(const orc_kzg_vk *vk, const orc_vs_key_ext *ext, const orc_vs_shape *sh,
+                              const orc_vs_circuit_vk *circuits, const orc_vs_proof2 *proofs, size_t n,
+                              const uint8_t *randomizers, uint8_t *alg_ok, orc_g1_affine totals[4], int threads) {
+    return orc_vs3_verify_aggregated(vk, ext, sh, circuits, proofs, n, randomizers, alg_ok, totals, threads);
+}
+void orc_vs3_generate(uint64_t seed, size_t n, size_t n_circuits, uint32_t corrupt_per_1024, const orc_vs_shape *sh,
+                      orc_kzg_vk *vk, orc_vs_key_ext *ext, orc_vs_circuit_vk *circuits, void *records,
                       uint8_t *randomizers /* n x 48 */, uint8_t *expected) {
+    const size_t stride = vs3_stride(sh);
+    const int MI = sh->max_instances > 1 ? (sh->max_instances > ORC_VS_MAX_INSTANCES ? ORC_VS_MAX_INSTANCES : sh->max_instances) : 1;
+#define REC2(i) ((orc_vs_proof2 *)((uint8_t *)records + stride * (i)))
+#define REC3(i) ((orc_vs_proof3 *)((uint8_t *)records + stride * (i)))
+    const size_t EX = (size_t)(ORC_VS_MAX_INSTANCES - 1) * 2; /* further-instance polynomials per proof */
     smix g = {seed};
     fr_t tau, gam, shf[ORC_VS_MAX_BOUNDS];
     smix_fr(&g, &tau);
@@ -1001,10 +1104,15 @@ void orc_vs2_generate(uint64_t seed, size_t n, size_t n_circuits, uint32_t corru
     fr_t *ptau = (fr_t *)malloc(sizeof(fr_t) * n * PC);   /* p_k(tau) */
     fr_t *prho = (fr_t *)malloc(sizeof(fr_t) * n * PC);   /* hiding constants rho_k */
     fr_t *cval = (fr_t *)malloc(sizeof(fr_t) * n * PC * 2); /* commitment exponents: C_k, then S_k */
+    /* further instances (MI > 1): polynomials A_j, B_j, their values at tau, hiding constants, commitment exponents */
+    fr_t *xpoly = (fr_t *)calloc(n * EX * VS_DEG + 1, sizeof(fr_t));
+    fr_t *xtau = (fr_t *)calloc(n * EX + 1, sizeof(fr_t));
+    fr_t *xrho = (fr_t *)calloc(n * EX + 1, sizeof(fr_t));
+    fr_t *xcval = (fr_t *)calloc(n * EX + 1, sizeof(fr_t));
     for (size_t i = 0; i < n; i++) {
-        orc_vs_proof2 *p2 = &proofs[i];
+        orc_vs_proof2 *p2 = REC2(i);
         orc_vs_proof *p = &p2->base;
-        memset(p2, 0, sizeof *p2);
+        memset(p2, 0, stride);
         p->circuit = (uint32_t)(smix_next(&g) % n_circuits);
         for (int k = 0; k < ORC_VS_INPUTS; k++) smix_fr(&g, S(&p->inputs[k]));
         for (size_t k = 0; k < PC; k++)
@@ -1024,22 +1132,52 @@ void orc_vs2_generate(uint64_t seed, size_t n, size_t n_circuits, uint32_t corru
             else fr_zero(&cval[(i * PC + k) * 2 + 1]);
         }
         for (int k = 0; k < 48; k++) randomizers[48 * i + k] = (uint8_t)smix_next(&g);
+        if (MI > 1) {
+            orc_vs_proof3 *p3 = REC3(i);
+            p3->n_instances = 1 + (uint32_t)(smix_next(&g) % (uint64_t)MI);
+            for (uint32_t j = 0; j + 1 < p3->n_instances; j++) {
+                orc_vs_instance *in = &p3->extra[j];
+                for (int k = 0; k < ORC_VS_INPUTS; k++) smix_fr(&g, S(&in->inputs[k]));
+                for (int c = 0; c < 2; c++)
+                    for (int d = 0; d < VS_DEG; d++) smix_fr(&g, &xpoly[((i * EX) + 2 * j + c) * VS_DEG + d]);
+                poly_eval(&xtau[i * EX + 2 * j + 1], &xpoly[(i * EX + 2 * j + 1) * VS_DEG], &tau);
+                fr_t xh2, zn2, t2;
+                vs_input_eval(&xh2, &zn2, (const fr_t *)in->inputs, &tau);
+                fr_mul(&t2, &zn2, &xtau[i * EX + 2 * j + 1]);
+                fr_add(&xtau[i * EX + 2 * j], &xh2, &t2);
+                for (int c = 0; c < 2; c++) {
+                    if (sh->hiding) smix_fr(&g, &xrho[i * EX + 2 * j + c]);
+                    fr_mul(&t2, &gam, &xrho[i * EX + 2 * j + c]);
+                    fr_add(&xcval[i * EX + 2 * j + c], &xtau[i * EX + 2 * j + c], &t2);
+                }
+            }
+        }
     }
     orc_g1_affine *pcomm = (orc_g1_affine *)malloc(sizeof(orc_g1_affine) * n * PC * 2);
     orc_g1_fixed_base_batch(pcomm, (const orc_fr *)cval, n * PC * 2);
     for (size_t i = 0; i < n; i++)
         for (size_t k = 0; k < PC; k++) {
-            proofs[i].base.comms[k] = pcomm[(i * PC + k) * 2];
+            REC2(i)->base.comms[k] = pcomm[(i * PC + k) * 2];
             const int c = sh->bound_class[k];
-            if (c >= 0 && c < sh->n_bounds) proofs[i].shifted[k] = pcomm[(i * PC + k) * 2 + 1];
+            if (c >= 0 && c < sh->n_bounds) REC2(i)->shifted[k] = pcomm[(i * PC + k) * 2 + 1];
         }
+    if (MI > 1) {
+        orc_g1_affine *xcomm = (orc_g1_affine *)malloc(sizeof(orc_g1_affine) * n * EX);
+        orc_g1_fixed_base_batch(xcomm, (const orc_fr *)xcval, n * EX);
+        for (size_t i = 0; i < n; i++)
+            for (uint32_t j = 0; j + 1 < REC3(i)->n_instances; j++)
+                for (int c = 0; c < 2; c++) REC3(i)->extra[j].comms[c] = xcomm[i * EX + 2 * j + c];
+        free(xcomm);
+    }
     fr_t *wk = (fr_t *)malloc(sizeof(fr_t) * n * 2);
     for (size_t i = 0; i < n; i++) {
-        orc_vs_proof2 *p2 = &proofs[i];
+        orc_vs_proof2 *p2 = REC2(i);
         orc_vs_proof *p = &p2->base;
         const orc_vs_circuit_vk *cvk = &circuits[p->circuit];
+        const int m1 = MI > 1 ? (int)REC3(i)->n_instances - 1 : 0;
+        orc_vs_instance *inst = MI > 1 ? REC3(i)->extra : NULL;
         fr_t z[2], xi, xip, t, num[2], rv[2];
-        orc_vs_challenges(cvk, p, (orc_fr *)&z[0], (orc_fr *)&z[1], (orc_fr *)&xi);
+        vs_challenges_ex(cvk, p, (const uint8_t *)inst, m1, (orc_fr *)&z[0], (orc_fr *)&z[1], (orc_fr *)&xi);
         for (int k = 0; k < ORC_VS_EVALS; k++) {
             const int q = sh->query_of[k] & 1;
             const fr_t *poly = k < ORC_VS_PROOF_COMMS ? &ppoly[(i * PC + k) * VS_DEG]
@@ -1053,7 +1191,15 @@ void orc_vs2_generate(uint64_t seed, size_t n, size_t n_circuits, uint32_t corru
                 fr_add(S(&p->evals[0]), &xh, &t);
             }
         }
-        orc_vs_challenges(cvk, p, (orc_fr *)&z[0], (orc_fr *)&z[1], (orc_fr *)&xi);
+        for (int j = 0; j < m1; j++) { /* b_j = B_j(z_beta), a_j from the instance's identity */
+            fr_t xh, znm1;
+            poly_eval(S(&inst[j].evals[1]), &xpoly[(i * EX + 2 * j + 1) * VS_DEG], &z[0]);
+            if (vs_input_eval(&xh, &znm1, (const fr_t *)inst[j].inputs, &z[0])) {
+                fr_mul(&t, &znm1, S(&inst[j].evals[1]));
+                fr_add(S(&inst[j].evals[0]), &xh, &t);
+            }
+        }
+        vs_challenges_ex(cvk, p, (const uint8_t *)inst, m1, (orc_fr *)&z[0], (orc_fr *)&z[1], (orc_fr *)&xi);
         fr_one(&xip);
         for (int q = 0; q < 2; q++) { fr_zero(&num[q]); fr_zero(&rv[q]); }
         fr_t kap[4];
@@ -1072,6 +1218,18 @@ void orc_vs2_generate(uint64_t seed, size_t n, size_t n_circuits, uint32_t corru
             }
             fr_mul(&xip, &xip, &xi);
         }
+        if (m1) {
+            for (int j = 0; j < ORC_VS_PROOF_COMMS; j++) fr_mul(&xip, &xip, &xi); /* past the degree-bound terms: xi^30 */
+            for (int j = 0; j < m1; j++)
+                for (int c = 0; c < 2; c++) {
+                    fr_sub(&t, &xtau[i * EX + 2 * j + c], S(&inst[j].evals[c]));
+                    fr_mul(&t, &t, &xip);
+                    fr_add(&num[0], &num[0], &t);
+                    fr_mul(&t, &xip, &xrho[i * EX + 2 * j + c]);
+                    fr_add(&rv[0], &rv[0], &t);
+                    fr_mul(&xip, &xip, &xi);
+                }
+        }
         for (int q = 0; q < 2; q++) {
             fr_sub(&t, &tau, &z[q]);
             fr_inv(&t, &t);
@@ -1082,16 +1240,26 @@ void orc_vs2_generate(uint64_t seed, size_t n, size_t n_circuits, uint32_t corru
     orc_g1_affine *wc = (orc_g1_affine *)malloc(sizeof(orc_g1_affine) * n * 2);
     orc_g1_fixed_base_batch(wc, (const orc_fr *)wk, n * 2);
     for (size_t i = 0; i < n; i++) {
-        proofs[i].base.w[0] = wc[2 * i];
-        proofs[i].base.w[1] = wc[2 * i + 1];
+        REC2(i)->base.w[0] = wc[2 * i];
+        REC2(i)->base.w[1] = wc[2 * i + 1];
         expected[i] = 1;
     }
     for (size_t i = 0; i < n; i++) {
         if ((smix_next(&g) & 1023) >= corrupt_per_1024) continue;
-        orc_vs_proof2 *p2 = &proofs[i];
+        orc_vs_proof2 *p2 = REC2(i);
         orc_vs_proof *p = &p2->base;
         fr_t one;
         fr_one(&one);
+        if (MI > 1 && REC3(i)->n_instances > 1 && (smix_next(&g) & 1)) { /* spoil a further instance instead */
+            orc_vs_instance *in = &REC3(i)->extra[smix_next(&g) % (REC3(i)->n_instances - 1)];
+            switch ((int)(smix_next(&g) % 3)) {
+            case 0: fr_add(S(&in->evals[1]), S(&in->evals[1]), &one); break;
+            case 1: fr_add(S(&in->inputs[smix_next(&g) % ORC_VS_INPUTS]), S(&in->inputs[1]), &one); break;
+            default: in->comms[smix_next(&g) & 1] = vk->g; break;
+            }
+            expected[i] = 0;
+            continue;
+        }
         int kind = (int)(smix_next(&g) % 6);
         if (kind == 4 && !sh->hiding) kind = 0;
         if (kind == 5 && !sh->n_bounds) kind = 1;
@@ -1112,6 +1280,14 @@ void orc_vs2_generate(uint64_t seed, size_t n, size_t n_circuits, uint32_t corru
         expected[i] = 0;
     }
     free(cpoly); free(ctau); free(ccomm); free(ppoly); free(ptau); free(prho); free(cval); free(pcomm); free(wk); free(wc);
+    free(xpoly); free(xtau); free(xrho); free(xcval);
+#undef REC2
+#undef REC3
+}
+void orc_vs2_generate(uint64_t seed, size_t n, size_t n_circuits, uint32_t corrupt_per_1024, const orc_vs_shape *sh,
+                      orc_kzg_vk *vk, orc_vs_key_ext *ext, orc_vs_circuit_vk *circuits, orc_vs_proof2 *proofs,
+                      uint8_t *randomizers /* n x 48 */, uint8_t *expected) {
+    orc_vs3_generate(seed, n, n_circuits, corrupt_per_1024, sh, vk, ext, circuits, proofs, randomizers, expected);
 }
 
 /* ------------------------------------------------------------------ self test */

@@ -32,7 +32,7 @@ def lib():
         _LIB = C.CDLL(build())
         _LIB.orc_self_test.restype = C.c_int
         _LIB.orc_ntt.restype = C.c_int
-        for f in ("orc_kzg_check", "orc_kzg_batch_check", "orc_kzg_batch_check_hiding", "orc_vs2_verify_aggregated", "orc_vs_verify_one", "orc_vs_verify_aggregated",
+        for f in ("orc_kzg_check", "orc_kzg_batch_check", "orc_kzg_batch_check_hiding", "orc_vs2_verify_aggregated", "orc_vs3_verify_aggregated", "orc_vs_verify_one", "orc_vs_verify_aggregated",
                   "orc_g1_is_on_curve", "orc_g2_is_on_curve", "orc_fq12_is_one", "orc_pairing_product_is_one"):
             getattr(_LIB, f).restype = C.c_int
     return _LIB
@@ -333,7 +333,15 @@ VS2_PROOF_BYTES, VS2_KEY_EXT_BYTES, VS2_SHAPE_BYTES, VS2_RAND_BYTES = 3184, 480,
 VS1_QUERY_OF = [0] * 5 + [1] * 4 + [0] * 6 + [1] * 6
 
 
-def vs2_shape(query_of=None, bound_class=None, hiding=True, n_bounds=2, lc_kind=None):
+VS3_PROOF_BYTES, VS_MAX_INSTANCES = 5504, 4
+
+
+def vs2_record_bytes(shape):
+    """bytes per proof record under a shape: mi_vs_proof2, or mi_vs_proof3 when the shape carries instances"""
+    return VS3_PROOF_BYTES if int(np.asarray(shape).reshape(-1)[53]) > 1 else VS2_PROOF_BYTES
+
+
+def vs2_shape(query_of=None, bound_class=None, hiding=True, n_bounds=2, lc_kind=None, max_instances=1):
     """56-byte mi_vs_shape / orc_vs_shape: query table, degree-bound classes, hiding flag, linear-combination kinds
     (0: xi^p; bit 0: times z_beta^16 - 1; bit 1: times z_gamma^16 - 1)"""
     q = list(query_of if query_of is not None else VS1_QUERY_OF)
@@ -346,6 +354,8 @@ def vs2_shape(query_of=None, bound_class=None, hiding=True, n_bounds=2, lc_kind=
     out[21:30] = np.array(bc, dtype=np.int8).view(np.uint8)
     out[30], out[31] = int(bool(hiding)), n_bounds
     out[32:53] = lc
+    assert 1 <= max_instances <= VS_MAX_INSTANCES
+    out[53] = max_instances
     return out
 
 
@@ -358,11 +368,12 @@ class VS2Batch:
         self.vk = np.zeros(KZG_VK_BYTES, dtype=np.uint8)
         self.ext = np.zeros(VS2_KEY_EXT_BYTES, dtype=np.uint8)
         self.circuits = np.zeros(n_circuits * VS_CIRCUIT_VK_BYTES, dtype=np.uint8)
-        self.proofs = np.zeros(n * VS2_PROOF_BYTES, dtype=np.uint8)
+        self.record_bytes = vs2_record_bytes(self.shape)
+        self.proofs = np.zeros(n * self.record_bytes, dtype=np.uint8)
         self.randomizers = np.zeros(n * VS2_RAND_BYTES, dtype=np.uint8)
         self.expected = np.zeros(n, dtype=np.uint8)
         lib().orc_vs_set_transcript(C.c_int(transcript))
-        lib().orc_vs2_generate(C.c_uint64(seed), C.c_size_t(n), C.c_size_t(n_circuits), C.c_uint32(corrupt_per_1024), _p(self.shape),
+        lib().orc_vs3_generate(C.c_uint64(seed), C.c_size_t(n), C.c_size_t(n_circuits), C.c_uint32(corrupt_per_1024), _p(self.shape),
                                _p(self.vk), _p(self.ext), _p(self.circuits), _p(self.proofs), _p(self.randomizers), _p(self.expected))
 
     @classmethod
@@ -372,14 +383,15 @@ class VS2Batch:
         b.circuits = np.ascontiguousarray(circuits, dtype=np.uint8).reshape(-1)
         b.proofs = np.ascontiguousarray(proofs, dtype=np.uint8).reshape(-1)
         b.randomizers = np.ascontiguousarray(randomizers, dtype=np.uint8).reshape(-1)
-        b.n, b.n_circuits = b.proofs.size // VS2_PROOF_BYTES, b.circuits.size // VS_CIRCUIT_VK_BYTES
+        b.record_bytes = vs2_record_bytes(b.shape)
+        b.n, b.n_circuits = b.proofs.size // b.record_bytes, b.circuits.size // VS_CIRCUIT_VK_BYTES
         b.transcript, b.seed, b.expected = transcript, None, None
         return b
 
     def verify_cpu(self, threads=1):
         lib().orc_vs_set_transcript(C.c_int(self.transcript))
         v = np.zeros(self.n, dtype=np.uint8)
-        lib().orc_vs2_verify_batch_cpu(_p(self.vk), _p(self.ext), _p(self.shape), _p(self.circuits), _p(self.proofs), C.c_size_t(self.n),
+        lib().orc_vs3_verify_batch_cpu(_p(self.vk), _p(self.ext), _p(self.shape), _p(self.circuits), _p(self.proofs), C.c_size_t(self.n),
                                        _p(self.randomizers), _p(v), C.c_int(threads))
         return v
 
@@ -388,7 +400,7 @@ class VS2Batch:
         lib().orc_vs_set_transcript(C.c_int(self.transcript))
         alg = np.zeros(self.n, dtype=np.uint8)
         tot = u64((4, 12))
-        ok = lib().orc_vs2_verify_aggregated(_p(self.vk), _p(self.ext), _p(self.shape), _p(self.circuits), _p(self.proofs),
+        ok = lib().orc_vs3_verify_aggregated(_p(self.vk), _p(self.ext), _p(self.shape), _p(self.circuits), _p(self.proofs),
                                              C.c_size_t(self.n), _p(self.randomizers), _p(alg), _p(tot), C.c_int(threads))
         return bool(ok), alg, tot
 

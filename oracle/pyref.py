@@ -482,31 +482,42 @@ def _fs_embed(b):
 
 
 def vs_fs_elements(cvk, proof):
-    """The 73 absorbed elements, in order: tag, circuit digest, the 16 public inputs as two 128-bit limbs each (the
+    """The absorbed elements (73 for one instance; every further instance of a VarunaShaped-v2 proof with instances adds
+    its 16 inputs as two limbs each and the coordinates of its two commitments after C_1, and its two evaluations at
+    the end: 38 more), in order: tag, circuit digest, the 16 public inputs as two 128-bit limbs each (the
     nonnative absorb), the coordinates of C_0, C_1 | C_2..C_4 | C_5..C_8 | the 21 evaluations (the opening witnesses are
     made from xi and so come after it).  Two elements per permutation (the last block holds one): 19 + 3 + 4 + 11 = 37
     permutations; z_beta, z_gamma, xi are squeezed after the 22nd, 26th and 37th."""
     raw = proof["raw"]
     inputs, comms, evals = raw[16:528], raw[528:1392], raw[1392:2064]
+    extra = proof.get("extra_raw", [])
     els = [_fs_embed(VS_TAG), _fs_embed(cvk["digest"])]
     for k in range(VS_INPUTS):
         els += [_fs_embed(inputs[32 * k:32 * k + 16]), _fs_embed(inputs[32 * k + 16:32 * k + 32])]
-    els += [_fs_embed(comms[48 * c:48 * c + 48]) for c in range(18)]
+    els += [_fs_embed(comms[48 * c:48 * c + 48]) for c in range(4)]
+    for x in extra:  # 768 bytes: inputs, two commitments, two evaluations
+        for k in range(VS_INPUTS):
+            els += [_fs_embed(x[32 * k:32 * k + 16]), _fs_embed(x[32 * k + 16:32 * k + 32])]
+        els += [_fs_embed(x[512 + 48 * c:512 + 48 * c + 48]) for c in range(4)]
+    els += [_fs_embed(comms[48 * c:48 * c + 48]) for c in range(4, 18)]
     els += [_fs_embed(evals[32 * k:32 * k + 32]) for k in range(VS_EVALS)]
-    assert len(els) == 73
+    for x in extra:
+        els += [_fs_embed(x[704:736]), _fs_embed(x[736:768])]
+    assert len(els) == 73 + 38 * len(extra)
     return els
 
 
 def vs_challenges_poseidon(cvk, proof):
     els = vs_fs_elements(cvk, proof)
+    m1 = len(proof.get("extra_raw", []))  # instances beyond the first
     st = [0, 0, 0]
     out = []
-    for b in range(37):
+    for b in range(37 + 19 * m1):
         st[1] = (st[1] + els[2 * b]) % Q
         if 2 * b + 1 < len(els):
             st[2] = (st[2] + els[2 * b + 1]) % Q
         st = poseidon_permute(st)
-        if b in (21, 25, 36):
+        if b in (21 + 18 * m1, 25 + 18 * m1, 36 + 19 * m1):
             out.append(st[1] & ((1 << 128) - 1))  # low 128 bits of the canonical value of the first rate element
     return tuple(out)
 
@@ -540,12 +551,17 @@ def vs_challenges(cvk, proof):
     inputs = raw[16:16 + 512]
     comms = raw[528:528 + 864]
     evals = raw[1392:1392 + 672]
+    extra = proof.get("extra_raw", [])
     h = sha256(VS_TAG + cvk["digest"] + inputs + comms[:192])
+    for x in extra:  # every further instance: its inputs and two commitments, chained
+        h = sha256(h + x[:704])
     h = sha256(h + comms[192:480])
     zb = int.from_bytes(h[:16], "little")
     h = sha256(h + comms[480:864])
     zg = int.from_bytes(h[:16], "little")
     h = sha256(h + evals)
+    for x in extra:  # and its two evaluations
+        h = sha256(h + x[704:768])
     xi = int.from_bytes(h[:16], "little")
     return zb, zg, xi
 
@@ -604,6 +620,22 @@ def vs2_parse_proof(b):
     return d
 
 
+VS3_PROOF_BYTES, VS_MAX_INSTANCES, VS_INSTANCE_BYTES = 5504, 4, 768
+
+
+def vs3_parse_proof(b):
+    """mi_vs_proof3: a v2 record, the number of instances, and the further instances (inputs, A_j, B_j, a_j, b_j)"""
+    assert len(b) == VS3_PROOF_BYTES
+    d = vs2_parse_proof(b[:VS2_PROOF_BYTES])
+    n = int.from_bytes(b[3184:3188], "little")
+    d["n_instances"] = n
+    d["extra_raw"] = [bytes(b[3200 + 768 * j:3200 + 768 * (j + 1)]) for j in range(max(0, min(n, VS_MAX_INSTANCES) - 1))]
+    d["extra"] = [{"inputs": [_rd_fr(x[32 * k:32 * k + 32]) for k in range(VS_INPUTS)],
+                   "comms": [_rd_g1(x[512 + 96 * c:608 + 96 * c]) for c in range(2)],
+                   "evals": [_rd_fr(x[704 + 32 * k:736 + 32 * k]) for k in range(2)]} for x in d["extra_raw"]]
+    return d
+
+
 def vs2_verify_one(tau_h, gamma_g, shift_h, shape, circuits, proof, rs):
     """shape = {"query_of": [21], "bound_class": [9], "hiding": bool, "n_bounds": int}; rs = (r_beta, r_gamma, r_3).
     e(total_c, h) e(-total_w, tau h) prod_c e(bound_c, shift_h[c]) == 1 and the public-input identity."""
@@ -618,6 +650,18 @@ def vs2_verify_one(tau_h, gamma_g, shift_h, shape, circuits, proof, rs):
         ym = int.from_bytes(raw[2368 + 96 * j:2416 + 96 * j], "little")
         if xm >= Q or ym >= Q or ((xm or ym) and not g1_is_on_curve((fq_from_mont(xm), fq_from_mont(ym)))):
             return False
+    if "n_instances" in proof:  # a record with instances: 1 .. max_instances of the shape, each well-formed
+        if not 1 <= proof["n_instances"] <= shape.get("max_instances", 1):
+            return False
+        for x in proof["extra_raw"]:
+            for k in list(range(VS_INPUTS)) + [22, 23]:
+                if int.from_bytes(x[32 * k:32 * k + 32], "little") >= R:
+                    return False
+            for c in range(2):
+                xm = int.from_bytes(x[512 + 96 * c:560 + 96 * c], "little")
+                ym = int.from_bytes(x[560 + 96 * c:608 + 96 * c], "little")
+                if xm >= Q or ym >= Q or ((xm or ym) and not g1_is_on_curve((fq_from_mont(xm), fq_from_mont(ym)))):
+                    return False
     cvk = circuits[proof["circuit"]]
     zb, zg, xi = vs_challenges(cvk, proof)
     z = (zb, zg)
@@ -626,13 +670,25 @@ def vs2_verify_one(tau_h, gamma_g, shift_h, shape, circuits, proof, rs):
     if zn == 1:
         return False
     w = omega(4)
-    xhat = 0
-    for k in range(VS_INPUTS):
-        wk = pow(w, k, R)
-        xhat += proof["inputs"][k] * wk * inv((zb - wk) % R, R)
-    xhat = xhat * (zn - 1) * inv(VS_INPUTS, R) % R
-    alg_ok = ev[0] == (xhat + (zn - 1) * ev[1]) % R
+
+    def input_identity(inputs, v0, v1):
+        xhat = 0
+        for k in range(VS_INPUTS):
+            wk = pow(w, k, R)
+            xhat += inputs[k] * wk * inv((zb - wk) % R, R)
+        xhat = xhat * (zn - 1) * inv(VS_INPUTS, R) % R
+        return v0 == (xhat + (zn - 1) * v1) % R
+
+    alg_ok = input_identity(proof["inputs"], ev[0], ev[1])
     total_c, total_w, gs, hs = None, None, 0, 0
+    # every further instance: its own public-input identity, and its two polynomials join the beta query with the
+    # powers of xi after the 21 polynomials and the 9 degree-bound terms
+    for j, inst in enumerate(proof.get("extra", [])):
+        alg_ok = alg_ok and input_identity(inst["inputs"], inst["evals"][0], inst["evals"][1])
+        for c in range(2):
+            coef = rs[0] * pow(xi, VS_EVALS + VS_PROOF_COMMS + 2 * j + c, R) % R
+            total_c = g1_add(total_c, g1_mul(inst["comms"][c], coef))
+            gs = (gs + coef * inst["evals"][c]) % R
     bound = [None] * VS2_MAX_BOUNDS
     for p in range(VS_EVALS):
         q = shape["query_of"][p]

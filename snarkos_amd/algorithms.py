@@ -291,8 +291,9 @@ class VarunaShaped:
     def __init__(self, kzg_vk, circuit_vks, transcript="sha256", shape=None, key_ext=None):
         """transcript: "sha256" (the round-1 stand-in) or "poseidon" (sponge over Fq with the reference's absorb volume,
         mi_vs_ctx_create_ex(..., MI_VS_FS_POSEIDON)); proofs are bound to their transcript kind.
-        shape / key_ext: VarunaShaped-v2 (mi_vs_ctx_create_v2): the 32-byte mi_vs_shape (query-set table, degree-bound
-        classes, hiding) and the 480-byte mi_vs_key_ext (gamma_g, shift_h[2]); records are then 3184 bytes (mi_vs_proof2)
+        shape / key_ext: VarunaShaped-v2 (mi_vs_ctx_create_v2): the 56-byte mi_vs_shape (query-set table, degree-bound
+        classes, hiding, linear-combination kinds, instances per proof) and the 480-byte mi_vs_key_ext (gamma_g, shift_h[2]);
+        records are then 3184 bytes (mi_vs_proof2; 5504-byte mi_vs_proof3 when the shape carries instances)
         with three 128-bit randomizers (48 bytes) per proof."""
         vk = np.ascontiguousarray(kzg_vk).view(np.uint8).reshape(-1)
         cv = np.ascontiguousarray(circuit_vks).view(np.uint8).reshape(-1)
@@ -308,7 +309,7 @@ class VarunaShaped:
             assert sh.size == L.VS2_SHAPE_BYTES and (ext is None or ext.size == L.VS2_KEY_EXT_BYTES)
             L.check(L.lib().mi_vs_ctx_create_v2(L.ptr(vk), L.ptr(ext), L.ptr(sh), L.ptr(cv), C.c_size_t(self.n_circuits),
                                                 C.c_uint32(flags), C.byref(h)), "mi_vs_ctx_create_v2")
-            self.proof_bytes, self.rand_bytes = L.VS2_PROOF_BYTES, 48
+            self.proof_bytes, self.rand_bytes = (L.VS3_PROOF_BYTES if int(sh[53]) > 1 else L.VS2_PROOF_BYTES), 48
         else:
             L.check(L.lib().mi_vs_ctx_create_ex(L.ptr(vk), L.ptr(cv), C.c_size_t(self.n_circuits), C.c_uint32(flags), C.byref(h)),
                     "mi_vs_ctx_create_ex")

@@ -139,6 +139,8 @@ struct VsConsts {
     uint32_t class_count[MI_VS_MAX_BOUNDS];
     uint8_t query_of[MI_VS_EVALS];
     uint8_t lc_kind[MI_VS_EVALS];  // v2: bit 0: times z_beta^16 - 1, bit 1: times z_gamma^16 - 1
+    uint32_t max_inst;             // v2 with instances: 1 .. MI_VS_MAX_INSTANCES instances per proof (records: mi_vs_proof3)
+    uint32_t inst_slot;            // first of the 2 (max_inst - 1) H-side slots of the further instances' commitments
     int8_t bound_class[MI_VS_PROOF_COMMS];
     uint8_t _pad[2];
 };
@@ -327,6 +329,7 @@ int32_t vs_ctx_create(Context &cx, const mi_kzg_vk *vk, const mi_vs_key_ext *ext
         for (int p = 0; p < MI_VS_EVALS; p++)
             if (shape->lc_kind[p] > 3) return MI_ERR_BAD_ARGS;
         if ((shape->hiding || shape->n_bounds) && !ext) return MI_ERR_BAD_ARGS;
+        if (shape->max_instances > MI_VS_MAX_INSTANCES) return MI_ERR_BAD_ARGS;
     }
     std::shared_ptr<VsCtx> v(new VsCtx());
     v->n_circuits = n_circuits;
@@ -381,7 +384,10 @@ int32_t vs_ctx_create(Context &cx, const mi_kzg_vk *vk, const mi_vs_key_ext *ext
             g2_prepare_host(v->shift_prep[c], qa);
         }
     }
-    hc.per_proof = MI_VS_PROOF_COMMS + 2 + hc.n_bounded;
+    hc.max_inst = shape && shape->max_instances > 1 ? shape->max_instances : 1;
+    hc.inst_slot = MI_VS_PROOF_COMMS + 2 + hc.n_bounded;
+    hc.per_proof = hc.inst_slot + 2 * (hc.max_inst - 1);
+    if (hc.max_inst > 1) hc.proof_words = sizeof(mi_vs_proof3) / 4;
     {
         std::lock_guard<std::mutex> lk(g_vs_mu);
         v->id = g_vs_next++;
@@ -474,6 +480,17 @@ __global__ void __launch_bounds__(128) vs_derive_kernel(const void *__restrict__
     const uint32_t *inputs = pw + 4;                 // 16 x 8 words
     const uint32_t *comms = inputs + 128;            // 9 x 24 words
     const uint32_t *evals = comms + 216;             // 21 x 8 words
+    // records with instances (mi_vs_proof3): the count, then MI_VS_EXTRA_INSTANCES x {16 inputs, 2 commitments, 2
+    // evaluations} = 192 words each.  A count out of range fails the proof and leaves only its first instance.
+    const uint32_t MI = kc->max_inst, ISLOT = kc->inst_slot;
+    const uint32_t *xinst = pw + sizeof(mi_vs_proof2) / 4 + 4;
+    uint32_t m1 = 0;
+    bool count_ok = true;
+    if (MI > 1) {
+        const uint32_t ni = pw[sizeof(mi_vs_proof2) / 4];
+        count_ok = ni >= 1 && ni <= MI;
+        m1 = count_ok ? ni - 1 : 0;
+    }
     uint32_t h[8], zw[2][4], xw[4];
     bool well_formed = true;
     if (role == 0) {
@@ -482,6 +499,7 @@ __global__ void __launch_bounds__(128) vs_derive_kernel(const void *__restrict__
 #pragma unroll
             for (int k = 0; k < 8; k++) tag[k] = kc->tag[k];
             sha256_prefixed(h, tag, digest, 8, inputs, 128 + 48);
+            for (uint32_t j = 0; j < m1; j++) sha256_prefixed(h, h, xinst + 192 * j, 176, nullptr, 0);  // inputs, A_j, B_j
             sha256_prefixed(h, h, comms + 48, 72, nullptr, 0);
 #pragma unroll
             for (int k = 0; k < 4; k++) {
@@ -500,6 +518,17 @@ __global__ void __launch_bounds__(128) vs_derive_kernel(const void *__restrict__
             for (int q = 0; q < 2; q++) well_formed = well_formed && vs_limbs_below(extra + 8 * q, FrP::MOD, 8);
             for (int j = 0; j < MI_VS_PROOF_COMMS; j++) well_formed = well_formed && vs_point_ok(extra + 16 + 24 * j);
         }
+        for (uint32_t j = 0; j < m1; j++) {
+            const uint32_t *x = xinst + 192 * j;
+            for (int k = 0; k < MI_VS_INPUTS; k++) well_formed = well_formed && vs_limbs_below(x + 8 * k, FrP::MOD, 8);
+            for (int c = 0; c < 2; c++) well_formed = well_formed && vs_point_ok(x + 128 + 24 * c) && vs_limbs_below(x + 176 + 8 * c, FrP::MOD, 8);
+        }
+        for (uint32_t j = 0; j + 1 < MI; j++)  // the further instances' commitments: their H-side slots (infinity when absent)
+            for (uint32_t c = 0; c < 2; c++) {
+                G1Affine pt = G1Affine::inf();
+                if (j < m1) copy_g1(&pt, reinterpret_cast<const G1Affine *>(xinst + 192 * j + 128 + 24 * c));
+                copy_g1(pts1 + i * PP + ISLOT + 2 * j + c, &pt);
+            }
         circuit_of[i] = circuit;
         // ---- points into MSM order, randomizers as the tau-H side's scalars
         const G1Affine *pc = reinterpret_cast<const G1Affine *>(comms);
@@ -535,6 +564,7 @@ __global__ void __launch_bounds__(128) vs_derive_kernel(const void *__restrict__
 #pragma unroll
             for (int k = 0; k < 4; k++) zw[1][k] = __builtin_bswap32(h[k]);
             sha256_prefixed(h, h, evals, 168, nullptr, 0);
+            for (uint32_t j = 0; j < m1; j++) sha256_prefixed(h, h, xinst + 192 * j + 176, 16, nullptr, 0);  // a_j, b_j
 #pragma unroll
             for (int k = 0; k < 4; k++) xw[k] = __builtin_bswap32(h[k]);
         } else {
@@ -589,6 +619,20 @@ __global__ void __launch_bounds__(128) vs_derive_kernel(const void *__restrict__
                 xip = mul(xip, xi);
             }
         }
+        if (MI > 1) {  // the further instances' polynomials join the beta query with xi^(30 + 2j + c)
+            if (!NB)
+                for (int j = 0; j < MI_VS_PROOF_COMMS; j++) xip = mul(xip, xi);  // the powers the degree-bound terms would take
+            for (uint32_t j = 0; j + 1 < MI; j++)
+                for (uint32_t c = 0; c < 2; c++) {
+                    Fr s = Fr::zero();
+                    if (j < m1) {
+                        s = mul(r[0], xip);
+                        val[0] = add(val[0], mul(xip, fr_load(xinst + 192 * j + 176 + 8 * c)));
+                        xip = mul(xip, xi);
+                    }
+                    fr_store(sc1 + (i * PP + ISLOT + 2 * j + c) * 8, from_mont(s));
+                }
+        }
         Fr gs = Fr::zero(), hs = Fr::zero();
 #pragma unroll
         for (int q = 0; q < 2; q++) {
@@ -618,22 +662,26 @@ __global__ void __launch_bounds__(128) vs_derive_kernel(const void *__restrict__
 #pragma unroll
     for (int k = 0; k < 4; k++) zn = sqr(zn);
     Fr znm1 = sub(zn, Fr::one());
-    bool ok = !znm1.is_zero() && !bad_circuit && well_formed;  // z^16 = 1 rejects, as in the oracle
+    bool ok = !znm1.is_zero() && !bad_circuit && well_formed && count_ok;  // z^16 = 1 rejects, as in the oracle
     Fr pre[MI_VS_INPUTS], acc = Fr::one();
     for (int k = 0; k < MI_VS_INPUTS; k++) {  // pre[k] = prod_{j < k} d_j
         pre[k] = acc;
         acc = mul(acc, sub(zb, fr_load(&kc->omega16[k])));
     }
-    Fr rhs = Fr::zero(), suf = Fr::one();
-    for (int k = MI_VS_INPUTS - 1; k >= 0; k--) {  // suf = prod_{j > k} d_j
-        Fr wk = fr_load(&kc->omega16[k]);
-        rhs = add(rhs, mul(mul(fr_load(inputs + 8 * k), wk), mul(pre[k], suf)));
-        suf = mul(suf, sub(zb, wk));
-    }
-    Fr lhs = sub(fr_load(evals), mul(znm1, fr_load(evals + 8)));
+    for (uint32_t inst = 0; inst <= m1; inst++) {  // every instance's own identity (one instance: one pass)
+        const uint32_t *in_p = inst ? xinst + 192 * (inst - 1) : inputs;
+        const uint32_t *v0 = inst ? in_p + 176 : evals, *v1 = inst ? in_p + 184 : evals + 8;
+        Fr rhs = Fr::zero(), suf = Fr::one();
+        for (int k = MI_VS_INPUTS - 1; k >= 0; k--) {  // suf = prod_{j > k} d_j
+            Fr wk = fr_load(&kc->omega16[k]);
+            rhs = add(rhs, mul(mul(fr_load(in_p + 8 * k), wk), mul(pre[k], suf)));
+            suf = mul(suf, sub(zb, wk));
+        }
+        Fr lhs = sub(fr_load(v0), mul(znm1, fr_load(v1)));
 #pragma unroll
-    for (int k = 0; k < 4; k++) lhs = dbl(lhs);  // * 16
-    ok = ok && (lhs == rhs);
+        for (int k = 0; k < 4; k++) lhs = dbl(lhs);  // * 16
+        ok = ok && (lhs == rhs);
+    }
     alg_ok[i] = ok ? 1 : 0;
 }
 
@@ -657,17 +705,26 @@ __device__ __forceinline__ Fq28 f28_sel(bool c, const Fq28 &a, const Fq28 &b) {
     for (int k = 0; k < 14; k++) r.l[k] = c ? a.l[k] : b.l[k];
     return r;
 }
+// element e of the transcript of a proof with m1 further instances (73 + 38 m1 elements; oracle: fs_element): a run
+// of 16 / 32 / 48 bytes of the record taken as Montgomery limbs (zero-extended).  xinst: the further instances (192
+// words each: 16 inputs, two commitments, two evaluations); they sit after C_1 (36 elements each) and at the end (2).
 __device__ __forceinline__ Fq vs_fs_element(const mi_vs_proof *__restrict__ p, const uint32_t *__restrict__ digest,
-                                            const VsConsts *__restrict__ kc, int e) {
-    // element e of the transcript: a run of 16 / 32 / 48 bytes of the proof taken as Montgomery limbs (zero-extended)
+                                            const VsConsts *__restrict__ kc, const uint32_t *__restrict__ xinst, int m1, int e) {
     const uint32_t *pw = reinterpret_cast<const uint32_t *>(p);
     const uint32_t *src;
     int words;
     if (e == 0) { src = kc->tag_elem.l; words = 8; }
     else if (e == 1) { src = digest; words = 8; }
-    else if (e < 34) { src = pw + 4 + 4 * (e - 2); words = 4; }     // halves of the 16 inputs
-    else if (e < 52) { src = pw + 132 + 12 * (e - 34); words = 12; }  // coordinates of C_0..C_8
-    else { src = pw + 348 + 8 * (e - 52); words = 8; }               // evaluations
+    else if (e < 34) { src = pw + 4 + 4 * (e - 2); words = 4; }      // halves of the 16 inputs
+    else if (e < 38) { src = pw + 132 + 12 * (e - 34); words = 12; }  // coordinates of C_0, C_1
+    else if (e < 38 + 36 * m1) {
+        const int f = e - 38, j = f / 36, k = f - 36 * j;
+        const uint32_t *x = xinst + 192 * j;
+        if (k < 32) { src = x + 4 * k; words = 4; }                   // halves of the instance's inputs
+        else { src = x + 128 + 12 * (k - 32); words = 12; }           // coordinates of A_j, B_j
+    } else if (e < 52 + 36 * m1) { src = pw + 132 + 12 * (e - 36 * m1 - 34); words = 12; }  // coordinates of C_2..C_8
+    else if (e < 73 + 36 * m1) { src = pw + 348 + 8 * (e - 36 * m1 - 52); words = 8; }      // evaluations
+    else { const int f = e - 73 - 36 * m1; src = xinst + 192 * (f >> 1) + 176 + 8 * (f & 1); words = 8; }  // a_j, b_j
     Fq r;
 #pragma unroll
     for (int q = 0; q < 3; q++) {
@@ -702,13 +759,24 @@ __global__ void __launch_bounds__(4 * VS_FS_PROOFS_PER_BLOCK) vs_fs_poseidon_ker
         mcol[k] = load28(pc->mds[k][lc]);
         mrow[k] = load28(pc->mds[lc][k]);
     }
+    // further instances (mi_vs_proof3): every proof absorbs 38 more elements per instance; the block walks the shape's
+    // maximum number of permutations (the barriers are block-wide), a proof stops absorbing and squeezing at its own end
+    const uint32_t MI = kc->max_inst;
+    const uint32_t *xinst = reinterpret_cast<const uint32_t *>(p) + sizeof(mi_vs_proof2) / 4 + 4;
+    int m1 = 0;
+    if (MI > 1) {
+        const uint32_t ni = reinterpret_cast<const uint32_t *>(p)[sizeof(mi_vs_proof2) / 4];
+        m1 = (ni >= 1 && ni <= MI) ? (int)ni - 1 : 0;
+    }
+    const int n_el = VS_FS_ELEMS + 38 * m1, my_blocks = VS_FS_BLOCKS + 19 * m1, all_blocks = VS_FS_BLOCKS + 19 * ((int)MI - 1);
+    const int b_beta = 21 + 18 * m1, b_gamma = 25 + 18 * m1;
     Fq28 s;
 #pragma unroll
     for (int k = 0; k < 14; k++) s.l[k] = 0;
-    for (int b = 0; b < VS_FS_BLOCKS; b++) {
+    for (int b = 0; b < all_blocks; b++) {
         // ---- absorb: lane 1 takes element 2b, lane 2 element 2b + 1 (the last block holds one)
         const int e = 2 * b + (l == 2 ? 1 : 0);
-        if ((l == 1 || l == 2) && e < VS_FS_ELEMS) s = add28(s, load28(vs_fs_element(p, digest, kc, e)));
+        if ((l == 1 || l == 2) && e < n_el) s = add28(s, load28(vs_fs_element(p, digest, kc, xinst, m1, e)));
         // ---- permutation
         for (int r = 0; r < MI_POSEIDON_ROUNDS; r++) {
             s = normalise28(add28(s, load28(pc->ark[r][lc])));
@@ -741,9 +809,9 @@ __global__ void __launch_bounds__(4 * VS_FS_PROOFS_PER_BLOCK) vs_fs_poseidon_ker
             }
         }
         // ---- squeeze: the low 128 bits of the canonical value of the first rate element
-        if ((b == 21 || b == 25 || b == VS_FS_BLOCKS - 1) && l == 1 && i < n) {
+        if ((b == b_beta || b == b_gamma || b == my_blocks - 1) && l == 1 && i < n) {
             const Fq c = from_mont(store28(s));
-            const int which = b == 21 ? 0 : (b == 25 ? 1 : 2);
+            const int which = b == b_beta ? 0 : (b == b_gamma ? 1 : 2);
             reinterpret_cast<uint4 *>(chal)[3 * i + which] = make_uint4(c.l[0], c.l[1], c.l[2], c.l[3]);
         }
     }

@@ -32,6 +32,7 @@ VS_DEFAULT_LANES = 12
 VS_MAX_TICKETS = 8
 VS_FS_POSEIDON = 1  # mi_vs_ctx_create_ex flag: Poseidon Fiat-Shamir transcript
 VS2_PROOF_BYTES = 3184  # mi_vs_proof2
+VS3_PROOF_BYTES = 5504  # mi_vs_proof3 (shapes with max_instances > 1)
 VS2_KEY_EXT_BYTES = 480
 VS2_SHAPE_BYTES = 56
 

@@ -195,3 +195,49 @@ def test_full_size_batch_1024_v2(orc, mi):
         assert (cpu == want).all()
     finally:
         v.close()
+
+
+@pytest.mark.parametrize("transcript", ["sha256", "poseidon"])
+def test_instances_per_proof(orc, mi, transcript):
+    """per-circuit batch sizes (mi_vs_proof3): proofs with 1..4 instances; partial bit-exact against the oracle, verdicts
+    on a corrupted batch (base and further instances spoiled), counts out of range, the fallback and the stream"""
+    import torch
+    tr = orc.FS_POSEIDON if transcript == "poseidon" else orc.FS_SHA256
+    P3 = 5504
+    try:
+        sh = orc.vs2_shape(None, None, True, 2, lc_kind=[0, 0, 1, 2, 3, 0, 1, 3, 2] + [3, 1, 0, 2] * 3, max_instances=4)
+        good = orc.VS2Batch(0x31A, 48, 3, 0, shape=sh, transcript=tr)
+        v = _ctx(mi, good, transcript)
+        try:
+            assert v.proof_bytes == P3
+            gp, gr = torch.from_numpy(good.proofs).cuda(), torch.from_numpy(good.randomizers).cuda()
+            whole = v.accumulate(gp, gr)
+            assert (np.frombuffer(whole.tobytes(), dtype=np.uint8) == orc.vs_partial_from_oracle(good, 8)).all()
+            assert v.finalize([whole])
+            ok, verdicts = v.verify_batch(good.proofs, good.randomizers)
+            assert ok and verdicts.all()
+            bad = orc.VS2Batch(0x31B, 64, 3, 300, shape=sh, transcript=tr)
+            assert 0 < bad.expected.sum() < 64
+        finally:
+            v.close()
+        v = _ctx(mi, bad, transcript)
+        try:
+            ok, verdicts = v.verify_batch(bad.proofs, bad.randomizers)
+            assert not ok and (verdicts == bad.expected).all() and (verdicts == bad.verify_cpu(8)).all()
+            # instance counts out of range
+            good2 = orc.VS2Batch(0x31B, 64, 3, 0, shape=sh, transcript=tr)   # same keys as `bad` (same seed)
+            p = good2.proofs.copy()
+            p[7 * P3 + 3184] = 9
+            p[8 * P3 + 3184] = 0
+            ok, verdicts = v.verify_batch(p, good2.randomizers)
+            w = np.ones(64, dtype=np.uint8); w[7] = w[8] = 0
+            cpu = orc.VS2Batch.wrap(good2.vk, good2.ext, sh, good2.circuits, p, good2.randomizers, transcript=tr).verify_cpu(8)
+            assert (cpu == w).all() and not ok and (verdicts == w).all()
+            dp, dr = torch.from_numpy(p).cuda(), torch.from_numpy(good2.randomizers).cuda()
+            g2p = torch.from_numpy(good2.proofs).cuda()
+            got = list(v.verify_stream(iter([(g2p, dr), (dp, dr)]), verdicts=True))
+            assert got[0][0] and not got[1][0] and (got[1][1] == w).all()
+        finally:
+            v.close()
+    finally:
+        orc.lib().orc_vs_set_transcript(orc.FS_SHA256)
