@@ -77,11 +77,11 @@ const PairingConsts *pairing_consts(Context &cx, hipStream_t st) {
 
 // product over prepared (device-resident) G2 points; P's are host values passed as kernel arguments
 // enqueue one pairing product on `st`; the result lands in d_out (device)
-// unit < 0: a product somebody waits for (one batch on its own, a block, mi_pairing*): the two-launch form -- 21
-// workgroups per couple prepare the merged Miller factors, the product kernel is 48 rounds (159 for two couples)
-// shorter: 0.87 -> 0.76 ms.  unit >= 0: a product slot of the streamed verifier, where eight products are in flight
-// and nobody waits for one of them: the one-launch form (the extra workgroups of the other form cost the stream a
-// quarter of its throughput, measured).  MI_SNARK_PAIRING_LAUNCHES=1 / 2 forces either.
+// Two launches: 21 workgroups per couple prepare the merged Miller factors (pairing_lines_kernel), the product kernel
+// is 48 rounds (159 for two couples) shorter: 0.87 -> 0.76 ms for a product somebody waits for; in the streamed
+// verifier, where eight products are in flight, the product kernel runs 0.78 ms instead of 0.93 and the throughput is
+// the same within noise (tools/ab_pairing_launches.sh).  unit names the caller's product slot (its workspace for the
+// factors; -1: the synchronous path).  MI_SNARK_PAIRING_LAUNCHES=1 forces the one-launch form.
 void pairing_launch(Context &cx, const G1Affine *ps, const G2Prepared *const *d_qs, size_t n, Fq12 *d_out, hipStream_t st, int unit) {
     PairingArgs a;
     memset(&a, 0, sizeof a);
@@ -89,7 +89,7 @@ void pairing_launch(Context &cx, const G1Affine *ps, const G2Prepared *const *d_
     for (size_t i = 0; i < n; i++) { a.p[i] = ps[i]; a.q[i] = d_qs[i]; }
     const PairingConsts *pc = pairing_consts(cx, st);
     static const int force = getenv("MI_SNARK_PAIRING_LAUNCHES") ? atoi(getenv("MI_SNARK_PAIRING_LAUNCHES")) : 0;
-    const bool two_launches = force ? force == 2 : unit < 0;
+    const bool two_launches = force != 1;
     const int couples = (int)((n + 1) / 2);
     Fq *merged = nullptr;
     cx.prof.begin("pairing", st, n);
