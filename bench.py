@@ -257,12 +257,13 @@ def main():
 
 
 # ---- integer-ALU view of the dominant kernel (the verifier is latency / ALU bound: SURVEY.md 8d)
-# A pairing product launch is ONE workgroup of 3 waves on one compute unit.  Work per launch in 32x32-bit limb products
-# (v_mad_u64_u32): ~530 Fq12 rounds x 192 lanes x 179 limb products (108 product + 48 fold + 23 Barrett), plus the
-# up-front line evaluation / line products (~1 700 Montgomery products of 288 limb products).  Peak for the waves the
-# kernel owns: tools/ubench at one wave per SIMD sustains 50.25 G Fq products/s chip-wide = 49.1 M products/s per wave
-# = 14.1 G limb products/s per wave.
-PAIRING_LIMB_PRODUCTS = 530 * 192 * 179 + 1700 * 288
+# A pairing product is ONE workgroup of 3 waves on one compute unit (after a short first launch of 21 workgroups that
+# prepare the merged Miller factors: their ~30 us sit inside the bracketed time, their work is not counted here).  Work
+# of the product kernel in 32x32-bit limb products (v_mad_u64_u32): ~470 Fq12 rounds (81 Miller + ~390 final
+# exponentiation) x 192 lanes x 179 limb products (108 product + 48 fold + 23 Barrett).  Peak for the waves the kernel
+# owns: tools/ubench at one wave per SIMD sustains 50.25 G Fq products/s chip-wide = 49.1 M products/s per wave = 14.1 G
+# limb products/s per wave.
+PAIRING_LIMB_PRODUCTS = 470 * 192 * 179
 WAVE_LIMB_PRODUCT_RATE = 50.25e9 / 1024 * 288
 
 
@@ -274,8 +275,8 @@ def alu_view(kernels):
     ach = PAIRING_LIMB_PRODUCTS / t
     return {"kernel": "pairing", "unit": "32x32-bit limb products/s", "work_per_launch": PAIRING_LIMB_PRODUCTS,
             "achieved": ach, "waves": 3, "peak_for_those_waves": 3 * WAVE_LIMB_PRODUCT_RATE, "frac": ach / (3 * WAVE_LIMB_PRODUCT_RATE),
-            "note": "one workgroup (3 waves, one CU) per launch; several launches run side by side in the streamed region, so avg_us "
-                    "includes their mutual slowdown"}
+            "note": "one workgroup (3 waves, one CU) per product (plus its 21-workgroup line launch, inside avg_us); several "
+                    "products run side by side in the streamed region, so avg_us includes their mutual slowdown"}
 
 
 def native_comm(rank, world, flag_device):
