@@ -259,11 +259,11 @@ def main():
 # ---- integer-ALU view of the dominant kernel (the verifier is latency / ALU bound: SURVEY.md 8d)
 # A pairing product is ONE workgroup of 3 waves on one compute unit (after a short first launch of 21 workgroups that
 # prepare the merged Miller factors: their ~30 us sit inside the bracketed time, their work is not counted here).  Work
-# of the product kernel in 32x32-bit limb products (v_mad_u64_u32): ~470 Fq12 rounds (81 Miller + ~390 final
+# of the product kernel in 32x32-bit limb products (v_mad_u64_u32): ~450 Fq12 rounds (81 Miller + ~365 final
 # exponentiation) x 192 lanes x 179 limb products (108 product + 48 fold + 23 Barrett).  Peak for the waves the kernel
 # owns: tools/ubench at one wave per SIMD sustains 50.25 G Fq products/s chip-wide = 49.1 M products/s per wave = 14.1 G
 # limb products/s per wave.
-PAIRING_LIMB_PRODUCTS = 470 * 192 * 179
+PAIRING_LIMB_PRODUCTS = 450 * 192 * 179
 WAVE_LIMB_PRODUCT_RATE = 50.25e9 / 1024 * 288
 
 
