@@ -258,7 +258,7 @@ def main():
 
 # ---- integer-ALU view of the dominant kernel (the verifier is latency / ALU bound: SURVEY.md 8d)
 # A pairing product is ONE workgroup of 3 waves on one compute unit (after a short first launch of 21 workgroups that
-# prepare the merged Miller factors: their ~30 us sit inside the bracketed time, their work is not counted here).  Work
+# prepare the merged Miller factors: ~30 us, bracketed and counted separately).  Work
 # of the product kernel in 32x32-bit limb products (v_mad_u64_u32): ~450 Fq12 rounds (81 Miller + ~365 final
 # exponentiation) x 192 lanes x 179 limb products (108 product + 48 fold + 23 Barrett).  Peak for the waves the kernel
 # owns: tools/ubench at one wave per SIMD sustains 50.25 G Fq products/s chip-wide = 49.1 M products/s per wave = 14.1 G
@@ -275,7 +275,7 @@ def alu_view(kernels):
     ach = PAIRING_LIMB_PRODUCTS / t
     return {"kernel": "pairing", "unit": "32x32-bit limb products/s", "work_per_launch": PAIRING_LIMB_PRODUCTS,
             "achieved": ach, "waves": 3, "peak_for_those_waves": 3 * WAVE_LIMB_PRODUCT_RATE, "frac": ach / (3 * WAVE_LIMB_PRODUCT_RATE),
-            "note": "one workgroup (3 waves, one CU) per product (plus its 21-workgroup line launch, inside avg_us); several "
+            "note": "one workgroup (3 waves, one CU) per product (its 21-workgroup line launch is bracketed separately); several "
                     "products run side by side in the streamed region, so avg_us includes their mutual slowdown"}
 
 

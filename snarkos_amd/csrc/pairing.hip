@@ -92,15 +92,17 @@ void pairing_launch(Context &cx, const G1Affine *ps, const G2Prepared *const *d_
     const bool two_launches = force != 1;
     const int couples = (int)((n + 1) / 2);
     Fq *merged = nullptr;
-    cx.prof.begin("pairing", st, n);
     cx.raise_lds_limit((const void *)pairing_product_kernel, (int)PW_LDS_BYTES);
     if (two_launches && n > 0) {
         char nm[32];
         snprintf(nm, sizeof nm, "pairing.m%d", unit < 0 ? 99 : unit);
         merged = (Fq *)cx.buf(nm, sizeof(Fq) * 12 * PW_MILLER_GROUPS * (MI_MAX_PAIRS / 2));
         cx.raise_lds_limit((const void *)pairing_lines_kernel, (int)PW_LDS_BYTES);
+        cx.prof.begin("pairing_lines", st, n);
         hipLaunchKernelGGL(pairing_lines_kernel, dim3(PW_MILLER_GROUPS, couples), dim3(PW_THREADS), PW_LDS_BYTES, st, a, pc, merged);
+        cx.prof.end("pairing_lines", st);
     }
+    cx.prof.begin("pairing", st, n);  // the product kernel alone (what the kernel trace calls pairing_product_kernel)
     hipLaunchKernelGGL(pairing_product_kernel, dim3(1), dim3(PW_THREADS), PW_LDS_BYTES, st, a, pc, d_out, (const Fq *)merged);
     cx.prof.end("pairing", st);
     MI_HIP(hipGetLastError());
