@@ -615,11 +615,17 @@ def extras(dev, verifier, proofs, rnd):
         bad[i * L.VS_PROOF_BYTES + ev_off + 32 * 7] ^= 1  # flip one bit of evaluation 7
     d_bad = torch.from_numpy(bad).to(dev)
     d_rnd = torch.from_numpy(rnd).to(dev)
-    verifier.verify_batch(d_bad, d_rnd)
-    t0 = time.perf_counter()
-    ok, verdicts = verifier.verify_batch(d_bad, d_rnd)
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
+    def timed(fn, reps=5):
+        """median wall time of fn over reps calls after one untimed call (each call ends with its verdicts on the host)"""
+        fn()
+        ts = []
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            r = fn()
+            ts.append(time.perf_counter() - t0)
+        return r, sorted(ts)[len(ts) // 2]
+
+    (ok, verdicts), dt = timed(lambda: verifier.verify_batch(d_bad, d_rnd))
     want = np.ones(1024, dtype=np.uint8)
     want[idx] = 0
     ex["batch_1pct_corrupted"] = {"proofs_per_s": 1024 / dt, "ms": 1e3 * dt, "all_ok": ok,
@@ -631,18 +637,13 @@ def extras(dev, verifier, proofs, rnd):
         for i in which:
             b2[i * L.VS_PROOF_BYTES + ev_off + 32 * 7] ^= 1
         d_b2 = torch.from_numpy(b2).to(dev)
-        verifier.verify_batch(d_b2, d_rnd)
-        t0 = time.perf_counter()
-        ok2, v2 = verifier.verify_batch(d_b2, d_rnd)
-        dt2 = time.perf_counter() - t0
+        (ok2, v2), dt2 = timed(lambda: verifier.verify_batch(d_b2, d_rnd))
         w2 = np.ones(1024, dtype=np.uint8)
         w2[which] = 0
         ex["batch_1pct_corrupted"]["ms_" + name] = 1e3 * dt2
         ex["batch_1pct_corrupted"]["verdicts_correct"] &= bool((v2 == w2).all()) and not ok2
-    verifier.identify(d_bad, d_rnd)
-    t0 = time.perf_counter()
-    v3 = verifier.identify(d_bad, d_rnd)
-    ex["batch_1pct_corrupted"]["ms_identify_only"] = 1e3 * (time.perf_counter() - t0)
+    v3, dt3 = timed(lambda: verifier.identify(d_bad, d_rnd))
+    ex["batch_1pct_corrupted"]["ms_identify_only"] = 1e3 * dt3
     ex["batch_1pct_corrupted"]["verdicts_correct"] &= bool((v3 == want).all())
     return ex
 
