@@ -149,8 +149,11 @@ def main():
                 stamps.append(time.perf_counter())
         assert len(oks) == k and all(oks), "synthetic batch must verify"
 
+    trace = (lambda m: print("[bench] " + m, file=sys.stderr, flush=True)) if os.environ.get("MI_BENCH_TRACE") else (lambda m: None)
+    trace("warm-up stream")
     if args.warmup:
         run(args.warmup)
+    trace("timed stream")
     # ---- timed region: exactly K batches, no profiling hooks
     L.prof_enable(0)
     sync_all(dist_on)
@@ -165,8 +168,10 @@ def main():
     # ---- outside the timed region: the steady state of the same stream (pipeline full).  K batches include ~2 ms of
     # pipeline fill and drain -- a third of the timed region at K = 20 -- so a longer stream is run once more and the
     # verdict-to-verdict spacing of its middle half reported beside ms_per_step.
+    trace("steady-state stream")
     run(max(args.steps, 240), stamp=True)
     sync_all(dist_on)
+    trace("bracketed stream")
     lo, hi = len(stamps) // 4, len(stamps) - 1 - len(stamps) // 4
     steady = 1e3 * (stamps[hi] - stamps[lo]) / (hi - lo)
     # ---- the same K batches again with HIP-event brackets around the headline kernels, on the streams they run on
@@ -179,6 +184,7 @@ def main():
     run(args.steps)
     sync_all(dist_on)
     L.prof_enable(False)
+    trace("streams done")
 
     kernels = {}
     for k, per_unit in ALG_BYTES.items():
@@ -232,6 +238,7 @@ def main():
         "roofline": roofline, "alu": alu_view(kernels), "kernels": kernels,
     }
     if world == 1:
+        trace("one batch on its own")
         verifier.verify_batch(d_proofs, d_rnd)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
@@ -244,6 +251,7 @@ def main():
         for _ in range(5):
             verifier.accumulate(d_proofs, d_rnd)
         out["accumulate_stage_ms"] = 1e3 * (time.perf_counter() - t0) / 5
+        trace("latency done")
 
     if world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(vk, circuits, proofs, rnd)

@@ -394,6 +394,22 @@ class VarunaShaped:
         L.check(L.lib().mi_vs_accumulate_end(C.c_uint64(self.ctx), C.c_uint64(handle), L.ptr(part)), "mi_vs_accumulate_end")
         return part
 
+    def accumulate_begin_pair(self, proofs_a, randomizers_a, proofs_b, randomizers_b, stream=None):
+        """Two batches in one lane pass (mi_vs_accumulate_begin_pair): each keeps its own partial.  Raises MiError
+        (MI_ERR_BAD_ARGS) for shapes that do not pair (degree-bound classes, Poseidon transcript, too large)."""
+        na = proofs_a.numel() * proofs_a.element_size() // self.proof_bytes
+        nb = proofs_b.numel() * proofs_b.element_size() // self.proof_bytes
+        h = C.c_uint64(0)
+        L.check(L.lib().mi_vs_accumulate_begin_pair(C.c_uint64(self.ctx), L.dptr(proofs_a), C.c_size_t(na), L.dptr(randomizers_a),
+                                                    L.dptr(proofs_b), C.c_size_t(nb), L.dptr(randomizers_b),
+                                                    L.stream_ptr(stream), C.byref(h)), "mi_vs_accumulate_begin_pair")
+        return h.value
+
+    def accumulate_end_pair(self, handle):
+        parts = np.zeros((2, L.VS_PARTIAL_BYTES), dtype=np.uint8)
+        L.check(L.lib().mi_vs_accumulate_end_pair(C.c_uint64(self.ctx), C.c_uint64(handle), L.ptr(parts)), "mi_vs_accumulate_end_pair")
+        return parts
+
     def finalize_async(self, partials):
         """Enqueue the pairing product for these partials on the context's own stream; returns a ticket."""
         parts = np.ascontiguousarray(partials, dtype=np.uint8).reshape(-1, L.VS_PARTIAL_BYTES)

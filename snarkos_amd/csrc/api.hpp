@@ -71,6 +71,9 @@ int32_t vs_accumulate_device(Context &cx, uint64_t id, const void *d_proofs, siz
 int32_t vs_accumulate_begin(Context &cx, uint64_t id, const void *d_proofs, size_t n, const void *d_rand, hipStream_t st,
                             uint64_t *handle);
 int32_t vs_accumulate_end(Context &cx, uint64_t id, uint64_t handle, mi_vs_partial *out);
+int32_t vs_accumulate_begin_pair(Context &cx, uint64_t id, const void *d_proofs_a, size_t n_a, const void *d_rand_a,
+                                 const void *d_proofs_b, size_t n_b, const void *d_rand_b, hipStream_t st, uint64_t *handle);
+int32_t vs_accumulate_end_pair(Context &cx, uint64_t id, uint64_t handle, mi_vs_partial *out2);
 int32_t vs_finalize(Context &cx, uint64_t id, const mi_vs_partial *parts, size_t np, uint8_t *all_ok, hipStream_t st);
 int32_t vs_finalize_async(Context &cx, uint64_t id, const mi_vs_partial *parts, size_t np, uint64_t *ticket);
 int32_t vs_finalize_wait(Context &cx, uint64_t id, uint64_t ticket, uint8_t *all_ok);

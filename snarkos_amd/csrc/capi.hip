@@ -259,6 +259,11 @@ extern "C" {
 int32_t mi_init(const int32_t *device_ids, int32_t n_devices) {
     if (n_devices < 0 || n_devices > 64 || (n_devices > 0 && !device_ids)) return MI_ERR_BAD_ARGS;
     if (!host_cpu_ok()) return MI_ERR_NO_DEVICE;
+    // The streamed verifier keeps ~20 HIP streams busy; the runtime maps them onto 4 hardware queues unless told
+    // otherwise, and a 20-batch stream then takes 11 ms instead of 6 (tools/short_stream_probe.py).  The variable is
+    // read when the runtime comes up, so this only helps an embedding process that has not touched HIP yet (a node
+    // whose first HIP call is this one); it never overrides the operator's own setting.
+    setenv("GPU_MAX_HW_QUEUES", "32", 0);
     if (n_devices == 0) return ensure_init();  // the current HIP device becomes the primary
     int count = 0;
     if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) return MI_ERR_NO_DEVICE;
@@ -888,6 +893,20 @@ int32_t mi_vs_accumulate_end(uint64_t c, uint64_t handle, mi_vs_partial *partial
     if (!partial_out) return MI_ERR_BAD_ARGS;
     if (ensure_init() != MI_OK) return MI_ERR_NO_DEVICE;
     return guarded_on(context_at((int)((handle >> 8) & 0xff)), [&](Context &cx) -> int32_t { return vs_accumulate_end(cx, c, handle, partial_out); });
+}
+int32_t mi_vs_accumulate_begin_pair(uint64_t c, const void *d_proofs_a, size_t n_a, const void *d_randomizers128_a,
+                                    const void *d_proofs_b, size_t n_b, const void *d_randomizers128_b, void *stream,
+                                    uint64_t *handle_out) {
+    if (!d_proofs_a || !n_a || !d_randomizers128_a || !d_proofs_b || !n_b || !d_randomizers128_b || !handle_out) return MI_ERR_BAD_ARGS;
+    return guarded_ptr(d_proofs_a, [&](Context &cx) -> int32_t {
+        return vs_accumulate_begin_pair(cx, c, d_proofs_a, n_a, d_randomizers128_a, d_proofs_b, n_b, d_randomizers128_b,
+                                        (hipStream_t)stream, handle_out);
+    });
+}
+int32_t mi_vs_accumulate_end_pair(uint64_t c, uint64_t handle, mi_vs_partial *partials_out) {
+    if (!partials_out) return MI_ERR_BAD_ARGS;
+    if (ensure_init() != MI_OK) return MI_ERR_NO_DEVICE;
+    return guarded_on(context_at((int)((handle >> 8) & 0xff)), [&](Context &cx) -> int32_t { return vs_accumulate_end_pair(cx, c, handle, partials_out); });
 }
 int32_t mi_vs_finalize_async(uint64_t c, const mi_vs_partial *partials, size_t n_partials, uint64_t *ticket_out) {
     if (!partials || !n_partials || !ticket_out) return MI_ERR_BAD_ARGS;

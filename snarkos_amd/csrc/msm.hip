@@ -617,6 +617,101 @@ __global__ void __launch_bounds__(64) msm_bit_sums_queue_kernel(const G1Xyzz *__
     if (lane == 0) store_xyzz(&out[g], have ? xyzz28_store(acc) : G1Xyzz::inf());
 }
 
+// Four groups per 256-lane block: the walk above, one group per wave, then ONE tree for the block through LDS.  A
+// wave on its own pays six full additions for its six tree levels although level k has work for 64 >> k lanes; here
+// level 1 of the four groups fills two waves, level 2 one, and the rest a shrinking part of wave 0: 7 wave-additions
+// per four groups instead of 24, while the other waves sleep at the barrier and leave their SIMDs to other batches.
+// The verifier's pair of MSMs needs 5 376 wave-additions in the one-wave form, 3 200 here; measured: the kernel alone
+// 217 -> 203 us, the streamed verifier +2.5 %.
+// NOT THE DEFAULT (MI_SNARK_BITSUM_LPG=4 selects it): with this kernel in the stream, one `bench.py --steps 400` run in
+// five to ten ended in "Memory access fault by GPU" at a 2 MB-aligned address, in the middle of a stream of identical
+// batches; 14 runs with the one-wave kernel (and every run before this kernel existed) were clean, and so were 17
+// runs in which this kernel served pair passes.  Its index arithmetic, its wave-level queue (also tried with
+// workgroup-scope fences) and its generated code (no scratch, no flat accesses, pointers live where they are used)
+// were checked without finding an out-of-range access; what it does differently is hold 60 KB of LDS per block with
+// two blocks per compute unit.  Unexplained, therefore off.  tools/fault_hunt.sh is the bounded reproduction.
+#define BS_GROUPS 4
+__global__ void __launch_bounds__(64 * BS_GROUPS) msm_bit_sums_block_kernel(const G1Xyzz *__restrict__ chunk_partial,
+                                                                            const uint32_t *__restrict__ chunk_off,
+                                                                            const uint32_t *__restrict__ chunk_bucket, uint32_t B, int c,
+                                                                            uint32_t n_groups, G1Xyzz *__restrict__ out) {
+    constexpr int NT = 64 * BS_GROUPS;
+    __shared__ uint32_t queue[BS_GROUPS][128];
+    __shared__ int32_t slot[56][NT];  // word k of lane p's partial at slot[k][p]: conflict-free for consecutive lanes
+    __shared__ uint32_t slot_have[NT];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const uint32_t g = blockIdx.x * BS_GROUPS + (uint32_t)wv;
+    const bool live = g < n_groups;
+    const uint32_t w = live ? g / (uint32_t)c : 0, bit = g - w * (uint32_t)c;
+    const uint32_t lo = live ? chunk_off[(size_t)w * B] : 0, hi = live ? chunk_off[(size_t)(w + 1) * B] : 0;
+    G1Xyzz28 acc;
+    bool have = false;
+    uint32_t head = 0, tail = 0, base = lo;  // wave-uniform
+    uint32_t *q = queue[wv];
+    while (true) {
+        const bool more = base < hi;
+        if (more) {
+            const uint32_t e = base + lane;
+            const bool match = e < hi && (((chunk_bucket[e] - w * B + 1) >> bit) & 1u);
+            const uint64_t mm = __ballot(match);
+            if (match) q[(tail + (uint32_t)__popcll(mm & ((1ull << lane) - 1ull))) & 127u] = e;
+            tail += (uint32_t)__popcll(mm);
+            base += 64;
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");  // the wave's own queue: its writes before its reads
+            __builtin_amdgcn_wave_barrier();
+        }
+        const uint32_t avail = tail - head;
+        if (avail >= 64 || (!more && avail > 0)) {
+            const uint32_t take = avail < 64 ? avail : 64;
+            if ((uint32_t)lane < take) {
+                const G1Xyzz v = load_xyzz(&chunk_partial[q[(head + lane) & 127u]]);
+                xyzz_acc28(acc, have, xyzz28_from(v), !v.is_inf());
+            }
+            head += take;
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        } else if (!more) {
+            break;
+        }
+    }
+    // the block's tree: slot p = 64 * (group in block) + lane
+    auto put = [&](int p, const G1Xyzz28 &v, bool hv) {
+#pragma unroll
+        for (int k = 0; k < 14; k++) {
+            slot[k][p] = v.x.l[k];
+            slot[14 + k][p] = v.y.l[k];
+            slot[28 + k][p] = v.zz.l[k];
+            slot[42 + k][p] = v.zzz.l[k];
+        }
+        slot_have[p] = hv ? 1u : 0u;
+    };
+    auto get = [&](int p, G1Xyzz28 &v) {
+#pragma unroll
+        for (int k = 0; k < 14; k++) {
+            v.x.l[k] = slot[k][p];
+            v.y.l[k] = slot[14 + k][p];
+            v.zz.l[k] = slot[28 + k][p];
+            v.zzz.l[k] = slot[42 + k][p];
+        }
+        return slot_have[p] != 0;
+    };
+    put(tid, acc, have);
+#pragma unroll 1
+    for (int stride = 32; stride >= 1; stride >>= 1) {
+        __syncthreads();
+        if (tid < BS_GROUPS * stride) {
+            const int p = 64 * (tid / stride) + (tid % stride);  // read by this lane alone at this level: no hazard on the write
+            G1Xyzz28 other;
+            have = get(p, acc);
+            const bool have_other = get(p + stride, other);
+            xyzz_acc28(acc, have, other, have_other);
+            if (stride > 1) put(p, acc, have);
+        }
+    }
+    if (tid < BS_GROUPS && blockIdx.x * BS_GROUPS + (uint32_t)tid < n_groups)
+        store_xyzz(&out[blockIdx.x * BS_GROUPS + tid], have ? xyzz28_store(acc) : G1Xyzz::inf());
+}
+
 template <int LPG>  // lanes per group: 64 (one group per wave) or 32 (two: half the tree work, twice the walk)
 __global__ void __launch_bounds__(64) msm_bit_sums_wave_kernel(const G1Xyzz *__restrict__ chunk_partial,
                                                                const uint32_t *__restrict__ chunk_off,
@@ -951,9 +1046,12 @@ void msm_enqueue(Context &cx, const G1Affine *d_points, const uint32_t *d_scalar
         job->h = (G1Xyzz *)cx.pin_named(pn, sizeof(G1Xyzz) * all_groups);
         cx.prof.begin("msm_bitsums", st, n);
         static const int lpg = getenv("MI_SNARK_BITSUM_LPG") ? atoi(getenv("MI_SNARK_BITSUM_LPG")) : 0;  // 0: queue-balanced (default)
-        if (lpg == 0)
+        if (lpg == 0)  // one wave per group, its own six tree levels
             hipLaunchKernelGGL(msm_bit_sums_queue_kernel, dim3((unsigned)all_groups), dim3(64), 0, st, chunk_partial, chunk_off,
                                chunk_bucket, pl.B, pl.c, job->h);
+        else if (lpg == 4)  // four groups per block, one tree through LDS: NOT the default, see the kernel's comment
+            hipLaunchKernelGGL(msm_bit_sums_block_kernel, dim3((unsigned)((all_groups + BS_GROUPS - 1) / BS_GROUPS)), dim3(64 * BS_GROUPS), 0,
+                               st, chunk_partial, chunk_off, chunk_bucket, pl.B, pl.c, (uint32_t)all_groups, job->h);
         else if (lpg == 32)
             hipLaunchKernelGGL(msm_bit_sums_wave_kernel<32>, dim3((unsigned)((all_groups + 1) / 2)), dim3(64), 0, st, chunk_partial,
                                chunk_off, chunk_bucket, pl.B, pl.c, (uint32_t)all_groups, job->h);

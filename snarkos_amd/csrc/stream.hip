@@ -3,9 +3,11 @@
 // What the reference does with rayon over transactions (reference cli/src/commands/start.rs:616-642 sizes the pools;
 // VM::check_transactions walks a block in chunks) becomes three stages here: the caller's thread enqueues batches
 // (mi_vs_accumulate_begin: derive + both MSMs on a free lane), `fold_threads` threads wait for accumulations and fold
-// them on the host (mi_vs_accumulate_end), one finisher exchanges partials (multi-GPU callback), starts the pairing
-// products (mi_vs_finalize_async, up to `products` in flight) and publishes verdicts in submission order.  The entry
-// points drop the library lock around their waits and folds, so the stages overlap.  Pure host code: no kernels here.
+// them on the host (mi_vs_accumulate_end), one finisher exchanges partials (multi-GPU callback) and starts the pairing
+// products (mi_vs_finalize_async, up to `products` in flight), one publisher waits for them and hands the verdicts out
+// in submission order.  Under load two consecutive batches share one lane pass (mi_vs_accumulate_begin_pair).  The
+// entry points drop the library lock around their waits and folds, so the stages overlap.  Pure host code: no kernels.
+#include <stdlib.h>
 #include <string.h>
 #include <condition_variable>
 #include <deque>
@@ -26,18 +28,28 @@ struct Stream {
 
     std::mutex mu;
     std::condition_variable cv;
-    std::deque<std::pair<uint64_t, uint64_t>> to_fold;  // (sequence number, accumulate handle), submission order
+    struct Pass { uint64_t seq, handle; bool pair; };    // a lane pass: batch seq (and seq + 1 when it carries a pair)
+    std::deque<Pass> to_fold;                           // submission order
     std::map<uint64_t, mi_vs_partial> folded;           // sequence number -> this rank's partial
     std::deque<int32_t> results;                        // 0 / 1 verdicts, or a negative status
     struct Sub { const void *proofs; size_t n; const void *rand; };
     std::deque<Sub> pending;                            // submitted batches whose verdict has not been taken, oldest first
     uint64_t submitted = 0, open = 0;                   // batches submitted; accumulations begun and not yet folded
+    // Under load two consecutive batches share one lane pass (mi_vs_accumulate_begin_pair): a batch submitted while
+    // `pair_at` or more passes are open is HELD until the next submission joins it -- or until a pass ends, the stream
+    // is finished or somebody blocks on a verdict, whichever comes first; then it runs alone.  0: never pair.
+    int pair_at = 4;
+    bool can_pair = true;                               // cleared when the library refuses a pair for this context's shape
+    bool have_held = false;
+    Sub held{nullptr, 0, nullptr};
+    void *held_stream = nullptr;
+    bool launching = false;                             // somebody is between taking the held batch and queueing its pass
     bool finished = false;                              // no more submissions
     bool finisher_done = false;
     int32_t error = MI_OK;                              // first failure inside the pipeline
 
     std::vector<std::thread> folders;
-    std::thread finisher;
+    std::thread finisher, publisher;
 
     void fail(int32_t st) {  // mu held
         if (error == MI_OK) error = st;
@@ -46,39 +58,138 @@ struct Stream {
 
     void folder_main() {
         for (;;) {
-            std::pair<uint64_t, uint64_t> item;
+            Pass item;
             {
                 std::unique_lock<std::mutex> lk(mu);
-                cv.wait(lk, [&] { return !to_fold.empty() || finished || error != MI_OK; });
+                cv.wait(lk, [&] { return !to_fold.empty() || (finished && !have_held && !launching) || error != MI_OK; });
                 if (to_fold.empty()) return;  // finished (or failed) and nothing left to fold
                 item = to_fold.front();
                 to_fold.pop_front();
             }
-            mi_vs_partial part;
-            const int32_t st = mi_vs_accumulate_end(ctx, item.second, &part);  // waits for the GPU, folds
-            std::lock_guard<std::mutex> lk(mu);
+            mi_vs_partial part[2];
+            const int32_t st = item.pair ? mi_vs_accumulate_end_pair(ctx, item.handle, part)  // waits for the GPU, folds
+                                         : mi_vs_accumulate_end(ctx, item.handle, &part[0]);
+            {
+                std::lock_guard<std::mutex> lk(mu);
+                open--;
+                if (st != MI_OK) fail(st);
+                else {
+                    folded[item.seq] = part[0];
+                    if (item.pair) folded[item.seq + 1] = part[1];
+                }
+                cv.notify_all();
+            }
+            flush_held(false);  // a pass has ended: a held batch does not wait for company any longer than that
+        }
+    }
+
+    // Launch one pass: batch a alone, or a and b together.  mu NOT held; the caller has reserved the lane (open++) and
+    // set `launching`.  Queues the pass for the folders.
+    int32_t launch(const Sub &a, void *st_a, const Sub *b) {
+        uint64_t h = 0;
+        int32_t st = MI_ERR_BAD_ARGS;
+        bool paired = false;
+        if (b) {
+            st = mi_vs_accumulate_begin_pair(ctx, a.proofs, a.n, a.rand, b->proofs, b->n, b->rand, st_a, &h);
+            paired = st == MI_OK;
+        }
+        if (!paired) st = mi_vs_accumulate_begin(ctx, a.proofs, a.n, a.rand, st_a, &h);
+        uint64_t h2 = 0;
+        int32_t st2 = MI_OK;
+        if (st == MI_OK && b && !paired) {  // the shape does not pair: the second batch takes its own pass
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                can_pair = false;
+                cv.wait(lk, [&] { return (int)open < lanes || error != MI_OK; });
+                if (error != MI_OK) st2 = error;
+                else open++;
+            }
+            if (st2 == MI_OK) {
+                st2 = mi_vs_accumulate_begin(ctx, b->proofs, b->n, b->rand, st_a, &h2);
+                if (st2 != MI_OK) {
+                    std::lock_guard<std::mutex> lk(mu);
+                    open--;
+                }
+            }
+        }
+        std::lock_guard<std::mutex> lk(mu);
+        launching = false;
+        if (st != MI_OK) {
             open--;
-            if (st != MI_OK) fail(st);
-            else folded[item.first] = part;
+            fail(st);
+            return st;
+        }
+        to_fold.push_back(Pass{submitted, h, paired});
+        submitted += paired ? 2 : 1;
+        pending.push_back(a);
+        if (b) {
+            pending.push_back(*b);
+            if (!paired) {
+                if (st2 != MI_OK) {
+                    fail(st2);
+                    return st2;
+                }
+                to_fold.push_back(Pass{submitted++, h2, false});
+            }
+        }
+        cv.notify_all();
+        return MI_OK;
+    }
+
+    // run the held batch alone (wait: block for a lane; otherwise only if one is free right now)
+    int32_t flush_held(bool wait) {
+        Sub a;
+        void *st_a;
+        {
+            std::unique_lock<std::mutex> lk(mu);
+            if (!have_held || launching || error != MI_OK) return MI_OK;
+            if ((int)open >= lanes) {
+                if (!wait) return MI_OK;  // every lane is busy: the next pass to end comes back here
+                cv.wait(lk, [&] { return (int)open < lanes || error != MI_OK || !have_held || launching; });
+                if (!have_held || launching || error != MI_OK) return MI_OK;
+            }
+            a = held;
+            st_a = held_stream;
+            have_held = false;
+            launching = true;
+            open++;
+        }
+        return launch(a, st_a, nullptr);
+    }
+
+    // The finisher starts pairing products as partials arrive; the PUBLISHER waits for them in order and hands the
+    // verdicts out.  (One thread doing both published a verdict only when it needed the product's slot back or the
+    // stream was finished: a caller trickling batches in would wait for ever.)
+    std::deque<uint64_t> tickets;  // products started, oldest first (mu)
+    int inflight = 0;              // started and not yet published (mu)
+    bool launches_done = false;    // the finisher has ended (mu)
+
+    void publisher_main() {
+        for (;;) {
+            uint64_t tk = 0;
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                cv.wait(lk, [&] { return !tickets.empty() || launches_done; });
+                if (tickets.empty()) {  // the finisher has ended and every product has been published
+                    finisher_done = true;
+                    cv.notify_all();
+                    return;
+                }
+                tk = tickets.front();
+                tickets.pop_front();
+            }
+            uint8_t ok = 0;
+            const int32_t st = mi_vs_finalize_wait(ctx, tk, &ok);
+            std::lock_guard<std::mutex> lk(mu);
+            results.push_back(st == MI_OK ? (int32_t)ok : st);
+            inflight--;
             cv.notify_all();
         }
     }
 
     void finisher_main() {
-        std::deque<uint64_t> tickets;
         std::vector<mi_vs_partial> mine(8), all(8 * 64), one(64);
         uint64_t seq = 0;
-        auto publish = [&](int32_t v) {
-            std::lock_guard<std::mutex> lk(mu);
-            results.push_back(v);
-            cv.notify_all();
-        };
-        auto wait_oldest = [&]() {
-            uint8_t ok = 0;
-            const int32_t st = mi_vs_finalize_wait(ctx, tickets.front(), &ok);
-            tickets.pop_front();
-            publish(st == MI_OK ? (int32_t)ok : st);
-        };
         bool failed = false;
         while (!failed) {
             // the next group: batches [seq, seq + count), count = group, or what is left of a finished stream
@@ -87,15 +198,17 @@ struct Stream {
                 std::unique_lock<std::mutex> lk(mu);
                 auto ready = [&]() -> bool {
                     if (error != MI_OK) return true;
-                    const uint64_t want = finished && submitted - seq < (uint64_t)group ? submitted - seq : (uint64_t)group;
-                    if (want == 0) return finished;
+                    const bool fin = finished && !have_held && !launching;  // every submitted batch has its pass
+                    const uint64_t want = fin && submitted - seq < (uint64_t)group ? submitted - seq : (uint64_t)group;
+                    if (want == 0) return fin;
                     for (uint64_t k = 0; k < want; k++)
                         if (!folded.count(seq + k)) return false;
-                    return finished || want == (uint64_t)group;
+                    return fin || want == (uint64_t)group;
                 };
                 cv.wait(lk, ready);
                 if (error != MI_OK) break;
-                count = (size_t)(finished && submitted - seq < (uint64_t)group ? submitted - seq : (uint64_t)group);
+                const bool fin = finished && !have_held && !launching;
+                count = (size_t)(fin && submitted - seq < (uint64_t)group ? submitted - seq : (uint64_t)group);
                 if (count == 0) break;  // finished and drained
                 for (size_t k = 0; k < count; k++) {
                     mine[k] = folded[seq + k];
@@ -117,25 +230,34 @@ struct Stream {
             }
             for (size_t k = 0; k < count && !failed; k++) {
                 for (size_t r = 0; r < world; r++) one[r] = src[r * count + k];
-                if ((int)tickets.size() >= products) wait_oldest();
+                {
+                    std::unique_lock<std::mutex> lk(mu);
+                    cv.wait(lk, [&] { return inflight < products; });
+                }
                 uint64_t tk = 0;
                 int32_t st = mi_vs_finalize_async(ctx, one.data(), world, &tk);
-                while (st == MI_ERR_AGAIN && !tickets.empty()) {  // fewer product slots than `products` (MI_SNARK_VS_SLOTS), or another stream holds them
-                    wait_oldest();
+                while (st == MI_ERR_AGAIN) {  // fewer product slots than `products` (MI_SNARK_VS_SLOTS), or another stream holds them
+                    {
+                        std::unique_lock<std::mutex> lk(mu);
+                        if (inflight == 0) break;  // none of ours to wait for: the failure stands
+                        const int before = inflight;
+                        cv.wait(lk, [&] { return inflight < before; });
+                    }
                     st = mi_vs_finalize_async(ctx, one.data(), world, &tk);
                 }
+                std::lock_guard<std::mutex> lk(mu);
                 if (st != MI_OK) {
-                    std::lock_guard<std::mutex> lk(mu);
                     fail(st);
                     failed = true;
                     break;
                 }
                 tickets.push_back(tk);
+                inflight++;
+                cv.notify_all();
             }
         }
-        while (!tickets.empty()) wait_oldest();  // products already in flight still get their verdicts
         std::lock_guard<std::mutex> lk(mu);
-        finisher_done = true;
+        launches_done = true;  // products already in flight still get their verdicts (publisher)
         cv.notify_all();
     }
 };
@@ -166,9 +288,12 @@ int32_t mi_vs_stream_open(uint64_t ctx, int32_t fold_threads, int32_t products, 
     s->group = exchange_group < 1 ? 1 : (exchange_group > 8 ? 8 : exchange_group);
     if (fold_threads < 1) fold_threads = 1;
     if (fold_threads > 8) fold_threads = 8;
+    if (const char *e = getenv("MI_SNARK_STREAM_PAIR_AT")) s->pair_at = atoi(e);  // 0: one batch per pass, always
+    if (exchange) s->pair_at = 0;  // multi-rank streams: every rank must take the same batches to the same collective
     Stream *raw = s.get();
     for (int i = 0; i < fold_threads; i++) s->folders.emplace_back([raw] { raw->folder_main(); });
     s->finisher = std::thread([raw] { raw->finisher_main(); });
+    s->publisher = std::thread([raw] { raw->publisher_main(); });
     std::lock_guard<std::mutex> lk(g_mu);
     const uint64_t id = g_next++;
     g_streams[id] = s;
@@ -179,34 +304,58 @@ int32_t mi_vs_stream_open(uint64_t ctx, int32_t fold_threads, int32_t products, 
 int32_t mi_vs_stream_submit(uint64_t stream, const void *d_proofs, size_t n, const void *d_randomizers128, void *hip_stream) {
     auto s = find(stream);
     if (!s || !d_proofs || !n || !d_randomizers128) return MI_ERR_BAD_ARGS;
+    const Stream::Sub mine{d_proofs, n, d_randomizers128};
+    bool join;
+    {
+        std::lock_guard<std::mutex> lk(s->mu);
+        if (s->finished) return MI_ERR_BAD_ARGS;
+        join = s->have_held && s->held_stream == hip_stream;
+    }
+    if (!join) {  // a pass is ordered behind ONE caller stream: a held batch whose inputs came on another stream runs alone
+        const int32_t st = s->flush_held(true);
+        if (st != MI_OK) return st;
+    }
+    Stream::Sub first = mine;
+    void *first_stream = hip_stream;
+    bool with_second = false;
     {
         std::unique_lock<std::mutex> lk(s->mu);
-        if (s->finished) return MI_ERR_BAD_ARGS;
-        s->cv.wait(lk, [&] { return (int)s->open < s->lanes || s->error != MI_OK; });
+        s->cv.wait(lk, [&] { return !s->launching || s->error != MI_OK; });  // a folder is launching the held batch
         if (s->error != MI_OK) return s->error;
+        if (s->have_held && s->held_stream == hip_stream) {  // the held batch gets its company
+            first = s->held;
+            first_stream = s->held_stream;
+            with_second = true;
+            s->have_held = false;
+        } else if (s->have_held) {
+            return MI_ERR_AGAIN;  // two submitting threads with different streams raced: the caller may simply retry
+        } else if (s->pair_at > 0 && s->can_pair && (int)s->open >= s->pair_at) {
+            s->held = mine;
+            s->held_stream = hip_stream;
+            s->have_held = true;
+            return MI_OK;  // runs with the next submission, or alone when a pass ends / the stream finishes / someone waits
+        }
+        s->launching = true;
+        s->cv.wait(lk, [&] { return (int)s->open < s->lanes || s->error != MI_OK; });
+        if (s->error != MI_OK) {
+            s->launching = false;
+            s->cv.notify_all();
+            return s->error;
+        }
         s->open++;  // reserved: a lane of ours is free
     }
-    uint64_t h = 0;
-    int32_t st = mi_vs_accumulate_begin(s->ctx, d_proofs, n, d_randomizers128, hip_stream, &h);
-    std::lock_guard<std::mutex> lk(s->mu);
-    if (st != MI_OK) {
-        s->open--;
-        s->fail(st);
-        return st;
-    }
-    s->to_fold.emplace_back(s->submitted++, h);
-    s->pending.push_back(Stream::Sub{d_proofs, n, d_randomizers128});
-    s->cv.notify_all();
-    return MI_OK;
+    return s->launch(first, first_stream, with_second ? &mine : nullptr);
 }
 
 int32_t mi_vs_stream_finish(uint64_t stream) {
     auto s = find(stream);
     if (!s) return MI_ERR_BAD_ARGS;
-    std::lock_guard<std::mutex> lk(s->mu);
-    s->finished = true;
-    s->cv.notify_all();
-    return MI_OK;
+    {
+        std::lock_guard<std::mutex> lk(s->mu);
+        s->finished = true;
+        s->cv.notify_all();
+    }
+    return s->flush_held(true);
 }
 
 int32_t mi_vs_stream_next_verdicts(uint64_t stream, int32_t block, uint8_t *all_ok, uint8_t *verdicts, size_t capacity,
@@ -214,6 +363,10 @@ int32_t mi_vs_stream_next_verdicts(uint64_t stream, int32_t block, uint8_t *all_
     auto s = find(stream);
     if (!s || !all_ok) return MI_ERR_BAD_ARGS;
     Stream::Sub sub{nullptr, 0, nullptr};
+    if (block) {
+        const int32_t st = s->flush_held(true);  // a caller who waits for verdicts is not going to bring the held batch company
+        if (st != MI_OK) return st;
+    }
     {
         std::unique_lock<std::mutex> lk(s->mu);
         for (;;) {
@@ -262,8 +415,10 @@ int32_t mi_vs_stream_close(uint64_t stream) {
         s->finished = true;
         s->cv.notify_all();
     }
+    (void)s->flush_held(true);
     for (auto &t : s->folders) t.join();
     s->finisher.join();
+    s->publisher.join();
     return MI_OK;
 }
 

@@ -152,6 +152,14 @@ struct VsOut {
     uint8_t *alg_ok;
     uint32_t *circuit_of;
 };
+// A lane pass over TWO batches (mi_vs_accumulate_begin_pair): the blocks from first_block on serve the second one
+struct VsSecond {
+    const void *proofs = nullptr;  // null: single batch
+    const uint8_t *rand = nullptr;
+    size_t n = 0;
+    uint32_t first_block = 0;
+    VsOut o;
+};
 #define VS_SLOTS MI_VS_MAX_TICKETS
 #define VS_ACC_DEPTH MI_VS_MAX_OPEN_ACCUMULATIONS  // accumulations (derive + both MSMs) that may be enqueued before the oldest is folded
 struct VsSlot {  // one in-flight pairing product (pipelined finalize)
@@ -194,9 +202,9 @@ struct VsKeyTable {
 struct VsAcc {  // an accumulation whose kernels are enqueued but whose host fold is still to come
     bool open = false;
     uint64_t handle = 0, ctx = 0;
-    size_t n = 0;
+    size_t n = 0, n_b = 0;  // n_b: the second batch of a pair pass (0: single)
     hipStream_t st = nullptr;
-    MsmJob j[4];         // H side, tau-H side, class 0, class 1
+    MsmJob j[4];         // H side, tau-H side, class 0, class 1 (pair pass: j[0] carries both batches' two MSMs)
     size_t nb[MI_VS_MAX_BOUNDS] = {0, 0};
     bool fused = false;  // j[0] carries all MSMs
     bool closing = false;
@@ -460,10 +468,19 @@ template <int FS>
 __global__ void __launch_bounds__(128) vs_derive_kernel(const void *__restrict__ proofs, size_t n,
                                                         const uint8_t *__restrict__ rand128,
                                                         const mi_vs_circuit_vk *__restrict__ circuits, size_t n_circuits,
-                                                        const VsConsts *__restrict__ kc, VsOut o, const uint32_t *__restrict__ chal) {
+                                                        const VsConsts *__restrict__ kc, VsOut o, const uint32_t *__restrict__ chal,
+                                                        VsSecond second) {
     __shared__ uint32_t zb_lds[64][4];
     const int lane = threadIdx.x & 63, role = threadIdx.x >> 6;  // role 0: transcript + scalars, role 1: points + check
-    const size_t i = (size_t)blockIdx.x * 64 + lane;
+    uint32_t block = blockIdx.x;
+    if (second.proofs && block >= second.first_block) {  // block-uniform: this block belongs to the pass's second batch
+        block -= second.first_block;
+        proofs = second.proofs;
+        n = second.n;
+        rand128 = second.rand;
+        o = second.o;
+    }
+    const size_t i = (size_t)block * 64 + lane;
     const bool live = i < n;
     const uint32_t PW = kc->proof_words, PP = kc->per_proof, RB = kc->rand_bytes, NB = kc->n_bounds;
     const bool v2 = PW != sizeof(mi_vs_proof) / 4;
@@ -824,8 +841,17 @@ __global__ void __launch_bounds__(256) vs_merge_kernel(const Fr *__restrict__ vk
                                                        const Fr *__restrict__ h_scal, const uint32_t *__restrict__ circuit_of, size_t n,
                                                        const mi_vs_circuit_vk *__restrict__ circuits, size_t n_circuits,
                                                        const VsConsts *__restrict__ kc, G1Affine *__restrict__ pts1,
-                                                       uint32_t *__restrict__ sc1) {
+                                                       uint32_t *__restrict__ sc1, VsSecond second) {
     __shared__ uint32_t lds[8 * 256];
+    if (blockIdx.y) {  // the pass's second batch
+        vk_scal = second.o.vk_scal;
+        g_scal = second.o.g_scal;
+        h_scal = second.o.h_scal;
+        circuit_of = second.o.circuit_of;
+        n = second.n;
+        pts1 = second.o.pts1;
+        sc1 = second.o.sc1;
+    }
     const size_t slot = blockIdx.x, n_vk_slots = n_circuits * MI_VS_VK_COMMS;
     const int t = threadIdx.x;
     Fr acc = Fr::zero();
@@ -1099,14 +1125,34 @@ struct VsWork {
     size_t n1, n2, nb[MI_VS_MAX_BOUNDS];  // points of the H side, the tau-H side, the class accumulators
 };
 
-static VsWork vs_run_derive(Context &cx, VsKeys &v, const void *d_proofs, size_t n, const void *d_rand, hipStream_t st,
-                            int lane) {
-    VsWork w;
+static void vs_work_sizes(const VsKeys &v, size_t n, VsWork &w) {
     const VsConsts &hc = v.shape;  // host copy of the device constants
     w.n1 = n * hc.per_proof + v.n_circuits * MI_VS_VK_COMMS + 1 + hc.hiding;
     w.n2 = n * 2;
     for (int c = 0; c < MI_VS_MAX_BOUNDS; c++) w.nb[c] = c < (int)hc.n_bounds ? n * hc.class_count[c] : 0;
-    const size_t total = w.n1 + w.n2 + w.nb[0] + w.nb[1];
+}
+static size_t vs_work_total(const VsWork &w) { return w.n1 + w.n2 + w.nb[0] + w.nb[1]; }
+// May two batches of these sizes share one lane pass?  One launch sequence carries at most four MSM problems (two per
+// batch: no degree-bound classes), the small-MSM path must hold both, and the Poseidon transcript kernel is per batch.
+static bool vs_pair_ok(const VsKeys &v, size_t n_a, size_t n_b) {
+    if (v.fs_poseidon || v.shape.n_bounds) return false;
+    VsWork a, b;
+    vs_work_sizes(v, n_a, a);
+    vs_work_sizes(v, n_b, b);
+    return vs_work_total(a) + vs_work_total(b) <= msm_small_limit();
+}
+
+// derive (+ merge) of one batch, or of two in one launch each (second: d_proofs_b, n_b, d_rand_b -> *w_b): the second
+// batch's operands follow the first's in the lane's operand arrays, so both batches' MSMs are one launch sequence
+static VsWork vs_run_derive(Context &cx, VsKeys &v, const void *d_proofs, size_t n, const void *d_rand, hipStream_t st,
+                            int lane, const void *d_proofs_b = nullptr, size_t n_b = 0, const void *d_rand_b = nullptr,
+                            VsWork *w_b = nullptr) {
+    VsWork w, wb;
+    const VsConsts &hc = v.shape;
+    const bool pair = d_proofs_b != nullptr;
+    vs_work_sizes(v, n, w);
+    vs_work_sizes(v, pair ? n_b : n, wb);
+    const size_t total = vs_work_total(w), total_b = vs_work_total(wb);
     // every operand array exists once per lane: several batches are in flight on different streams
     char nm[32];
     auto W = [&](const char *name) {
@@ -1114,21 +1160,49 @@ static VsWork vs_run_derive(Context &cx, VsKeys &v, const void *d_proofs, size_t
         return nm;
     };
     // one array for all MSMs' operands (H side, tau-H side, then the class accumulators): they run as ONE launch
-    // sequence when they fit the small-MSM path
+    // sequence when they fit the small-MSM path.  Always with room for a second batch (of the same size when there is
+    // none): a pair pass must not regrow the workspaces of a lane that single batches primed.
+    G1Affine *pts = (G1Affine *)cx.buf(W("pts"), sizeof(G1Affine) * (total + total_b));
+    uint32_t *sc = (uint32_t *)cx.buf(W("sc"), 32 * (total + total_b));
+    auto place = [&](VsWork &x, G1Affine *p0, uint32_t *s0) {
+        VsOut &o = x.o;
+        o.pts1 = p0;
+        o.sc1 = s0;
+        o.pts2 = o.pts1 + x.n1;
+        o.sc2 = o.sc1 + 8 * x.n1;
+        o.ptsb[0] = o.pts2 + x.n2;
+        o.scb[0] = o.sc2 + 8 * x.n2;
+        o.ptsb[1] = o.ptsb[0] + x.nb[0];
+        o.scb[1] = o.scb[0] + 8 * x.nb[0];
+    };
+    place(w, pts, sc);
+    place(wb, pts + total, sc + 8 * total);
+    const size_t cap = n > n_b ? n : n_b;  // the per-proof arrays of both halves share a size: no regrowth either way
+    auto per_proof = [&](VsWork &x, const char *suffix) {
+        VsOut &o = x.o;
+        char nn[24];
+        snprintf(nn, sizeof nn, "vk_scal%s", suffix);
+        o.vk_scal = (Fr *)cx.buf(W(nn), sizeof(Fr) * cap * MI_VS_VK_COMMS);
+        snprintf(nn, sizeof nn, "g_scal%s", suffix);
+        o.g_scal = (Fr *)cx.buf(W(nn), sizeof(Fr) * 2 * cap);
+        o.h_scal = o.g_scal + cap;
+        snprintf(nn, sizeof nn, "alg_ok%s", suffix);
+        o.alg_ok = (uint8_t *)cx.buf(W(nn), cap);
+        snprintf(nn, sizeof nn, "circuit_of%s", suffix);
+        o.circuit_of = (uint32_t *)cx.buf(W(nn), 4 * cap);
+    };
+    per_proof(w, "");
+    per_proof(wb, ".b");
     VsOut &o = w.o;
-    o.pts1 = (G1Affine *)cx.buf(W("pts"), sizeof(G1Affine) * total);
-    o.sc1 = (uint32_t *)cx.buf(W("sc"), 32 * total);
-    o.pts2 = o.pts1 + w.n1;
-    o.sc2 = o.sc1 + 8 * w.n1;
-    o.ptsb[0] = o.pts2 + w.n2;
-    o.scb[0] = o.sc2 + 8 * w.n2;
-    o.ptsb[1] = o.ptsb[0] + w.nb[0];
-    o.scb[1] = o.scb[0] + 8 * w.nb[0];
-    o.vk_scal = (Fr *)cx.buf(W("vk_scal"), sizeof(Fr) * n * MI_VS_VK_COMMS);
-    o.g_scal = (Fr *)cx.buf(W("g_scal"), sizeof(Fr) * 2 * n);
-    o.h_scal = o.g_scal + n;
-    o.alg_ok = (uint8_t *)cx.buf(W("alg_ok"), n);
-    o.circuit_of = (uint32_t *)cx.buf(W("circuit_of"), 4 * n);
+    VsSecond second;
+    if (pair) {
+        second.proofs = d_proofs_b;
+        second.rand = (const uint8_t *)d_rand_b;
+        second.n = n_b;
+        second.first_block = (uint32_t)cdiv(n, 64);
+        second.o = wb.o;
+    }
+    const unsigned derive_blocks = (unsigned)(cdiv(n, 64) + (pair ? cdiv(n_b, 64) : 0));
     const uint32_t *chal = nullptr;
     if (v.fs_poseidon) {
         uint32_t *ch = (uint32_t *)cx.buf(W("chal"), 48 * n);
@@ -1144,18 +1218,19 @@ static VsWork vs_run_derive(Context &cx, VsKeys &v, const void *d_proofs, size_t
         cx.prof.end("vs_fs_poseidon", st);
         chal = ch;
     }
-    cx.prof.begin("vs_derive", st, n);
+    cx.prof.begin("vs_derive", st, n + (pair ? n_b : 0));
     if (v.fs_poseidon)
-        hipLaunchKernelGGL(vs_derive_kernel<1>, dim3(cdiv(n, 64)), dim3(128), 0, st, d_proofs, n, (const uint8_t *)d_rand,
-                           (const mi_vs_circuit_vk *)v.circuits.p, v.n_circuits, (const VsConsts *)v.consts.p, o, chal);
+        hipLaunchKernelGGL(vs_derive_kernel<1>, dim3(derive_blocks), dim3(128), 0, st, d_proofs, n, (const uint8_t *)d_rand,
+                           (const mi_vs_circuit_vk *)v.circuits.p, v.n_circuits, (const VsConsts *)v.consts.p, o, chal, second);
     else
-        hipLaunchKernelGGL(vs_derive_kernel<0>, dim3(cdiv(n, 64)), dim3(128), 0, st, d_proofs, n, (const uint8_t *)d_rand,
-                           (const mi_vs_circuit_vk *)v.circuits.p, v.n_circuits, (const VsConsts *)v.consts.p, o, chal);
+        hipLaunchKernelGGL(vs_derive_kernel<0>, dim3(derive_blocks), dim3(128), 0, st, d_proofs, n, (const uint8_t *)d_rand,
+                           (const mi_vs_circuit_vk *)v.circuits.p, v.n_circuits, (const VsConsts *)v.consts.p, o, chal, second);
     cx.prof.end("vs_derive", st);
-    hipLaunchKernelGGL(vs_merge_kernel, dim3((unsigned)(v.n_circuits * MI_VS_VK_COMMS + 1 + hc.hiding)), dim3(256), 0, st, o.vk_scal,
-                       o.g_scal, o.h_scal, o.circuit_of, n, (const mi_vs_circuit_vk *)v.circuits.p, v.n_circuits,
-                       (const VsConsts *)v.consts.p, o.pts1, o.sc1);
+    hipLaunchKernelGGL(vs_merge_kernel, dim3((unsigned)(v.n_circuits * MI_VS_VK_COMMS + 1 + hc.hiding), pair ? 2 : 1), dim3(256), 0, st,
+                       o.vk_scal, o.g_scal, o.h_scal, o.circuit_of, n, (const mi_vs_circuit_vk *)v.circuits.p, v.n_circuits,
+                       (const VsConsts *)v.consts.p, o.pts1, o.sc1, second);
     MI_HIP(hipGetLastError());
+    if (w_b) *w_b = wb;
     return w;
 }
 
@@ -1194,6 +1269,13 @@ static bool vs_enqueue_msms(Context &cx, const VsWork &w, hipStream_t st, int la
     return false;
 }
 
+// both batches of a pair pass: (H side, tau-H side) of the first, then of the second -- four problems of one launch sequence
+static void vs_enqueue_msms_pair(Context &cx, const VsWork &a, const VsWork &b, hipStream_t st, int lane, MsmJob j[4], int force_c) {
+    const size_t ta = vs_work_total(a), tb = vs_work_total(b);
+    if (a.o.pts1 + ta != b.o.pts1 || a.nb[0] || a.nb[1] || b.nb[0] || b.nb[1]) throw HipError{hipErrorInvalidValue, "pair pass layout", __LINE__};
+    msm_enqueue(cx, a.o.pts1, a.o.sc1, ta + tb, st, 254, 8 + 4 * lane, &j[0], force_c, lane, MsmSplits(a.n1, ta, ta + b.n1));
+}
+
 // accumulate one shard: partial sums + algebraic failures (+ optional per-proof alg flags to host)
 // accumulate = begin (enqueue derive + both MSMs, no host synchronisation) + end (wait, fold on the host).
 // VS_ACC_DEPTH begin/end pairs may be open at once per device: every lane has its own stream, device workspaces and
@@ -1201,10 +1283,14 @@ static bool vs_enqueue_msms(Context &cx, const VsWork &w, hipStream_t st, int la
 // WAITS for one (the device lock is released meanwhile): a synchronous verify beside a saturated stream is late, not
 // refused.
 // msm = false: derive only (the caller wants the lane's workspaces for the per-proof fallback, not the aggregate)
+// d_proofs_b: a second batch for the same pass (vs_pair_ok shapes only): its own operands, accumulators and partial
 static int32_t vs_accumulate_begin_impl(Context &cx, const VsCtx &vc, const void *d_proofs, size_t n, const void *d_rand,
-                                        hipStream_t st, uint64_t *handle, VsWork *work_out, bool msm = true) {
+                                        hipStream_t st, uint64_t *handle, VsWork *work_out, bool msm = true,
+                                        const void *d_proofs_b = nullptr, size_t n_b = 0, const void *d_rand_b = nullptr) {
     VsKeys &v = vs_keys(cx, vc);
     VsPipe &pp = vs_pipe(cx);
+    const bool pair = d_proofs_b != nullptr;
+    if (pair && (!msm || !vs_pair_ok(v, n, n_b))) return MI_ERR_BAD_ARGS;
     int par = -1;
     for (;;) {
         for (int p = 0; p < pp.lanes; p++)
@@ -1223,19 +1309,25 @@ static int32_t vs_accumulate_begin_impl(Context &cx, const VsCtx &vc, const void
         pp.primed = true;
         HostSpan hs("begin.prime");
         for (int p = 0; p < pp.lanes; p++) {
-            if (p == par || pp.acc[p].open) continue;
+            if (pp.acc[p].open) continue;  // the lane this call takes is primed too: its real pass follows on the same stream
             hipStream_t sp = pp.acc_st[p];
             MI_HIP(hipEventRecord(pp.acc_ev[p], st));
             MI_HIP(hipStreamWaitEvent(sp, pp.acc_ev[p], 0));
-            VsWork w = vs_run_derive(cx, v, d_proofs, n, d_rand, sp, p);
+            // a shape that may run pair passes is primed with one (the batch twice): the larger workspaces exist
+            // before a stream under load starts pairing
+            const bool pp_pair = vs_pair_ok(v, n, n);
+            VsWork w2;
+            VsWork w = pp_pair ? vs_run_derive(cx, v, d_proofs, n, d_rand, sp, p, d_proofs, n, d_rand, &w2)
+                               : vs_run_derive(cx, v, d_proofs, n, d_rand, sp, p);
             char nm[32];
             snprintf(nm, sizeof nm, "vs.alg_pin%d", p);
-            (void)cx.pin_named(nm, n);
+            (void)cx.pin_named(nm, 2 * n);
             MsmJob jj[4];
-            (void)vs_enqueue_msms(cx, w, sp, p, jj, 0);
+            if (pp_pair) vs_enqueue_msms_pair(cx, w, w2, sp, p, jj, 0);
+            else (void)vs_enqueue_msms(cx, w, sp, p, jj, 0);
         }
         for (int p = 0; p < pp.lanes; p++)
-            if (p != par && !pp.acc[p].open) MI_HIP(hipStreamSynchronize(pp.acc_st[p]));
+            if (!pp.acc[p].open) MI_HIP(hipStreamSynchronize(pp.acc_st[p]));
     }
     const uint64_t hd = vs_make_id(pp.next_acc++, cx.index, par);
     VsAcc &a = pp.acc[par];
@@ -1247,26 +1339,34 @@ static int32_t vs_accumulate_begin_impl(Context &cx, const VsCtx &vc, const void
         MI_HIP(hipEventRecord(pp.acc_ev[par], st));
         MI_HIP(hipStreamWaitEvent(sa, pp.acc_ev[par], 0));
     }
-    VsWork w;
+    VsWork w, w2;
     {
         HostSpan hs("begin.derive");
-        w = vs_run_derive(cx, v, d_proofs, n, d_rand, sa, par);
+        w = pair ? vs_run_derive(cx, v, d_proofs, n, d_rand, sa, par, d_proofs_b, n_b, d_rand_b, &w2)
+                 : vs_run_derive(cx, v, d_proofs, n, d_rand, sa, par);
     }
     char nm[32];
     snprintf(nm, sizeof nm, "vs.alg_pin%d", par);
-    a.h_alg = (uint8_t *)cx.pin_named(nm, n);
+    a.h_alg = (uint8_t *)cx.pin_named(nm, 2 * (n > n_b ? n : n_b));  // both halves of a pair pass; the same size for a single batch
     if (msm) {
         {
             HostSpan hs("begin.alg_copy");
             MI_HIP(hipMemcpyAsync(a.h_alg, w.o.alg_ok, n, hipMemcpyDeviceToHost, sa));  // ahead of the MSMs: their done-event covers it
+            if (pair) MI_HIP(hipMemcpyAsync(a.h_alg + n, w2.o.alg_ok, n_b, hipMemcpyDeviceToHost, sa));
         }
         HostSpan hs_msm("begin.msm_enqueue");
         static const int vs_c = getenv("MI_SNARK_VS_C") ? atoi(getenv("MI_SNARK_VS_C")) : 0;  // window width override (experiments)
-        a.fused = vs_enqueue_msms(cx, w, sa, par, a.j, vs_c);
+        if (pair) {
+            vs_enqueue_msms_pair(cx, w, w2, sa, par, a.j, vs_c);
+            a.fused = true;
+        } else {
+            a.fused = vs_enqueue_msms(cx, w, sa, par, a.j, vs_c);
+        }
     }
     a.nb[0] = w.nb[0];
     a.nb[1] = w.nb[1];
     a.n = n;
+    a.n_b = pair ? n_b : 0;
     a.st = sa;
     a.handle = hd;
     a.ctx = vc.id;
@@ -1276,20 +1376,28 @@ static int32_t vs_accumulate_begin_impl(Context &cx, const VsCtx &vc, const void
     return MI_OK;
 }
 // keep_lane: the caller goes on using the lane's workspaces (per-proof fallback) and releases it itself
-static int32_t vs_accumulate_end_impl(Context &cx, uint64_t handle, mi_vs_partial *out, bool keep_lane = false) {
+// out_b: the second batch's partial (a pair pass has to be ended with one, a single pass without)
+static int32_t vs_accumulate_end_impl(Context &cx, uint64_t handle, mi_vs_partial *out, bool keep_lane = false,
+                                      mi_vs_partial *out_b = nullptr) {
     if ((handle & 0xff) >= VS_ACC_DEPTH || (int)((handle >> 8) & 0xff) != cx.index) return MI_ERR_BAD_ARGS;
     VsAcc &a = vs_pipe(cx).acc[handle & 0xff];
     if (!a.open || a.handle != handle || a.closing) return MI_ERR_BAD_ARGS;
+    if ((a.n_b != 0) != (out_b != nullptr)) return MI_ERR_BAD_ARGS;
     a.closing = true;  // the lane stays taken until the fold is done; the device lock is not held meanwhile
     // host folds (~250 doublings + ~250 additions for 254-bit scalars, half that for the randomizer side), each
     // split over two pool threads
-    uint64_t fails = 0;
+    uint64_t fails = 0, fails_b = 0;
     try {
         Unlocked unlocked;
         const G1Jac inf = G1Jac{Fq::one(), Fq::one(), Fq::zero()};
         memcpy(&out->bound[0], &inf, sizeof inf);
         memcpy(&out->bound[1], &inf, sizeof inf);
-        if (a.fused) {
+        if (out_b) {
+            memcpy(&out_b->bound[0], &inf, sizeof inf);
+            memcpy(&out_b->bound[1], &inf, sizeof inf);
+            msm_finish(cx, &a.j[0], a.st, &out->total_c, &out->total_w, &out_b->total_c, &out_b->total_w);
+            for (size_t i = 0; i < a.n_b; i++) fails_b += a.h_alg[a.n + i] ? 0 : 1;
+        } else if (a.fused) {
             msm_finish(cx, &a.j[0], a.st, &out->total_c, &out->total_w, a.nb[0] ? &out->bound[0] : nullptr,
                        a.nb[1] ? &out->bound[a.nb[0] ? 1 : 0] : nullptr);
             if (a.nb[1] && !a.nb[0]) {  // only class 1 in use: it was the third problem
@@ -1309,6 +1417,10 @@ static int32_t vs_accumulate_end_impl(Context &cx, uint64_t handle, mi_vs_partia
     }
     out->n_proofs = a.n;
     out->n_alg_fail = fails;
+    if (out_b) {
+        out_b->n_proofs = a.n_b;
+        out_b->n_alg_fail = fails_b;
+    }
     if (keep_lane) a.closing = false;  // still open: nobody else can take it
     else vs_release_lane(cx, a);
     return MI_OK;
@@ -1322,6 +1434,16 @@ int32_t vs_accumulate_begin(Context &cx, uint64_t id, const void *d_proofs, size
 int32_t vs_accumulate_end(Context &cx, uint64_t id, uint64_t handle, mi_vs_partial *out) {
     if (!vs_find(id)) return MI_ERR_BAD_ARGS;
     return vs_accumulate_end_impl(cx, handle, out);
+}
+int32_t vs_accumulate_begin_pair(Context &cx, uint64_t id, const void *d_proofs_a, size_t n_a, const void *d_rand_a,
+                                 const void *d_proofs_b, size_t n_b, const void *d_rand_b, hipStream_t st, uint64_t *handle) {
+    std::shared_ptr<VsCtx> v = vs_find(id);
+    if (!v) return MI_ERR_BAD_ARGS;
+    return vs_accumulate_begin_impl(cx, *v, d_proofs_a, n_a, d_rand_a, st, handle, nullptr, true, d_proofs_b, n_b, d_rand_b);
+}
+int32_t vs_accumulate_end_pair(Context &cx, uint64_t id, uint64_t handle, mi_vs_partial *out2) {
+    if (!vs_find(id)) return MI_ERR_BAD_ARGS;
+    return vs_accumulate_end_impl(cx, handle, &out2[0], false, &out2[1]);
 }
 int32_t vs_accumulate_device(Context &cx, uint64_t id, const void *d_proofs, size_t n, const void *d_rand,
                              mi_vs_partial *out, hipStream_t st) {

@@ -463,3 +463,98 @@ def test_reject_path_group_testing(orc, mi, n_bad):
             assert ok == bool(want[:cut].all()) and (verdicts == want[:cut]).all(), cut
     finally:
         v.close()
+
+
+def test_pair_pass_partials_bit_exact(orc, mi):
+    """mi_vs_accumulate_begin_pair / _end_pair: two batches in one lane pass (one derive, one merge, one four-problem
+    MSM launch sequence) give byte for byte the partials of two single passes and of the oracle -- equal and unequal
+    sizes, a batch with an invalid proof, the same tensor twice; shapes that do not pair are refused"""
+    import torch
+    from snarkos_amd.lib import MiError
+    a = orc.VSBatch(0x9A11, 48, 3, 0)
+    v = _ctx(mi, a)
+    try:
+        pa, ra = torch.from_numpy(a.proofs).cuda(), torch.from_numpy(a.randomizers).cuda()
+        # a second batch under the SAME verifying key: a slice of a's proofs with other randomizers, one of them broken
+        nb = 31
+        pb_np = a.proofs[: nb * 2256].copy()
+        pb_np[5 * 2256 + 16 + 512 + 864 + 32 * 9] ^= 1
+        rb_np = a.randomizers[::-1].copy()[: nb * 32]
+        pb, rb = torch.from_numpy(pb_np).cuda(), torch.from_numpy(np.ascontiguousarray(rb_np)).cuda()
+        single_a, single_b = v.accumulate(pa, ra), v.accumulate(pb, rb)
+        assert (single_a == orc.vs_partial_from_oracle(a)).all()
+        assert (single_b == orc.vs_partial_from_oracle(orc.VSArrays(a.vk, a.circuits, pb_np, np.ascontiguousarray(rb_np)))).all()
+        for (p1, r1, w1), (p2, r2, w2) in (((pa, ra, single_a), (pb, rb, single_b)), ((pb, rb, single_b), (pa, ra, single_a)),
+                                           ((pa, ra, single_a), (pa, ra, single_a))):
+            parts = v.accumulate_end_pair(v.accumulate_begin_pair(p1, r1, p2, r2))
+            assert (parts[0] == w1).all() and (parts[1] == w2).all()
+        assert v.finalize([single_a]) and not v.finalize([single_b])
+        # a pair handle cannot be ended as a single pass, nor the other way round; both stay usable
+        h = v.accumulate_begin_pair(pa, ra, pb, rb)
+        with pytest.raises(MiError):
+            v.accumulate_end(h)
+        parts = v.accumulate_end_pair(h)
+        assert (parts[0] == single_a).all() and (parts[1] == single_b).all()
+        h = v.accumulate_begin(pa, ra)
+        with pytest.raises(MiError):
+            v.accumulate_end_pair(h)
+        assert (v.accumulate_end(h) == single_a).all()
+    finally:
+        v.close()
+    # the Poseidon transcript does not pair
+    vp = mi.VarunaShaped(a.vk, a.circuits, transcript="poseidon")
+    try:
+        with pytest.raises(MiError):
+            vp.accumulate_begin_pair(pa, ra, pa, ra)
+    finally:
+        vp.close()
+
+
+def test_stream_pairs_batches_under_load(orc, mi, monkeypatch):
+    """the native stream driver with pairing from the first open pass on (MI_SNARK_STREAM_PAIR_AT=1): verdicts come back
+    in submission order, a failing batch inside a pair fails alone and is taken apart correctly, odd tails and
+    blocking polls flush the held batch; pairing switched off gives the same answers"""
+    import ctypes as C
+    import torch
+    from snarkos_amd import lib as L
+    good = orc.VSBatch(0x57EF, 40, 3, 0)
+    v = _ctx(mi, good)
+    try:
+        gp, gr = torch.from_numpy(good.proofs).cuda(), torch.from_numpy(good.randomizers).cuda()
+        bad_np = good.proofs.copy(); bad_np[11 * 2256 + 16 + 512 + 864 + 32 * 9] ^= 1
+        bp = torch.from_numpy(bad_np).cuda()
+        seq = [(gp, gr), (gp, gr), (bp, gr), (gp, gr), (gp, gr), (bp, gr), (bp, gr), (gp, gr), (gp, gr), (gp, gr), (bp, gr)]
+        want = [p is not bp for p, _ in seq]
+        w11 = np.ones(40, dtype=np.uint8); w11[11] = 0
+        for pair_at in ("1", "0", "3"):
+            monkeypatch.setenv("MI_SNARK_STREAM_PAIR_AT", pair_at)
+            assert list(v.verify_stream(iter(seq))) == want
+            assert list(v.verify_stream(iter(seq[:4]))) == want[:4]
+            got = list(v.verify_stream(iter(seq), verdicts=True))
+            assert [g[0] for g in got] == want
+            for (ok, vec), exp in zip(got, want):
+                assert (vec is None) if exp else (vec == w11).all()
+        # a held batch does not wait for company for ever: submit three (the third is held behind two open passes),
+        # then only poll without blocking -- the pass that ends releases it
+        monkeypatch.setenv("MI_SNARK_STREAM_PAIR_AT", "1")
+        lib = L.lib()
+        sid, ok = C.c_uint64(0), C.c_uint8(0)
+        L.check(lib.mi_vs_stream_open(C.c_uint64(v.ctx), 2, 4, 6, C.cast(None, L.VS_EXCHANGE_FN), None, 1, C.byref(sid)), "open")
+        try:
+            for _ in range(2):
+                assert lib.mi_vs_stream_submit(sid, L.dptr(gp), C.c_size_t(40), L.dptr(gr), L.stream_ptr(None)) == L.MI_OK
+            import time
+            seen, t0 = 0, time.time()
+            while seen < 2 and time.time() - t0 < 20:
+                st = lib.mi_vs_stream_next(sid, 0, C.byref(ok))
+                if st == L.MI_OK:
+                    assert ok.value == 1
+                    seen += 1
+                else:
+                    assert st == L.MI_ERR_AGAIN
+                    time.sleep(0.001)
+            assert seen == 2
+        finally:
+            assert lib.mi_vs_stream_close(sid) == L.MI_OK
+    finally:
+        v.close()

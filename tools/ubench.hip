@@ -101,6 +101,44 @@ __global__ void __launch_bounds__(256) fmul28_kernel(Fq *out, int iters) {
     out[i] = store28(sub28(a, b));
 }
 
+// the same loop with only the first `active` lanes of every wave enabled: does a partly masked wave issue faster?
+__global__ void __launch_bounds__(256) fmul28_masked_kernel(Fq *out, int iters, int active) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    Fq a0 = Fq::one(), b0 = Fq::r2();
+    a0.l[0] += (uint32_t)i;
+    Fq28 a = load28(a0), b = load28(b0);
+    if ((int)(threadIdx.x & 63) < active)
+        for (int k = 0; k < iters; k++) { a = mul28(a, b); b = mul28(b, a); }
+    out[i] = store28(sub28(a, b));
+}
+
+// arbitrary lane mask
+__global__ void __launch_bounds__(256) fmul28_lanemask_kernel(Fq *out, int iters, unsigned long long mask) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    Fq a0 = Fq::one(), b0 = Fq::r2();
+    a0.l[0] += (uint32_t)i;
+    Fq28 a = load28(a0), b = load28(b0);
+    if ((mask >> (threadIdx.x & 63)) & 1ull)
+        for (int k = 0; k < iters; k++) { a = mul28(a, b); b = mul28(b, a); }
+    out[i] = store28(sub28(a, b));
+}
+
+// mixed launch: even blocks run with all lanes, odd blocks with `active` lanes; per-block duration in ticks of the
+// constant 100 MHz counter -- separates an issue-rate effect of the mask from a clock (power-state) effect
+__global__ void __launch_bounds__(256) fmul28_mixed_kernel(Fq *out, int iters, int active, unsigned long long *ticks) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    Fq a0 = Fq::one(), b0 = Fq::r2();
+    a0.l[0] += (uint32_t)i;
+    Fq28 a = load28(a0), b = load28(b0);
+    const int lanes = (blockIdx.x & 1) ? active : 64;
+    const unsigned long long t0 = wall_clock64();
+    if ((int)(threadIdx.x & 63) < lanes)
+        for (int k = 0; k < iters; k++) { a = mul28(a, b); b = mul28(b, a); }
+    const unsigned long long t1 = wall_clock64();
+    if (threadIdx.x == 0) ticks[blockIdx.x] = t1 - t0;
+    out[i] = store28(sub28(a, b));
+}
+
 template <class K, class... A>
 static double time_kernel(K k, dim3 g, dim3 b, A... args) {
     hipEvent_t e0, e1;
@@ -161,6 +199,31 @@ int main() {
         const double ts = time_kernel(fmul28_kernel<1>, dim3(blocks), dim3(256), (Fq *)d, 200);
         printf("waves/SIMD=%d  28-bit limbs: Fq mul %.2f Gmul/s (%.0f ns per mul per wave)   sqr %.2f G/s\n", wps,
                400.0 * blocks * 256 / tm / 1e9, tm / 400 * 1e9, 400.0 * blocks * 256 / ts / 1e9);
+    }
+    for (int active = 64; active >= 1; active >>= 1) {
+        const double tm = time_kernel(fmul28_masked_kernel, dim3(256), dim3(256), (Fq *)d, 200, active);
+        printf("1 wave/SIMD, %2d lanes of 64 enabled: %.0f ns per 28-bit product per wave\n", active, tm / 400 * 1e9);
+    }
+    {
+        const unsigned long long masks[] = {0xffffull, 0xfffull, 0x1ffull, 0xffull, 0x00ff00ffull, 0x5555ull, 0x0f0f0f0full, 0x1111111111111111ull,
+                                            0x8000000000000001ull, 0x0001000100010001ull, 0x00000000ffff0000ull, 0xff00ull, 0x3ffull, 0x7fffull};
+        for (unsigned long long m : masks) {
+            const double tm = time_kernel(fmul28_lanemask_kernel, dim3(256), dim3(256), (Fq *)d, 200, m);
+            printf("1 wave/SIMD, lane mask %016llx (%2d lanes): %.0f ns per 28-bit product per wave\n", m, __builtin_popcountll(m), tm / 400 * 1e9);
+        }
+    }
+    {
+        unsigned long long *dt, ht[512];
+        CHECK(hipMalloc(&dt, sizeof ht));
+        for (int active = 32; active >= 1; active >>= 1) {
+            hipLaunchKernelGGL(fmul28_mixed_kernel, dim3(512), dim3(256), 0, 0, (Fq *)d, 200, active, dt);
+            CHECK(hipMemcpy(ht, dt, sizeof ht, hipMemcpyDeviceToHost));
+            double full = 0, part = 0;
+            for (int b = 0; b < 512; b++) (b & 1 ? part : full) += (double)ht[b];
+            printf("mixed launch: blocks with 64 lanes %.0f ns per product, blocks with %2d lanes %.0f ns per product\n", full / 256 * 10 / 400,
+                   active, part / 256 * 10 / 400);
+        }
+        hipFree(dt);
     }
     hipFree(d);
     return 0;
