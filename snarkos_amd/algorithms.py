@@ -432,7 +432,7 @@ class VarunaShaped:
                                               L.ptr(verdicts), L.stream_ptr(stream)), "mi_vs_identify_device")
         return verdicts
 
-    def verify_stream(self, batches, gather=None, depth=8, acc_depth=12, fold_threads=3, exchange_group=1, comm=None,
+    def verify_stream(self, batches, gather=None, depth=10, acc_depth=10, fold_threads=3, exchange_group=1, comm=None,
                       verdicts=False):
         """Pipelined verification of a stream of batches (chunks of a block, or mempool traffic): yields all_ok per
         batch, in order.
@@ -442,7 +442,7 @@ class VarunaShaped:
         for accumulations and fold them on the host; one finisher thread takes the partials in batch order,
         exchanges them (`gather`, optional: maps this rank's (count, 592) partials of `exchange_group` consecutive
         batches to all ranks' (world, count, 592) -- one collective per group, issued from that one thread) and starts
-        the pairing products; up to `depth` (<= 8) products are in flight, each on its own stream.  `batches` yields
+        the pairing products; up to `depth` (<= 16, the device has MI_SNARK_VS_SLOTS = 10) products are in flight, each on its own stream.  `batches` yields
         (proofs_cuda, randomizers_cuda).  `comm` (a handle of lib.comm_init_rank) makes the exchange native instead:
         the library's own mi_vs_exchange_rccl (ncclAllGather from the finisher thread, no Python on the data path).
         Submitted tensors are kept alive until their verdict has been yielded.

@@ -215,13 +215,15 @@ struct VsAcc {  // an accumulation whose kernels are enqueued but whose host fol
 // shared workspaces, so two verifier contexts must never hold the same lane, and HIP keeps a destroyed stream's queue
 // and scratch (measured: 45 MB of device memory per create/destroy cycle when every context made its own 20 streams).
 // All streams are created at once, lanes first, then product slots.  Measured on the box: HIP spreads streams over
-// at most 24 hardware queues in creation order; with this order 12 lanes + 8 slots run side by side (4.3e6 proofs/s),
-// created lazily in order of first use (lane, slot, lane, ...) the same streams reach 2.7e6, and with more than ~24
-// streams on the device a 1.6 ms pairing kernel ends up queued in front of other batches' MSMs.
-// MI_SNARK_VS_LANES (1..14, default 12; read once) trims the lane count when the process needs queues for something
-// else (RCCL, other libraries).
+// at most 24 hardware queues in creation order; with this order 12 lanes + 8 slots ran side by side (4.3e6 proofs/s
+// in round 1), created lazily in order of first use (lane, slot, lane, ...) the same streams reached 2.7e6, and with
+// more than ~20 of our streams on the device a pairing kernel ends up queued in front of other batches' MSMs
+// (10 lanes + 12 slots: half the throughput of 10 + 10).  Since a lane pass carries two batches under load
+// (mi_vs_accumulate_begin_pair) the split is 10 lanes + 10 slots.
+// MI_SNARK_VS_LANES (1..14, default 10) / MI_SNARK_VS_SLOTS (1..16, default 10), read once, trim the counts when the
+// process needs queues for something else (RCCL, other libraries).
 struct VsPipe {
-    int lanes = 12, nslots = VS_SLOTS;
+    int lanes = 10, nslots = 10;
     VsAcc acc[VS_ACC_DEPTH];
     hipStream_t acc_st[VS_ACC_DEPTH] = {};  // one stream per accumulation lane
     hipEvent_t acc_ev[VS_ACC_DEPTH] = {};
@@ -237,10 +239,12 @@ struct VsPipe {
             MI_HIP(hipStreamCreateWithFlags(&acc_st[p], hipStreamNonBlocking));
             MI_HIP(hipEventCreateWithFlags(&acc_ev[p], hipEventDisableTiming));
         }
-        if (const char *e = getenv("MI_SNARK_VS_SLOTS")) {  // product slots (1..8): fewer streams when queues are scarce
+        if (const char *e = getenv("MI_SNARK_VS_SLOTS")) {  // product slots (1..16): fewer streams when queues are scarce
             const int x = atoi(e);
             if (x >= 1 && x <= VS_SLOTS) nslots = x;
         }
+        // (Product streams at the device's highest stream priority were tried -- a product is one workgroup somebody
+        // waits for -- and cost a quarter of the throughput: 7.3e6 -> 5.4e6 proofs/s.)
         for (int i = 0; i < nslots; i++) {
             VsSlot &sl = slots[i];
             MI_HIP(hipStreamCreateWithFlags(&sl.stream, hipStreamNonBlocking));

@@ -27,9 +27,9 @@ KZG_VK_BYTES = 480
 VS_PROOF_BYTES = 2256
 VS_CIRCUIT_VK_BYTES = 1184
 VS_PARTIAL_BYTES = 592
-VS_MAX_OPEN_ACCUMULATIONS = 14  # compile-time cap; a context has MI_SNARK_VS_LANES (default 12) lanes
-VS_DEFAULT_LANES = 12
-VS_MAX_TICKETS = 8
+VS_MAX_OPEN_ACCUMULATIONS = 14  # compile-time cap; a device has MI_SNARK_VS_LANES (default 10) lanes
+VS_DEFAULT_LANES = 10
+VS_MAX_TICKETS = 16  # compile-time cap; a device has MI_SNARK_VS_SLOTS (default 10) product slots
 VS_FS_POSEIDON = 1  # mi_vs_ctx_create_ex flag: Poseidon Fiat-Shamir transcript
 VS2_PROOF_BYTES = 3184  # mi_vs_proof2
 VS3_PROOF_BYTES = 5504  # mi_vs_proof3 (shapes with max_instances > 1)

@@ -48,14 +48,16 @@ def one(k, fold, depth, lanes):
 
 
 list(v.verify_stream(((pp, pr) for _ in range(5))))
-for fold, depth, lanes in ((3, 8, 12), (3, 8, 20), (4, 8, 12), (3, 8, 8), (3, 8, 6), (2, 8, 12)):
-    best = None
-    for rep in range(7):
-        r = one(K, fold, depth, lanes)
-        if best is None or r[4] < best[4]:
-            best = r
-    t_open, subs, outs, t_last, t_all = best
-    print("fold=%d products=%d lanes=%d  K=%d: total %.3f ms (%.3f ms/step)  open %.3f  last submit %.3f  first verdict %.3f  last verdict %.3f  close %.3f"
-          % (fold, depth, lanes, K, 1e3 * t_all, 1e3 * t_all / K, 1e3 * t_open, 1e3 * subs[-1], 1e3 * outs[0], 1e3 * t_last, 1e3 * (t_all - t_last)))
-    print("   submits:", " ".join("%.2f" % (1e3 * s) for s in subs))
-    print("   verdicts:", " ".join("%.2f" % (1e3 * s) for s in outs))
+for pair_at in ("0", "1", "2", "4", "6"):
+    os.environ["MI_SNARK_STREAM_PAIR_AT"] = pair_at  # read when a stream is opened
+    for fold, depth, lanes in ((3, 8, 12), (4, 8, 12)):
+        best = None
+        for rep in range(9):
+            r = one(K, fold, depth, lanes)
+            if best is None or r[4] < best[4]:
+                best = r
+        t_open, subs, outs, t_last, t_all = best
+        print("pair_at=%s fold=%d products=%d lanes=%d  K=%d: total %.3f ms (%.3f ms/step)  open %.3f  last submit %.3f  first verdict %.3f  last verdict %.3f  close %.3f"
+              % (pair_at, fold, depth, lanes, K, 1e3 * t_all, 1e3 * t_all / K, 1e3 * t_open, 1e3 * subs[-1], 1e3 * outs[0], 1e3 * t_last, 1e3 * (t_all - t_last)))
+        print("   submits:", " ".join("%.2f" % (1e3 * s) for s in subs))
+        print("   verdicts:", " ".join("%.2f" % (1e3 * s) for s in outs))
