@@ -981,7 +981,13 @@ void msm_enqueue(Context &cx, const G1Affine *d_points, const uint32_t *d_scalar
     // chunking: T = twice the mean bucket load of a full window, so only over-full buckets are split
     uint32_t T = (uint32_t)(2 * ((n + pl.B - 1) / pl.B));
     if (T < 16) T = 16;
-    if (small) T = msm_small_chunk();
+    if (small) {
+        T = msm_small_chunk();
+        // four problems in one launch sequence = a pair pass of the streamed verifier, i.e. the device is busy and the
+        // total work counts, not the chain length: MI_SNARK_MSM_SMALL_T4 (experiments)
+        static const int t4 = getenv("MI_SNARK_MSM_SMALL_T4") ? atoi(getenv("MI_SNARK_MSM_SMALL_T4")) : 0;
+        if (problems == 4 && t4 >= 4 && t4 <= 256) T = (uint32_t)t4;
+    }
     const uint32_t HEAVY = 1;  // every bucket with more than one chunk is summed by the heavy kernel (a wave each)
     const size_t max_chunks = nb + (n * (size_t)pl.nwin) / T + 1;
     uint32_t *chunk_off = (uint32_t *)cx.buf(W("chunk_off"), sizeof(uint32_t) * (nb + 1));
