@@ -263,8 +263,8 @@ int32_t mi_vs_accumulate_end(uint64_t ctx, uint64_t handle, mi_vs_partial *parti
 /* Two batches in ONE lane pass: both batches' derive, merge and MSM kernels are single launches (the four MSMs are four
  * problems of one launch sequence), each batch keeps its own randomizers, accumulators and partial.  A lane pass is a
  * chain of latency-bound kernels and the lanes are few (hardware queues): under load two batches per pass is what
- * raises the throughput.  Only for shapes without degree-bound classes under the SHA-256 transcript, and when both
- * batches fit the small-MSM path together (MI_ERR_BAD_ARGS otherwise: run them as two single passes).
+ * raises the throughput.  Only for shapes without degree-bound classes (either transcript), and when both batches fit
+ * the small-MSM path together (MI_ERR_BAD_ARGS otherwise: run them as two single passes).
  * _end_pair writes partials_out[0] (batch a) and partials_out[1] (batch b). */
 int32_t mi_vs_accumulate_begin_pair(uint64_t ctx, const void *d_proofs_a, size_t n_a, const void *d_randomizers128_a,
                                     const void *d_proofs_b, size_t n_b, const void *d_randomizers128_b, void *stream,

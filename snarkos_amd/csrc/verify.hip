@@ -157,7 +157,8 @@ struct VsSecond {
     const void *proofs = nullptr;  // null: single batch
     const uint8_t *rand = nullptr;
     size_t n = 0;
-    uint32_t first_block = 0;
+    uint32_t first_block = 0;     // derive and transcript kernels both give a block 64 proofs
+    const uint32_t *chal = nullptr;  // Poseidon transcript: the second batch's challenges
     VsOut o;
 };
 #define VS_SLOTS MI_VS_MAX_TICKETS
@@ -483,6 +484,7 @@ __global__ void __launch_bounds__(128) vs_derive_kernel(const void *__restrict__
         n = second.n;
         rand128 = second.rand;
         o = second.o;
+        chal = second.chal;
     }
     const size_t i = (size_t)block * 64 + lane;
     const bool live = i < n;
@@ -761,14 +763,21 @@ __device__ __forceinline__ Fq vs_fs_element(const mi_vs_proof *__restrict__ p, c
 __global__ void __launch_bounds__(4 * VS_FS_PROOFS_PER_BLOCK) vs_fs_poseidon_kernel(const void *__restrict__ proofs, size_t n,
                                                              const mi_vs_circuit_vk *__restrict__ circuits, size_t n_circuits,
                                                              const VsConsts *__restrict__ kc, const PoseidonConsts *__restrict__ pc,
-                                                             uint32_t *__restrict__ chal) {
+                                                             uint32_t *__restrict__ chal, VsSecond second) {
     // The permutation runs in the reduced-radix arithmetic of field28.hpp (14 signed 28-bit limbs: one instruction per
     // limb product, a dedicated squaring for the S-box chain, carry-free additions): the state never leaves it between
     // the first absorb and the last squeeze; constants and absorbed elements enter as they are stored.
     __shared__ Fq28 xs[VS_FS_PROOFS_PER_BLOCK][3];     // the state of each proof (full rounds), or lane 0's new element in slot 0 (partial)
     __shared__ Fq28 xt[VS_FS_PROOFS_PER_BLOCK][2][3];  // partial rounds: lane l's products mds[i][l] s_l, l = 1, 2
     const int t = threadIdx.x, ps = t >> 2, l = t & 3, lc = l < 3 ? l : 0;
-    const size_t i = (size_t)blockIdx.x * VS_FS_PROOFS_PER_BLOCK + ps;
+    uint32_t block = blockIdx.x;
+    if (second.proofs && block >= second.first_block) {  // block-uniform: the pass's second batch
+        block -= second.first_block;
+        proofs = second.proofs;
+        n = second.n;
+        chal = const_cast<uint32_t *>(second.chal);
+    }
+    const size_t i = (size_t)block * VS_FS_PROOFS_PER_BLOCK + ps;
     const mi_vs_proof *p = reinterpret_cast<const mi_vs_proof *>(reinterpret_cast<const uint32_t *>(proofs) + (i < n ? i : 0) * (size_t)kc->proof_words);
     uint32_t circuit = reinterpret_cast<const uint32_t *>(p)[0];
     if (circuit >= n_circuits) circuit = 0;
@@ -1137,9 +1146,9 @@ static void vs_work_sizes(const VsKeys &v, size_t n, VsWork &w) {
 }
 static size_t vs_work_total(const VsWork &w) { return w.n1 + w.n2 + w.nb[0] + w.nb[1]; }
 // May two batches of these sizes share one lane pass?  One launch sequence carries at most four MSM problems (two per
-// batch: no degree-bound classes), the small-MSM path must hold both, and the Poseidon transcript kernel is per batch.
+// batch: no degree-bound classes) and the small-MSM path must hold both.
 static bool vs_pair_ok(const VsKeys &v, size_t n_a, size_t n_b) {
-    if (v.fs_poseidon || v.shape.n_bounds) return false;
+    if (v.shape.n_bounds) return false;
     VsWork a, b;
     vs_work_sizes(v, n_a, a);
     vs_work_sizes(v, n_b, b);
@@ -1209,7 +1218,8 @@ static VsWork vs_run_derive(Context &cx, VsKeys &v, const void *d_proofs, size_t
     const unsigned derive_blocks = (unsigned)(cdiv(n, 64) + (pair ? cdiv(n_b, 64) : 0));
     const uint32_t *chal = nullptr;
     if (v.fs_poseidon) {
-        uint32_t *ch = (uint32_t *)cx.buf(W("chal"), 48 * n);
+        uint32_t *ch = (uint32_t *)cx.buf(W("chal"), 48 * (n + (pair ? n_b : n)));  // both halves of a pair pass
+        if (pair) second.chal = ch + 12 * n;
         const PoseidonConsts *pc = poseidon_consts(cx, st);
         cx.prof.begin("vs_fs_poseidon", st, n);
         // 64 proofs (4 waves, one per SIMD) per block, and a block asks for more than half a CU's LDS: the transcript
@@ -1217,8 +1227,9 @@ static VsWork vs_run_derive(Context &cx, VsKeys &v, const void *d_proofs, size_t
         // larger than the instruction cache; waves of different batches on one CU sit at different places in it and
         // fetch against each other (4 concurrent kernels each ran 2.2x slower before).
         static const size_t fs_pad = getenv("MI_SNARK_FS_LDS_PAD") ? (size_t)atoi(getenv("MI_SNARK_FS_LDS_PAD")) : 50 * 1024;
-        hipLaunchKernelGGL(vs_fs_poseidon_kernel, dim3(cdiv(n, VS_FS_PROOFS_PER_BLOCK)), dim3(4 * VS_FS_PROOFS_PER_BLOCK), fs_pad, st, d_proofs, n,
-                           (const mi_vs_circuit_vk *)v.circuits.p, v.n_circuits, (const VsConsts *)v.consts.p, pc, ch);
+        static_assert(VS_FS_PROOFS_PER_BLOCK == 64, "VsSecond::first_block is shared with the derive kernel");
+        hipLaunchKernelGGL(vs_fs_poseidon_kernel, dim3(derive_blocks), dim3(4 * VS_FS_PROOFS_PER_BLOCK), fs_pad, st, d_proofs, n,
+                           (const mi_vs_circuit_vk *)v.circuits.p, v.n_circuits, (const VsConsts *)v.consts.p, pc, ch, second);
         cx.prof.end("vs_fs_poseidon", st);
         chal = ch;
     }

@@ -397,6 +397,16 @@ def test_poseidon_transcript_batches(orc, mi):
         finally:
             vs.close()
         assert list(v.verify_stream(iter([(p, r)] * 5))) == [True] * 5
+        # pair passes from the second batch on (the transcript kernel then serves two batches per launch); a batch with
+        # a flipped evaluation fails alone
+        bp_np = b.proofs.copy(); bp_np[13 * 2256 + 16 + 512 + 864 + 32 * 9] ^= 1
+        bp = torch.from_numpy(bp_np).cuda()
+        os.environ["MI_SNARK_STREAM_PAIR_AT"] = "1"
+        try:
+            seq = [(p, r), (p, r), (bp, r), (p, r), (bp, r), (p, r), (p, r)]
+            assert list(v.verify_stream(iter(seq))) == [q is p for q, _ in seq]
+        finally:
+            del os.environ["MI_SNARK_STREAM_PAIR_AT"]
     finally:
         v.close()
     d = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "vs_batch_1024_poseidon.npz"))
@@ -468,7 +478,7 @@ def test_reject_path_group_testing(orc, mi, n_bad):
 def test_pair_pass_partials_bit_exact(orc, mi):
     """mi_vs_accumulate_begin_pair / _end_pair: two batches in one lane pass (one derive, one merge, one four-problem
     MSM launch sequence) give byte for byte the partials of two single passes and of the oracle -- equal and unequal
-    sizes, a batch with an invalid proof, the same tensor twice; shapes that do not pair are refused"""
+    sizes, a batch with an invalid proof, the same tensor twice, both transcripts; pairs that do not fit are refused"""
     import torch
     from snarkos_amd.lib import MiError
     a = orc.VSBatch(0x9A11, 48, 3, 0)
@@ -501,11 +511,19 @@ def test_pair_pass_partials_bit_exact(orc, mi):
         assert (v.accumulate_end(h) == single_a).all()
     finally:
         v.close()
-    # the Poseidon transcript does not pair
+    # the Poseidon transcript pairs too (its kernel serves both batches in one launch); two batches that do not fit the
+    # small-MSM path together are refused before anything is enqueued
     vp = mi.VarunaShaped(a.vk, a.circuits, transcript="poseidon")
     try:
+        sa, sb = vp.accumulate(pa, ra), vp.accumulate(pb, rb)
+        parts = vp.accumulate_end_pair(vp.accumulate_begin_pair(pa, ra, pb, rb))
+        assert (parts[0] == sa).all() and (parts[1] == sb).all()
+        parts = vp.accumulate_end_pair(vp.accumulate_begin_pair(pb, rb, pa, ra))
+        assert (parts[0] == sb).all() and (parts[1] == sa).all()
+        big_p, big_r = torch.cat([pa] * 60), torch.cat([ra] * 60)  # 2 880 proofs each: 2 x 37.5 k points > 2^16
         with pytest.raises(MiError):
-            vp.accumulate_begin_pair(pa, ra, pa, ra)
+            vp.accumulate_begin_pair(big_p, big_r, big_p, big_r)
+        assert (vp.accumulate(pa, ra) == sa).all()
     finally:
         vp.close()
 
