@@ -573,7 +573,7 @@ def extras(dev, verifier, proofs, rnd):
         lat = (time.perf_counter() - t0) / 5
         ms, launches, _ = L.prof_read("vs_fs_poseidon")
         L.prof_enable(0)
-        nb = 60
+        nb = 240
         list(vp.verify_stream(((pp, pr) for _ in range(12))))
         torch.cuda.synchronize()
         t0 = time.perf_counter()

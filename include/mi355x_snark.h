@@ -260,16 +260,23 @@ int32_t mi_vs_finalize(uint64_t ctx, const mi_vs_partial *partials, size_t n_par
 int32_t mi_vs_accumulate_begin(uint64_t ctx, const void *d_proofs, size_t n, const void *d_randomizers128, void *stream,
                                uint64_t *handle_out);
 int32_t mi_vs_accumulate_end(uint64_t ctx, uint64_t handle, mi_vs_partial *partial_out);
-/* Two batches in ONE lane pass: both batches' derive, merge and MSM kernels are single launches (the four MSMs are four
- * problems of one launch sequence), each batch keeps its own randomizers, accumulators and partial.  A lane pass is a
- * chain of latency-bound kernels and the lanes are few (hardware queues): under load two batches per pass is what
- * raises the throughput.  Only for shapes without degree-bound classes (either transcript), and when both batches fit
- * the small-MSM path together (MI_ERR_BAD_ARGS otherwise: run them as two single passes).
- * _end_pair writes partials_out[0] (batch a) and partials_out[1] (batch b). */
+/* Several batches in ONE lane pass: all batches' derive, merge (and Poseidon transcript) kernels are single launches
+ * and all their MSMs are problems of one launch sequence; each batch keeps its own randomizers, accumulators and
+ * partial.  A lane pass is a chain of latency-bound kernels and the lanes are few (hardware queues): under load more
+ * batches per pass is what raises the throughput.  A launch sequence carries 8 MSMs -- a batch brings two, plus one per
+ * degree-bound class -- and all batches must fit the small-MSM path together (2^16 points); otherwise
+ * MI_ERR_BAD_ARGS: run them as separate passes.  mi_vs_batches_per_pass tells how many batches of n proofs fit (1..4).
+ * All batches' inputs must be ready on `stream`.  _end_multi writes partials_out[k] for batch k; `count` must be the
+ * pass's own.  _pair = _multi with two batches. */
+#define MI_VS_MAX_BATCHES_PER_PASS 4
+int32_t mi_vs_accumulate_begin_multi(uint64_t ctx, int32_t count, const void *const *d_proofs, const size_t *n,
+                                     const void *const *d_randomizers128, void *stream, uint64_t *handle_out);
+int32_t mi_vs_accumulate_end_multi(uint64_t ctx, uint64_t handle, mi_vs_partial *partials_out, int32_t count);
 int32_t mi_vs_accumulate_begin_pair(uint64_t ctx, const void *d_proofs_a, size_t n_a, const void *d_randomizers128_a,
                                     const void *d_proofs_b, size_t n_b, const void *d_randomizers128_b, void *stream,
                                     uint64_t *handle_out);
 int32_t mi_vs_accumulate_end_pair(uint64_t ctx, uint64_t handle, mi_vs_partial *partials_out);
+int32_t mi_vs_batches_per_pass(uint64_t ctx, size_t n);  /* >= 1, or a negative status */
 int32_t mi_vs_finalize_async(uint64_t ctx, const mi_vs_partial *partials, size_t n_partials, uint64_t *ticket_out);
 int32_t mi_vs_finalize_wait(uint64_t ctx, uint64_t ticket, uint8_t *all_ok);
 

@@ -410,6 +410,31 @@ class VarunaShaped:
         L.check(L.lib().mi_vs_accumulate_end_pair(C.c_uint64(self.ctx), C.c_uint64(handle), L.ptr(parts)), "mi_vs_accumulate_end_pair")
         return parts
 
+    def accumulate_begin_multi(self, batches, stream=None):
+        """Up to four (proofs, randomizers) batches in one lane pass (mi_vs_accumulate_begin_multi); returns a handle for
+        accumulate_end_multi(handle, len(batches)).  Raises MiError (MI_ERR_BAD_ARGS) when they do not fit one pass."""
+        k = len(batches)
+        pr = (C.c_void_p * k)(*[L.dptr(p).value for p, _ in batches])
+        rn = (C.c_void_p * k)(*[L.dptr(r).value for _, r in batches])
+        ns = (C.c_size_t * k)(*[p.numel() * p.element_size() // self.proof_bytes for p, _ in batches])
+        h = C.c_uint64(0)
+        L.check(L.lib().mi_vs_accumulate_begin_multi(C.c_uint64(self.ctx), C.c_int32(k), pr, ns, rn, L.stream_ptr(stream), C.byref(h)),
+                "mi_vs_accumulate_begin_multi")
+        return h.value
+
+    def accumulate_end_multi(self, handle, count):
+        parts = np.zeros((count, L.VS_PARTIAL_BYTES), dtype=np.uint8)
+        L.check(L.lib().mi_vs_accumulate_end_multi(C.c_uint64(self.ctx), C.c_uint64(handle), L.ptr(parts), C.c_int32(count)),
+                "mi_vs_accumulate_end_multi")
+        return parts
+
+    def batches_per_pass(self, n_proofs):
+        """How many batches of n_proofs one lane pass takes for this context's shape (1..4)."""
+        r = L.lib().mi_vs_batches_per_pass(C.c_uint64(self.ctx), C.c_size_t(n_proofs))
+        if r < 1:
+            raise L.MiError(r, "mi_vs_batches_per_pass")
+        return r
+
     def finalize_async(self, partials):
         """Enqueue the pairing product for these partials on the context's own stream; returns a ticket."""
         parts = np.ascontiguousarray(partials, dtype=np.uint8).reshape(-1, L.VS_PARTIAL_BYTES)

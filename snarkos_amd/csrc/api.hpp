@@ -23,17 +23,25 @@ struct MsmJob {
     hipEvent_t done = nullptr;  // recorded after the copy into h
 };
 // split points of a fused launch: points [0, at[0]) are problem 0, [at[0], at[1]) problem 1, ...; 0 = unused
+#define MSM_MAX_PROBLEMS 8  // MSMs that may share one small-path launch sequence
 struct MsmSplits {
-    size_t at[3] = {0, 0, 0};
+    size_t at[MSM_MAX_PROBLEMS - 1] = {0, 0, 0, 0, 0, 0, 0};  // ascending; 0 = unused
     MsmSplits() {}
-    MsmSplits(size_t a, size_t b = 0, size_t c = 0) : at{a, b, c} {}
-    __host__ __device__ uint32_t problem_of(size_t i) const { return (uint32_t)(i >= at[0]) + (uint32_t)(i >= at[1]) + (uint32_t)(i >= at[2]); }
+    MsmSplits(size_t a, size_t b = 0, size_t c = 0) : at{a, b, c, 0, 0, 0, 0} {}
+    __host__ __device__ uint32_t problem_of(size_t i) const {
+        uint32_t p = 0;
+#pragma unroll
+        for (int k = 0; k < MSM_MAX_PROBLEMS - 1; k++) p += (uint32_t)(i >= at[k]);
+        return p;
+    }
 };
 void msm_enqueue(Context &cx, const G1Affine *d_points, const uint32_t *d_scalars, size_t n, hipStream_t st, int scalar_bits,
                  int slot, MsmJob *job, int force_c = 0, int pin_parity = 0, MsmSplits split = MsmSplits());
 // out_b .. out_d: the further problems' results when the job was enqueued with split points
 void msm_finish(Context &cx, MsmJob *job, hipStream_t st, mi_g1_jac *out, mi_g1_jac *out_b = nullptr, mi_g1_jac *out_c = nullptr,
                 mi_g1_jac *out_d = nullptr);
+// all problems' results: outs[p] may be null (result not wanted), n_outs <= MSM_MAX_PROBLEMS
+void msm_finish_all(Context &cx, MsmJob *job, hipStream_t st, mi_g1_jac *const *outs, int n_outs);
 size_t msm_small_limit();  // largest n on the latency-bound small path (the only one that takes a split)
 void msm_device(Context &cx, const G1Affine *d_points, const uint32_t *d_scalars, size_t n, mi_g1_jac *out,
                 hipStream_t st, int scalar_bits = 254, int force_c = 0);
@@ -71,9 +79,10 @@ int32_t vs_accumulate_device(Context &cx, uint64_t id, const void *d_proofs, siz
 int32_t vs_accumulate_begin(Context &cx, uint64_t id, const void *d_proofs, size_t n, const void *d_rand, hipStream_t st,
                             uint64_t *handle);
 int32_t vs_accumulate_end(Context &cx, uint64_t id, uint64_t handle, mi_vs_partial *out);
-int32_t vs_accumulate_begin_pair(Context &cx, uint64_t id, const void *d_proofs_a, size_t n_a, const void *d_rand_a,
-                                 const void *d_proofs_b, size_t n_b, const void *d_rand_b, hipStream_t st, uint64_t *handle);
-int32_t vs_accumulate_end_pair(Context &cx, uint64_t id, uint64_t handle, mi_vs_partial *out2);
+int32_t vs_accumulate_begin_multi(Context &cx, uint64_t id, int count, const void *const *d_proofs, const size_t *n,
+                                  const void *const *d_rand, hipStream_t st, uint64_t *handle);
+int32_t vs_accumulate_end_multi(Context &cx, uint64_t id, uint64_t handle, mi_vs_partial *outs, int count);
+int32_t vs_batches_per_pass(Context &cx, uint64_t id, size_t n);
 int32_t vs_finalize(Context &cx, uint64_t id, const mi_vs_partial *parts, size_t np, uint8_t *all_ok, hipStream_t st);
 int32_t vs_finalize_async(Context &cx, uint64_t id, const mi_vs_partial *parts, size_t np, uint64_t *ticket);
 int32_t vs_finalize_wait(Context &cx, uint64_t id, uint64_t ticket, uint8_t *all_ok);

@@ -894,19 +894,34 @@ int32_t mi_vs_accumulate_end(uint64_t c, uint64_t handle, mi_vs_partial *partial
     if (ensure_init() != MI_OK) return MI_ERR_NO_DEVICE;
     return guarded_on(context_at((int)((handle >> 8) & 0xff)), [&](Context &cx) -> int32_t { return vs_accumulate_end(cx, c, handle, partial_out); });
 }
+int32_t mi_vs_accumulate_begin_multi(uint64_t c, int32_t count, const void *const *d_proofs, const size_t *n,
+                                     const void *const *d_randomizers128, void *stream, uint64_t *handle_out) {
+    if (count < 1 || count > MI_VS_MAX_BATCHES_PER_PASS || !d_proofs || !n || !d_randomizers128 || !handle_out) return MI_ERR_BAD_ARGS;
+    for (int k = 0; k < count; k++)
+        if (!d_proofs[k] || !n[k] || !d_randomizers128[k]) return MI_ERR_BAD_ARGS;
+    return guarded_ptr(d_proofs[0], [&](Context &cx) -> int32_t {
+        return vs_accumulate_begin_multi(cx, c, count, d_proofs, n, d_randomizers128, (hipStream_t)stream, handle_out);
+    });
+}
+int32_t mi_vs_accumulate_end_multi(uint64_t c, uint64_t handle, mi_vs_partial *partials_out, int32_t count) {
+    if (!partials_out) return MI_ERR_BAD_ARGS;
+    if (ensure_init() != MI_OK) return MI_ERR_NO_DEVICE;
+    return guarded_on(context_at((int)((handle >> 8) & 0xff)),
+                      [&](Context &cx) -> int32_t { return vs_accumulate_end_multi(cx, c, handle, partials_out, count); });
+}
 int32_t mi_vs_accumulate_begin_pair(uint64_t c, const void *d_proofs_a, size_t n_a, const void *d_randomizers128_a,
                                     const void *d_proofs_b, size_t n_b, const void *d_randomizers128_b, void *stream,
                                     uint64_t *handle_out) {
-    if (!d_proofs_a || !n_a || !d_randomizers128_a || !d_proofs_b || !n_b || !d_randomizers128_b || !handle_out) return MI_ERR_BAD_ARGS;
-    return guarded_ptr(d_proofs_a, [&](Context &cx) -> int32_t {
-        return vs_accumulate_begin_pair(cx, c, d_proofs_a, n_a, d_randomizers128_a, d_proofs_b, n_b, d_randomizers128_b,
-                                        (hipStream_t)stream, handle_out);
-    });
+    const void *pr[2] = {d_proofs_a, d_proofs_b}, *rn[2] = {d_randomizers128_a, d_randomizers128_b};
+    const size_t ns[2] = {n_a, n_b};
+    return mi_vs_accumulate_begin_multi(c, 2, pr, ns, rn, stream, handle_out);
 }
 int32_t mi_vs_accumulate_end_pair(uint64_t c, uint64_t handle, mi_vs_partial *partials_out) {
-    if (!partials_out) return MI_ERR_BAD_ARGS;
-    if (ensure_init() != MI_OK) return MI_ERR_NO_DEVICE;
-    return guarded_on(context_at((int)((handle >> 8) & 0xff)), [&](Context &cx) -> int32_t { return vs_accumulate_end_pair(cx, c, handle, partials_out); });
+    return mi_vs_accumulate_end_multi(c, handle, partials_out, 2);
+}
+int32_t mi_vs_batches_per_pass(uint64_t c, size_t n) {
+    if (!n) return MI_ERR_BAD_ARGS;
+    return guarded([&](Context &cx) -> int32_t { return vs_batches_per_pass(cx, c, n); });
 }
 int32_t mi_vs_finalize_async(uint64_t c, const mi_vs_partial *partials, size_t n_partials, uint64_t *ticket_out) {
     if (!partials || !n_partials || !ticket_out) return MI_ERR_BAD_ARGS;

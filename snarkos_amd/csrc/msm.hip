@@ -902,7 +902,7 @@ void msm_enqueue(Context &cx, const G1Affine *d_points, const uint32_t *d_scalar
     // than their work): it takes short chunks, one fused planning kernel and the log-depth reduction below.
     const bool small = n <= msm_small_limit();
     int problems = 1;
-    for (int k = 0; k < 3; k++) {
+    for (int k = 0; k < MSM_MAX_PROBLEMS - 1; k++) {
         if (split.at[k] == 0 || split.at[k] >= n) split.at[k] = n;  // unused: no point lies beyond it
         else problems = k + 2;
     }
@@ -986,7 +986,7 @@ void msm_enqueue(Context &cx, const G1Affine *d_points, const uint32_t *d_scalar
         // four problems in one launch sequence = a pair pass of the streamed verifier, i.e. the device is busy and the
         // total work counts, not the chain length: MI_SNARK_MSM_SMALL_T4 (experiments)
         static const int t4 = getenv("MI_SNARK_MSM_SMALL_T4") ? atoi(getenv("MI_SNARK_MSM_SMALL_T4")) : 0;
-        if (problems == 4 && t4 >= 4 && t4 <= 256) T = (uint32_t)t4;
+        if (problems >= 4 && t4 >= 4 && t4 <= 256) T = (uint32_t)t4;
     }
     const uint32_t HEAVY = 1;  // every bucket with more than one chunk is summed by the heavy kernel (a wave each)
     const size_t max_chunks = nb + (n * (size_t)pl.nwin) / T + 1;
@@ -1169,9 +1169,15 @@ struct FoldSplit {
 };
 static std::atomic<int> g_folds_in_flight{0};
 void msm_finish(Context &cx, MsmJob *job, hipStream_t st, mi_g1_jac *out, mi_g1_jac *out_b, mi_g1_jac *out_c, mi_g1_jac *out_d) {
+    mi_g1_jac *outs[4] = {out, out_b, out_c, out_d};
+    msm_finish_all(cx, job, st, outs, 4);
+}
+void msm_finish_all(Context &cx, MsmJob *job, hipStream_t st, mi_g1_jac *const *outs_in, int n_outs) {
     (void)cx;
     (void)st;
-    mi_g1_jac *outs[4] = {out, out_b, out_c, out_d};
+    mi_g1_jac *outs[MSM_MAX_PROBLEMS] = {};
+    for (int p = 0; p < n_outs && p < MSM_MAX_PROBLEMS; p++) outs[p] = outs_in[p];
+    mi_g1_jac *out = outs[0];
     G1Jac res = G1Jac{Fq::one(), Fq::one(), Fq::zero()};
     if (job->n == 0) {
         for (mi_g1_jac *o : outs)
@@ -1196,7 +1202,7 @@ void msm_finish(Context &cx, MsmJob *job, hipStream_t st, mi_g1_jac *out, mi_g1_
         static const int force_k = getenv("MI_SNARK_FOLD_K") ? atoi(getenv("MI_SNARK_FOLD_K")) : 0;  // experiments
         const int K = force_k ? force_k : (in_flight.others == 0 ? 4 : 2);
         std::vector<FoldSplit> f;
-        f.reserve(4);
+        f.reserve(MSM_MAX_PROBLEMS);
         for (int p = 0; p < np; p++) f.emplace_back(h + (size_t)p * job->groups, job->groups, job->groups > 160 ? K : 2);
         std::vector<std::future<void>> tasks;
         for (int p = 0; p < np; p++) {
@@ -1220,7 +1226,7 @@ void msm_finish(Context &cx, MsmJob *job, hipStream_t st, mi_g1_jac *out, mi_g1_
             }
         }
         if (err) std::rethrow_exception(err);
-        G1Jac r[4];
+        G1Jac r[MSM_MAX_PROBLEMS];
         tasks.clear();
         for (int p = 1; p < np; p++) {
             FoldSplit *fp = &f[p];

@@ -28,20 +28,21 @@ struct Stream {
 
     std::mutex mu;
     std::condition_variable cv;
-    struct Pass { uint64_t seq, handle; bool pair; };    // a lane pass: batch seq (and seq + 1 when it carries a pair)
+    struct Pass { uint64_t seq, handle; int count; };    // a lane pass: batches seq .. seq + count - 1
     std::deque<Pass> to_fold;                           // submission order
     std::map<uint64_t, mi_vs_partial> folded;           // sequence number -> this rank's partial
     std::deque<int32_t> results;                        // 0 / 1 verdicts, or a negative status
     struct Sub { const void *proofs; size_t n; const void *rand; };
     std::deque<Sub> pending;                            // submitted batches whose verdict has not been taken, oldest first
     uint64_t submitted = 0, open = 0;                   // batches submitted; accumulations begun and not yet folded
-    // Under load two consecutive batches share one lane pass (mi_vs_accumulate_begin_pair): a batch submitted while
-    // `pair_at` or more passes are open is HELD until the next submission joins it -- or until a pass ends, the stream
-    // is finished or somebody blocks on a verdict, whichever comes first; then it runs alone.  0: never pair.
+    // Under load consecutive batches share one lane pass (mi_vs_accumulate_begin_multi): a batch submitted while
+    // `pair_at` or more passes are open is HELD until `per_pass` batches are together -- or until a pass ends, the
+    // stream is finished or somebody blocks on a verdict, whichever comes first; then what is held runs as one pass.
+    // pair_at 0: one batch per pass, always.
     int pair_at = 4;
-    bool can_pair = true;                               // cleared when the library refuses a pair for this context's shape
-    bool have_held = false;
-    Sub held{nullptr, 0, nullptr};
+    int per_pass = 0;                                   // batches per pass for this context's shape (0: not asked yet)
+    int per_pass_max = 2;                               // MI_SNARK_STREAM_PER_PASS (measured: 2 is the best for both transcripts)
+    std::vector<Sub> held;
     void *held_stream = nullptr;
     bool launching = false;                             // somebody is between taking the held batch and queueing its pass
     bool finished = false;                              // no more submissions
@@ -61,100 +62,108 @@ struct Stream {
             Pass item;
             {
                 std::unique_lock<std::mutex> lk(mu);
-                cv.wait(lk, [&] { return !to_fold.empty() || (finished && !have_held && !launching) || error != MI_OK; });
+                cv.wait(lk, [&] { return !to_fold.empty() || (finished && held.empty() && !launching) || error != MI_OK; });
                 if (to_fold.empty()) return;  // finished (or failed) and nothing left to fold
                 item = to_fold.front();
                 to_fold.pop_front();
             }
-            mi_vs_partial part[2];
-            const int32_t st = item.pair ? mi_vs_accumulate_end_pair(ctx, item.handle, part)  // waits for the GPU, folds
-                                         : mi_vs_accumulate_end(ctx, item.handle, &part[0]);
+            mi_vs_partial part[MI_VS_MAX_BATCHES_PER_PASS];
+            const int32_t st = item.count > 1 ? mi_vs_accumulate_end_multi(ctx, item.handle, part, item.count)  // waits for the GPU, folds
+                                              : mi_vs_accumulate_end(ctx, item.handle, &part[0]);
             {
                 std::lock_guard<std::mutex> lk(mu);
                 open--;
                 if (st != MI_OK) fail(st);
-                else {
-                    folded[item.seq] = part[0];
-                    if (item.pair) folded[item.seq + 1] = part[1];
-                }
+                else
+                    for (int k = 0; k < item.count; k++) folded[item.seq + k] = part[k];
                 cv.notify_all();
             }
             flush_held(false);  // a pass has ended: a held batch does not wait for company any longer than that
         }
     }
 
-    // Launch one pass: batch a alone, or a and b together.  mu NOT held; the caller has reserved the lane (open++) and
-    // set `launching`.  Queues the pass for the folders.
-    int32_t launch(const Sub &a, void *st_a, const Sub *b) {
+    // Launch the batches as ONE pass when the library takes them together, else as one pass each.  mu NOT held; the
+    // caller has reserved one lane (open++) and set `launching`.  Queues the pass(es) for the folders.
+    int32_t launch(const std::vector<Sub> &bs, void *st_in) {
         uint64_t h = 0;
         int32_t st = MI_ERR_BAD_ARGS;
-        bool paired = false;
-        if (b) {
-            st = mi_vs_accumulate_begin_pair(ctx, a.proofs, a.n, a.rand, b->proofs, b->n, b->rand, st_a, &h);
-            paired = st == MI_OK;
+        bool together = false;
+        const int count = (int)bs.size();
+        if (count > 1) {
+            const void *pr[MI_VS_MAX_BATCHES_PER_PASS], *rn[MI_VS_MAX_BATCHES_PER_PASS];
+            size_t ns[MI_VS_MAX_BATCHES_PER_PASS];
+            for (int k = 0; k < count; k++) {
+                pr[k] = bs[k].proofs;
+                rn[k] = bs[k].rand;
+                ns[k] = bs[k].n;
+            }
+            st = mi_vs_accumulate_begin_multi(ctx, count, pr, ns, rn, st_in, &h);
+            together = st == MI_OK;
         }
-        if (!paired) st = mi_vs_accumulate_begin(ctx, a.proofs, a.n, a.rand, st_a, &h);
-        uint64_t h2 = 0;
-        int32_t st2 = MI_OK;
-        if (st == MI_OK && b && !paired) {  // the shape does not pair: the second batch takes its own pass
-            {
+        if (together || count == 1) {
+            if (count == 1) st = mi_vs_accumulate_begin(ctx, bs[0].proofs, bs[0].n, bs[0].rand, st_in, &h);
+            std::lock_guard<std::mutex> lk(mu);
+            launching = false;
+            if (st != MI_OK) {
+                open--;
+                fail(st);
+                return st;
+            }
+            to_fold.push_back(Pass{submitted, h, count});
+            submitted += (uint64_t)count;
+            for (const Sub &b : bs) pending.push_back(b);
+            cv.notify_all();
+            return MI_OK;
+        }
+        // the shape (or these sizes) does not share a pass: one pass each, in order
+        for (int k = 0; k < count; k++) {
+            if (k > 0) {
                 std::unique_lock<std::mutex> lk(mu);
-                can_pair = false;
+                per_pass = 1;
                 cv.wait(lk, [&] { return (int)open < lanes || error != MI_OK; });
-                if (error != MI_OK) st2 = error;
-                else open++;
-            }
-            if (st2 == MI_OK) {
-                st2 = mi_vs_accumulate_begin(ctx, b->proofs, b->n, b->rand, st_a, &h2);
-                if (st2 != MI_OK) {
-                    std::lock_guard<std::mutex> lk(mu);
-                    open--;
+                if (error != MI_OK) {
+                    launching = false;
+                    cv.notify_all();
+                    return error;
                 }
+                open++;
             }
+            st = mi_vs_accumulate_begin(ctx, bs[k].proofs, bs[k].n, bs[k].rand, st_in, &h);
+            std::lock_guard<std::mutex> lk(mu);
+            if (st != MI_OK) {
+                launching = false;
+                open--;
+                fail(st);
+                return st;
+            }
+            to_fold.push_back(Pass{submitted++, h, 1});
+            pending.push_back(bs[k]);
+            cv.notify_all();
         }
         std::lock_guard<std::mutex> lk(mu);
         launching = false;
-        if (st != MI_OK) {
-            open--;
-            fail(st);
-            return st;
-        }
-        to_fold.push_back(Pass{submitted, h, paired});
-        submitted += paired ? 2 : 1;
-        pending.push_back(a);
-        if (b) {
-            pending.push_back(*b);
-            if (!paired) {
-                if (st2 != MI_OK) {
-                    fail(st2);
-                    return st2;
-                }
-                to_fold.push_back(Pass{submitted++, h2, false});
-            }
-        }
         cv.notify_all();
         return MI_OK;
     }
 
-    // run the held batch alone (wait: block for a lane; otherwise only if one is free right now)
+    // run what is held as one pass (wait: block for a lane; otherwise only if one is free right now)
     int32_t flush_held(bool wait) {
-        Sub a;
-        void *st_a;
+        std::vector<Sub> bs;
+        void *st_in;
         {
             std::unique_lock<std::mutex> lk(mu);
-            if (!have_held || launching || error != MI_OK) return MI_OK;
+            if (held.empty() || launching || error != MI_OK) return MI_OK;
             if ((int)open >= lanes) {
                 if (!wait) return MI_OK;  // every lane is busy: the next pass to end comes back here
-                cv.wait(lk, [&] { return (int)open < lanes || error != MI_OK || !have_held || launching; });
-                if (!have_held || launching || error != MI_OK) return MI_OK;
+                cv.wait(lk, [&] { return (int)open < lanes || error != MI_OK || held.empty() || launching; });
+                if (held.empty() || launching || error != MI_OK) return MI_OK;
             }
-            a = held;
-            st_a = held_stream;
-            have_held = false;
+            bs.swap(held);
+            st_in = held_stream;
             launching = true;
             open++;
         }
-        return launch(a, st_a, nullptr);
+        return launch(bs, st_in);
     }
 
     // The finisher starts pairing products as partials arrive; the PUBLISHER waits for them in order and hands the
@@ -198,7 +207,7 @@ struct Stream {
                 std::unique_lock<std::mutex> lk(mu);
                 auto ready = [&]() -> bool {
                     if (error != MI_OK) return true;
-                    const bool fin = finished && !have_held && !launching;  // every submitted batch has its pass
+                    const bool fin = finished && held.empty() && !launching;  // every submitted batch has its pass
                     const uint64_t want = fin && submitted - seq < (uint64_t)group ? submitted - seq : (uint64_t)group;
                     if (want == 0) return fin;
                     for (uint64_t k = 0; k < want; k++)
@@ -207,7 +216,7 @@ struct Stream {
                 };
                 cv.wait(lk, ready);
                 if (error != MI_OK) break;
-                const bool fin = finished && !have_held && !launching;
+                const bool fin = finished && held.empty() && !launching;
                 count = (size_t)(fin && submitted - seq < (uint64_t)group ? submitted - seq : (uint64_t)group);
                 if (count == 0) break;  // finished and drained
                 for (size_t k = 0; k < count; k++) {
@@ -289,6 +298,10 @@ int32_t mi_vs_stream_open(uint64_t ctx, int32_t fold_threads, int32_t products, 
     if (fold_threads < 1) fold_threads = 1;
     if (fold_threads > 8) fold_threads = 8;
     if (const char *e = getenv("MI_SNARK_STREAM_PAIR_AT")) s->pair_at = atoi(e);  // 0: one batch per pass, always
+    if (const char *e = getenv("MI_SNARK_STREAM_PER_PASS")) {
+        const int x = atoi(e);
+        if (x >= 1 && x <= MI_VS_MAX_BATCHES_PER_PASS) s->per_pass_max = x;
+    }
     if (exchange) s->pair_at = 0;  // multi-rank streams: every rank must take the same batches to the same collective
     Stream *raw = s.get();
     for (int i = 0; i < fold_threads; i++) s->folders.emplace_back([raw] { raw->folder_main(); });
@@ -305,35 +318,37 @@ int32_t mi_vs_stream_submit(uint64_t stream, const void *d_proofs, size_t n, con
     auto s = find(stream);
     if (!s || !d_proofs || !n || !d_randomizers128) return MI_ERR_BAD_ARGS;
     const Stream::Sub mine{d_proofs, n, d_randomizers128};
-    bool join;
+    bool join, ask;
     {
         std::lock_guard<std::mutex> lk(s->mu);
         if (s->finished) return MI_ERR_BAD_ARGS;
-        join = s->have_held && s->held_stream == hip_stream;
+        join = !s->held.empty() && s->held_stream == hip_stream && s->held.front().n == n;
+        ask = s->per_pass == 0;
     }
-    if (!join) {  // a pass is ordered behind ONE caller stream: a held batch whose inputs came on another stream runs alone
+    if (ask) {  // how many batches of this size one pass takes (asked once: the shape is the context's)
+        const int32_t pp = mi_vs_batches_per_pass(s->ctx, n);
+        std::lock_guard<std::mutex> lk(s->mu);
+        s->per_pass = pp < 1 ? 1 : (pp > s->per_pass_max ? s->per_pass_max : pp);
+    }
+    if (!join) {  // a pass is ordered behind ONE caller stream and sized for equal batches: what is held runs without this one
         const int32_t st = s->flush_held(true);
         if (st != MI_OK) return st;
     }
-    Stream::Sub first = mine;
+    std::vector<Stream::Sub> bs;
     void *first_stream = hip_stream;
-    bool with_second = false;
     {
         std::unique_lock<std::mutex> lk(s->mu);
-        s->cv.wait(lk, [&] { return !s->launching || s->error != MI_OK; });  // a folder is launching the held batch
+        s->cv.wait(lk, [&] { return !s->launching || s->error != MI_OK; });  // a folder is launching what was held
         if (s->error != MI_OK) return s->error;
-        if (s->have_held && s->held_stream == hip_stream) {  // the held batch gets its company
-            first = s->held;
-            first_stream = s->held_stream;
-            with_second = true;
-            s->have_held = false;
-        } else if (s->have_held) {
-            return MI_ERR_AGAIN;  // two submitting threads with different streams raced: the caller may simply retry
-        } else if (s->pair_at > 0 && s->can_pair && (int)s->open >= s->pair_at) {
-            s->held = mine;
+        if (!s->held.empty() && !(s->held_stream == hip_stream && s->held.front().n == n)) return MI_ERR_AGAIN;  // two submitters raced: retry
+        const bool hold = s->pair_at > 0 && s->per_pass > 1 && (int)s->open >= s->pair_at;
+        if (!s->held.empty() || hold) {
+            s->held.push_back(mine);
             s->held_stream = hip_stream;
-            s->have_held = true;
-            return MI_OK;  // runs with the next submission, or alone when a pass ends / the stream finishes / someone waits
+            if ((int)s->held.size() < s->per_pass) return MI_OK;  // runs when its pass is full, or when a pass ends / the stream finishes / someone waits
+            bs.swap(s->held);
+        } else {
+            bs.push_back(mine);
         }
         s->launching = true;
         s->cv.wait(lk, [&] { return (int)s->open < s->lanes || s->error != MI_OK; });
@@ -344,7 +359,7 @@ int32_t mi_vs_stream_submit(uint64_t stream, const void *d_proofs, size_t n, con
         }
         s->open++;  // reserved: a lane of ours is free
     }
-    return s->launch(first, first_stream, with_second ? &mine : nullptr);
+    return s->launch(bs, first_stream);
 }
 
 int32_t mi_vs_stream_finish(uint64_t stream) {

@@ -152,14 +152,26 @@ struct VsOut {
     uint8_t *alg_ok;
     uint32_t *circuit_of;
 };
-// A lane pass over TWO batches (mi_vs_accumulate_begin_pair): the blocks from first_block on serve the second one
-struct VsSecond {
-    const void *proofs = nullptr;  // null: single batch
-    const uint8_t *rand = nullptr;
-    size_t n = 0;
-    uint32_t first_block = 0;     // derive and transcript kernels both give a block 64 proofs
-    const uint32_t *chal = nullptr;  // Poseidon transcript: the second batch's challenges
-    VsOut o;
+// A lane pass over SEVERAL batches (mi_vs_accumulate_begin_multi): the blocks from b[k].first_block on serve further
+// batch k (block ranges ascend with k)
+#define VS_MORE (MI_VS_MAX_BATCHES_PER_PASS - 1)
+struct VsMore {
+    int count = 0;  // further batches in this pass (0: single)
+    struct Batch {
+        const void *proofs;
+        const uint8_t *rand;
+        size_t n;
+        uint32_t first_block;  // derive and transcript kernels both give a block 64 proofs
+        const uint32_t *chal;  // Poseidon transcript: this batch's challenges
+        VsOut o;
+    } b[VS_MORE];
+    // which further batch a block belongs to (-1: the first batch); wave-uniform
+    __device__ __forceinline__ int of_block(uint32_t block) const {
+        int k = -1;
+        for (int j = 0; j < count; j++)
+            if (block >= b[j].first_block) k = j;
+        return k;
+    }
 };
 #define VS_SLOTS MI_VS_MAX_TICKETS
 #define VS_ACC_DEPTH MI_VS_MAX_OPEN_ACCUMULATIONS  // accumulations (derive + both MSMs) that may be enqueued before the oldest is folded
@@ -203,7 +215,10 @@ struct VsKeyTable {
 struct VsAcc {  // an accumulation whose kernels are enqueued but whose host fold is still to come
     bool open = false;
     uint64_t handle = 0, ctx = 0;
-    size_t n = 0, n_b = 0;  // n_b: the second batch of a pair pass (0: single)
+    size_t n = 0;
+    int count = 1;                                   // batches in this pass
+    size_t ns[MI_VS_MAX_BATCHES_PER_PASS] = {};      // their sizes (ns[0] == n)
+    size_t nbs[MI_VS_MAX_BATCHES_PER_PASS][MI_VS_MAX_BOUNDS] = {};  // their degree-bound class sizes
     hipStream_t st = nullptr;
     MsmJob j[4];         // H side, tau-H side, class 0, class 1 (pair pass: j[0] carries both batches' two MSMs)
     size_t nb[MI_VS_MAX_BOUNDS] = {0, 0};
@@ -474,17 +489,18 @@ __global__ void __launch_bounds__(128) vs_derive_kernel(const void *__restrict__
                                                         const uint8_t *__restrict__ rand128,
                                                         const mi_vs_circuit_vk *__restrict__ circuits, size_t n_circuits,
                                                         const VsConsts *__restrict__ kc, VsOut o, const uint32_t *__restrict__ chal,
-                                                        VsSecond second) {
+                                                        VsMore more) {
     __shared__ uint32_t zb_lds[64][4];
     const int lane = threadIdx.x & 63, role = threadIdx.x >> 6;  // role 0: transcript + scalars, role 1: points + check
     uint32_t block = blockIdx.x;
-    if (second.proofs && block >= second.first_block) {  // block-uniform: this block belongs to the pass's second batch
-        block -= second.first_block;
-        proofs = second.proofs;
-        n = second.n;
-        rand128 = second.rand;
-        o = second.o;
-        chal = second.chal;
+    const int mb = more.of_block(block);
+    if (mb >= 0) {  // block-uniform: this block belongs to a further batch of the pass
+        block -= more.b[mb].first_block;
+        proofs = more.b[mb].proofs;
+        n = more.b[mb].n;
+        rand128 = more.b[mb].rand;
+        o = more.b[mb].o;
+        chal = more.b[mb].chal;
     }
     const size_t i = (size_t)block * 64 + lane;
     const bool live = i < n;
@@ -763,7 +779,7 @@ __device__ __forceinline__ Fq vs_fs_element(const mi_vs_proof *__restrict__ p, c
 __global__ void __launch_bounds__(4 * VS_FS_PROOFS_PER_BLOCK) vs_fs_poseidon_kernel(const void *__restrict__ proofs, size_t n,
                                                              const mi_vs_circuit_vk *__restrict__ circuits, size_t n_circuits,
                                                              const VsConsts *__restrict__ kc, const PoseidonConsts *__restrict__ pc,
-                                                             uint32_t *__restrict__ chal, VsSecond second) {
+                                                             uint32_t *__restrict__ chal, VsMore more) {
     // The permutation runs in the reduced-radix arithmetic of field28.hpp (14 signed 28-bit limbs: one instruction per
     // limb product, a dedicated squaring for the S-box chain, carry-free additions): the state never leaves it between
     // the first absorb and the last squeeze; constants and absorbed elements enter as they are stored.
@@ -771,11 +787,12 @@ __global__ void __launch_bounds__(4 * VS_FS_PROOFS_PER_BLOCK) vs_fs_poseidon_ker
     __shared__ Fq28 xt[VS_FS_PROOFS_PER_BLOCK][2][3];  // partial rounds: lane l's products mds[i][l] s_l, l = 1, 2
     const int t = threadIdx.x, ps = t >> 2, l = t & 3, lc = l < 3 ? l : 0;
     uint32_t block = blockIdx.x;
-    if (second.proofs && block >= second.first_block) {  // block-uniform: the pass's second batch
-        block -= second.first_block;
-        proofs = second.proofs;
-        n = second.n;
-        chal = const_cast<uint32_t *>(second.chal);
+    const int mb = more.of_block(block);
+    if (mb >= 0) {  // block-uniform: a further batch of the pass
+        block -= more.b[mb].first_block;
+        proofs = more.b[mb].proofs;
+        n = more.b[mb].n;
+        chal = const_cast<uint32_t *>(more.b[mb].chal);
     }
     const size_t i = (size_t)block * VS_FS_PROOFS_PER_BLOCK + ps;
     const mi_vs_proof *p = reinterpret_cast<const mi_vs_proof *>(reinterpret_cast<const uint32_t *>(proofs) + (i < n ? i : 0) * (size_t)kc->proof_words);
@@ -854,16 +871,17 @@ __global__ void __launch_bounds__(256) vs_merge_kernel(const Fr *__restrict__ vk
                                                        const Fr *__restrict__ h_scal, const uint32_t *__restrict__ circuit_of, size_t n,
                                                        const mi_vs_circuit_vk *__restrict__ circuits, size_t n_circuits,
                                                        const VsConsts *__restrict__ kc, G1Affine *__restrict__ pts1,
-                                                       uint32_t *__restrict__ sc1, VsSecond second) {
+                                                       uint32_t *__restrict__ sc1, VsMore more) {
     __shared__ uint32_t lds[8 * 256];
-    if (blockIdx.y) {  // the pass's second batch
-        vk_scal = second.o.vk_scal;
-        g_scal = second.o.g_scal;
-        h_scal = second.o.h_scal;
-        circuit_of = second.o.circuit_of;
-        n = second.n;
-        pts1 = second.o.pts1;
-        sc1 = second.o.sc1;
+    if (blockIdx.y) {  // a further batch of the pass
+        const VsMore::Batch &mb = more.b[blockIdx.y - 1];
+        vk_scal = mb.o.vk_scal;
+        g_scal = mb.o.g_scal;
+        h_scal = mb.o.h_scal;
+        circuit_of = mb.o.circuit_of;
+        n = mb.n;
+        pts1 = mb.o.pts1;
+        sc1 = mb.o.sc1;
     }
     const size_t slot = blockIdx.x, n_vk_slots = n_circuits * MI_VS_VK_COMMS;
     const int t = threadIdx.x;
@@ -1145,107 +1163,131 @@ static void vs_work_sizes(const VsKeys &v, size_t n, VsWork &w) {
     for (int c = 0; c < MI_VS_MAX_BOUNDS; c++) w.nb[c] = c < (int)hc.n_bounds ? n * hc.class_count[c] : 0;
 }
 static size_t vs_work_total(const VsWork &w) { return w.n1 + w.n2 + w.nb[0] + w.nb[1]; }
-// May two batches of these sizes share one lane pass?  One launch sequence carries at most four MSM problems (two per
-// batch: no degree-bound classes) and the small-MSM path must hold both.
-static bool vs_pair_ok(const VsKeys &v, size_t n_a, size_t n_b) {
-    if (v.shape.n_bounds) return false;
-    VsWork a, b;
-    vs_work_sizes(v, n_a, a);
-    vs_work_sizes(v, n_b, b);
-    return vs_work_total(a) + vs_work_total(b) <= msm_small_limit();
+// May these batches share one lane pass?  A launch sequence carries MSM_MAX_PROBLEMS problems (a batch brings two, plus
+// one per degree-bound class) and the small-MSM path must hold all of them.
+static bool vs_multi_ok(const VsKeys &v, const size_t *ns, int count) {
+    if (count < 1 || count > MI_VS_MAX_BATCHES_PER_PASS) return false;
+    if (count == 1) return true;
+    size_t total = 0;
+    int problems = 0;
+    for (int k = 0; k < count; k++) {
+        VsWork w;
+        vs_work_sizes(v, ns[k], w);
+        total += vs_work_total(w);
+        problems += 2 + (w.nb[0] ? 1 : 0) + (w.nb[1] ? 1 : 0);
+    }
+    return problems <= MSM_MAX_PROBLEMS && total <= msm_small_limit();
+}
+// the most batches of n proofs that one pass takes
+static int vs_max_per_pass(const VsKeys &v, size_t n) {
+    size_t ns[MI_VS_MAX_BATCHES_PER_PASS];
+    for (int k = 0; k < MI_VS_MAX_BATCHES_PER_PASS; k++) ns[k] = n;
+    int best = 1;
+    for (int c = 2; c <= MI_VS_MAX_BATCHES_PER_PASS; c++)
+        if (vs_multi_ok(v, ns, c)) best = c;
+    return best;
 }
 
-// derive (+ merge) of one batch, or of two in one launch each (second: d_proofs_b, n_b, d_rand_b -> *w_b): the second
-// batch's operands follow the first's in the lane's operand arrays, so both batches' MSMs are one launch sequence
-static VsWork vs_run_derive(Context &cx, VsKeys &v, const void *d_proofs, size_t n, const void *d_rand, hipStream_t st,
-                            int lane, const void *d_proofs_b = nullptr, size_t n_b = 0, const void *d_rand_b = nullptr,
-                            VsWork *w_b = nullptr) {
-    VsWork w, wb;
+// derive (+ merge) of the pass's batches, one launch each for all of them: the further batches' operands follow the
+// first's in the lane's operand arrays, so all their MSMs are one launch sequence.  ws[k] describes batch k.
+static void vs_run_derive(Context &cx, VsKeys &v, const void *const *d_proofs, const size_t *ns, const void *const *d_rand, int count,
+                          hipStream_t st, int lane, VsWork *ws) {
     const VsConsts &hc = v.shape;
-    const bool pair = d_proofs_b != nullptr;
-    vs_work_sizes(v, n, w);
-    vs_work_sizes(v, pair ? n_b : n, wb);
-    const size_t total = vs_work_total(w), total_b = vs_work_total(wb);
-    // every operand array exists once per lane: several batches are in flight on different streams
+    // every operand array exists once per lane: several passes are in flight on different streams
     char nm[32];
     auto W = [&](const char *name) {
         snprintf(nm, sizeof nm, "vs%d.%s", lane, name);
         return nm;
     };
-    // one array for all MSMs' operands (H side, tau-H side, then the class accumulators): they run as ONE launch
-    // sequence when they fit the small-MSM path.  Always with room for a second batch (of the same size when there is
-    // none): a pair pass must not regrow the workspaces of a lane that single batches primed.
-    G1Affine *pts = (G1Affine *)cx.buf(W("pts"), sizeof(G1Affine) * (total + total_b));
-    uint32_t *sc = (uint32_t *)cx.buf(W("sc"), 32 * (total + total_b));
-    auto place = [&](VsWork &x, G1Affine *p0, uint32_t *s0) {
+    size_t total = 0, cap = 0, n_all = 0;
+    for (int k = 0; k < count; k++) {
+        vs_work_sizes(v, ns[k], ws[k]);
+        total += vs_work_total(ws[k]);
+        if (ns[k] > cap) cap = ns[k];
+        n_all += ns[k];
+    }
+    // one array for all MSMs' operands (per batch: H side, tau-H side, then the class accumulators): they run as ONE
+    // launch sequence when they fit the small-MSM path
+    G1Affine *pts = (G1Affine *)cx.buf(W("pts"), sizeof(G1Affine) * total);
+    uint32_t *sc = (uint32_t *)cx.buf(W("sc"), 32 * total);
+    size_t at = 0;
+    static const char *const suffix[MI_VS_MAX_BATCHES_PER_PASS] = {"", ".b", ".c", ".d"};
+    for (int k = 0; k < count; k++) {
+        VsWork &x = ws[k];
         VsOut &o = x.o;
-        o.pts1 = p0;
-        o.sc1 = s0;
+        o.pts1 = pts + at;
+        o.sc1 = sc + 8 * at;
         o.pts2 = o.pts1 + x.n1;
         o.sc2 = o.sc1 + 8 * x.n1;
         o.ptsb[0] = o.pts2 + x.n2;
         o.scb[0] = o.sc2 + 8 * x.n2;
         o.ptsb[1] = o.ptsb[0] + x.nb[0];
         o.scb[1] = o.scb[0] + 8 * x.nb[0];
-    };
-    place(w, pts, sc);
-    place(wb, pts + total, sc + 8 * total);
-    const size_t cap = n > n_b ? n : n_b;  // the per-proof arrays of both halves share a size: no regrowth either way
-    auto per_proof = [&](VsWork &x, const char *suffix) {
-        VsOut &o = x.o;
+        at += vs_work_total(x);
         char nn[24];
-        snprintf(nn, sizeof nn, "vk_scal%s", suffix);
+        snprintf(nn, sizeof nn, "vk_scal%s", suffix[k]);
         o.vk_scal = (Fr *)cx.buf(W(nn), sizeof(Fr) * cap * MI_VS_VK_COMMS);
-        snprintf(nn, sizeof nn, "g_scal%s", suffix);
+        snprintf(nn, sizeof nn, "g_scal%s", suffix[k]);
         o.g_scal = (Fr *)cx.buf(W(nn), sizeof(Fr) * 2 * cap);
         o.h_scal = o.g_scal + cap;
-        snprintf(nn, sizeof nn, "alg_ok%s", suffix);
+        snprintf(nn, sizeof nn, "alg_ok%s", suffix[k]);
         o.alg_ok = (uint8_t *)cx.buf(W(nn), cap);
-        snprintf(nn, sizeof nn, "circuit_of%s", suffix);
+        snprintf(nn, sizeof nn, "circuit_of%s", suffix[k]);
         o.circuit_of = (uint32_t *)cx.buf(W(nn), 4 * cap);
-    };
-    per_proof(w, "");
-    per_proof(wb, ".b");
-    VsOut &o = w.o;
-    VsSecond second;
-    if (pair) {
-        second.proofs = d_proofs_b;
-        second.rand = (const uint8_t *)d_rand_b;
-        second.n = n_b;
-        second.first_block = (uint32_t)cdiv(n, 64);
-        second.o = wb.o;
     }
-    const unsigned derive_blocks = (unsigned)(cdiv(n, 64) + (pair ? cdiv(n_b, 64) : 0));
+    VsOut &o = ws[0].o;
+    VsMore more;
+    more.count = count - 1;
+    unsigned derive_blocks = (unsigned)cdiv(ns[0], 64);
+    for (int k = 1; k < count; k++) {
+        VsMore::Batch &mb = more.b[k - 1];
+        mb.proofs = d_proofs[k];
+        mb.rand = (const uint8_t *)d_rand[k];
+        mb.n = ns[k];
+        mb.first_block = derive_blocks;
+        mb.chal = nullptr;
+        mb.o = ws[k].o;
+        derive_blocks += (unsigned)cdiv(ns[k], 64);
+    }
+    const size_t n = ns[0];
     const uint32_t *chal = nullptr;
     if (v.fs_poseidon) {
-        uint32_t *ch = (uint32_t *)cx.buf(W("chal"), 48 * (n + (pair ? n_b : n)));  // both halves of a pair pass
-        if (pair) second.chal = ch + 12 * n;
+        uint32_t *ch = (uint32_t *)cx.buf(W("chal"), 48 * n_all);  // every batch of the pass
+        size_t off = n;
+        for (int k = 1; k < count; k++) {
+            more.b[k - 1].chal = ch + 12 * off;
+            off += ns[k];
+        }
         const PoseidonConsts *pc = poseidon_consts(cx, st);
-        cx.prof.begin("vs_fs_poseidon", st, n);
+        cx.prof.begin("vs_fs_poseidon", st, n_all);
         // 64 proofs (4 waves, one per SIMD) per block, and a block asks for more than half a CU's LDS: the transcript
         // kernels of the batches in flight then never share a CU.  Their loop body (~70 KB of unrolled products) is
         // larger than the instruction cache; waves of different batches on one CU sit at different places in it and
         // fetch against each other (4 concurrent kernels each ran 2.2x slower before).
         static const size_t fs_pad = getenv("MI_SNARK_FS_LDS_PAD") ? (size_t)atoi(getenv("MI_SNARK_FS_LDS_PAD")) : 50 * 1024;
-        static_assert(VS_FS_PROOFS_PER_BLOCK == 64, "VsSecond::first_block is shared with the derive kernel");
-        hipLaunchKernelGGL(vs_fs_poseidon_kernel, dim3(derive_blocks), dim3(4 * VS_FS_PROOFS_PER_BLOCK), fs_pad, st, d_proofs, n,
-                           (const mi_vs_circuit_vk *)v.circuits.p, v.n_circuits, (const VsConsts *)v.consts.p, pc, ch, second);
+        static_assert(VS_FS_PROOFS_PER_BLOCK == 64, "VsMore::first_block is shared with the derive kernel");
+        hipLaunchKernelGGL(vs_fs_poseidon_kernel, dim3(derive_blocks), dim3(4 * VS_FS_PROOFS_PER_BLOCK), fs_pad, st, d_proofs[0], n,
+                           (const mi_vs_circuit_vk *)v.circuits.p, v.n_circuits, (const VsConsts *)v.consts.p, pc, ch, more);
         cx.prof.end("vs_fs_poseidon", st);
         chal = ch;
     }
-    cx.prof.begin("vs_derive", st, n + (pair ? n_b : 0));
+    cx.prof.begin("vs_derive", st, n_all);
     if (v.fs_poseidon)
-        hipLaunchKernelGGL(vs_derive_kernel<1>, dim3(derive_blocks), dim3(128), 0, st, d_proofs, n, (const uint8_t *)d_rand,
-                           (const mi_vs_circuit_vk *)v.circuits.p, v.n_circuits, (const VsConsts *)v.consts.p, o, chal, second);
+        hipLaunchKernelGGL(vs_derive_kernel<1>, dim3(derive_blocks), dim3(128), 0, st, d_proofs[0], n, (const uint8_t *)d_rand[0],
+                           (const mi_vs_circuit_vk *)v.circuits.p, v.n_circuits, (const VsConsts *)v.consts.p, o, chal, more);
     else
-        hipLaunchKernelGGL(vs_derive_kernel<0>, dim3(derive_blocks), dim3(128), 0, st, d_proofs, n, (const uint8_t *)d_rand,
-                           (const mi_vs_circuit_vk *)v.circuits.p, v.n_circuits, (const VsConsts *)v.consts.p, o, chal, second);
+        hipLaunchKernelGGL(vs_derive_kernel<0>, dim3(derive_blocks), dim3(128), 0, st, d_proofs[0], n, (const uint8_t *)d_rand[0],
+                           (const mi_vs_circuit_vk *)v.circuits.p, v.n_circuits, (const VsConsts *)v.consts.p, o, chal, more);
     cx.prof.end("vs_derive", st);
-    hipLaunchKernelGGL(vs_merge_kernel, dim3((unsigned)(v.n_circuits * MI_VS_VK_COMMS + 1 + hc.hiding), pair ? 2 : 1), dim3(256), 0, st,
+    hipLaunchKernelGGL(vs_merge_kernel, dim3((unsigned)(v.n_circuits * MI_VS_VK_COMMS + 1 + hc.hiding), (unsigned)count), dim3(256), 0, st,
                        o.vk_scal, o.g_scal, o.h_scal, o.circuit_of, n, (const mi_vs_circuit_vk *)v.circuits.p, v.n_circuits,
-                       (const VsConsts *)v.consts.p, o.pts1, o.sc1, second);
+                       (const VsConsts *)v.consts.p, o.pts1, o.sc1, more);
     MI_HIP(hipGetLastError());
-    if (w_b) *w_b = wb;
+}
+// one batch
+static VsWork vs_run_derive(Context &cx, VsKeys &v, const void *d_proofs, size_t n, const void *d_rand, hipStream_t st, int lane) {
+    VsWork w;
+    vs_run_derive(cx, v, &d_proofs, &n, &d_rand, 1, st, lane, &w);
     return w;
 }
 
@@ -1284,11 +1326,27 @@ static bool vs_enqueue_msms(Context &cx, const VsWork &w, hipStream_t st, int la
     return false;
 }
 
-// both batches of a pair pass: (H side, tau-H side) of the first, then of the second -- four problems of one launch sequence
-static void vs_enqueue_msms_pair(Context &cx, const VsWork &a, const VsWork &b, hipStream_t st, int lane, MsmJob j[4], int force_c) {
-    const size_t ta = vs_work_total(a), tb = vs_work_total(b);
-    if (a.o.pts1 + ta != b.o.pts1 || a.nb[0] || a.nb[1] || b.nb[0] || b.nb[1]) throw HipError{hipErrorInvalidValue, "pair pass layout", __LINE__};
-    msm_enqueue(cx, a.o.pts1, a.o.sc1, ta + tb, st, 254, 8 + 4 * lane, &j[0], force_c, lane, MsmSplits(a.n1, ta, ta + b.n1));
+// all batches of a pass: per batch (H side, tau-H side, class accumulators) -- every one a problem of one launch sequence
+static void vs_enqueue_msms_multi(Context &cx, const VsWork *ws, int count, hipStream_t st, int lane, MsmJob j[4], int force_c) {
+    MsmSplits sp;
+    int np = 0;
+    size_t at = 0;
+    auto problem = [&](size_t len) {
+        if (np > 0) {
+            if (np - 1 >= MSM_MAX_PROBLEMS - 1) throw HipError{hipErrorInvalidValue, "pass carries too many MSMs", __LINE__};
+            sp.at[np - 1] = at;
+        }
+        at += len;
+        np++;
+    };
+    for (int k = 0; k < count; k++) {
+        if (ws[0].o.pts1 + at != ws[k].o.pts1) throw HipError{hipErrorInvalidValue, "pass operand layout", __LINE__};
+        problem(ws[k].n1);
+        problem(ws[k].n2);
+        for (int c = 0; c < MI_VS_MAX_BOUNDS; c++)
+            if (ws[k].nb[c]) problem(ws[k].nb[c]);
+    }
+    msm_enqueue(cx, ws[0].o.pts1, ws[0].o.sc1, at, st, 254, 8 + 4 * lane, &j[0], force_c, lane, sp);
 }
 
 // accumulate one shard: partial sums + algebraic failures (+ optional per-proof alg flags to host)
@@ -1298,14 +1356,25 @@ static void vs_enqueue_msms_pair(Context &cx, const VsWork &a, const VsWork &b, 
 // WAITS for one (the device lock is released meanwhile): a synchronous verify beside a saturated stream is late, not
 // refused.
 // msm = false: derive only (the caller wants the lane's workspaces for the per-proof fallback, not the aggregate)
-// d_proofs_b: a second batch for the same pass (vs_pair_ok shapes only): its own operands, accumulators and partial
+// more: further batches for the same pass (vs_multi_ok shapes only): each has its own operands, accumulators and partial
+struct VsBatches {
+    int count = 1;
+    const void *proofs[MI_VS_MAX_BATCHES_PER_PASS] = {};
+    const void *rand[MI_VS_MAX_BATCHES_PER_PASS] = {};
+    size_t n[MI_VS_MAX_BATCHES_PER_PASS] = {};
+};
 static int32_t vs_accumulate_begin_impl(Context &cx, const VsCtx &vc, const void *d_proofs, size_t n, const void *d_rand,
                                         hipStream_t st, uint64_t *handle, VsWork *work_out, bool msm = true,
-                                        const void *d_proofs_b = nullptr, size_t n_b = 0, const void *d_rand_b = nullptr) {
+                                        const VsBatches *all = nullptr) {
     VsKeys &v = vs_keys(cx, vc);
     VsPipe &pp = vs_pipe(cx);
-    const bool pair = d_proofs_b != nullptr;
-    if (pair && (!msm || !vs_pair_ok(v, n, n_b))) return MI_ERR_BAD_ARGS;
+    VsBatches one;
+    one.proofs[0] = d_proofs;
+    one.rand[0] = d_rand;
+    one.n[0] = n;
+    const VsBatches &bt = all ? *all : one;
+    const bool multi = bt.count > 1;
+    if (multi && (!msm || !vs_multi_ok(v, bt.n, bt.count))) return MI_ERR_BAD_ARGS;
     int par = -1;
     for (;;) {
         for (int p = 0; p < pp.lanes; p++)
@@ -1328,18 +1397,24 @@ static int32_t vs_accumulate_begin_impl(Context &cx, const VsCtx &vc, const void
             hipStream_t sp = pp.acc_st[p];
             MI_HIP(hipEventRecord(pp.acc_ev[p], st));
             MI_HIP(hipStreamWaitEvent(sp, pp.acc_ev[p], 0));
-            // a shape that may run pair passes is primed with one (the batch twice): the larger workspaces exist
-            // before a stream under load starts pairing
-            const bool pp_pair = vs_pair_ok(v, n, n);
-            VsWork w2;
-            VsWork w = pp_pair ? vs_run_derive(cx, v, d_proofs, n, d_rand, sp, p, d_proofs, n, d_rand, &w2)
-                               : vs_run_derive(cx, v, d_proofs, n, d_rand, sp, p);
+            // a shape that may run passes of several batches is primed with the largest (the batch repeated): the
+            // larger workspaces exist before a stream under load starts sharing passes
+            const int per_pass = vs_max_per_pass(v, n);
+            VsBatches rep;
+            rep.count = per_pass;
+            for (int k = 0; k < per_pass; k++) {
+                rep.proofs[k] = d_proofs;
+                rep.rand[k] = d_rand;
+                rep.n[k] = n;
+            }
+            VsWork ws[MI_VS_MAX_BATCHES_PER_PASS];
+            vs_run_derive(cx, v, rep.proofs, rep.n, rep.rand, per_pass, sp, p, ws);
             char nm[32];
             snprintf(nm, sizeof nm, "vs.alg_pin%d", p);
-            (void)cx.pin_named(nm, 2 * n);
+            (void)cx.pin_named(nm, MI_VS_MAX_BATCHES_PER_PASS * n);
             MsmJob jj[4];
-            if (pp_pair) vs_enqueue_msms_pair(cx, w, w2, sp, p, jj, 0);
-            else (void)vs_enqueue_msms(cx, w, sp, p, jj, 0);
+            if (per_pass > 1) vs_enqueue_msms_multi(cx, ws, per_pass, sp, p, jj, 0);
+            else (void)vs_enqueue_msms(cx, ws[0], sp, p, jj, 0);
         }
         for (int p = 0; p < pp.lanes; p++)
             if (!pp.acc[p].open) MI_HIP(hipStreamSynchronize(pp.acc_st[p]));
@@ -1354,25 +1429,34 @@ static int32_t vs_accumulate_begin_impl(Context &cx, const VsCtx &vc, const void
         MI_HIP(hipEventRecord(pp.acc_ev[par], st));
         MI_HIP(hipStreamWaitEvent(sa, pp.acc_ev[par], 0));
     }
-    VsWork w, w2;
+    VsWork ws[MI_VS_MAX_BATCHES_PER_PASS];
     {
         HostSpan hs("begin.derive");
-        w = pair ? vs_run_derive(cx, v, d_proofs, n, d_rand, sa, par, d_proofs_b, n_b, d_rand_b, &w2)
-                 : vs_run_derive(cx, v, d_proofs, n, d_rand, sa, par);
+        vs_run_derive(cx, v, bt.proofs, bt.n, bt.rand, bt.count, sa, par, ws);
+    }
+    const VsWork &w = ws[0];
+    size_t n_max = 0, n_all = 0;
+    for (int k = 0; k < bt.count; k++) {
+        if (bt.n[k] > n_max) n_max = bt.n[k];
+        n_all += bt.n[k];
     }
     char nm[32];
     snprintf(nm, sizeof nm, "vs.alg_pin%d", par);
-    a.h_alg = (uint8_t *)cx.pin_named(nm, 2 * (n > n_b ? n : n_b));  // both halves of a pair pass; the same size for a single batch
+    const size_t pin_want = MI_VS_MAX_BATCHES_PER_PASS * n_max;  // the same size whatever the pass carries: no regrowth in a stream
+    a.h_alg = (uint8_t *)cx.pin_named(nm, pin_want > n_all ? pin_want : n_all);
     if (msm) {
         {
             HostSpan hs("begin.alg_copy");
-            MI_HIP(hipMemcpyAsync(a.h_alg, w.o.alg_ok, n, hipMemcpyDeviceToHost, sa));  // ahead of the MSMs: their done-event covers it
-            if (pair) MI_HIP(hipMemcpyAsync(a.h_alg + n, w2.o.alg_ok, n_b, hipMemcpyDeviceToHost, sa));
+            size_t off = 0;
+            for (int k = 0; k < bt.count; k++) {  // ahead of the MSMs: their done-event covers the copies
+                MI_HIP(hipMemcpyAsync(a.h_alg + off, ws[k].o.alg_ok, bt.n[k], hipMemcpyDeviceToHost, sa));
+                off += bt.n[k];
+            }
         }
         HostSpan hs_msm("begin.msm_enqueue");
         static const int vs_c = getenv("MI_SNARK_VS_C") ? atoi(getenv("MI_SNARK_VS_C")) : 0;  // window width override (experiments)
-        if (pair) {
-            vs_enqueue_msms_pair(cx, w, w2, sa, par, a.j, vs_c);
+        if (multi) {
+            vs_enqueue_msms_multi(cx, ws, bt.count, sa, par, a.j, vs_c);
             a.fused = true;
         } else {
             a.fused = vs_enqueue_msms(cx, w, sa, par, a.j, vs_c);
@@ -1381,37 +1465,53 @@ static int32_t vs_accumulate_begin_impl(Context &cx, const VsCtx &vc, const void
     a.nb[0] = w.nb[0];
     a.nb[1] = w.nb[1];
     a.n = n;
-    a.n_b = pair ? n_b : 0;
+    a.count = bt.count;
+    for (int k = 0; k < bt.count; k++) {
+        a.ns[k] = bt.n[k];
+        a.nbs[k][0] = ws[k].nb[0];
+        a.nbs[k][1] = ws[k].nb[1];
+    }
     a.st = sa;
     a.handle = hd;
     a.ctx = vc.id;
     a.open = true;
-    if (work_out) *work_out = w;
+    if (work_out) *work_out = ws[0];
     *handle = hd;
     return MI_OK;
 }
 // keep_lane: the caller goes on using the lane's workspaces (per-proof fallback) and releases it itself
-// out_b: the second batch's partial (a pair pass has to be ended with one, a single pass without)
-static int32_t vs_accumulate_end_impl(Context &cx, uint64_t handle, mi_vs_partial *out, bool keep_lane = false,
-                                      mi_vs_partial *out_b = nullptr) {
+// count: the batches the caller expects the pass to hold (out[0 .. count)); a pass has to be ended with its own count
+static int32_t vs_accumulate_end_impl(Context &cx, uint64_t handle, mi_vs_partial *out, bool keep_lane = false, int count = 1) {
     if ((handle & 0xff) >= VS_ACC_DEPTH || (int)((handle >> 8) & 0xff) != cx.index) return MI_ERR_BAD_ARGS;
     VsAcc &a = vs_pipe(cx).acc[handle & 0xff];
     if (!a.open || a.handle != handle || a.closing) return MI_ERR_BAD_ARGS;
-    if ((a.n_b != 0) != (out_b != nullptr)) return MI_ERR_BAD_ARGS;
+    if (a.count != count) return MI_ERR_BAD_ARGS;
     a.closing = true;  // the lane stays taken until the fold is done; the device lock is not held meanwhile
     // host folds (~250 doublings + ~250 additions for 254-bit scalars, half that for the randomizer side), each
     // split over two pool threads
-    uint64_t fails = 0, fails_b = 0;
+    uint64_t fails = 0, fails_more[MI_VS_MAX_BATCHES_PER_PASS] = {};
     try {
         Unlocked unlocked;
         const G1Jac inf = G1Jac{Fq::one(), Fq::one(), Fq::zero()};
         memcpy(&out->bound[0], &inf, sizeof inf);
         memcpy(&out->bound[1], &inf, sizeof inf);
-        if (out_b) {
-            memcpy(&out_b->bound[0], &inf, sizeof inf);
-            memcpy(&out_b->bound[1], &inf, sizeof inf);
-            msm_finish(cx, &a.j[0], a.st, &out->total_c, &out->total_w, &out_b->total_c, &out_b->total_w);
-            for (size_t i = 0; i < a.n_b; i++) fails_b += a.h_alg[a.n + i] ? 0 : 1;
+        if (count > 1) {
+            mi_g1_jac *outs[MSM_MAX_PROBLEMS] = {};
+            int np = 0;
+            size_t off = 0;
+            for (int k = 0; k < count; k++) {
+                memcpy(&out[k].bound[0], &inf, sizeof inf);
+                memcpy(&out[k].bound[1], &inf, sizeof inf);
+                outs[np++] = &out[k].total_c;
+                outs[np++] = &out[k].total_w;
+                for (int c = 0; c < MI_VS_MAX_BOUNDS; c++)
+                    if (a.nbs[k][c]) outs[np++] = &out[k].bound[c];
+            }
+            msm_finish_all(cx, &a.j[0], a.st, outs, np);  // waits for the pass's event: the flags below are there after it
+            for (int k = 0; k < count; k++) {
+                for (size_t i = 0; i < a.ns[k]; i++) fails_more[k] += a.h_alg[off + i] ? 0 : 1;
+                off += a.ns[k];
+            }
         } else if (a.fused) {
             msm_finish(cx, &a.j[0], a.st, &out->total_c, &out->total_w, a.nb[0] ? &out->bound[0] : nullptr,
                        a.nb[1] ? &out->bound[a.nb[0] ? 1 : 0] : nullptr);
@@ -1425,17 +1525,19 @@ static int32_t vs_accumulate_end_impl(Context &cx, uint64_t handle, mi_vs_partia
                 if (a.nb[c]) msm_finish(cx, &a.j[2 + c], a.st, &out->bound[c]);
             msm_finish(cx, &a.j[0], a.st, &out->total_c);
         }
-        for (size_t i = 0; i < a.n; i++) fails += a.h_alg[i] ? 0 : 1;
+        if (count == 1)
+            for (size_t i = 0; i < a.n; i++) fails += a.h_alg[i] ? 0 : 1;
     } catch (...) {
         vs_release_lane(cx, a);
         throw;
     }
     out->n_proofs = a.n;
     out->n_alg_fail = fails;
-    if (out_b) {
-        out_b->n_proofs = a.n_b;
-        out_b->n_alg_fail = fails_b;
-    }
+    if (count > 1)
+        for (int k = 0; k < count; k++) {
+            out[k].n_proofs = a.ns[k];
+            out[k].n_alg_fail = fails_more[k];
+        }
     if (keep_lane) a.closing = false;  // still open: nobody else can take it
     else vs_release_lane(cx, a);
     return MI_OK;
@@ -1450,15 +1552,27 @@ int32_t vs_accumulate_end(Context &cx, uint64_t id, uint64_t handle, mi_vs_parti
     if (!vs_find(id)) return MI_ERR_BAD_ARGS;
     return vs_accumulate_end_impl(cx, handle, out);
 }
-int32_t vs_accumulate_begin_pair(Context &cx, uint64_t id, const void *d_proofs_a, size_t n_a, const void *d_rand_a,
-                                 const void *d_proofs_b, size_t n_b, const void *d_rand_b, hipStream_t st, uint64_t *handle) {
+int32_t vs_accumulate_begin_multi(Context &cx, uint64_t id, int count, const void *const *d_proofs, const size_t *n,
+                                  const void *const *d_rand, hipStream_t st, uint64_t *handle) {
     std::shared_ptr<VsCtx> v = vs_find(id);
-    if (!v) return MI_ERR_BAD_ARGS;
-    return vs_accumulate_begin_impl(cx, *v, d_proofs_a, n_a, d_rand_a, st, handle, nullptr, true, d_proofs_b, n_b, d_rand_b);
+    if (!v || count < 1 || count > MI_VS_MAX_BATCHES_PER_PASS) return MI_ERR_BAD_ARGS;
+    VsBatches bt;
+    bt.count = count;
+    for (int k = 0; k < count; k++) {
+        bt.proofs[k] = d_proofs[k];
+        bt.rand[k] = d_rand[k];
+        bt.n[k] = n[k];
+    }
+    return vs_accumulate_begin_impl(cx, *v, d_proofs[0], n[0], d_rand[0], st, handle, nullptr, true, &bt);
 }
-int32_t vs_accumulate_end_pair(Context &cx, uint64_t id, uint64_t handle, mi_vs_partial *out2) {
-    if (!vs_find(id)) return MI_ERR_BAD_ARGS;
-    return vs_accumulate_end_impl(cx, handle, &out2[0], false, &out2[1]);
+int32_t vs_accumulate_end_multi(Context &cx, uint64_t id, uint64_t handle, mi_vs_partial *outs, int count) {
+    if (!vs_find(id) || count < 1 || count > MI_VS_MAX_BATCHES_PER_PASS) return MI_ERR_BAD_ARGS;
+    return vs_accumulate_end_impl(cx, handle, outs, false, count);
+}
+int32_t vs_batches_per_pass(Context &cx, uint64_t id, size_t n) {
+    std::shared_ptr<VsCtx> v = vs_find(id);
+    if (!v || !n) return MI_ERR_BAD_ARGS;
+    return vs_max_per_pass(vs_keys(cx, *v), n);
 }
 int32_t vs_accumulate_device(Context &cx, uint64_t id, const void *d_proofs, size_t n, const void *d_rand,
                              mi_vs_partial *out, hipStream_t st) {

@@ -576,3 +576,40 @@ def test_stream_pairs_batches_under_load(orc, mi, monkeypatch):
             assert lib.mi_vs_stream_close(sid) == L.MI_OK
     finally:
         v.close()
+
+
+def test_multi_batch_passes_bit_exact(orc, mi):
+    """mi_vs_accumulate_begin_multi: three and four batches in one lane pass (eight MSM problems in one launch
+    sequence) give the partials of single passes byte for byte, in order, for ragged sizes and a batch with an invalid
+    proof, under both transcripts; the count must match at _end; mi_vs_batches_per_pass"""
+    import torch
+    from snarkos_amd.lib import MiError
+    a = orc.VSBatch(0x9A21, 40, 3, 0)
+    pa, ra = torch.from_numpy(a.proofs).cuda(), torch.from_numpy(a.randomizers).cuda()
+    batches = [(pa, ra)]
+    for k, nb in enumerate((33, 40, 7)):
+        p_np = a.proofs[: nb * 2256].copy()
+        if k == 1:
+            p_np[3 * 2256 + 16 + 512 + 864 + 32 * 9] ^= 1
+        r_np = np.ascontiguousarray(np.roll(a.randomizers, 32 * (k + 1))[: nb * 32])
+        batches.append((torch.from_numpy(p_np).cuda(), torch.from_numpy(r_np).cuda()))
+    for transcript in ("sha256", "poseidon"):
+        v = mi.VarunaShaped(a.vk, a.circuits, transcript=transcript)
+        try:
+            assert v.batches_per_pass(40) == 4 and v.batches_per_pass(1024) == 4 and v.batches_per_pass(2000) == 2 and v.batches_per_pass(5000) == 1
+            singles = [v.accumulate(p, r) for p, r in batches]
+            for sel in ([0, 1, 2], [3, 2, 1, 0], [1, 1, 1, 1], [2, 0]):
+                got = v.accumulate_end_multi(v.accumulate_begin_multi([batches[i] for i in sel]), len(sel))
+                for g, i in zip(got, sel):
+                    assert (g == singles[i]).all(), (transcript, sel, i)
+            h = v.accumulate_begin_multi(batches[:3])
+            with pytest.raises(MiError):
+                v.accumulate_end_multi(h, 2)
+            with pytest.raises(MiError):
+                v.accumulate_end(h)
+            got = v.accumulate_end_multi(h, 3)
+            assert all((g == s).all() for g, s in zip(got, singles))
+            if transcript == "sha256":
+                assert v.finalize([singles[0]]) and not v.finalize([singles[2]])
+        finally:
+            v.close()

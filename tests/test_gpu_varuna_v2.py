@@ -241,3 +241,31 @@ def test_instances_per_proof(orc, mi, transcript):
             v.close()
     finally:
         orc.lib().orc_vs_set_transcript(orc.FS_SHA256)
+
+
+def test_v2_batches_share_a_pass(orc, mi, monkeypatch):
+    """a shape with two degree-bound classes brings four MSMs per batch: two such batches share one lane pass (eight
+    problems), three do not; partials byte for byte those of single passes; the stream pairs them under load"""
+    import torch
+    from snarkos_amd.lib import MiError
+    b = orc.VS2Batch(0x20C1, 44, 3, 0)
+    v = _ctx(mi, b)
+    try:
+        p, r = torch.from_numpy(b.proofs).cuda(), torch.from_numpy(b.randomizers).cuda()
+        p2_np = b.proofs[: 30 * P2].copy(); p2_np[9 * P2 + 16 + 512 + 864 + 32 * 9] ^= 1
+        p2, r2 = torch.from_numpy(p2_np).cuda(), torch.from_numpy(np.ascontiguousarray(b.randomizers[14 * 48:44 * 48])).cuda()
+        s1, s2 = v.accumulate(p, r), v.accumulate(p2, r2)
+        assert (np.frombuffer(s1.tobytes(), dtype=np.uint8) == orc.vs_partial_from_oracle(b, 8)).all()
+        assert v.batches_per_pass(44) == 2
+        for first, second, w1, w2 in ((p, p2, s1, s2), (p2, p, s2, s1)):
+            rr1, rr2 = (r, r2) if first is p else (r2, r)
+            got = v.accumulate_end_multi(v.accumulate_begin_multi([(first, rr1), (second, rr2)]), 2)
+            assert (got[0] == w1).all() and (got[1] == w2).all()
+        with pytest.raises(MiError):
+            v.accumulate_begin_multi([(p, r)] * 3)
+        assert v.finalize([s1]) and not v.finalize([s2])
+        monkeypatch.setenv("MI_SNARK_STREAM_PAIR_AT", "1")
+        seq = [(p, r), (p, r), (p2, r2), (p, r), (p, r), (p2, r2), (p, r)]
+        assert list(v.verify_stream(iter(seq))) == [q is p for q, _ in seq]
+    finally:
+        v.close()
