@@ -628,8 +628,9 @@ __global__ void __launch_bounds__(64) msm_bit_sums_queue_kernel(const G1Xyzz *__
 // batches; 14 runs with the one-wave kernel (and every run before this kernel existed) were clean, and so were 17
 // runs in which this kernel served pair passes.  Its index arithmetic, its wave-level queue (also tried with
 // workgroup-scope fences) and its generated code (no scratch, no flat accesses, pointers live where they are used)
-// were checked without finding an out-of-range access; what it does differently is hold 60 KB of LDS per block with
-// two blocks per compute unit.  Unexplained, therefore off.  tools/fault_hunt.sh is the bounded reproduction.
+// were checked without finding an out-of-range access.  The LDS footprint alone is not it: the one-wave kernel asking
+// for 60 KB of LDS it never touches (MI_SNARK_BITSUM_LDS_PAD) ran 16 benches clean.  Unexplained, therefore off.
+// tools/fault_hunt.sh is the bounded reproduction.
 #define BS_GROUPS 4
 __global__ void __launch_bounds__(64 * BS_GROUPS) msm_bit_sums_block_kernel(const G1Xyzz *__restrict__ chunk_partial,
                                                                             const uint32_t *__restrict__ chunk_off,
@@ -1052,8 +1053,11 @@ void msm_enqueue(Context &cx, const G1Affine *d_points, const uint32_t *d_scalar
         job->h = (G1Xyzz *)cx.pin_named(pn, sizeof(G1Xyzz) * all_groups);
         cx.prof.begin("msm_bitsums", st, n);
         static const int lpg = getenv("MI_SNARK_BITSUM_LPG") ? atoi(getenv("MI_SNARK_BITSUM_LPG")) : 0;  // 0: queue-balanced (default)
+        // MI_SNARK_BITSUM_LDS_PAD: dynamic LDS the one-wave kernel asks for and never touches (an experiment on the
+        // fault described at msm_bit_sums_block_kernel: does the LDS footprint alone bring it about?)
+        static const size_t lds_pad = getenv("MI_SNARK_BITSUM_LDS_PAD") ? (size_t)atoi(getenv("MI_SNARK_BITSUM_LDS_PAD")) : 0;
         if (lpg == 0)  // one wave per group, its own six tree levels
-            hipLaunchKernelGGL(msm_bit_sums_queue_kernel, dim3((unsigned)all_groups), dim3(64), 0, st, chunk_partial, chunk_off,
+            hipLaunchKernelGGL(msm_bit_sums_queue_kernel, dim3((unsigned)all_groups), dim3(64), lds_pad, st, chunk_partial, chunk_off,
                                chunk_bucket, pl.B, pl.c, job->h);
         else if (lpg == 4)  // four groups per block, one tree through LDS: NOT the default, see the kernel's comment
             hipLaunchKernelGGL(msm_bit_sums_block_kernel, dim3((unsigned)((all_groups + BS_GROUPS - 1) / BS_GROUPS)), dim3(64 * BS_GROUPS), 0,
