@@ -144,6 +144,24 @@ impl BatchVerifier {
         check(mi_vs_identify_device(self.0, d_proofs, n, d_randomizers128, verdicts.as_mut_ptr(), hip_stream))?;
         Ok(verdicts)
     }
+    /// Several chunks in ONE lane pass (at most `MI_VS_MAX_BATCHES_PER_PASS`; `batches_per_pass` tells how many of a
+    /// size fit): each chunk keeps its own partial.  `chunks`: (device proofs, count, device randomizers).
+    pub unsafe fn accumulate_multi(&self, chunks: &[(*const c_void, usize, *const c_void)], hip_stream: *mut c_void)
+                                   -> Result<Vec<mi_vs_partial>, Status> {
+        let k = chunks.len();
+        let (pr, ns, rn): (Vec<_>, Vec<_>, Vec<_>) = (chunks.iter().map(|c| c.0).collect(), chunks.iter().map(|c| c.1).collect(),
+                                                      chunks.iter().map(|c| c.2).collect());
+        let mut h = 0u64;
+        check(mi_vs_accumulate_begin_multi(self.0, k as i32, pr.as_ptr(), ns.as_ptr(), rn.as_ptr(), hip_stream, &mut h))?;
+        let mut parts: Vec<mi_vs_partial> = Vec::with_capacity(k);
+        check(mi_vs_accumulate_end_multi(self.0, h, parts.as_mut_ptr(), k as i32))?;
+        parts.set_len(k);
+        Ok(parts)
+    }
+    pub fn batches_per_pass(&self, n: usize) -> Result<usize, Status> {
+        let r = unsafe { mi_vs_batches_per_pass(self.0, n) };
+        if r < 1 { Err(Status(r)) } else { Ok(r as usize) }
+    }
     /// Streamed chunks (mempool admission, block sync): `exchange` = None on one GPU, or
     /// `Some(ffi::mi_vs_exchange_rccl)` with `user` = a communicator of `mi_comm_init_rank` when one process per GPU
     /// verifies one block together.
