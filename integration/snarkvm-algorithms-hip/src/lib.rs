@@ -160,7 +160,7 @@ impl BatchVerifier {
     }
     pub fn batches_per_pass(&self, n: usize) -> Result<usize, Status> {
         let r = unsafe { mi_vs_batches_per_pass(self.0, n) };
-        if r < 1 { Err(Status(r)) } else { Ok(r as usize) }
+        if r < 1 { Err(r) } else { Ok(r as usize) }
     }
     /// Streamed chunks (mempool admission, block sync): `exchange` = None on one GPU, or
     /// `Some(ffi::mi_vs_exchange_rccl)` with `user` = a communicator of `mi_comm_init_rank` when one process per GPU
