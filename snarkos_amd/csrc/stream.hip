@@ -302,7 +302,8 @@ int32_t mi_vs_stream_open(uint64_t ctx, int32_t fold_threads, int32_t products, 
         const int x = atoi(e);
         if (x >= 1 && x <= MI_VS_MAX_BATCHES_PER_PASS) s->per_pass_max = x;
     }
-    if (exchange) s->pair_at = 0;  // multi-rank streams: every rank must take the same batches to the same collective
+    // (Streams with an exchange pair as well: the collectives go by batch sequence number, in order, whatever pass a
+    // batch rode on; a held batch never waits for a collective, only for a pass to end.)
     Stream *raw = s.get();
     for (int i = 0; i < fold_threads; i++) s->folders.emplace_back([raw] { raw->folder_main(); });
     s->finisher = std::thread([raw] { raw->finisher_main(); });
