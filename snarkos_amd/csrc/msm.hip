@@ -617,6 +617,64 @@ __global__ void __launch_bounds__(64) msm_bit_sums_queue_kernel(const G1Xyzz *__
     if (lane == 0) store_xyzz(&out[g], have ? xyzz28_store(acc) : G1Xyzz::inf());
 }
 
+// Several groups per WAVE (LPG lanes each): the same walk with a queue per group, every lane taking 64 / LPG times as
+// many partials, and a tree of log2(LPG) levels that serves all the wave's groups at once.  Per group that is
+// matches / LPG + log2(LPG) / (64 / LPG) wave-additions instead of matches / 64 + 6: 9.5 instead of 13 for the
+// verifier's windows at LPG = 32 -- less work, a longer chain (14 instead of 7 additions before the tree).  The trade
+// for passes that carry several batches: those only exist when the device is busy.  Measured (MI_SNARK_BITSUM_PART=32,
+// five interleaved runs each): 6.89e6 proofs/s against 7.3e6 with one group per wave -- the longer chain costs more
+// than the saved work brings, so it is NOT the default.
+template <int LPG>
+__global__ void __launch_bounds__(64) msm_bit_sums_part_kernel(const G1Xyzz *__restrict__ chunk_partial,
+                                                               const uint32_t *__restrict__ chunk_off,
+                                                               const uint32_t *__restrict__ chunk_bucket, uint32_t B, int c,
+                                                               uint32_t n_groups, G1Xyzz *__restrict__ out) {
+    constexpr int GPW = 64 / LPG;
+    __shared__ uint32_t queue[GPW][128];
+    const int lane = threadIdx.x, sub = lane / LPG, sl = lane % LPG;
+    const uint32_t g = blockIdx.x * GPW + (uint32_t)sub;
+    const bool live = g < n_groups;
+    const uint32_t w = live ? g / (uint32_t)c : 0, bit = live ? g - w * (uint32_t)c : 0;
+    const uint32_t lo = live ? chunk_off[(size_t)w * B] : 0, hi = live ? chunk_off[(size_t)(w + 1) * B] : 0;
+    const uint64_t sub_mask = (LPG == 64 ? ~0ull : ((1ull << LPG) - 1ull)) << (sub * LPG);
+    G1Xyzz28 acc;
+    bool have = false;
+    uint32_t head = 0, tail = 0, base = lo;  // uniform within the group's lanes
+    uint32_t *q = queue[sub];
+    bool done = false;
+    while (!__all(done)) {
+        const bool more = base < hi;
+        const uint32_t e = base + (uint32_t)sl;
+        const bool match = more && e < hi && (((chunk_bucket[e] - w * B + 1) >> bit) & 1u);
+        const uint64_t mm = __ballot(match) & sub_mask;  // this group's matches
+        if (match) q[(tail + (uint32_t)__popcll(mm & ((1ull << lane) - 1ull))) & 127u] = e;
+        tail += (uint32_t)__popcll(mm);
+        if (more) base += LPG;
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");  // the wave's own queues: its writes before its reads
+        __builtin_amdgcn_wave_barrier();
+        const uint32_t avail = tail - head;
+        if (avail >= (uint32_t)LPG || (!more && avail > 0)) {
+            const uint32_t take = avail < (uint32_t)LPG ? avail : (uint32_t)LPG;
+            if ((uint32_t)sl < take) {
+                const G1Xyzz v = load_xyzz(&chunk_partial[q[(head + (uint32_t)sl) & 127u]]);
+                xyzz_acc28(acc, have, xyzz28_from(v), !v.is_inf());
+            }
+            head += take;
+        } else if (!more) {
+            done = true;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+#pragma unroll 1
+    for (int stride = LPG / 2; stride >= 1; stride >>= 1) {
+        const G1Xyzz28 other = xyzz28_shfl_down(acc, stride);
+        const bool have_other = __shfl_down((int)have, stride, 64) != 0;
+        if (sl < stride) xyzz_acc28(acc, have, other, have_other);
+    }
+    if (sl == 0 && live) store_xyzz(&out[g], have ? xyzz28_store(acc) : G1Xyzz::inf());
+}
+
 // Four groups per 256-lane block: the walk above, one group per wave, then ONE tree for the block through LDS.  A
 // wave on its own pays six full additions for its six tree levels although level k has work for 64 >> k lanes; here
 // level 1 of the four groups fills two waves, level 2 one, and the rest a shrinking part of wave 0: 7 wave-additions
@@ -1056,7 +1114,15 @@ void msm_enqueue(Context &cx, const G1Affine *d_points, const uint32_t *d_scalar
         // MI_SNARK_BITSUM_LDS_PAD: dynamic LDS the one-wave kernel asks for and never touches (an experiment on the
         // fault described at msm_bit_sums_block_kernel: does the LDS footprint alone bring it about?)
         static const size_t lds_pad = getenv("MI_SNARK_BITSUM_LDS_PAD") ? (size_t)atoi(getenv("MI_SNARK_BITSUM_LDS_PAD")) : 0;
-        if (lpg == 0)  // one wave per group, its own six tree levels
+        // passes that carry several batches (four or more MSMs): groups of `part` lanes, several to a wave
+        static const int part = getenv("MI_SNARK_BITSUM_PART") ? atoi(getenv("MI_SNARK_BITSUM_PART")) : 0;
+        if (lpg == 0 && problems >= 4 && part == 32)
+            hipLaunchKernelGGL(msm_bit_sums_part_kernel<32>, dim3((unsigned)((all_groups + 1) / 2)), dim3(64), 0, st, chunk_partial,
+                               chunk_off, chunk_bucket, pl.B, pl.c, (uint32_t)all_groups, job->h);
+        else if (lpg == 0 && problems >= 4 && part == 16)
+            hipLaunchKernelGGL(msm_bit_sums_part_kernel<16>, dim3((unsigned)((all_groups + 3) / 4)), dim3(64), 0, st, chunk_partial,
+                               chunk_off, chunk_bucket, pl.B, pl.c, (uint32_t)all_groups, job->h);
+        else if (lpg == 0)  // one wave per group, its own six tree levels
             hipLaunchKernelGGL(msm_bit_sums_queue_kernel, dim3((unsigned)all_groups), dim3(64), lds_pad, st, chunk_partial, chunk_off,
                                chunk_bucket, pl.B, pl.c, job->h);
         else if (lpg == 4)  // four groups per block, one tree through LDS: NOT the default, see the kernel's comment

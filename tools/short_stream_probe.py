@@ -24,14 +24,18 @@ pp, pr = torch.from_numpy(d["proofs"]).to(dev), torch.from_numpy(d["randomizers"
 lib = L.lib()
 
 
-def one(k, fold, depth, lanes):
+def one(k, fold, depth, lanes, gap=0.0):
     sid, ok = C.c_uint64(0), C.c_uint8(0)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     L.check(lib.mi_vs_stream_open(C.c_uint64(v.ctx), fold, depth, lanes, C.cast(None, L.VS_EXCHANGE_FN), None, 1, C.byref(sid)), "open")
     t_open = time.perf_counter() - t0
     subs, outs = [], []
-    for _ in range(k):
+    for j in range(k):
+        if gap and j:
+            t_next = t0 + t_open + j * gap
+            while time.perf_counter() < t_next:
+                pass
         L.check(lib.mi_vs_stream_submit(sid, L.dptr(pp), C.c_size_t(1024), L.dptr(pr), L.stream_ptr(None)), "submit")
         subs.append(time.perf_counter() - t0)
         while lib.mi_vs_stream_next(sid, 0, C.byref(ok)) == L.MI_OK:
@@ -48,16 +52,11 @@ def one(k, fold, depth, lanes):
 
 
 list(v.verify_stream(((pp, pr) for _ in range(5))))
-for pair_at in ("2", "4"):
-    os.environ["MI_SNARK_STREAM_PAIR_AT"] = pair_at  # read when a stream is opened
-    for fold, depth, lanes in ((3, 10, 10), (5, 10, 10), (6, 10, 10), (8, 10, 10)):
-        best = None
-        for rep in range(9):
-            r = one(K, fold, depth, lanes)
-            if best is None or r[4] < best[4]:
-                best = r
-        t_open, subs, outs, t_last, t_all = best
-        print("pair_at=%s fold=%d products=%d lanes=%d  K=%d: total %.3f ms (%.3f ms/step)  open %.3f  last submit %.3f  first verdict %.3f  last verdict %.3f  close %.3f"
-              % (pair_at, fold, depth, lanes, K, 1e3 * t_all, 1e3 * t_all / K, 1e3 * t_open, 1e3 * subs[-1], 1e3 * outs[0], 1e3 * t_last, 1e3 * (t_all - t_last)))
-        print("   submits:", " ".join("%.2f" % (1e3 * s) for s in subs))
-        print("   verdicts:", " ".join("%.2f" % (1e3 * s) for s in outs))
+import statistics
+cfgs = [tuple(int(x) for x in c.split(",")) for c in (sys.argv[2].split() if len(sys.argv) > 2 else ["10,10"])]
+for lanes, depth in cfgs:
+    fold = 3
+    runs = [one(K, fold, depth, lanes) for rep in range(60)]
+    tot = sorted(1e3 * r[4] for r in runs)
+    print("lanes=%d products=%d K=%d: median %.2f ms  p90 %.2f  max %.2f  runs over 1.3 x median: %d of %d"
+          % (lanes, depth, K, statistics.median(tot), tot[int(0.9 * len(tot))], tot[-1], sum(t > 1.3 * statistics.median(tot) for t in tot), len(tot)))
