@@ -556,6 +556,28 @@ def extras(dev, verifier, proofs, rnd):
     ex["poseidon_fq"] = {"sponges": npos, "absorbed_each": mpos, "ms": 1e3 * dt, "permutations_per_s": npos * (mpos // 2) / dt,
                          "fq_products_per_s": npos * (mpos // 2) * 626 / dt}
     del x
+    # --- compressed points: the 11 264 commitments of a 1024-proof batch (9 + 2 per proof) decoded in one launch
+    # (square root in Fq, sign, subgroup check), inputs resident; the points are the batch's own commitments
+    try:
+        pr = proofs.reshape(-1, L.VS_PROOF_BYTES)
+        off_c, off_w = 16 + 512, 16 + 512 + 864 + 672
+        pts_b = np.concatenate([pr[:, off_c:off_c + 864].reshape(-1, 96), pr[:, off_w:off_w + 192].reshape(-1, 96)])
+        comp = A.G1Codec.compress(pts_b.view(np.uint64).reshape(-1, 12))
+        d_comp = torch.from_numpy(comp).to(dev)
+        codec = {"points": int(len(comp))}
+        for check, key in ((True, "ms_with_subgroup_check"), (False, "ms_without_subgroup_check")):
+            outp, okp = A.G1Codec.decompress(d_comp, check)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(5):
+                outp, okp = A.G1Codec.decompress(d_comp, check)
+            torch.cuda.synchronize()
+            codec[key] = 1e3 * (time.perf_counter() - t0) / 5
+        codec["all_decoded"] = bool(okp.all().item()) and bool((outp.cpu().numpy().view(np.uint64) == pts_b.view(np.uint64).reshape(-1, 12)).all())
+        codec["points_per_s_checked"] = len(comp) / (1e-3 * codec["ms_with_subgroup_check"])
+        ex["g1_decompress_batch_commitments"] = codec
+    except Exception as e:  # noqa: BLE001
+        ex["g1_decompress_batch_commitments"] = {"error": str(e)}
     # --- the 1024-proof batch under the Poseidon Fiat-Shamir transcript (row A9 on the path: 37 permutations per proof)
     try:
         dp = np.load(os.path.join(ROOT, "tests", "golden", "vs_batch_1024_poseidon.npz"))

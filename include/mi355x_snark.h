@@ -321,6 +321,19 @@ int32_t mi_comm_destroy(uint64_t comm);
 int32_t mi_comm_all_gather(uint64_t comm, const void *mine, size_t bytes, void *all);
 int32_t mi_vs_exchange_rccl(void *user, const mi_vs_partial *mine, size_t count, mi_vs_partial *all, size_t max_partials);
 
+/* ---- compressed G1 points: snarkVM's CanonicalSerialize with compression (snarkvm-curves templates/
+ * short_weierstrass_jacobian + SWFlags [RECALL: the crate is not in /root/reference]; replaces the per-point
+ * `G1Affine::deserialize_compressed` a Rust caller runs on the commitments of a Proof / CircuitVerifyingKey found in
+ * Transaction bytes: reference node/router/messages/src/unconfirmed_transaction.rs:25-28,
+ * node/bft/events/src/block_response.rs:64-70).  48 bytes per point: x little-endian, below q; bit 7 of byte 47 =
+ * y is the larger of the two roots (y > (q - 1) / 2); bit 6 = infinity (x = 0).  ok[i] = 0 (and out[i] = infinity)
+ * for x >= q, a non-residue x^3 + 1, a malformed infinity and, with check_subgroup != 0, a curve point outside the
+ * order-r subgroup (snarkVM checks that on deserialisation).  The _device form runs on `stream`; its input must be
+ * 16-byte aligned. */
+int32_t mi_g1_decompress(const uint8_t *compressed48, size_t n, int32_t check_subgroup, mi_g1_affine *out, uint8_t *ok);
+int32_t mi_g1_decompress_device(const void *d_compressed48, size_t n, int32_t check_subgroup, void *d_out, void *d_ok, void *stream);
+int32_t mi_g1_compress(const mi_g1_affine *points, size_t n, uint8_t *compressed48_out);
+
 /* ---- crypto_hash::PoseidonSponge<Fq, 2, 1>, many independent sponges at once ----
  * Structure as snarkVM's (width 3, S-box x^17, 8 full + 31 partial rounds); the round constants and MDS matrix
  * are this library's own (tools/gen_constants.py): snarkVM's are not available offline, so this is the kernel a

@@ -107,6 +107,38 @@ def main():
              "values": [hx(v) for v in vs], "random_v": [hx(x) for x in rbars], "bad_random_v": [hx(x) for x in bad_rb],
              "witnesses": [pt(w) for w in hws], "randomizers": [hx(r) for r in rs]}
     json.dump(kzg_h, open(os.path.join(OUT, "kzg_hiding.json"), "w"), indent=0)
+    # --- compressed G1 points (pyref.g1_compress / g1_decompress): points of the subgroup with both signs of y, the
+    # point at infinity, an x whose x^3 + 1 is a non-residue, an x >= q, a curve point outside the order-r subgroup,
+    # a malformed infinity
+    comp = []
+    for k in (1, 2, 3, 7, 1 << 60, rng.below(P.R, 9), rng.below(P.R, 10), P.R - 1):
+        pnt = P.g1_mul(P.G1_GEN, k)
+        for q in (pnt, P.g1_neg(pnt)):
+            c = P.g1_compress(q)
+            ok, back = P.g1_decompress(c)
+            assert ok and back == q
+            comp.append({"bytes": c.hex(), "ok": True, "ok_unchecked": True, "point": pt(q)})
+    comp.append({"bytes": P.g1_compress(None).hex(), "ok": True, "ok_unchecked": True, "point": pt(None)})
+    x = 5
+    while P.fq_sqrt(x * x * x + 1) is not None:
+        x += 1
+    comp.append({"bytes": x.to_bytes(48, "little").hex(), "ok": False, "ok_unchecked": False, "point": pt(None)})
+    comp.append({"bytes": P.Q.to_bytes(48, "little").hex(), "ok": False, "ok_unchecked": False, "point": pt(None)})
+    x = 1
+    while True:  # a curve point that is not in the order-r subgroup (the cofactor is large: almost every point)
+        y = P.fq_sqrt(x * x * x + 1)
+        if y is not None and P._g1_mul_any((x, y), P.R) is not None:
+            break
+        x += 1
+    ok_u, pu = P.g1_decompress(P.g1_compress((x, y)), check_subgroup=False)
+    assert ok_u and pu == (x, y) and not P.g1_decompress(P.g1_compress((x, y)))[0]
+    comp.append({"bytes": P.g1_compress((x, y)).hex(), "ok": False, "ok_unchecked": True, "point": pt((x, y))})
+    bad_inf = bytearray(P.g1_compress(None))
+    bad_inf[3] = 1
+    comp.append({"bytes": bytes(bad_inf).hex(), "ok": False, "ok_unchecked": False, "point": pt(None)})
+    roots = [{"a": hx(a), "root": hx(P.fq_sqrt(a)) if P.fq_sqrt(a) is not None else None}
+             for a in [0, 1, 4, 15, P.Q - 1] + [rng.below(P.Q, 11 + i) for i in range(6)]]
+    json.dump({"points": comp, "sqrt": roots}, open(os.path.join(OUT, "g1_compressed.json"), "w"), indent=0)
     print("golden vectors written to", OUT)
 
 

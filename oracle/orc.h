@@ -63,6 +63,10 @@ void orc_g1_add(orc_g1_jac *r, const orc_g1_jac *a, const orc_g1_jac *b);
 void orc_g1_add_mixed(orc_g1_jac *r, const orc_g1_jac *a, const orc_g1_affine *b);
 void orc_g1_double(orc_g1_jac *r, const orc_g1_jac *a);
 void orc_g1_neg_affine(orc_g1_affine *r, const orc_g1_affine *a);
+/* compressed points (48 bytes; convention in orc_core.c) */
+int orc_fq_sqrt(orc_fq *out, const orc_fq *a);
+void orc_g1_compress(uint8_t out[48], const orc_g1_affine *p);
+int orc_g1_decompress(orc_g1_affine *out, const uint8_t in[48], int check_subgroup);
 void orc_g1_from_affine(orc_g1_jac *r, const orc_g1_affine *a);
 void orc_g1_to_affine(orc_g1_affine *r, const orc_g1_jac *a);
 void orc_g1_batch_to_affine(orc_g1_affine *r, const orc_g1_jac *a, size_t n);

@@ -278,6 +278,103 @@ int orc_g1_is_on_curve(const orc_g1_affine *p) {
     fq_add(&r, &r, &one);
     return fq_eq(&l, &r);
 }
+/* ---- compressed G1 points: snarkVM's CanonicalSerialize of a short-Weierstrass affine point, compressed [RECALL:
+ * snarkvm-curves templates/short_weierstrass_jacobian + SWFlags, not in /root/reference]: 48 bytes, x little-endian and
+ * below q; bit 7 of the last byte = y is the larger root (y > (q - 1) / 2), bit 6 = infinity (x = 0).  parity unpinned. */
+static void fq_pow_limbs(fq_t *r, const fq_t *a, const uint64_t *e, int n_limbs) {
+    fq_t acc;
+    fq_one(&acc);
+    for (int i = 64 * n_limbs - 1; i >= 0; i--) {
+        fq_sqr(&acc, &acc);
+        if ((e[i / 64] >> (i % 64)) & 1) fq_mul(&acc, &acc, a);
+    }
+    *r = acc;
+}
+/* Tonelli-Shanks over the 2^46-th roots of unity; returns 0 when a is not a square */
+int orc_fq_sqrt(orc_fq *out, const orc_fq *a_in) {
+    const fq_t *a = (const fq_t *)a_in;
+    fq_t w, x, b, c, one;
+    fq_one(&one);
+    if (fq_is_zero(a)) { *(fq_t *)out = *a; return 1; }
+    fq_pow_limbs(&w, a, ORC_FQ_T_MINUS1_HALF, 6); /* a^((t-1)/2) */
+    fq_mul(&x, a, &w);                            /* a^((t+1)/2) */
+    fq_mul(&b, &x, &w);                           /* a^t */
+    memcpy(&c, ORC_FQ_2SYLOW_GEN, sizeof c);
+    int m = ORC_FQ_TWO_ADICITY;
+    while (!fq_eq(&b, &one)) {
+        int i = 0;
+        fq_t b2 = b;
+        while (!fq_eq(&b2, &one)) {
+            fq_sqr(&b2, &b2);
+            if (++i == m) return 0; /* b has order 2^m: a is not a square */
+        }
+        fq_t g = c;
+        for (int k = 0; k < m - i - 1; k++) fq_sqr(&g, &g);
+        fq_mul(&x, &x, &g);
+        fq_sqr(&c, &g);
+        fq_mul(&b, &b, &c);
+        m = i;
+    }
+    *(fq_t *)out = x;
+    return 1;
+}
+static int fq_is_larger_root(const fq_t *y) {
+    uint64_t c[6];
+    orc_fq_to_canonical(c, (const orc_fq *)y);
+    for (int i = 5; i >= 0; i--) {
+        if (c[i] > ORC_FQ_HALF[i]) return 1;
+        if (c[i] < ORC_FQ_HALF[i]) return 0;
+    }
+    return 0;
+}
+void orc_g1_compress(uint8_t out[48], const orc_g1_affine *p) {
+    memset(out, 0, 48);
+    if (g1a_is_inf(p)) { out[47] = 0x40; return; }
+    uint64_t c[6];
+    orc_fq_to_canonical(c, &p->x);
+    for (int i = 0; i < 48; i++) out[i] = (uint8_t)(c[i / 8] >> (8 * (i % 8)));
+    if (fq_is_larger_root(F(&p->y))) out[47] |= 0x80;
+}
+/* r P for ANY curve point (the scalar is the group order itself, not reduced): is the result infinity? */
+static int g1_in_subgroup(const orc_g1_affine *p) {
+    orc_g1_jac acc;
+    orc_g1_affine inf;
+    memset(&inf, 0, sizeof inf);
+    orc_g1_from_affine(&acc, &inf);
+    for (int i = 252; i >= 0; i--) {
+        orc_g1_double(&acc, &acc);
+        if ((ORC_FR_MODULUS[i / 64] >> (i % 64)) & 1) orc_g1_add_mixed(&acc, &acc, p);
+    }
+    return fq_is_zero(F(&acc.z));
+}
+int orc_g1_decompress(orc_g1_affine *out, const uint8_t in[48], int check_subgroup) {
+    memset(out, 0, sizeof *out);
+    const uint8_t flags = in[47] & 0xC0;
+    uint64_t c[6] = {0, 0, 0, 0, 0, 0};
+    for (int i = 0; i < 48; i++) c[i / 8] |= (uint64_t)(i == 47 ? (in[i] & 0x3F) : in[i]) << (8 * (i % 8));
+    int zero = 1;
+    for (int i = 0; i < 6; i++) zero = zero && c[i] == 0;
+    if (flags & 0x40) return zero && !(flags & 0x80);
+    for (int i = 5; i >= 0; i--) { /* x < q */
+        if (c[i] < ORC_FQ_MODULUS[i]) break;
+        if (c[i] > ORC_FQ_MODULUS[i] || i == 0) return 0;
+    }
+    fq_t x, rhs, one, y;
+    orc_fq_from_canonical((orc_fq *)&x, c);
+    fq_one(&one);
+    fq_sqr(&rhs, &x);
+    fq_mul(&rhs, &rhs, &x);
+    fq_add(&rhs, &rhs, &one);
+    if (!orc_fq_sqrt((orc_fq *)&y, (const orc_fq *)&rhs)) return 0;
+    fq_t chk;
+    fq_sqr(&chk, &y);
+    if (!fq_eq(&chk, &rhs)) return 0;
+    if (fq_is_larger_root(&y) != ((flags & 0x80) != 0)) fq_neg(&y, &y);
+    *F(&out->x) = x;
+    *F(&out->y) = y;
+    if (check_subgroup && !g1_in_subgroup(out)) { memset(out, 0, sizeof *out); return 0; }
+    return 1;
+}
 void orc_g1_neg_affine(orc_g1_affine *r, const orc_g1_affine *a) {
     r->x = a->x;
     fq_neg(F(&r->y), F(&a->y));

@@ -150,6 +150,35 @@ def g2_generator():
     return g
 
 
+def g1_compress(points):
+    """(n, 12) Montgomery affine points -> (n, 48) bytes (orc_g1_compress)"""
+    pts = np.ascontiguousarray(points, dtype=np.uint64).reshape(-1, 12)
+    out = np.zeros((len(pts), 48), dtype=np.uint8)
+    for i in range(len(pts)):
+        lib().orc_g1_compress(_p(out[i]), _p(pts[i]))
+    return out
+
+
+def g1_decompress(data, check_subgroup=True):
+    """(n, 48) bytes -> ((n, 12) Montgomery affine points, (n,) ok flags) (orc_g1_decompress)"""
+    d = np.ascontiguousarray(data, dtype=np.uint8).reshape(-1, 48)
+    out = np.zeros((len(d), 12), dtype=np.uint64)
+    ok = np.zeros(len(d), dtype=np.uint8)
+    f = lib().orc_g1_decompress
+    f.restype = C.c_int
+    for i in range(len(d)):
+        ok[i] = f(_p(out[i]), _p(d[i]), C.c_int(1 if check_subgroup else 0))
+    return out, ok
+
+
+def fq_sqrt(a):
+    """canonical integer -> canonical square root, or None"""
+    out = u64(6)
+    f = lib().orc_fq_sqrt
+    f.restype = C.c_int
+    return fq_to_int(out) if f(_p(out), _p(fq_from_int(a))) else None
+
+
 def g1_mul(p, k):
     out = u64(18)
     lib().orc_g1_mul(_p(out), _p(np.ascontiguousarray(p)), _p(int_to_limbs(k, 4)))

@@ -185,6 +185,73 @@ def g1_mul(P, k):
     return acc
 
 
+# ----------------------------------------------------------------------------- compressed G1 points
+# snarkVM's CanonicalSerialize of a short-Weierstrass affine point, compressed [RECALL: snarkvm-curves
+# templates/short_weierstrass_jacobian + SWFlags; not in /root/reference]: 48 bytes, x as a little-endian integer below q
+# (377 bits); bit 7 of the last byte is set when y is the LARGER of the two roots (y > (q - 1) / 2 as integers),
+# bit 6 marks the point at infinity (x = 0 then).  Big-integer restatement, independent of the C oracle.
+def fq_sqrt(a):
+    """a square root of a mod Q (Tonelli-Shanks over the 2^46-th roots of unity), or None"""
+    a %= Q
+    if a == 0:
+        return 0
+    if pow(a, (Q - 1) // 2, Q) != 1:
+        return None
+    s, t = 0, Q - 1
+    while t % 2 == 0:
+        s, t = s + 1, t // 2
+    z = pow(15, t, Q)
+    m, c, x, b = s, z, pow(a, (t + 1) // 2, Q), pow(a, t, Q)
+    while b != 1:
+        i, b2 = 0, b
+        while b2 != 1:
+            b2, i = b2 * b2 % Q, i + 1
+        g = pow(c, 1 << (m - i - 1), Q)
+        m, c, x, b = i, g * g % Q, x * g % Q, b * g * g % Q
+    return x
+
+
+def g1_compress(P):
+    if P is None:
+        return bytes(47) + bytes([0x40])
+    x, y = P
+    out = bytearray(x.to_bytes(48, "little"))
+    if y > (Q - 1) // 2:
+        out[47] |= 0x80
+    return bytes(out)
+
+
+def g1_decompress(data, check_subgroup=True):
+    """(ok, point): ok False for x >= q, a non-residue x^3 + 1, a malformed infinity, or (checked) a point outside the
+    order-r subgroup"""
+    assert len(data) == 48
+    flags = data[47] & 0xC0
+    x = int.from_bytes(bytes(data[:47]) + bytes([data[47] & 0x3F]), "little")
+    if flags & 0x40:
+        return (x == 0 and not flags & 0x80), None
+    if x >= Q:
+        return False, None
+    y = fq_sqrt(x * x * x + 1)
+    if y is None:
+        return False, None
+    if (y > (Q - 1) // 2) != bool(flags & 0x80):
+        y = (Q - y) % Q
+    P = (x, y)
+    if check_subgroup and _g1_mul_any(P, R) is not None:
+        return False, None
+    return True, P
+
+
+def _g1_mul_any(P, k):
+    """k P without reducing k mod r (P need not lie in the order-r subgroup)"""
+    acc = None
+    for bit in bin(k)[2:]:
+        acc = g1_add(acc, acc)
+        if bit == "1":
+            acc = g1_add(acc, P)
+    return acc
+
+
 def msm(bases, scalars):
     """VariableBase::msm semantic: sum scalars[i]*bases[i] over min(len) items."""
     acc = None

@@ -250,6 +250,37 @@ class PoseidonSponge:
         return out
 
 
+class G1Codec:
+    """`CanonicalDeserialize::deserialize_compressed` / `serialize_compressed` of `G1Affine`, a batch per call
+    (48 bytes per point; convention in include/mi355x_snark.h, [RECALL])."""
+
+    @staticmethod
+    def decompress(data, check_subgroup=True, stream=None):
+        """data: (n, 48) uint8 (numpy, or a 16-byte aligned CUDA tensor).  Returns (points (n, 12) uint64 Montgomery,
+        ok (n,) uint8); a refused encoding yields ok = 0 and the point at infinity."""
+        if _is_torch_cuda(data):
+            import torch
+            n = data.numel() // 48
+            out = torch.empty((n, 12), dtype=torch.int64, device=data.device)
+            ok = torch.empty(n, dtype=torch.uint8, device=data.device)
+            L.check(L.lib().mi_g1_decompress_device(L.dptr(data), C.c_size_t(n), C.c_int32(1 if check_subgroup else 0), L.dptr(out),
+                                                    L.dptr(ok), L.stream_ptr(stream)), "mi_g1_decompress_device")
+            return out, ok
+        d = np.ascontiguousarray(data, dtype=np.uint8).reshape(-1, 48)
+        out = np.zeros((len(d), 12), dtype=np.uint64)
+        ok = np.zeros(len(d), dtype=np.uint8)
+        L.check(L.lib().mi_g1_decompress(L.ptr(d), C.c_size_t(len(d)), C.c_int32(1 if check_subgroup else 0), L.ptr(out), L.ptr(ok)),
+                "mi_g1_decompress")
+        return out, ok
+
+    @staticmethod
+    def compress(points):
+        pts = np.ascontiguousarray(points, dtype=np.uint64).reshape(-1, 12)
+        out = np.zeros((len(pts), 48), dtype=np.uint8)
+        L.check(L.lib().mi_g1_compress(L.ptr(pts), C.c_size_t(len(pts)), L.ptr(out)), "mi_g1_compress")
+        return out
+
+
 class KZG10:
     """snarkvm_algorithms::polycommit::kzg10::KZG10"""
 

@@ -6,6 +6,7 @@
 #include "api.hpp"
 #include "field28.hpp"
 #include "tower.hpp"
+#include "codec.hpp"
 
 extern "C" int mi_host_cpu_ok(void);  // cpu_probe.cpp (built without the x86-64-v3 / ADX flags)
 
@@ -180,6 +181,40 @@ __device__ __attribute__((noinline)) void poseidon_permute(Fq st[3], const Posei
         for (int i = 0; i < 3; i++) st[i] = o[i];
     }
 }
+// a lane per point; the data-dependent loops of the square root run in lockstep over the wave (worst lane decides)
+__global__ void __launch_bounds__(64) g1_decompress_kernel(const uint8_t *__restrict__ in, size_t n, int check_subgroup,
+                                                           G1Affine *__restrict__ out, uint8_t *__restrict__ ok) {
+    const size_t i = (size_t)blockIdx.x * 64 + threadIdx.x;
+    if (i >= n) return;
+    uint8_t b[48];
+    const uint4 *src = reinterpret_cast<const uint4 *>(in + 48 * i);  // 48 i is a multiple of 16
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        const uint4 v = src[k];
+        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int j = 0; j < 16; j++) b[16 * k + j] = (uint8_t)(w[j >> 2] >> (8 * (j & 3)));
+    }
+    G1Affine p;
+    const bool good = g1_decompress_one(b, check_subgroup != 0, p);
+    out[i] = p;
+    ok[i] = good ? 1 : 0;
+}
+__global__ void __launch_bounds__(64) g1_compress_kernel(const G1Affine *__restrict__ in, size_t n, uint8_t *__restrict__ out) {
+    const size_t i = (size_t)blockIdx.x * 64 + threadIdx.x;
+    if (i >= n) return;
+    uint8_t b[48];
+    g1_compress_one(in[i], b);
+    for (int k = 0; k < 48; k++) out[48 * i + k] = b[k];
+}
+void g1_decompress_device(Context &cx, const uint8_t *d_in, size_t n, int check_subgroup, G1Affine *d_out, uint8_t *d_ok, hipStream_t st) {
+    if (!n) return;
+    cx.prof.begin("g1_decompress", st, n);
+    hipLaunchKernelGGL(g1_decompress_kernel, dim3(cdiv(n, 64)), dim3(64), 0, st, d_in, n, check_subgroup, d_out, d_ok);
+    cx.prof.end("g1_decompress", st);
+    MI_HIP(hipGetLastError());
+}
+
 __global__ void __launch_bounds__(64) poseidon_hash_many_kernel(const Fq *__restrict__ in, size_t n, size_t m, size_t k,
                                                                  const PoseidonConsts *__restrict__ pc, Fq *__restrict__ out) {
     size_t s = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -755,6 +790,42 @@ int32_t mi_kzg_batch_check_hiding(const mi_kzg_vk *vk, const mi_g1_affine *gamma
     if ((gamma_g == nullptr) != (random_v == nullptr)) return MI_ERR_BAD_ARGS;
     return guarded([&](Context &cx) -> int32_t {
         return kzg_batch_check_host(cx, vk, gamma_g, comms, points, values, witnesses, random_v, n, randomizers128, ok_out);
+    });
+}
+
+// ------------------------------------------------------------ compressed points
+int32_t mi_g1_decompress(const uint8_t *compressed48, size_t n, int32_t check_subgroup, mi_g1_affine *out, uint8_t *ok) {
+    if (!n || !compressed48 || !out || !ok) return MI_ERR_BAD_ARGS;
+    return guarded([&](Context &cx) -> int32_t {
+        uint8_t *din = (uint8_t *)cx.buf("codec.in", 48 * n + 16);
+        G1Affine *dout = (G1Affine *)cx.buf("codec.out", sizeof(G1Affine) * n);
+        uint8_t *dok = (uint8_t *)cx.buf("codec.ok", n);
+        MI_HIP(hipMemcpyAsync(din, compressed48, 48 * n, hipMemcpyHostToDevice, cx.stream));
+        g1_decompress_device(cx, din, n, check_subgroup, dout, dok, cx.stream);
+        MI_HIP(hipMemcpyAsync(out, dout, sizeof(G1Affine) * n, hipMemcpyDeviceToHost, cx.stream));
+        MI_HIP(hipMemcpyAsync(ok, dok, n, hipMemcpyDeviceToHost, cx.stream));
+        MI_HIP(hipStreamSynchronize(cx.stream));
+        return MI_OK;
+    });
+}
+int32_t mi_g1_decompress_device(const void *d_compressed48, size_t n, int32_t check_subgroup, void *d_out, void *d_ok, void *stream) {
+    if (!n || !d_compressed48 || !d_out || !d_ok || ((uintptr_t)d_compressed48 & 15)) return MI_ERR_BAD_ARGS;
+    return guarded_ptr(d_out, [&](Context &cx) -> int32_t {
+        g1_decompress_device(cx, (const uint8_t *)d_compressed48, n, check_subgroup, (G1Affine *)d_out, (uint8_t *)d_ok, (hipStream_t)stream);
+        return MI_OK;
+    });
+}
+int32_t mi_g1_compress(const mi_g1_affine *points, size_t n, uint8_t *compressed48_out) {
+    if (!n || !points || !compressed48_out) return MI_ERR_BAD_ARGS;
+    return guarded([&](Context &cx) -> int32_t {
+        G1Affine *din = (G1Affine *)cx.buf("codec.out", sizeof(G1Affine) * n);
+        uint8_t *dout = (uint8_t *)cx.buf("codec.in", 48 * n + 16);
+        MI_HIP(hipMemcpyAsync(din, points, sizeof(G1Affine) * n, hipMemcpyHostToDevice, cx.stream));
+        hipLaunchKernelGGL(g1_compress_kernel, dim3(cdiv(n, 64)), dim3(64), 0, cx.stream, din, n, dout);
+        MI_HIP(hipGetLastError());
+        MI_HIP(hipMemcpyAsync(compressed48_out, dout, 48 * n, hipMemcpyDeviceToHost, cx.stream));
+        MI_HIP(hipStreamSynchronize(cx.stream));
+        return MI_OK;
     });
 }
 

@@ -4,6 +4,7 @@
 #include <string.h>
 #include "../../snarkos_amd/csrc/tower.hpp"
 #include "../../snarkos_amd/csrc/glv.hpp"
+#include "../../snarkos_amd/csrc/codec.hpp"
 
 using namespace mi;
 
@@ -83,6 +84,10 @@ void hc_glv_digits(int w, const uint32_t *v4, int *out) {  // out[NW]
 }
 void hc_glv_mul(int w, const G1Affine *p, const uint32_t *k8, G1Affine *o) { *o = w == 3 ? glv_mul_host<3>(*p, k8) : glv_mul_host<4>(*p, k8); }
 void hc_fq_sqr(const Fq *a, Fq *o) { *o = sqr(*a); }
+int hc_fq_sqrt(const Fq *a, Fq *o) { return fq_sqrt(*a, *o) ? 1 : 0; }
+int hc_g1_decompress(const uint8_t *in, int check, G1Affine *o) { return g1_decompress_one(in, check != 0, *o) ? 1 : 0; }
+void hc_g1_compress(const G1Affine *p, uint8_t *out) { g1_compress_one(*p, out); }
+int hc_g1_in_subgroup(const G1Affine *p) { return g1_in_subgroup(*p) ? 1 : 0; }
 int hc_constants_ok() {
     // the 32-bit limb tables in field.hpp must equal the generated 64-bit constants
     for (int i = 0; i < 6; i++) {

@@ -179,3 +179,40 @@ def test_fq12_and_pairing(hc, orc):
     hc.hc_pairing_product(_p(ps), _p(qs), C.c_int(2), _p(out))
     one = np.zeros(72, dtype=np.uint64); one[:6] = orc.int_to_limbs(P.FQ_MONT_R, 6)
     assert (out == one).all()
+
+
+def test_compressed_points_host_build(hc, orc):
+    """csrc/codec.hpp compiled for the host: the square root, the encoding both ways and the endomorphism subgroup
+    test (u (u P) == -phi^2(P)) against the oracle's definition (r P == O) on the golden vectors -- subgroup points,
+    the other root, a curve point outside the subgroup, non-residues -- and on random curve points."""
+    import ctypes as C
+    import golden_util as G
+    import pyref as P
+    d = G.load("g1_compressed.json")
+    for c in d["points"]:
+        raw = np.frombuffer(bytes.fromhex(c["bytes"]), dtype=np.uint8).copy()
+        for check, key in ((1, "ok"), (0, "ok_unchecked")):
+            out = np.zeros(12, dtype=np.uint64)
+            ok = hc.hc_g1_decompress(orc._p(raw), C.c_int(check), orc._p(out))
+            assert bool(ok) == c[key]
+            assert orc.g1_to_ints(out) == (G.pt(c["point"]) if c[key] else None)
+        if c["ok"]:
+            back = np.zeros(48, dtype=np.uint8)
+            hc.hc_g1_compress(orc._p(orc.g1_from_ints(G.pt(c["point"]))), orc._p(back))
+            assert bytes(back).hex() == c["bytes"]
+    rng = P.SplitMix64(0xC0DEC)
+    in_sub = 0
+    for k in range(40):
+        x = rng.below(P.Q, k)
+        y = P.fq_sqrt(x * x * x + 1)
+        root = np.zeros(6, dtype=np.uint64)
+        got = hc.hc_fq_sqrt(orc._p(orc.fq_from_int((x * x * x + 1) % P.Q)), orc._p(root))
+        assert bool(got) == (y is not None)
+        if y is None:
+            continue
+        assert orc.fq_to_int(root) in (y, P.Q - y)
+        pt = (x, y) if k % 2 else P.g1_mul(P.G1_GEN, x % P.R)  # a random curve point, or a subgroup point
+        want = P._g1_mul_any(pt, P.R) is None
+        assert bool(hc.hc_g1_in_subgroup(orc._p(orc.g1_from_ints(pt)))) == want
+        in_sub += want
+    assert 0 < in_sub < 40

@@ -128,6 +128,10 @@ POSEIDON_ARK = [[int.from_bytes(hashlib.sha256(POSEIDON_TAG + bytes([r, i]) + b"
 POSEIDON_MDS = [[pow(i + 3 + j, -1, Q) for j in range(3)] for i in range(3)]
 
 
+FQ_T = (Q - 1) >> 46
+assert (Q - 1) == FQ_T << 46 and FQ_T & 1 and pow(15, (Q - 1) // 2, Q) == Q - 1
+
+
 def limbs(v, n):
     return [(v >> (64 * i)) & 0xFFFFFFFFFFFFFFFF for i in range(n)]
 
@@ -172,6 +176,14 @@ def emit(prefix, static_kw):
     a("%s uint64_t %sGLV_BETA[6] = %s; /* Montgomery */" % (static_kw, prefix, fq(BETA)))
     a("%s uint64_t %sGLV_LAMBDA[2] = %s;" % (static_kw, prefix, arr(LAMBDA, 2)))
     a("%s uint64_t %sGLV_MU[3] = %s;" % (static_kw, prefix, arr(GLV_MU, 3)))
+    a("/* square roots in Fq (Tonelli-Shanks): q - 1 = 2^46 t, t odd; FQ_T_MINUS1_HALF = (t - 1) / 2 (330 bits);")
+    a(" * FQ_2SYLOW_GEN = 15^t (15 is a quadratic non-residue): a generator of the 2^46-th roots of unity, Montgomery;")
+    a(" * FQ_HALF = (q - 1) / 2: y is the 'larger' root of its pair when its canonical value exceeds this */")
+    a("#define %sFQ_TWO_ADICITY 46" % prefix)
+    a("%s uint64_t %sFQ_T_MINUS1_HALF[6] = %s;" % (static_kw, prefix, arr((FQ_T - 1) // 2, 6)))
+    a("%s uint64_t %sFQ_2SYLOW_GEN[6] = %s;" % (static_kw, prefix, fq(pow(15, FQ_T, Q))))
+    a("%s uint64_t %sFQ_HALF[6] = %s;" % (static_kw, prefix, arr((Q - 1) // 2, 6)))
+    a("%s uint64_t %sFR_MODULUS_BITS[4] = %s; /* r itself: the subgroup check multiplies by it */" % (static_kw, prefix, arr(R, 4)))
     a("/* FROB[e-1][k] = gamma_e^k (Montgomery): multiply the Fq coefficient of w^k, k = i + 2j + 6b for c_i.c_j.c_b */")
     a("%s uint64_t %sFROB[3][12][6] = {" % (static_kw, prefix))
     for e in range(3):
