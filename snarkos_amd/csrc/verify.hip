@@ -775,7 +775,12 @@ __device__ __forceinline__ Fq vs_fs_element(const mi_vs_proof *__restrict__ p, c
 }
 #define VS_FS_BLOCKS 37
 #define VS_FS_ELEMS 73
+// 64 proofs = 4 waves, one per SIMD.  128 (two waves per SIMD; -DVS_FS_PROOFS_PER_BLOCK=128) was measured: the kernel
+// takes 16.3 ms instead of 9.3 and the streamed rate drops from 1.2e6 to 0.8e6 proofs/s -- one wave of this chain
+// already keeps its SIMD's multiplier busy.
+#ifndef VS_FS_PROOFS_PER_BLOCK
 #define VS_FS_PROOFS_PER_BLOCK 64
+#endif
 __global__ void __launch_bounds__(4 * VS_FS_PROOFS_PER_BLOCK) vs_fs_poseidon_kernel(const void *__restrict__ proofs, size_t n,
                                                              const mi_vs_circuit_vk *__restrict__ circuits, size_t n_circuits,
                                                              const VsConsts *__restrict__ kc, const PoseidonConsts *__restrict__ pc,
@@ -786,15 +791,17 @@ __global__ void __launch_bounds__(4 * VS_FS_PROOFS_PER_BLOCK) vs_fs_poseidon_ker
     __shared__ Fq28 xs[VS_FS_PROOFS_PER_BLOCK][3];     // the state of each proof (full rounds), or lane 0's new element in slot 0 (partial)
     __shared__ Fq28 xt[VS_FS_PROOFS_PER_BLOCK][2][3];  // partial rounds: lane l's products mds[i][l] s_l, l = 1, 2
     const int t = threadIdx.x, ps = t >> 2, l = t & 3, lc = l < 3 ? l : 0;
-    uint32_t block = blockIdx.x;
+    // the pass's batches are laid out in units of 64 proofs (VsMore::first_block, shared with the derive kernel): a
+    // block of this kernel takes VS_FS_PROOFS_PER_BLOCK / 64 consecutive units, each 4 waves
+    uint32_t block = blockIdx.x * (VS_FS_PROOFS_PER_BLOCK / 64) + (uint32_t)(ps >> 6);
     const int mb = more.of_block(block);
-    if (mb >= 0) {  // block-uniform: a further batch of the pass
+    if (mb >= 0) {  // uniform over the unit's waves: a further batch of the pass
         block -= more.b[mb].first_block;
         proofs = more.b[mb].proofs;
         n = more.b[mb].n;
         chal = const_cast<uint32_t *>(more.b[mb].chal);
     }
-    const size_t i = (size_t)block * VS_FS_PROOFS_PER_BLOCK + ps;
+    const size_t i = (size_t)block * 64 + (size_t)(ps & 63);
     const mi_vs_proof *p = reinterpret_cast<const mi_vs_proof *>(reinterpret_cast<const uint32_t *>(proofs) + (i < n ? i : 0) * (size_t)kc->proof_words);
     uint32_t circuit = reinterpret_cast<const uint32_t *>(p)[0];
     if (circuit >= n_circuits) circuit = 0;
@@ -1265,8 +1272,8 @@ static void vs_run_derive(Context &cx, VsKeys &v, const void *const *d_proofs, c
         // larger than the instruction cache; waves of different batches on one CU sit at different places in it and
         // fetch against each other (4 concurrent kernels each ran 2.2x slower before).
         static const size_t fs_pad = getenv("MI_SNARK_FS_LDS_PAD") ? (size_t)atoi(getenv("MI_SNARK_FS_LDS_PAD")) : 50 * 1024;
-        static_assert(VS_FS_PROOFS_PER_BLOCK == 64, "VsMore::first_block is shared with the derive kernel");
-        hipLaunchKernelGGL(vs_fs_poseidon_kernel, dim3(derive_blocks), dim3(4 * VS_FS_PROOFS_PER_BLOCK), fs_pad, st, d_proofs[0], n,
+        static_assert(VS_FS_PROOFS_PER_BLOCK % 64 == 0, "VsMore::first_block counts units of 64 proofs");
+        hipLaunchKernelGGL(vs_fs_poseidon_kernel, dim3(cdiv(derive_blocks, VS_FS_PROOFS_PER_BLOCK / 64)), dim3(4 * VS_FS_PROOFS_PER_BLOCK), fs_pad, st, d_proofs[0], n,
                            (const mi_vs_circuit_vk *)v.circuits.p, v.n_circuits, (const VsConsts *)v.consts.p, pc, ch, more);
         cx.prof.end("vs_fs_poseidon", st);
         chal = ch;

@@ -1,8 +1,8 @@
-# Poseidon-transcript and v2-shape streams against batches per pass
+# Poseidon-transcript stream against the LDS pad (block exclusivity) -- for builds with other transcript block sizes
 cd $GRAFT_REPO_ROOT
-for pp in 2 3 4; do
-  MI_SNARK_STREAM_PER_PASS=$pp timeout -k 10 300 python bench.py --steps 100 --warmup 5 --no-cpu-baseline 2>/dev/null | python -c "
+for pad in 20000 40000 1000; do
+  MI_SNARK_FS_LDS_PAD=$pad timeout -k 10 300 python bench.py --steps 60 --warmup 5 --no-cpu-baseline 2>/dev/null | python -c "
 import json,sys
-d=json.loads(sys.stdin.read()); e=d['extra']
-print('per_pass=$pp headline %.0f  poseidon %.0f (%.3f ms/batch)  v2 %.0f' % (d['value'], e['batch_1024_poseidon_fs']['streamed_proofs_per_s'], e['batch_1024_poseidon_fs']['streamed_ms_per_batch'], e['batch_1024_v2_shape']['streamed_proofs_per_s']))"
+d=json.loads(sys.stdin.read()); e=d['extra']['batch_1024_poseidon_fs']
+print('pad=$pad  poseidon streamed %.0f (%.3f ms/batch)  latency %.2f  kernel %.2f ms' % (e['streamed_proofs_per_s'], e['streamed_ms_per_batch'], e['latency_ms_one_batch_unpipelined'], e['transcript_kernel_ms']))"
 done
