@@ -221,7 +221,10 @@ def main():
         # the MSM accumulation kernel's view, beside the dominant-by-time kernel above
         ka = kernels["msm_accumulate"]
         roofline["msm_accumulate_view"] = {
-            "points_per_proof": ka["units_per_launch"] / PROOFS_PER_GPU, "algorithmic_bytes_per_launch": 128.0 * ka["units_per_launch"],
+            # a launch serves one lane pass = one or two batches: proofs per launch from the derive kernel's units
+            "points_per_proof": ka["units_per_launch"] / (kernels["vs_derive"]["units_per_launch"] if "vs_derive" in kernels else PROOFS_PER_GPU),
+            "proofs_per_launch": kernels["vs_derive"]["units_per_launch"] if "vs_derive" in kernels else PROOFS_PER_GPU,
+            "algorithmic_bytes_per_launch": 128.0 * ka["units_per_launch"],
             "avg_launch_us": ka["avg_us"], "achieved": ka["achieved_GBps"], "frac": ka["achieved_GBps"] / HBM_PEAK_GBPS,
             "note": "integer-ALU bound: see extra.msm_2^20.accumulate_frac_of_measured_alu_peak for the same kernel at full occupancy"}
 
