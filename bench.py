@@ -68,11 +68,11 @@ def main():
     ap.add_argument("--no-extra", action="store_true", help="skip the MSM / NTT / corrupted-batch side measurements")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--acc-depth", type=int, default=0,
-                    help="accumulation lanes (lane passes on the GPU before the oldest is folded, <= 14); default 10, or 8 when RCCL needs queues too")
+                    help="accumulation lanes (lane passes on the GPU before the oldest is folded, <= 14); default 12, or 8 when RCCL needs queues too")
     ap.add_argument("--exchange-group", type=int, default=0,
                     help="batches per partial exchange when sharded (fewer, larger all-gathers); default 4 with a process group")
     ap.add_argument("--fold-threads", type=int, default=3, help="host threads folding finished accumulations")
-    ap.add_argument("--products", type=int, default=0, help="pairing products in flight (<= 16); default 10, or 6 when RCCL needs queues too")
+    ap.add_argument("--products", type=int, default=0, help="pairing products in flight (<= 16); default 8, or 6 when RCCL needs queues too")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for rehearsals on one GPU)")
     ap.add_argument("--exchange", default="auto", choices=["auto", "native", "torch"],
                     help="partial exchange when sharded: the library's own RCCL all-gather (native) or the torch.distributed "
@@ -87,13 +87,13 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if args.acc_depth <= 0:
         # HIP maps streams onto 24 hardware queues and the pipeline falls off a cliff when its streams share them: 20
-        # streams are the library's budget.  Under load a lane pass carries two batches, so 10 lanes feed 10 product
-        # slots (measured, 400 batches: 12 + 8 -> 6.3e6 proofs/s, 10 + 10 -> 7.3e6, 8 + 12 -> 6.7e6, 10 + 12 -> 3.6e6);
-        # with a process group RCCL's own streams must fit too
-        args.acc_depth = 10 if world == 1 else 8  # measured with an RCCL group up: 12 -> 0.64, 10 -> 0.29, 8 -> 0.31 ms/batch
+        # streams are the library's budget.  Under load a lane pass carries two batches and a product ticket up to four
+        # products (measured, 400 / 20 batches: 10 + 10 -> 7.4e6 / 3.7e6 proofs/s, 12 + 8 -> 7.8e6 / 3.85e6, 14 + 6 ->
+        # 8.0e6 / 2.7e6, 10 + 12 -> 3.6e6); with a process group RCCL's own streams must fit too
+        args.acc_depth = 12 if world == 1 else 8  # measured with an RCCL group up: 12 -> 0.64, 10 -> 0.29, 8 -> 0.31 ms/batch
     os.environ["MI_SNARK_VS_LANES"] = str(args.acc_depth)  # read when the verifier context is created
     if args.products <= 0:
-        args.products = 10 if world == 1 else 6  # 8 lanes + 6 product streams: room for RCCL's own queues below the 24-queue cliff
+        args.products = 8 if world == 1 else 6  # 8 lanes + 6 product streams: room for RCCL's own queues below the 24-queue cliff
     os.environ["MI_SNARK_VS_SLOTS"] = str(args.products)
     if args.exchange_group <= 0:
         args.exchange_group = 4 if world > 1 else 1
@@ -121,7 +121,7 @@ def main():
     verifier = A.VarunaShaped(vk, circuits)
 
     # The K batches are verified as a stream (chunks of a block / mempool traffic): up to 8 batches are accumulating
-    # on their own stream lanes while earlier ones are folded on host threads and up to 10 pairing products run on
+    # on their own stream lanes while earlier ones are folded on host threads and up to 8 product tickets (four products each at most) run on
     # their own streams.  Every batch is fully verified inside the timed region; "latency_ms" below is one batch on
     # its own, unpipelined.
     def gather_all(part):  # runs on verify_stream's finisher thread: every collective comes from that one thread

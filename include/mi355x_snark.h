@@ -238,21 +238,21 @@ int32_t mi_vs_verify_block_device(uint64_t ctx, const void *const *d_proofs, con
 int32_t mi_vs_accumulate_device(uint64_t ctx, const void *d_proofs, size_t n, const void *d_randomizers128,
                                 mi_vs_partial *partial_out, void *stream);
 int32_t mi_vs_finalize(uint64_t ctx, const mi_vs_partial *partials, size_t n_partials, uint8_t *all_ok);
-#define MI_VS_MAX_OPEN_ACCUMULATIONS 14 /* mi_vs_accumulate_begin without a matching _end: 10 by default, env
+#define MI_VS_MAX_OPEN_ACCUMULATIONS 14 /* mi_vs_accumulate_begin without a matching _end: 12 by default, env
                                            MI_SNARK_VS_LANES = 1..14, read when a device is first used.  Lanes and
                                            product slots (streams, workspaces) belong to the DEVICE and are shared by
                                            all verifier contexts: the limits hold across contexts.  A begin (and
                                            every call built on it) WAITS for a lane when all are taken. */
-#define MI_VS_MAX_TICKETS 16            /* mi_vs_finalize_async without a matching _wait: 10 by default, env
+#define MI_VS_MAX_TICKETS 16            /* mi_vs_finalize_async without a matching _wait: 8 by default, env
                                            MI_SNARK_VS_SLOTS = 1..16.  Lanes + slots are HIP streams: keep their sum
                                            at 20 or below (the pipeline loses half its throughput when streams have
                                            to share hardware queues) */
 /* pipelined form: the pairing product of batch i runs on the context's own stream while the caller accumulates
  * batch i+1 (VM::check_transactions walks a block in chunks of <= 1000 executions; mempool admission streams).
- * At most 10 (MI_SNARK_VS_SLOTS) tickets may be outstanding (each product has its own stream); all must be waited for before the
+ * At most 8 (MI_SNARK_VS_SLOTS) tickets may be outstanding (each product has its own stream); all must be waited for before the
  * context is destroyed. */
 /* split accumulate: _begin enqueues the shard's kernels and returns at once, _end waits and folds on the host.
- * Up to 10 (MI_SNARK_VS_LANES) may be open at a time (each has its own stream and workspaces), so the next batches run on the GPU
+ * Up to 12 (MI_SNARK_VS_LANES) may be open at a time (each has its own stream and workspaces), so the next batches run on the GPU
  * while batch k is folded and finalised.  Thread safety: every entry point may be called from any host thread; the
  * context lock is dropped around host-side waits and folds, so one thread can enqueue (_begin) while others fold
  * (_end, any order) and a third finalises (set GPU_MAX_HW_QUEUES=32: HIP then maps streams onto 24 hardware queues; keep lanes + products + the
@@ -279,6 +279,14 @@ int32_t mi_vs_accumulate_end_pair(uint64_t ctx, uint64_t handle, mi_vs_partial *
 int32_t mi_vs_batches_per_pass(uint64_t ctx, size_t n);  /* >= 1, or a negative status */
 int32_t mi_vs_finalize_async(uint64_t ctx, const mi_vs_partial *partials, size_t n_partials, uint64_t *ticket_out);
 int32_t mi_vs_finalize_wait(uint64_t ctx, uint64_t ticket, uint8_t *all_ok);
+/* Several pairing products under ONE ticket (one product stream, a workgroup per product): product k sums
+ * partials[k * n_partials_each .. (k + 1) * n_partials_each).  What becomes ready together -- the batches of a lane
+ * pass, a burst of chunks -- then needs one of the ten product slots, not one each.  _wait_multi writes all_ok[k];
+ * `count` must be the ticket's own. */
+#define MI_VS_MAX_PRODUCTS_PER_TICKET 4
+int32_t mi_vs_finalize_async_multi(uint64_t ctx, const mi_vs_partial *partials, size_t n_partials_each, int32_t count,
+                                   uint64_t *ticket_out);
+int32_t mi_vs_finalize_wait_multi(uint64_t ctx, uint64_t ticket, uint8_t *all_ok, int32_t count);
 
 /* ---- native streaming driver over the split entry points above (what rayon workers would otherwise hand-roll) ----
  * One driver owns host threads: `fold_threads` wait for accumulations and fold them, one finisher turns partials into

@@ -466,6 +466,19 @@ class VarunaShaped:
             raise L.MiError(r, "mi_vs_batches_per_pass")
         return r
 
+    def finalize_multi(self, groups):
+        """Several pairing products under one ticket (mi_vs_finalize_async_multi / _wait_multi): groups is a list of
+        equally long lists of partials (one list per product: the shards of one batch); returns one bool per product."""
+        k, each = len(groups), len(groups[0])
+        assert all(len(g) == each for g in groups)
+        parts = np.ascontiguousarray(np.stack([np.stack([np.asarray(p, dtype=np.uint8).reshape(-1) for p in g]) for g in groups]))
+        t = C.c_uint64(0)
+        L.check(L.lib().mi_vs_finalize_async_multi(C.c_uint64(self.ctx), L.ptr(parts), C.c_size_t(each), C.c_int32(k), C.byref(t)),
+                "mi_vs_finalize_async_multi")
+        ok = np.zeros(k, dtype=np.uint8)
+        L.check(L.lib().mi_vs_finalize_wait_multi(C.c_uint64(self.ctx), t, L.ptr(ok), C.c_int32(k)), "mi_vs_finalize_wait_multi")
+        return [bool(x) for x in ok]
+
     def finalize_async(self, partials):
         """Enqueue the pairing product for these partials on the context's own stream; returns a ticket."""
         parts = np.ascontiguousarray(partials, dtype=np.uint8).reshape(-1, L.VS_PARTIAL_BYTES)
@@ -488,7 +501,7 @@ class VarunaShaped:
                                               L.ptr(verdicts), L.stream_ptr(stream)), "mi_vs_identify_device")
         return verdicts
 
-    def verify_stream(self, batches, gather=None, depth=10, acc_depth=10, fold_threads=3, exchange_group=1, comm=None,
+    def verify_stream(self, batches, gather=None, depth=8, acc_depth=12, fold_threads=3, exchange_group=1, comm=None,
                       verdicts=False):
         """Pipelined verification of a stream of batches (chunks of a block, or mempool traffic): yields all_ok per
         batch, in order.
@@ -498,7 +511,7 @@ class VarunaShaped:
         for accumulations and fold them on the host; one finisher thread takes the partials in batch order,
         exchanges them (`gather`, optional: maps this rank's (count, 592) partials of `exchange_group` consecutive
         batches to all ranks' (world, count, 592) -- one collective per group, issued from that one thread) and starts
-        the pairing products; up to `depth` (<= 16, the device has MI_SNARK_VS_SLOTS = 10) products are in flight, each on its own stream.  `batches` yields
+        the pairing products; up to `depth` (<= 16, the device has MI_SNARK_VS_SLOTS = 8) product tickets are in flight, each on its own stream.  `batches` yields
         (proofs_cuda, randomizers_cuda).  `comm` (a handle of lib.comm_init_rank) makes the exchange native instead:
         the library's own mi_vs_exchange_rccl (ncclAllGather from the finisher thread, no Python on the data path).
         Submitted tensors are kept alive until their verdict has been yielded.

@@ -56,6 +56,8 @@ void pairing_product_prepared(Context &cx, const G1Affine *ps, const G2Prepared 
 void pairing_product_host_args(Context &cx, const G1Affine *ps, const G2Affine *qs, size_t n, Fq12 *out_host,
                                hipStream_t st);
 void pairing_launch(Context &cx, const G1Affine *ps, const G2Prepared *const *d_qs, size_t n, Fq12 *d_out, hipStream_t st, int unit);
+void pairing_launch_multi(Context &cx, const G1Affine *ps, const G2Prepared *const *d_qs, size_t n, int count, Fq12 *d_out, hipStream_t st,
+                          int unit);
 const PairingConsts *pairing_consts(Context &cx, hipStream_t st);
 
 // capi.hip: Poseidon over Fq (width 3, x^17, 4 + 31 + 4 rounds), constants resident per device
@@ -86,6 +88,8 @@ int32_t vs_batches_per_pass(Context &cx, uint64_t id, size_t n);
 int32_t vs_finalize(Context &cx, uint64_t id, const mi_vs_partial *parts, size_t np, uint8_t *all_ok, hipStream_t st);
 int32_t vs_finalize_async(Context &cx, uint64_t id, const mi_vs_partial *parts, size_t np, uint64_t *ticket);
 int32_t vs_finalize_wait(Context &cx, uint64_t id, uint64_t ticket, uint8_t *all_ok);
+int32_t vs_finalize_async_multi(Context &cx, uint64_t id, const mi_vs_partial *parts, size_t np, int count, uint64_t *ticket);
+int32_t vs_finalize_wait_multi(Context &cx, uint64_t id, uint64_t ticket, uint8_t *all_ok, int count);
 int32_t vs_identify_device(Context &cx, uint64_t id, const void *d_proofs, size_t n, const void *d_rand, uint8_t *verdicts,
                            hipStream_t st);
 int32_t vs_verify_batch_device(Context &cx, uint64_t id, const void *d_proofs, size_t n, const void *d_rand,

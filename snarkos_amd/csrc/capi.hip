@@ -998,6 +998,16 @@ int32_t mi_vs_finalize_async(uint64_t c, const mi_vs_partial *partials, size_t n
     if (!partials || !n_partials || !ticket_out) return MI_ERR_BAD_ARGS;
     return guarded([&](Context &cx) -> int32_t { return vs_finalize_async(cx, c, partials, n_partials, ticket_out); });
 }
+int32_t mi_vs_finalize_async_multi(uint64_t c, const mi_vs_partial *partials, size_t n_partials_each, int32_t count, uint64_t *ticket_out) {
+    if (!partials || !n_partials_each || !ticket_out || count < 1 || count > MI_VS_MAX_PRODUCTS_PER_TICKET) return MI_ERR_BAD_ARGS;
+    return guarded([&](Context &cx) -> int32_t { return vs_finalize_async_multi(cx, c, partials, n_partials_each, count, ticket_out); });
+}
+int32_t mi_vs_finalize_wait_multi(uint64_t c, uint64_t ticket, uint8_t *all_ok, int32_t count) {
+    if (!all_ok) return MI_ERR_BAD_ARGS;
+    if (ensure_init() != MI_OK) return MI_ERR_NO_DEVICE;
+    return guarded_on(context_at((int)((ticket >> 8) & 0xff)),
+                      [&](Context &cx) -> int32_t { return vs_finalize_wait_multi(cx, c, ticket, all_ok, count); });
+}
 int32_t mi_vs_finalize_wait(uint64_t c, uint64_t ticket, uint8_t *all_ok) {
     if (!all_ok) return MI_ERR_BAD_ARGS;
     if (ensure_init() != MI_OK) return MI_ERR_NO_DEVICE;

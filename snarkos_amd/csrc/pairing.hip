@@ -34,6 +34,33 @@ __global__ void __launch_bounds__(PW_THREADS) pairing_lines_kernel(PairingArgs a
     pw_miller_group(S, live_q, p0, live_n - p0 >= 2 ? 2 : 1, blockIdx.x, merged + ((size_t)couple * PW_MILLER_GROUPS + blockIdx.x) * 12);
 }
 
+// Several independent products in ONE launch each (a workgroup per product; the line launch adds a grid dimension):
+// products that become ready together -- the batches of a lane pass, a burst -- need one product stream, not one each.
+struct PairingArgsN {
+    int count;
+    PairingArgs a[MI_VS_MAX_PRODUCTS_PER_TICKET];
+};
+__global__ void __launch_bounds__(PW_THREADS) pairing_product_multi_kernel(PairingArgsN args, const PairingConsts *__restrict__ pc,
+                                                                           Fq12 *out, const Fq *merged, size_t merged_stride) {
+    extern __shared__ uint4 pw_lds[];  // PW_LDS_BYTES
+    LShared &S = *(LShared *)pw_lds;
+    const PairingArgs &a = args.a[blockIdx.x];
+    pw_pairing_product(S, a.p, a.q, a.n, pc, out + blockIdx.x, merged ? merged + blockIdx.x * merged_stride : nullptr);
+}
+__global__ void __launch_bounds__(PW_THREADS) pairing_lines_multi_kernel(PairingArgsN args, const PairingConsts *__restrict__ pc, Fq *merged,
+                                                                         size_t merged_stride) {
+    extern __shared__ uint4 pw_lds[];  // PW_LDS_BYTES
+    LShared &S = *(LShared *)pw_lds;
+    __shared__ const G2Prepared *live_q[MI_MAX_PAIRS];
+    __shared__ int live_n_s;
+    const PairingArgs &a = args.a[blockIdx.z];
+    const int live_n = pw_live_pairs(S, a.p, a.q, a.n, live_q, &live_n_s, pc);
+    const int couple = blockIdx.y, p0 = 2 * couple;
+    if (p0 >= live_n) return;  // uniform
+    pw_miller_group(S, live_q, p0, live_n - p0 >= 2 ? 2 : 1, blockIdx.x,
+                    merged + blockIdx.z * merged_stride + ((size_t)couple * PW_MILLER_GROUPS + blockIdx.x) * 12);
+}
+
 struct PairingState {  // per device (Context::mod)
     DevBuf consts;
     bool ready = false;
@@ -104,6 +131,40 @@ void pairing_launch(Context &cx, const G1Affine *ps, const G2Prepared *const *d_
     }
     cx.prof.begin("pairing", st, n);  // the product kernel alone (what the kernel trace calls pairing_product_kernel)
     hipLaunchKernelGGL(pairing_product_kernel, dim3(1), dim3(PW_THREADS), PW_LDS_BYTES, st, a, pc, d_out, (const Fq *)merged);
+    cx.prof.end("pairing", st);
+    MI_HIP(hipGetLastError());
+}
+
+// `count` products at once: product k pairs ps[k * MI_MAX_PAIRS + i] with d_qs[i], i < n (the same prepared G2 points and
+// the same number of pairs for all: one verifier context); results in d_out[0 .. count)
+void pairing_launch_multi(Context &cx, const G1Affine *ps, const G2Prepared *const *d_qs, size_t n, int count, Fq12 *d_out, hipStream_t st,
+                          int unit) {
+    if (count == 1) return pairing_launch(cx, ps, d_qs, n, d_out, st, unit);
+    if (count < 1 || count > MI_VS_MAX_PRODUCTS_PER_TICKET || n == 0) throw HipError{hipErrorInvalidValue, "pairing_launch_multi", __LINE__};
+    PairingArgsN a;
+    memset(&a, 0, sizeof a);
+    a.count = count;
+    for (int k = 0; k < count; k++) {
+        a.a[k].n = (int)n;
+        for (size_t i = 0; i < n; i++) {
+            a.a[k].p[i] = ps[(size_t)k * MI_MAX_PAIRS + i];
+            a.a[k].q[i] = d_qs[i];
+        }
+    }
+    const PairingConsts *pc = pairing_consts(cx, st);
+    const int couples = (int)((n + 1) / 2);
+    const size_t stride = (size_t)12 * PW_MILLER_GROUPS * (MI_MAX_PAIRS / 2);  // Fq per product
+    char nm[32];
+    snprintf(nm, sizeof nm, "pairing.mm%d", unit < 0 ? 99 : unit);
+    Fq *merged = (Fq *)cx.buf(nm, sizeof(Fq) * stride * MI_VS_MAX_PRODUCTS_PER_TICKET);
+    cx.raise_lds_limit((const void *)pairing_product_multi_kernel, (int)PW_LDS_BYTES);
+    cx.raise_lds_limit((const void *)pairing_lines_multi_kernel, (int)PW_LDS_BYTES);
+    cx.prof.begin("pairing_lines", st, n * count);
+    hipLaunchKernelGGL(pairing_lines_multi_kernel, dim3(PW_MILLER_GROUPS, couples, count), dim3(PW_THREADS), PW_LDS_BYTES, st, a, pc, merged,
+                       stride);
+    cx.prof.end("pairing_lines", st);
+    cx.prof.begin("pairing", st, n * count);
+    hipLaunchKernelGGL(pairing_product_multi_kernel, dim3(count), dim3(PW_THREADS), PW_LDS_BYTES, st, a, pc, d_out, (const Fq *)merged, stride);
     cx.prof.end("pairing", st);
     MI_HIP(hipGetLastError());
 }

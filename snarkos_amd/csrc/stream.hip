@@ -169,13 +169,13 @@ struct Stream {
     // The finisher starts pairing products as partials arrive; the PUBLISHER waits for them in order and hands the
     // verdicts out.  (One thread doing both published a verdict only when it needed the product's slot back or the
     // stream was finished: a caller trickling batches in would wait for ever.)
-    std::deque<uint64_t> tickets;  // products started, oldest first (mu)
+    std::deque<std::pair<uint64_t, int>> tickets;  // (ticket, products under it): started, oldest first (mu)
     int inflight = 0;              // started and not yet published (mu)
     bool launches_done = false;    // the finisher has ended (mu)
 
     void publisher_main() {
         for (;;) {
-            uint64_t tk = 0;
+            std::pair<uint64_t, int> tk;
             {
                 std::unique_lock<std::mutex> lk(mu);
                 cv.wait(lk, [&] { return !tickets.empty() || launches_done; });
@@ -187,17 +187,17 @@ struct Stream {
                 tk = tickets.front();
                 tickets.pop_front();
             }
-            uint8_t ok = 0;
-            const int32_t st = mi_vs_finalize_wait(ctx, tk, &ok);
+            uint8_t ok[MI_VS_MAX_PRODUCTS_PER_TICKET] = {};
+            const int32_t st = mi_vs_finalize_wait_multi(ctx, tk.first, ok, tk.second);
             std::lock_guard<std::mutex> lk(mu);
-            results.push_back(st == MI_OK ? (int32_t)ok : st);
+            for (int k = 0; k < tk.second; k++) results.push_back(st == MI_OK ? (int32_t)ok[k] : st);
             inflight--;
             cv.notify_all();
         }
     }
 
     void finisher_main() {
-        std::vector<mi_vs_partial> mine(8), all(8 * 64), one(64);
+        std::vector<mi_vs_partial> mine(8), all(8 * 64), one(64 * MI_VS_MAX_PRODUCTS_PER_TICKET);
         uint64_t seq = 0;
         bool failed = false;
         while (!failed) {
@@ -219,6 +219,10 @@ struct Stream {
                 const bool fin = finished && held.empty() && !launching;
                 count = (size_t)(fin && submitted - seq < (uint64_t)group ? submitted - seq : (uint64_t)group);
                 if (count == 0) break;  // finished and drained
+                // without an exchange nothing ties the group size: whatever is folded already (the other batches of
+                // the pass, a burst) goes along, so that it can share a ticket
+                if (!exchange)
+                    while (count < (size_t)MI_VS_MAX_PRODUCTS_PER_TICKET && folded.count(seq + count)) count++;
                 for (size_t k = 0; k < count; k++) {
                     mine[k] = folded[seq + k];
                     folded.erase(seq + k);
@@ -229,7 +233,7 @@ struct Stream {
             const mi_vs_partial *src = mine.data();
             if (exchange) {
                 const int32_t got = exchange(user, mine.data(), count, all.data(), all.size());
-                if (got <= 0 || (size_t)got * count > all.size() || (size_t)got > one.size()) {
+                if (got <= 0 || (size_t)got * count > all.size() || (size_t)got > 64) {
                     std::lock_guard<std::mutex> lk(mu);
                     fail(got < 0 ? got : MI_ERR_BAD_ARGS);
                     break;
@@ -237,14 +241,18 @@ struct Stream {
                 world = (size_t)got;
                 src = all.data();
             }
-            for (size_t k = 0; k < count && !failed; k++) {
-                for (size_t r = 0; r < world; r++) one[r] = src[r * count + k];
+            // the group's batches go out under as few tickets as possible: one product stream serves up to
+            // MI_VS_MAX_PRODUCTS_PER_TICKET products that are ready together
+            for (size_t k0 = 0; k0 < count && !failed; k0 += MI_VS_MAX_PRODUCTS_PER_TICKET) {
+                const int m = (int)(count - k0 < (size_t)MI_VS_MAX_PRODUCTS_PER_TICKET ? count - k0 : (size_t)MI_VS_MAX_PRODUCTS_PER_TICKET);
+                for (int j = 0; j < m; j++)
+                    for (size_t r = 0; r < world; r++) one[(size_t)j * world + r] = src[r * count + k0 + (size_t)j];
                 {
                     std::unique_lock<std::mutex> lk(mu);
                     cv.wait(lk, [&] { return inflight < products; });
                 }
                 uint64_t tk = 0;
-                int32_t st = mi_vs_finalize_async(ctx, one.data(), world, &tk);
+                int32_t st = mi_vs_finalize_async_multi(ctx, one.data(), world, m, &tk);
                 while (st == MI_ERR_AGAIN) {  // fewer product slots than `products` (MI_SNARK_VS_SLOTS), or another stream holds them
                     {
                         std::unique_lock<std::mutex> lk(mu);
@@ -252,7 +260,7 @@ struct Stream {
                         const int before = inflight;
                         cv.wait(lk, [&] { return inflight < before; });
                     }
-                    st = mi_vs_finalize_async(ctx, one.data(), world, &tk);
+                    st = mi_vs_finalize_async_multi(ctx, one.data(), world, m, &tk);
                 }
                 std::lock_guard<std::mutex> lk(mu);
                 if (st != MI_OK) {
@@ -260,7 +268,7 @@ struct Stream {
                     failed = true;
                     break;
                 }
-                tickets.push_back(tk);
+                tickets.push_back(std::make_pair(tk, m));
                 inflight++;
                 cv.notify_all();
             }

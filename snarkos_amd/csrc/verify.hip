@@ -179,6 +179,8 @@ struct VsSlot {  // one in-flight pairing product (pipelined finalize)
     uint64_t ticket = 0;
     bool busy = false;
     uint64_t fails = 0;
+    int count = 1;                                           // products of this ticket
+    uint64_t fails_n[MI_VS_MAX_PRODUCTS_PER_TICKET] = {};    // algebraic failures per product
     hipEvent_t done = nullptr;
     hipStream_t stream = nullptr;  // each slot has its own stream: products of different batches run side by side
     Fq12 *h_out = nullptr;  // pinned
@@ -234,12 +236,14 @@ struct VsAcc {  // an accumulation whose kernels are enqueued but whose host fol
 // at most 24 hardware queues in creation order; with this order 12 lanes + 8 slots ran side by side (4.3e6 proofs/s
 // in round 1), created lazily in order of first use (lane, slot, lane, ...) the same streams reached 2.7e6, and with
 // more than ~20 of our streams on the device a pairing kernel ends up queued in front of other batches' MSMs
-// (10 lanes + 12 slots: half the throughput of 10 + 10).  Since a lane pass carries two batches under load
-// (mi_vs_accumulate_begin_pair) the split is 10 lanes + 10 slots.
-// MI_SNARK_VS_LANES (1..14, default 10) / MI_SNARK_VS_SLOTS (1..16, default 10), read once, trim the counts when the
+// (10 lanes + 12 slots: half the throughput of 10 + 10).  A lane pass carries two batches under load
+// (mi_vs_accumulate_begin_multi) and a ticket up to four products (mi_vs_finalize_async_multi), so the split is 12
+// lanes + 8 slots (measured, 400 / 20 batches: 10 + 10 7.4e6 / 3.7e6 proofs/s, 12 + 8 7.8e6 / 3.85e6, 14 + 6 8.0e6 /
+// 2.7e6: a burst needs the slots).
+// MI_SNARK_VS_LANES (1..14, default 12) / MI_SNARK_VS_SLOTS (1..16, default 8), read once, trim the counts when the
 // process needs queues for something else (RCCL, other libraries).
 struct VsPipe {
-    int lanes = 10, nslots = 10;
+    int lanes = 12, nslots = 8;
     VsAcc acc[VS_ACC_DEPTH];
     hipStream_t acc_st[VS_ACC_DEPTH] = {};  // one stream per accumulation lane
     hipEvent_t acc_ev[VS_ACC_DEPTH] = {};
@@ -265,7 +269,7 @@ struct VsPipe {
             VsSlot &sl = slots[i];
             MI_HIP(hipStreamCreateWithFlags(&sl.stream, hipStreamNonBlocking));
             MI_HIP(hipEventCreateWithFlags(&sl.done, hipEventDisableTiming));
-            MI_HIP(hipHostMalloc((void **)&sl.h_out, sizeof(Fq12), hipHostMallocDefault));
+            MI_HIP(hipHostMalloc((void **)&sl.h_out, sizeof(Fq12) * MI_VS_MAX_PRODUCTS_PER_TICKET, hipHostMallocDefault));
         }
         // HIP creates a stream's hardware queue at its first use (milliseconds each): do that now, in creation order,
         // not inside the first block a node verifies
@@ -1632,18 +1636,21 @@ int32_t vs_finalize(Context &cx, uint64_t id, const mi_vs_partial *parts, size_t
 
 // pipelined finalize: sum the partials on the host, enqueue the pairing product on one of the device's product
 // streams and return a ticket; the caller goes on to accumulate the next batch while the product runs
-static int32_t vs_slot_wait(VsSlot &sl, uint8_t *all_ok) {
+static int32_t vs_slot_wait(VsSlot &sl, uint8_t *all_ok, int count = 1) {
+    if (count != sl.count) return MI_ERR_BAD_ARGS;
     {
         Unlocked unlocked;  // other threads keep enqueueing and folding while this one waits for the product
         MI_HIP(hipEventSynchronize(sl.done));
     }
-    if (all_ok) *all_ok = (sl.h_out->is_one() && sl.fails == 0) ? 1 : 0;
+    if (all_ok)
+        for (int k = 0; k < count; k++) all_ok[k] = (sl.h_out[k].is_one() && sl.fails_n[k] == 0) ? 1 : 0;
     sl.busy = false;
     return MI_OK;
 }
-int32_t vs_finalize_async(Context &cx, uint64_t id, const mi_vs_partial *parts, size_t np, uint64_t *ticket) {
+// count products in one ticket: product k sums parts[k * np .. (k + 1) * np) (np ranks each)
+int32_t vs_finalize_async_multi(Context &cx, uint64_t id, const mi_vs_partial *parts, size_t np, int count, uint64_t *ticket) {
     std::shared_ptr<VsCtx> vc = vs_find(id);
-    if (!vc) return MI_ERR_BAD_ARGS;
+    if (!vc || count < 1 || count > MI_VS_MAX_PRODUCTS_PER_TICKET) return MI_ERR_BAD_ARGS;
     VsKeys &v = vs_keys(cx, *vc);
     VsPipe &pp = vs_pipe(cx);
     int slot = -1;
@@ -1656,25 +1663,35 @@ int32_t vs_finalize_async(Context &cx, uint64_t id, const mi_vs_partial *parts, 
     const uint64_t tk = vs_make_id(pp.next_ticket++, cx.index, slot);
     VsSlot &sl = pp.slots[slot];
     HostSpan hs("finalize_async");
-    G1Affine ps[MI_MAX_PAIRS];
-    uint64_t fails = 0;
-    vs_sum_partials(parts, np, ps, &fails);
+    G1Affine ps[MI_VS_MAX_PRODUCTS_PER_TICKET * MI_MAX_PAIRS];
+    for (int k = 0; k < count; k++) {
+        uint64_t fails = 0;
+        vs_sum_partials(parts + (size_t)k * np, np, ps + (size_t)k * MI_MAX_PAIRS, &fails);
+        sl.fails_n[k] = fails;
+    }
     const G2Prepared *qs[MI_MAX_PAIRS];
     const int K = vs_g2_keys(v, qs);
-    pairing_launch(cx, ps, qs, K, sl.h_out, sl.stream, slot);  // the kernel stores its result in pinned host memory
+    pairing_launch_multi(cx, ps, qs, K, count, sl.h_out, sl.stream, slot);  // the kernels store their results in pinned host memory
     MI_HIP(hipEventRecord(sl.done, sl.stream));
     sl.ticket = tk;
     sl.busy = true;
-    sl.fails = fails;
+    sl.fails = sl.fails_n[0];
+    sl.count = count;
     *ticket = tk;
     return MI_OK;
 }
-int32_t vs_finalize_wait(Context &cx, uint64_t id, uint64_t ticket, uint8_t *all_ok) {
+int32_t vs_finalize_async(Context &cx, uint64_t id, const mi_vs_partial *parts, size_t np, uint64_t *ticket) {
+    return vs_finalize_async_multi(cx, id, parts, np, 1, ticket);
+}
+int32_t vs_finalize_wait_multi(Context &cx, uint64_t id, uint64_t ticket, uint8_t *all_ok, int count) {
     if (!vs_find(id)) return MI_ERR_BAD_ARGS;
     if ((ticket & 0xff) >= VS_SLOTS || (int)((ticket >> 8) & 0xff) != cx.index) return MI_ERR_BAD_ARGS;
     VsSlot &sl = vs_pipe(cx).slots[ticket & 0xff];
     if (!sl.busy || sl.ticket != ticket) return MI_ERR_BAD_ARGS;
-    return vs_slot_wait(sl, all_ok);
+    return vs_slot_wait(sl, all_ok, count);
+}
+int32_t vs_finalize_wait(Context &cx, uint64_t id, uint64_t ticket, uint8_t *all_ok) {
+    return vs_finalize_wait_multi(cx, id, ticket, all_ok, 1);
 }
 
 // name the invalid proofs of a batch whose aggregate check failed: terms, sums, group products, per-proof products, all

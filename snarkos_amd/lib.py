@@ -27,9 +27,9 @@ KZG_VK_BYTES = 480
 VS_PROOF_BYTES = 2256
 VS_CIRCUIT_VK_BYTES = 1184
 VS_PARTIAL_BYTES = 592
-VS_MAX_OPEN_ACCUMULATIONS = 14  # compile-time cap; a device has MI_SNARK_VS_LANES (default 10) lanes
-VS_DEFAULT_LANES = 10
-VS_MAX_TICKETS = 16  # compile-time cap; a device has MI_SNARK_VS_SLOTS (default 10) product slots
+VS_MAX_OPEN_ACCUMULATIONS = 14  # compile-time cap; a device has MI_SNARK_VS_LANES (default 12) lanes
+VS_DEFAULT_LANES = 12
+VS_MAX_TICKETS = 16  # compile-time cap; a device has MI_SNARK_VS_SLOTS (default 8) product slots
 VS_FS_POSEIDON = 1  # mi_vs_ctx_create_ex flag: Poseidon Fiat-Shamir transcript
 VS2_PROOF_BYTES = 3184  # mi_vs_proof2
 VS3_PROOF_BYTES = 5504  # mi_vs_proof3 (shapes with max_instances > 1)
@@ -46,7 +46,7 @@ EXPORTS = [
     "mi_pairing_product_is_one", "mi_pairing", "mi_kzg_batch_check", "mi_kzg_batch_check_hiding",
     "mi_poseidon_fq_hash_many", "mi_poseidon_fq_hash_many_device",
     "mi_vs_ctx_create", "mi_vs_ctx_create_ex", "mi_vs_ctx_create_v2", "mi_vs_ctx_destroy", "mi_vs_verify_batch", "mi_vs_verify_batch_device", "mi_vs_identify_device",
-    "mi_vs_accumulate_device", "mi_vs_accumulate_begin", "mi_vs_accumulate_end", "mi_vs_accumulate_begin_pair", "mi_vs_accumulate_end_pair", "mi_vs_accumulate_begin_multi", "mi_vs_accumulate_end_multi", "mi_vs_batches_per_pass", "mi_g1_decompress", "mi_g1_decompress_device", "mi_g1_compress", "mi_vs_finalize", "mi_vs_finalize_async", "mi_vs_finalize_wait",
+    "mi_vs_accumulate_device", "mi_vs_accumulate_begin", "mi_vs_accumulate_end", "mi_vs_accumulate_begin_pair", "mi_vs_accumulate_end_pair", "mi_vs_accumulate_begin_multi", "mi_vs_accumulate_end_multi", "mi_vs_batches_per_pass", "mi_g1_decompress", "mi_g1_decompress_device", "mi_g1_compress", "mi_vs_finalize", "mi_vs_finalize_async", "mi_vs_finalize_wait", "mi_vs_finalize_async_multi", "mi_vs_finalize_wait_multi",
     "mi_vs_verify_block", "mi_vs_verify_block_device",
     "mi_vs_stream_open", "mi_vs_stream_submit", "mi_vs_stream_finish", "mi_vs_stream_next", "mi_vs_stream_next_verdicts", "mi_vs_stream_close",
     "mi_comm_unique_id", "mi_comm_init_rank", "mi_comm_init_local", "mi_comm_world", "mi_comm_destroy", "mi_comm_all_gather",

@@ -613,3 +613,34 @@ def test_multi_batch_passes_bit_exact(orc, mi):
                 assert v.finalize([singles[0]]) and not v.finalize([singles[2]])
         finally:
             v.close()
+
+
+def test_products_under_one_ticket(orc, mi):
+    """mi_vs_finalize_async_multi: up to four pairing products in one launch each (a workgroup per product) give the
+    verdicts of the products taken one at a time -- a failing batch among valid ones, shards of one batch summed per
+    product, the count checked at _wait"""
+    import ctypes as C
+    import torch
+    from snarkos_amd import lib as L
+    a = orc.VSBatch(0x7A11, 36, 3, 0)
+    v = _ctx(mi, a)
+    try:
+        p, r = torch.from_numpy(a.proofs).cuda(), torch.from_numpy(a.randomizers).cuda()
+        bad_np = a.proofs.copy(); bad_np[20 * 2256 + 16 + 512 + 864 + 32 * 9] ^= 1
+        good, bad = v.accumulate(p, r), v.accumulate(torch.from_numpy(bad_np).cuda(), r)
+        h1 = v.accumulate(p[: 10 * 2256].contiguous(), r[: 10 * 32].contiguous())
+        h2 = v.accumulate(p[10 * 2256:].contiguous(), r[10 * 32:].contiguous())
+        assert v.finalize([good]) and not v.finalize([bad]) and v.finalize([h1, h2])
+        assert v.finalize_multi([[good], [bad], [good], [good]]) == [True, False, True, True]
+        assert v.finalize_multi([[bad], [good]]) == [False, True]
+        assert v.finalize_multi([[good]]) == [True]
+        assert v.finalize_multi([[h1, h2], [h2, bad], [h1, h1]]) == [True, False, True]  # the check is linear: a valid shard twice passes
+        t = C.c_uint64(0)
+        parts = np.ascontiguousarray(np.stack([good, good]))
+        L.check(L.lib().mi_vs_finalize_async_multi(C.c_uint64(v.ctx), L.ptr(parts), C.c_size_t(1), C.c_int32(2), C.byref(t)), "async")
+        ok = np.zeros(2, dtype=np.uint8)
+        assert L.lib().mi_vs_finalize_wait_multi(C.c_uint64(v.ctx), t, L.ptr(ok), C.c_int32(1)) == -1  # the ticket holds two
+        assert L.lib().mi_vs_finalize_wait_multi(C.c_uint64(v.ctx), t, L.ptr(ok), C.c_int32(2)) == 0 and ok.all()
+        assert L.lib().mi_vs_finalize_async_multi(C.c_uint64(v.ctx), L.ptr(parts), C.c_size_t(1), C.c_int32(5), C.byref(t)) == -1
+    finally:
+        v.close()

@@ -60,3 +60,7 @@ for lanes, depth in cfgs:
     tot = sorted(1e3 * r[4] for r in runs)
     print("lanes=%d products=%d K=%d: median %.2f ms  p90 %.2f  max %.2f  runs over 1.3 x median: %d of %d"
           % (lanes, depth, K, statistics.median(tot), tot[int(0.9 * len(tot))], tot[-1], sum(t > 1.3 * statistics.median(tot) for t in tot), len(tot)))
+    med = sorted(runs, key=lambda r: r[4])[len(runs) // 2]
+    print("   median run: open %.2f  close %.2f" % (1e3 * med[0], 1e3 * (med[4] - med[3])))
+    print("   submits:", " ".join("%.2f" % (1e3 * s) for s in med[1]))
+    print("   verdicts:", " ".join("%.2f" % (1e3 * s) for s in med[2]))

@@ -1,9 +1,9 @@
-# streamed throughput against batches per pass, lanes and product slots (lanes + slots = 20 HIP streams)
+# streamed throughput (400 and 20 batches) against lanes / product slots now that a ticket carries up to four products
 cd $GRAFT_REPO_ROOT
-for cfg in "2 10 10 4" "4 10 10 4" "4 8 12 4" "4 6 14 4" "3 8 12 4" "4 8 12 2" "4 7 13 4" "3 10 10 4"; do
+for cfg in "10 10" "12 8" "13 7" "14 6" "12 6" "14 4"; do
   set -- $cfg
-  for k in 400 400 20; do
-  v=$(MI_SNARK_STREAM_PER_PASS=$1 MI_SNARK_STREAM_PAIR_AT=$4 MI_SNARK_VS_LANES=$2 MI_SNARK_VS_SLOTS=$3 timeout -k 10 120 python bench.py --steps $k --warmup 5 --no-extra --no-cpu-baseline --acc-depth $2 --products $3 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('%.0f step %.4f steady %.4f latency %.3f' % (d['value'], d['ms_per_step'], d.get('steady_state_ms_per_step', 0), d['latency_ms_one_batch_unpipelined']))")
-  echo "per_pass=$1 lanes=$2 slots=$3 pair_at=$4 K=$k -> $v"
+  for k in 400 400 20 20 20; do
+  v=$(MI_SNARK_VS_LANES=$1 MI_SNARK_VS_SLOTS=$2 timeout -k 10 120 python bench.py --steps $k --warmup 5 --no-extra --no-cpu-baseline --acc-depth $1 --products $2 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('%.0f step %.4f steady %.4f' % (d['value'], d['ms_per_step'], d.get('steady_state_ms_per_step', 0)))")
+  echo "lanes=$1 slots=$2 K=$k -> $v"
   done
 done
