@@ -288,8 +288,9 @@ def alu_view(kernels):
     ach = PAIRING_LIMB_PRODUCTS / t
     return {"kernel": "pairing", "unit": "32x32-bit limb products/s", "work_per_launch": PAIRING_LIMB_PRODUCTS,
             "achieved": ach, "waves": 3, "peak_for_those_waves": 3 * WAVE_LIMB_PRODUCT_RATE, "frac": ach / (3 * WAVE_LIMB_PRODUCT_RATE),
-            "note": "one workgroup (3 waves, one CU) per product (its 21-workgroup line launch is bracketed separately); several "
-                    "products run side by side in the streamed region, so avg_us includes their mutual slowdown"}
+            "note": "one workgroup (3 waves, one CU) per product (its 21-workgroup line launch is bracketed separately); a launch carries "
+                    "one to four products (a workgroup each: same duration, work and waves scale together, so the fraction is per "
+                    "product); several launches run side by side in the streamed region, so avg_us includes their mutual slowdown"}
 
 
 def native_comm(rank, world, flag_device):

@@ -23,7 +23,7 @@ src = os.path.join(ROOT, "gpurun_out", tag)
 dst = os.path.join(ROOT, "profiles")
 os.makedirs(dst, exist_ok=True)
 
-SHORT = {"pairing_product_kernel": "pairing", "msm_accumulate_kernel": "msm_accumulate", "vs_derive_kernel": "vs_derive",
+SHORT = {"pairing_product_multi_kernel": "pairing_multi", "pairing_product_kernel": "pairing", "msm_accumulate_kernel": "msm_accumulate", "vs_derive_kernel": "vs_derive",
          "ntt_pass_kernel": "ntt_pass", "ntt_lds_pass_kernel": "ntt_lds_pass", "msm_bit_sums_queue_kernel": "msm_bit_sums_queue"}
 
 
@@ -77,14 +77,16 @@ json.dump(traffic, open(os.path.join(dst, "pmc_traffic.json"), "w"), indent=1, s
 # ---- overlap of pairing products in the streamed region
 f = newest("stats/*/*_kernel_trace.csv")
 if f:
-    ev, durs, first, last = [], [], None, None
+    ev, durs, first, last, n_products = [], [], None, None, 0
     for r in csv.DictReader(open(f)):
-        if "pairing_product_kernel" not in r["Kernel_Name"]:
+        if "pairing_product_kernel" not in r["Kernel_Name"] and "pairing_product_multi_kernel" not in r["Kernel_Name"]:
             continue
         s, e = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
-        ev.append((s, 1))
-        ev.append((e, -1))
+        products = int(r["Grid_Size_X"]) // int(r["Workgroup_Size_X"])  # a workgroup per product (one, or up to four under one ticket)
+        ev.append((s, products))
+        ev.append((e, -products))
         durs.append(e - s)
+        n_products += products
         first = s if first is None else min(first, s)
         last = e if last is None else max(last, e)
     ev.sort()
@@ -97,12 +99,13 @@ if f:
         mx = max(mx, cur)
         prev = t
     n = len(durs)
-    out = {"kernel": "pairing_product_kernel", "launches": n, "avg_kernel_us": sum(durs) / n / 1e3 if n else None,
-           "max_concurrent": mx, "mean_concurrent_while_any_runs": area / busy if busy else None,
-           "wall_us_with_a_product_running": busy / 1e3, "wall_us_per_launch": busy / n / 1e3 if n else None,
-           "cu_busy_us_per_launch": area / n / 1e3 if n else None,
-           "note": "one workgroup (3 waves, one CU) per launch: a step's wall time is the kernel's duration divided by the "
-                   "number of products in flight; trace of `bench.py --steps 20 --warmup 5` (warm-up, timed, steady-state and "
-                   "event-bracketed passes together)"}
+    out = {"kernel": "pairing_product_kernel + pairing_product_multi_kernel", "launches": n, "products": n_products,
+           "avg_kernel_us": sum(durs) / n / 1e3 if n else None,
+           "max_concurrent_products": mx, "mean_concurrent_products_while_any_runs": area / busy if busy else None,
+           "wall_us_with_a_product_running": busy / 1e3, "wall_us_per_product": busy / n_products / 1e3 if n_products else None,
+           "cu_busy_us_per_product": area / n_products / 1e3 if n_products else None,
+           "note": "one workgroup (3 waves, one CU) per product, one to four products per launch: a step's wall time is the "
+                   "kernel's duration divided by the number of products in flight; trace of `bench.py --steps 20 --warmup 5` "
+                   "(warm-up, timed, steady-state and event-bracketed passes together)"}
     json.dump(out, open(os.path.join(dst, "%s_overlap.json" % tag), "w"), indent=1)
 print("profiles/ updated from", src)
