@@ -183,6 +183,11 @@ def emit(prefix, static_kw):
     a("%s uint64_t %sFQ_T_MINUS1_HALF[6] = %s;" % (static_kw, prefix, arr((FQ_T - 1) // 2, 6)))
     a("%s uint64_t %sFQ_2SYLOW_GEN[6] = %s;" % (static_kw, prefix, fq(pow(15, FQ_T, Q))))
     a("%s uint64_t %sFQ_HALF[6] = %s;" % (static_kw, prefix, arr((Q - 1) // 2, 6)))
+    a("/* FQ_2SYLOW_POW[j] = FQ_2SYLOW_GEN^(2^j), j < 46 (Montgomery): every g and c of the Tonelli-Shanks loop is one of these */")
+    a("%s uint64_t %sFQ_2SYLOW_POW[46][6] = {" % (static_kw, prefix))
+    for j in range(46):
+        a("  %s," % fq(pow(15, FQ_T << j, Q)))
+    a("};")
     a("%s uint64_t %sFR_MODULUS_BITS[4] = %s; /* r itself: the subgroup check multiplies by it */" % (static_kw, prefix, arr(R, 4)))
     a("/* FROB[e-1][k] = gamma_e^k (Montgomery): multiply the Fq coefficient of w^k, k = i + 2j + 6b for c_i.c_j.c_b */")
     a("%s uint64_t %sFROB[3][12][6] = {" % (static_kw, prefix))
