@@ -793,7 +793,7 @@ __global__ void __launch_bounds__(4 * VS_FS_PROOFS_PER_BLOCK) vs_fs_poseidon_ker
     // limb product, a dedicated squaring for the S-box chain, carry-free additions): the state never leaves it between
     // the first absorb and the last squeeze; constants and absorbed elements enter as they are stored.
     __shared__ Fq28 xs[VS_FS_PROOFS_PER_BLOCK][3];     // the state of each proof (full rounds), or lane 0's new element in slot 0 (partial)
-    __shared__ Fq28 xt[VS_FS_PROOFS_PER_BLOCK][2][3];  // partial rounds: lane l's products mds[i][l] s_l, l = 1, 2
+    __shared__ Fq28 xt[VS_FS_PROOFS_PER_BLOCK][3][3];  // partial rounds: lane l's products mds[i][l] s_l, l = 1, 2; [2]: lane 3's mds[i][0] s_0
     const int t = threadIdx.x, ps = t >> 2, l = t & 3, lc = l < 3 ? l : 0;
     // the pass's batches are laid out in units of 64 proofs (VsMore::first_block, shared with the derive kernel): a
     // block of this kernel takes VS_FS_PROOFS_PER_BLOCK / 64 consecutive units, each 4 waves
@@ -848,21 +848,23 @@ __global__ void __launch_bounds__(4 * VS_FS_PROOFS_PER_BLOCK) vs_fs_poseidon_ker
                 s = add28(add28(mul28(mrow[0], a0), mul28(mrow[1], a1)), mul28(mrow[2], a2));
                 __syncthreads();
             } else {
-                const bool sb = l == 0;  // the S-box lane; lanes 1, 2 run their MDS column beside it
+                // Lane 0 squares its way to s_0^16; lanes 1, 2 run their MDS columns beside it, and lane 3 -- which
+                // mirrors lane 0's state -- the column of s_0 itself: mds[i][0] s_0^17 = (mds[i][0] s_0) s_0^16, so the
+                // product x^16 x leaves the chain (four products, the exchange, one product: five in sequence, not six)
+                const bool sb = l == 0;
                 const Fq28 x2 = mul28(f28_sel(sb, s, mcol[0]), s);
                 const Fq28 x4 = mul28(f28_sel(sb, x2, mcol[1]), f28_sel(sb, x2, s));
                 const Fq28 x8 = mul28(f28_sel(sb, x4, mcol[2]), f28_sel(sb, x4, s));
-                const Fq28 x16 = sqr28(x8);   // lanes 1, 2: idle slots (results unused)
-                const Fq28 x17 = mul28(x16, s);
-                if (l == 0) xs[ps][0] = x17;
-                if (l == 1 || l == 2) {
-                    xt[ps][l - 1][0] = x2;
-                    xt[ps][l - 1][1] = x4;
-                    xt[ps][l - 1][2] = x8;
+                const Fq28 x16 = sqr28(x8);   // lanes 1, 2, 3: an idle slot (result unused)
+                if (l == 0) xs[ps][0] = x16;
+                else {
+                    const int col = l == 3 ? 2 : l - 1;
+                    xt[ps][col][0] = x2;
+                    xt[ps][col][1] = x4;
+                    xt[ps][col][2] = x8;
                 }
                 __syncthreads();
-                const Fq28 s0 = xs[ps][0];
-                s = add28(add28(mul28(mrow[0], s0), xt[ps][0][lc]), xt[ps][1][lc]);
+                s = add28(add28(mul28(xs[ps][0], xt[ps][2][lc]), xt[ps][0][lc]), xt[ps][1][lc]);
                 __syncthreads();
             }
         }
