@@ -792,8 +792,18 @@ __global__ void __launch_bounds__(4 * VS_FS_PROOFS_PER_BLOCK) vs_fs_poseidon_ker
     // The permutation runs in the reduced-radix arithmetic of field28.hpp (14 signed 28-bit limbs: one instruction per
     // limb product, a dedicated squaring for the S-box chain, carry-free additions): the state never leaves it between
     // the first absorb and the last squeeze; constants and absorbed elements enter as they are stored.
-    __shared__ Fq28 xs[VS_FS_PROOFS_PER_BLOCK][3];     // the state of each proof (full rounds), or lane 0's new element in slot 0 (partial)
-    __shared__ Fq28 xt[VS_FS_PROOFS_PER_BLOCK][3][3];  // partial rounds: lane l's products mds[i][l] s_l, l = 1, 2; [2]: lane 3's mds[i][0] s_0
+    // Exchange buffers, TWO sets used alternately (round parity): a round writes its set, one barrier, reads it; the next
+    // round's writes go to the other set, whose readers passed the barrier before -- one barrier per round, not two.
+    // xs: the state of each proof (full rounds), or lane 0's s_0^16 in slot 0 (partial); xt: partial rounds, lane l's
+    // products mds[i][l] s_l (l = 1, 2) and, in [2], lane 3's mds[i][0] s_0.  Dynamic LDS: 2 x 43 KB is more than half
+    // a compute unit's LDS, which is also what keeps a CU to one batch (see the launch).
+    struct FsExchange {
+        Fq28 xs[VS_FS_PROOFS_PER_BLOCK][3];
+        Fq28 xt[VS_FS_PROOFS_PER_BLOCK][3][3];
+    };
+    extern __shared__ uint4 fs_lds[];
+    FsExchange *const ex2 = reinterpret_cast<FsExchange *>(fs_lds);
+    int par = 0;
     const int t = threadIdx.x, ps = t >> 2, l = t & 3, lc = l < 3 ? l : 0;
     // the pass's batches are laid out in units of 64 proofs (VsMore::first_block, shared with the derive kernel): a
     // block of this kernel takes VS_FS_PROOFS_PER_BLOCK / 64 consecutive units, each 4 waves
@@ -842,11 +852,12 @@ __global__ void __launch_bounds__(4 * VS_FS_PROOFS_PER_BLOCK) vs_fs_poseidon_ker
             if (full) {
                 const Fq28 x2 = sqr28(s), x4 = sqr28(x2), x8 = sqr28(x4), x16 = sqr28(x8);
                 s = mul28(x16, s);
-                if (l < 3) xs[ps][l] = s;
+                FsExchange &X = ex2[par];
+                par ^= 1;
+                if (l < 3) X.xs[ps][l] = s;
                 __syncthreads();
-                const Fq28 a0 = xs[ps][0], a1 = xs[ps][1], a2 = xs[ps][2];
+                const Fq28 a0 = X.xs[ps][0], a1 = X.xs[ps][1], a2 = X.xs[ps][2];
                 s = add28(add28(mul28(mrow[0], a0), mul28(mrow[1], a1)), mul28(mrow[2], a2));
-                __syncthreads();
             } else {
                 // Lane 0 squares its way to s_0^16; lanes 1, 2 run their MDS columns beside it, and lane 3 -- which
                 // mirrors lane 0's state -- the column of s_0 itself: mds[i][0] s_0^17 = (mds[i][0] s_0) s_0^16, so the
@@ -856,16 +867,17 @@ __global__ void __launch_bounds__(4 * VS_FS_PROOFS_PER_BLOCK) vs_fs_poseidon_ker
                 const Fq28 x4 = mul28(f28_sel(sb, x2, mcol[1]), f28_sel(sb, x2, s));
                 const Fq28 x8 = mul28(f28_sel(sb, x4, mcol[2]), f28_sel(sb, x4, s));
                 const Fq28 x16 = sqr28(x8);   // lanes 1, 2, 3: an idle slot (result unused)
-                if (l == 0) xs[ps][0] = x16;
+                FsExchange &X = ex2[par];
+                par ^= 1;
+                if (l == 0) X.xs[ps][0] = x16;
                 else {
                     const int col = l == 3 ? 2 : l - 1;
-                    xt[ps][col][0] = x2;
-                    xt[ps][col][1] = x4;
-                    xt[ps][col][2] = x8;
+                    X.xt[ps][col][0] = x2;
+                    X.xt[ps][col][1] = x4;
+                    X.xt[ps][col][2] = x8;
                 }
                 __syncthreads();
-                s = add28(add28(mul28(xs[ps][0], xt[ps][2][lc]), xt[ps][0][lc]), xt[ps][1][lc]);
-                __syncthreads();
+                s = add28(add28(mul28(X.xs[ps][0], X.xt[ps][2][lc]), X.xt[ps][0][lc]), X.xt[ps][1][lc]);
             }
         }
         // ---- squeeze: the low 128 bits of the canonical value of the first rate element
@@ -1277,7 +1289,11 @@ static void vs_run_derive(Context &cx, VsKeys &v, const void *const *d_proofs, c
         // kernels of the batches in flight then never share a CU.  Their loop body (~70 KB of unrolled products) is
         // larger than the instruction cache; waves of different batches on one CU sit at different places in it and
         // fetch against each other (4 concurrent kernels each ran 2.2x slower before).
-        static const size_t fs_pad = getenv("MI_SNARK_FS_LDS_PAD") ? (size_t)atoi(getenv("MI_SNARK_FS_LDS_PAD")) : 50 * 1024;
+        // (the kernel's two exchange sets are 2 x 43 KB of dynamic LDS: more than half a CU's by themselves;
+        // MI_SNARK_FS_LDS_PAD adds to that for experiments)
+        static const size_t fs_pad = 2 * (size_t)VS_FS_PROOFS_PER_BLOCK * 12 * sizeof(Fq28) +
+                                     (getenv("MI_SNARK_FS_LDS_PAD") ? (size_t)atoi(getenv("MI_SNARK_FS_LDS_PAD")) : 0);
+        cx.raise_lds_limit((const void *)vs_fs_poseidon_kernel, (int)fs_pad);
         static_assert(VS_FS_PROOFS_PER_BLOCK % 64 == 0, "VsMore::first_block counts units of 64 proofs");
         hipLaunchKernelGGL(vs_fs_poseidon_kernel, dim3(cdiv(derive_blocks, VS_FS_PROOFS_PER_BLOCK / 64)), dim3(4 * VS_FS_PROOFS_PER_BLOCK), fs_pad, st, d_proofs[0], n,
                            (const mi_vs_circuit_vk *)v.circuits.p, v.n_circuits, (const VsConsts *)v.consts.p, pc, ch, more);
