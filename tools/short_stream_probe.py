@@ -54,12 +54,13 @@ def one(k, fold, depth, lanes, gap=0.0):
 list(v.verify_stream(((pp, pr) for _ in range(5))))
 import statistics
 cfgs = [tuple(int(x) for x in c.split(",")) for c in (sys.argv[2].split() if len(sys.argv) > 2 else ["10,10"])]
-for lanes, depth in cfgs:
-    fold = 3
+for cfg in cfgs:
+    lanes, depth = cfg[0], cfg[1]
+    fold = cfg[2] if len(cfg) > 2 else 3
     runs = [one(K, fold, depth, lanes) for rep in range(60)]
     tot = sorted(1e3 * r[4] for r in runs)
-    print("lanes=%d products=%d K=%d: median %.2f ms  p90 %.2f  max %.2f  runs over 1.3 x median: %d of %d"
-          % (lanes, depth, K, statistics.median(tot), tot[int(0.9 * len(tot))], tot[-1], sum(t > 1.3 * statistics.median(tot) for t in tot), len(tot)))
+    print("lanes=%d products=%d fold=%d K=%d: median %.2f ms  p90 %.2f  max %.2f  runs over 1.3 x median: %d of %d"
+          % (lanes, depth, fold, K, statistics.median(tot), tot[int(0.9 * len(tot))], tot[-1], sum(t > 1.3 * statistics.median(tot) for t in tot), len(tot)))
     med = sorted(runs, key=lambda r: r[4])[len(runs) // 2]
     print("   median run: open %.2f  close %.2f" % (1e3 * med[0], 1e3 * (med[4] - med[3])))
     print("   submits:", " ".join("%.2f" % (1e3 * s) for s in med[1]))
