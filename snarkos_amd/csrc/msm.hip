@@ -687,7 +687,9 @@ __global__ void __launch_bounds__(64) msm_bit_sums_part_kernel(const G1Xyzz *__r
 // runs in which this kernel served pair passes.  Its index arithmetic, its wave-level queue (also tried with
 // workgroup-scope fences) and its generated code (no scratch, no flat accesses, pointers live where they are used)
 // were checked without finding an out-of-range access.  The LDS footprint alone is not it: the one-wave kernel asking
-// for 60 KB of LDS it never touches (MI_SNARK_BITSUM_LDS_PAD) ran 16 benches clean.  Unexplained, therefore off.
+// for 60 KB of LDS it never touches (MI_SNARK_BITSUM_LDS_PAD) ran 16 benches clean; nor the undefined accumulator
+// registers that waves without matches put into LDS (zero-initialised: 26 clean runs, then the same fault).
+// Unexplained, therefore off.
 // tools/fault_hunt.sh is the bounded reproduction.
 #define BS_GROUPS 4
 __global__ void __launch_bounds__(64 * BS_GROUPS) msm_bit_sums_block_kernel(const G1Xyzz *__restrict__ chunk_partial,
