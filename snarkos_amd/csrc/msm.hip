@@ -688,8 +688,13 @@ __global__ void __launch_bounds__(64) msm_bit_sums_part_kernel(const G1Xyzz *__r
 // workgroup-scope fences) and its generated code (no scratch, no flat accesses, pointers live where they are used)
 // were checked without finding an out-of-range access.  The LDS footprint alone is not it: the one-wave kernel asking
 // for 60 KB of LDS it never touches (MI_SNARK_BITSUM_LDS_PAD) ran 16 benches clean; nor the undefined accumulator
-// registers that waves without matches put into LDS (zero-initialised: 26 clean runs, then the same fault).
-// Unexplained, therefore off.
+// registers that waves without matches put into LDS (zero-initialised: 26 clean runs, then the same fault).  What
+// separates the good from the bad is the number of waves in the block: BS_GROUPS = 1 (this very code, one wave per
+// block, the tree through LDS) ran 30 benches clean; BS_GROUPS = 2 ended its tenth in
+// HSA_STATUS_ERROR_ILLEGAL_INSTRUCTION -- a wave's program counter gone astray, as a 2 MB-aligned fault address also
+// suggests -- so it is waves parked at the level loop's barrier for ~100 us while another wave of the block works
+// that this platform does not always survive (the other multi-wave kernels on the path wait microseconds).
+// Unexplained below that level, therefore off.
 // tools/fault_hunt.sh is the bounded reproduction.
 #define BS_GROUPS 4
 __global__ void __launch_bounds__(64 * BS_GROUPS) msm_bit_sums_block_kernel(const G1Xyzz *__restrict__ chunk_partial,
