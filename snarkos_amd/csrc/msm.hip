@@ -692,9 +692,9 @@ __global__ void __launch_bounds__(64) msm_bit_sums_part_kernel(const G1Xyzz *__r
 // separates the good from the bad is the number of waves in the block: BS_GROUPS = 1 (this very code, one wave per
 // block, the tree through LDS) ran 30 benches clean; BS_GROUPS = 2 ended its tenth in
 // HSA_STATUS_ERROR_ILLEGAL_INSTRUCTION -- a wave's program counter gone astray, as a 2 MB-aligned fault address also
-// suggests -- so it is waves parked at the level loop's barrier for ~100 us while another wave of the block works
-// that this platform does not always survive (the other multi-wave kernels on the path wait microseconds).
-// Unexplained below that level, therefore off.
+// suggests.  It is not the barrier either: a variant in which waves 1..3 post their partials, count themselves in
+// LDS and END while wave 0 runs the whole tree (no wave ever parked at an s_barrier) ended its 17th run the same way.
+// Multi-wave blocks of THIS kernel fail, one-wave blocks of the same code do not; unexplained below that, therefore off.
 // tools/fault_hunt.sh is the bounded reproduction.
 #define BS_GROUPS 4
 __global__ void __launch_bounds__(64 * BS_GROUPS) msm_bit_sums_block_kernel(const G1Xyzz *__restrict__ chunk_partial,
