@@ -644,3 +644,44 @@ def test_products_under_one_ticket(orc, mi):
         assert L.lib().mi_vs_finalize_async_multi(C.c_uint64(v.ctx), L.ptr(parts), C.c_size_t(1), C.c_int32(5), C.byref(t)) == -1
     finally:
         v.close()
+
+
+def test_two_pairing_streams_and_a_synchronous_caller(orc, mi, monkeypatch):
+    """two streams of the same context on two host threads, both pairing from their second batch on, while a third
+    thread verifies synchronously: every verdict right, nothing hangs (the lanes and product slots are the device's,
+    shared by all of them)"""
+    import threading
+    import torch
+    monkeypatch.setenv("MI_SNARK_STREAM_PAIR_AT", "1")
+    good = orc.VSBatch(0x57F1, 40, 3, 0)
+    v = _ctx(mi, good)
+    try:
+        gp, gr = torch.from_numpy(good.proofs).cuda(), torch.from_numpy(good.randomizers).cuda()
+        bad_np = good.proofs.copy(); bad_np[17 * 2256 + 16 + 512 + 864 + 32 * 9] ^= 1
+        bp = torch.from_numpy(bad_np).cuda()
+        out, errs = {}, []
+
+        def stream(name, pattern):
+            try:
+                seq = [(bp, gr) if k % pattern == pattern - 1 else (gp, gr) for k in range(45)]
+                out[name] = (list(v.verify_stream(iter(seq))), [q is gp for q, _ in seq])
+            except BaseException as e:  # noqa: BLE001
+                errs.append(e)
+
+        def sync():
+            try:
+                res = [v.verify_batch(bp if k % 2 else gp, gr)[0] for k in range(12)]
+                out["sync"] = (res, [k % 2 == 0 for k in range(12)])
+            except BaseException as e:  # noqa: BLE001
+                errs.append(e)
+
+        ts = [threading.Thread(target=stream, args=("a", 5)), threading.Thread(target=stream, args=("b", 7)), threading.Thread(target=sync)]
+        for t in ts:
+            t.start()
+        for t in ts:
+            t.join(120)
+        assert not errs and not any(t.is_alive() for t in ts)
+        for name in ("a", "b", "sync"):
+            assert out[name][0] == out[name][1], name
+    finally:
+        v.close()
