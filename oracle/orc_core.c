@@ -369,6 +369,7 @@ int orc_g1_decompress(orc_g1_affine *out, const uint8_t in[48], int check_subgro
     fq_t chk;
     fq_sqr(&chk, &y);
     if (!fq_eq(&chk, &rhs)) return 0;
+    if (fq_is_zero(&y) && (flags & 0x80)) return 0; /* y = 0 is its own negative: the sign flag selects nothing (non-canonical) */
     if (fq_is_larger_root(&y) != ((flags & 0x80) != 0)) fq_neg(&y, &y);
     *F(&out->x) = x;
     *F(&out->y) = y;

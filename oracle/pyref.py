@@ -234,6 +234,8 @@ def g1_decompress(data, check_subgroup=True):
     y = fq_sqrt(x * x * x + 1)
     if y is None:
         return False, None
+    if y == 0 and flags & 0x80:
+        return False, None  # y = 0 is its own negative: the "larger root" flag has nothing to select (non-canonical)
     if (y > (Q - 1) // 2) != bool(flags & 0x80):
         y = (Q - y) % Q
     P = (x, y)
@@ -559,6 +561,9 @@ def vs_fs_elements(cvk, proof):
     inputs, comms, evals = raw[16:528], raw[528:1392], raw[1392:2064]
     extra = proof.get("extra_raw", [])
     els = [_fs_embed(VS_TAG), _fs_embed(cvk["digest"])]
+    parts = proof.get("parts_used", [])  # VarunaShaped-v3: the further circuits of the proof (header, digest | vk evaluations)
+    for pr in parts:
+        els += [_fs_embed(pr["raw"][:16]), _fs_embed(pr["digest"])]
     for k in range(VS_INPUTS):
         els += [_fs_embed(inputs[32 * k:32 * k + 16]), _fs_embed(inputs[32 * k + 16:32 * k + 32])]
     els += [_fs_embed(comms[48 * c:48 * c + 48]) for c in range(4)]
@@ -570,21 +575,24 @@ def vs_fs_elements(cvk, proof):
     els += [_fs_embed(evals[32 * k:32 * k + 32]) for k in range(VS_EVALS)]
     for x in extra:
         els += [_fs_embed(x[704:736]), _fs_embed(x[736:768])]
-    assert len(els) == 73 + 38 * len(extra)
+    for pr in parts:
+        els += [_fs_embed(pr["raw"][16 + 32 * k:48 + 32 * k]) for k in range(VS_VK_COMMS)]
+    assert len(els) == 73 + 38 * len(extra) + 14 * len(parts)
     return els
 
 
 def vs_challenges_poseidon(cvk, proof):
     els = vs_fs_elements(cvk, proof)
     m1 = len(proof.get("extra_raw", []))  # instances beyond the first
+    d1 = len(proof.get("parts_used", []))  # circuits beyond the first
     st = [0, 0, 0]
     out = []
-    for b in range(37 + 19 * m1):
+    for b in range(37 + 19 * m1 + 7 * d1):
         st[1] = (st[1] + els[2 * b]) % Q
         if 2 * b + 1 < len(els):
             st[2] = (st[2] + els[2 * b + 1]) % Q
         st = poseidon_permute(st)
-        if b in (21 + 18 * m1, 25 + 18 * m1, 36 + 19 * m1):
+        if b in (21 + 18 * m1 + d1, 25 + 18 * m1 + d1, 36 + 19 * m1 + 7 * d1):
             out.append(st[1] & ((1 << 128) - 1))  # low 128 bits of the canonical value of the first rate element
     return tuple(out)
 
@@ -620,6 +628,8 @@ def vs_challenges(cvk, proof):
     evals = raw[1392:1392 + 672]
     extra = proof.get("extra_raw", [])
     h = sha256(VS_TAG + cvk["digest"] + inputs + comms[:192])
+    for pr in proof.get("parts_used", []):  # every further circuit: its header (id, first instance) and digest
+        h = sha256(h + pr["raw"][:16] + pr["digest"])
     for x in extra:  # every further instance: its inputs and two commitments, chained
         h = sha256(h + x[:704])
     h = sha256(h + comms[192:480])
@@ -629,6 +639,8 @@ def vs_challenges(cvk, proof):
     h = sha256(h + evals)
     for x in extra:  # and its two evaluations
         h = sha256(h + x[704:768])
+    for pr in proof.get("parts_used", []):  # and the evaluations of every further circuit's polynomials
+        h = sha256(h + pr["raw"][16:400])
     xi = int.from_bytes(h[:16], "little")
     return zb, zg, xi
 
@@ -730,12 +742,30 @@ def vs2_verify_one(tau_h, gamma_g, shift_h, shape, circuits, proof, rs):
                 if xm >= Q or ym >= Q or ((xm or ym) and not g1_is_on_curve((fq_from_mont(xm), fq_from_mont(ym)))):
                     return False
     cvk = circuits[proof["circuit"]]
+    if "n_circuits" in proof:  # VarunaShaped-v3: the record names the further circuits of the proof
+        if not vs4_circuits_ok(proof, shape, len(circuits)):
+            return False
+        for pr in proof["parts"]:
+            for k in range(VS_VK_COMMS):
+                if int.from_bytes(pr["raw"][16 + 32 * k:48 + 32 * k], "little") >= R:
+                    return False
+            pr["digest"] = circuits[pr["circuit"]]["digest"]
+        proof["parts_used"] = proof["parts"]
     zb, zg, xi = vs_challenges(cvk, proof)
     z = (zb, zg)
     ev = proof["evals"]
     zn = pow(zb, VS_INPUTS, R)
     if zn == 1:
         return False
+    lc_kinds = shape.get("lc_kind", [0] * VS_EVALS)
+    if any(k & 4 for k in lc_kinds) and zb == zg:
+        return False  # a coefficient 1 / (z_beta - z_gamma) does not exist
+    inv_diff = inv((zb - zg) % R, R)
+
+    def kappa(kind):
+        k = pow((pow(zb, 16, R) - 1) % R, kind & 1, R) * pow((pow(zg, 16, R) - 1) % R, (kind >> 1) & 1, R) % R
+        return k * inv_diff % R if kind & 4 else k
+
     w = omega(4)
 
     def input_identity(inputs, v0, v1):
@@ -760,11 +790,18 @@ def vs2_verify_one(tau_h, gamma_g, shift_h, shape, circuits, proof, rs):
     for p in range(VS_EVALS):
         q = shape["query_of"][p]
         cm = proof["comms"][p] if p < VS_PROOF_COMMS else cvk["comms"][p - VS_PROOF_COMMS]
-        kind = shape.get("lc_kind", [0] * VS_EVALS)[p]
-        kap = pow((pow(zb, 16, R) - 1) % R, kind & 1, R) * pow((pow(zg, 16, R) - 1) % R, (kind >> 1) & 1, R) % R
-        coef = rs[q] * pow(xi, p, R) * kap % R
+        coef = rs[q] * pow(xi, p, R) * kappa(lc_kinds[p]) % R
         total_c = g1_add(total_c, g1_mul(cm, coef))
         gs = (gs + coef * ev[p]) % R
+    # every further circuit of the proof: its 12 polynomials open like the first circuit's (same query and
+    # linear-combination tables) with the powers of xi after the instances': xi^(36 + 12 (d - 1) + k)
+    for d, pr in enumerate(proof.get("parts_used", [])):
+        for k in range(VS_VK_COMMS):
+            p = VS_PROOF_COMMS + k
+            q = shape["query_of"][p]
+            coef = rs[q] * pow(xi, VS4_FIRST_POWER + VS_VK_COMMS * d + k, R) * kappa(lc_kinds[p]) % R
+            total_c = g1_add(total_c, g1_mul(circuits[pr["circuit"]]["comms"][k], coef))
+            gs = (gs + coef * pr["vk_evals"][k]) % R
     for q in range(2):
         total_c = g1_add(total_c, g1_mul(proof["w"][q], rs[q] * z[q] % R))
         total_w = g1_add(total_w, g1_mul(proof["w"][q], rs[q]))
@@ -782,6 +819,171 @@ def vs2_verify_one(tau_h, gamma_g, shift_h, shape, circuits, proof, rs):
         bound[c] = g1_add(bound[c], g1_mul(proof["comms"][j], rho))
     pairs = [(total_c, G2_GEN), (g1_neg(total_w), tau_h)] + [(bound[c], shift_h[c]) for c in range(shape["n_bounds"])]
     return alg_ok and pairing_product_is_one(pairs)
+
+
+# ----------------------------------------------------------------------------- VarunaShaped-v3 (rows A7 + 8f-2)
+# (a) proofs that cover instances of SEVERAL circuits (Varuna's keys_to_inputs: BTreeMap<vk, &[inputs]>): record
+#     mi_vs_proof4 = a proof3 record, the number of distinct circuits and, for every circuit after the first, a part
+#     {circuit id, index of its first instance, the evaluations of its 12 polynomials}.  Circuit ids ascend strictly
+#     (a BTreeMap's key order), every circuit covers at least one instance; instance 0 belongs to the first circuit.
+# (b) linear-combination coefficients that need the inverse of a challenge: lc_kind bit 2 = times 1 / (z_beta - z_gamma).
+# (c) the WIRE form of a record (what the node holds inside Transaction bytes): every G1 point compressed to 48 bytes,
+#     every Fr field canonical little-endian, headers as they are; slots the record does not use (shifted commitments of
+#     unbounded polynomials, instances and circuits beyond the counts) are zero and are not decoded.
+VS4_PROOF_BYTES, VS_MAX_CIRCUITS, VS_CIRCUIT_PART_BYTES, VS4_FIRST_POWER = 6320, 3, 400, 36
+
+
+def vs4_parse_proof(b):
+    """mi_vs_proof4: a proof3 record, n_circuits, and the further circuits' parts"""
+    assert len(b) == VS4_PROOF_BYTES
+    d = vs3_parse_proof(b[:VS3_PROOF_BYTES])
+    nc = int.from_bytes(b[5504:5508], "little")
+    d["n_circuits"] = nc
+    d["parts"] = []
+    for k in range(max(0, min(nc, VS_MAX_CIRCUITS) - 1)):
+        raw = bytes(b[5520 + 400 * k:5520 + 400 * (k + 1)])
+        d["parts"].append({"raw": raw, "circuit": int.from_bytes(raw[:4], "little"), "first": int.from_bytes(raw[4:8], "little"),
+                           "vk_evals": [_rd_fr(raw[16 + 32 * j:48 + 32 * j]) for j in range(VS_VK_COMMS)]})
+    return d
+
+
+def vs4_circuits_ok(proof, shape, n_ctx_circuits):
+    """1 <= n_circuits <= min(max_circuits, n_instances); circuit ids strictly ascending from the first circuit's and
+    below the context's count; first-instance indices strictly ascending in [1, n_instances)"""
+    nc, ni = proof["n_circuits"], proof["n_instances"]
+    if not 1 <= nc <= min(shape.get("max_circuits", 1), VS_MAX_CIRCUITS) or nc > ni:
+        return False
+    c_prev, f_prev = proof["circuit"], 0
+    for pr in proof["parts"]:
+        if not (c_prev < pr["circuit"] < n_ctx_circuits and f_prev < pr["first"] < ni):
+            return False
+        c_prev, f_prev = pr["circuit"], pr["first"]
+    return True
+
+
+def vs_record_layout(kind):
+    """segments of a record: ("raw", bytes) | ("fr", count) | ("g1", count, slot class); kind 1..4 = mi_vs_proof ..
+    mi_vs_proof4.  Slot classes: "base" (always used), "shifted", ("inst", j), ("part", d)"""
+    seg = [("raw", 16, "base"), ("fr", VS_INPUTS, "base"), ("g1", VS_PROOF_COMMS, "base"), ("fr", VS_EVALS, "base"), ("g1", 2, "base")]
+    if kind >= 2:
+        seg += [("fr", 2, "base"), ("g1", VS_PROOF_COMMS, "shifted")]
+    if kind >= 3:
+        seg += [("raw", 16, "base")]
+        for j in range(VS_MAX_INSTANCES - 1):
+            seg += [("fr", VS_INPUTS, ("inst", j)), ("g1", 2, ("inst", j)), ("fr", 2, ("inst", j))]
+    if kind >= 4:
+        seg += [("raw", 16, "base")]
+        for d in range(VS_MAX_CIRCUITS - 1):
+            seg += [("raw", 16, ("part", d)), ("fr", VS_VK_COMMS, ("part", d))]
+    return seg
+
+
+VS_RECORD_BYTES = {1: VS_PROOF_BYTES, 2: VS2_PROOF_BYTES, 3: VS3_PROOF_BYTES, 4: VS4_PROOF_BYTES}
+VS_WIRE_BYTES = {1: 1728, 2: 2224, 3: 4256, 4: 5072}
+
+
+def vs_record_kind(shape):
+    if shape is None:
+        return 1
+    if shape.get("max_circuits", 1) > 1:
+        return 4
+    return 3 if shape.get("max_instances", 1) > 1 else 2
+
+
+def _vs_slot_used(cls, j_in_seg, shape, m1, d1):
+    if cls == "base":
+        return True
+    if cls == "shifted":
+        c = shape["bound_class"][j_in_seg] if shape else -1
+        return 0 <= c < shape["n_bounds"]
+    if cls[0] == "inst":
+        return cls[1] < m1
+    return cls[1] < d1
+
+
+def _vs_counts(rec_or_wire, kind, shape, wire):
+    """(m1, d1): further instances / circuits the record's headers announce, clamped to what the shape allows (a count
+    out of range leaves the first instance / circuit only, as in the uncompressed path)"""
+    m1 = d1 = 0
+    if kind >= 3:
+        off = VS_WIRE_BYTES[2] if wire else VS2_PROOF_BYTES
+        ni = int.from_bytes(rec_or_wire[off:off + 4], "little")
+        if 1 <= ni <= min(shape.get("max_instances", 1), VS_MAX_INSTANCES):
+            m1 = ni - 1
+    if kind >= 4:
+        off = VS_WIRE_BYTES[3] if wire else VS3_PROOF_BYTES
+        nc = int.from_bytes(rec_or_wire[off:off + 4], "little")
+        if 1 <= nc <= min(shape.get("max_circuits", 1), VS_MAX_CIRCUITS):
+            d1 = nc - 1
+    return m1, d1
+
+
+def vs_wire_encode(record, shape=None):
+    """uncompressed record (Montgomery fields, affine points) -> wire bytes; unused slots become zero"""
+    kind = vs_record_kind(shape)
+    assert len(record) == VS_RECORD_BYTES[kind]
+    m1, d1 = _vs_counts(record, kind, shape or {}, False)
+    out, o = bytearray(), 0
+    for seg in vs_record_layout(kind):
+        if seg[0] == "raw":
+            out += record[o:o + seg[1]] if _vs_slot_used(seg[2], 0, shape, m1, d1) else bytes(seg[1])
+            o += seg[1]
+        elif seg[0] == "fr":
+            for j in range(seg[1]):
+                used = _vs_slot_used(seg[2], j, shape, m1, d1)
+                out += fr_from_mont(int.from_bytes(record[o:o + 32], "little") % R).to_bytes(32, "little") if used else bytes(32)
+                o += 32
+        else:
+            for j in range(seg[1]):
+                used = _vs_slot_used(seg[2], j, shape, m1, d1)
+                out += g1_compress(_rd_g1(record[o:o + 96])) if used else bytes(48)
+                o += 96
+    assert o == len(record) and len(out) == VS_WIRE_BYTES[kind]
+    return bytes(out)
+
+
+def vs_wire_decode(wire, shape=None):
+    """wire bytes -> (uncompressed record, ok).  ok is False when a used point is not the encoding of a point of the
+    order-r subgroup or a used Fr field is not below r; that field is then zero (the point: infinity) in the record."""
+    kind = vs_record_kind(shape)
+    assert len(wire) == VS_WIRE_BYTES[kind]
+    m1, d1 = _vs_counts(wire, kind, shape or {}, True)
+    out, o, ok = bytearray(), 0, True
+    for seg in vs_record_layout(kind):
+        if seg[0] == "raw":
+            out += wire[o:o + seg[1]] if _vs_slot_used(seg[2], 0, shape, m1, d1) else bytes(seg[1])
+            o += seg[1]
+        elif seg[0] == "fr":
+            for j in range(seg[1]):
+                v = int.from_bytes(wire[o:o + 32], "little")
+                o += 32
+                if not _vs_slot_used(seg[2], j, shape, m1, d1):
+                    out += bytes(32)
+                elif v >= R:
+                    ok = False
+                    out += bytes(32)
+                else:
+                    out += fr_to_mont(v).to_bytes(32, "little")
+        else:
+            for j in range(seg[1]):
+                enc = wire[o:o + 48]
+                o += 48
+                if not _vs_slot_used(seg[2], j, shape, m1, d1):
+                    out += bytes(96)
+                    continue
+                good, pt = g1_decompress(enc)
+                if not good:
+                    ok = False
+                if not good or pt is None:
+                    out += bytes(96)
+                else:
+                    out += fq_to_mont(pt[0]).to_bytes(48, "little") + fq_to_mont(pt[1]).to_bytes(48, "little")
+    assert o == len(wire) and len(out) == VS_RECORD_BYTES[kind]
+    return bytes(out), ok
+
+
+def vs_parse_record(b, shape=None):
+    return {1: vs_parse_proof, 2: vs2_parse_proof, 3: vs3_parse_proof, 4: vs4_parse_proof}[vs_record_kind(shape)](b)
 
 
 # ----------------------------------------------------------------------------- Poseidon sponge over Fq (row A9)

@@ -294,11 +294,11 @@ extern "C" {
 int32_t mi_init(const int32_t *device_ids, int32_t n_devices) {
     if (n_devices < 0 || n_devices > 64 || (n_devices > 0 && !device_ids)) return MI_ERR_BAD_ARGS;
     if (!host_cpu_ok()) return MI_ERR_NO_DEVICE;
-    // The streamed verifier keeps ~20 HIP streams busy; the runtime maps them onto 4 hardware queues unless told
-    // otherwise, and a 20-batch stream then takes 11 ms instead of 6 (tools/short_stream_probe.py).  The variable is
-    // read when the runtime comes up, so this only helps an embedding process that has not touched HIP yet (a node
-    // whose first HIP call is this one); it never overrides the operator's own setting.
-    setenv("GPU_MAX_HW_QUEUES", "32", 0);
+    // The streamed verifier keeps ~20 HIP streams busy; the runtime maps them onto 4 hardware queues unless
+    // GPU_MAX_HW_QUEUES says otherwise, and a 20-batch stream then takes 11 ms instead of 6.  The variable is the
+    // embedding process's to set, before its first HIP call and before it has threads: the library
+    // never calls setenv (glibc's setenv races with any concurrent getenv of a multithreaded caller);
+    // mi_runtime_hints() reports when it is missing.
     if (n_devices == 0) return ensure_init();  // the current HIP device becomes the primary
     int count = 0;
     if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) return MI_ERR_NO_DEVICE;

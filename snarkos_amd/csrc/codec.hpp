@@ -133,6 +133,7 @@ MI_HD bool g1_decompress_one(const uint8_t *in, bool check_subgroup, G1Affine &o
     Fq y;
     if (!fq_sqrt(rhs, y)) return false;
     if (!(sqr(y) == rhs)) return false;
+    if (y.is_zero() && (flags & 0x80)) return false;  // y = 0 is its own negative: the sign flag selects nothing (non-canonical)
     if (fq_is_larger_root(y) != ((flags & 0x80) != 0)) y = neg(y);
     const G1Affine p{x, y};
     if (check_subgroup && !g1_in_subgroup(p)) return false;

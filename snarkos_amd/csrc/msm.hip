@@ -617,194 +617,11 @@ __global__ void __launch_bounds__(64) msm_bit_sums_queue_kernel(const G1Xyzz *__
     if (lane == 0) store_xyzz(&out[g], have ? xyzz28_store(acc) : G1Xyzz::inf());
 }
 
-// Several groups per WAVE (LPG lanes each): the same walk with a queue per group, every lane taking 64 / LPG times as
-// many partials, and a tree of log2(LPG) levels that serves all the wave's groups at once.  Per group that is
-// matches / LPG + log2(LPG) / (64 / LPG) wave-additions instead of matches / 64 + 6: 9.5 instead of 13 for the
-// verifier's windows at LPG = 32 -- less work, a longer chain (14 instead of 7 additions before the tree).  The trade
-// for passes that carry several batches: those only exist when the device is busy.  Measured (MI_SNARK_BITSUM_PART=32,
-// five interleaved runs each): 6.89e6 proofs/s against 7.3e6 with one group per wave -- the longer chain costs more
-// than the saved work brings, so it is NOT the default.
-template <int LPG>
-__global__ void __launch_bounds__(64) msm_bit_sums_part_kernel(const G1Xyzz *__restrict__ chunk_partial,
-                                                               const uint32_t *__restrict__ chunk_off,
-                                                               const uint32_t *__restrict__ chunk_bucket, uint32_t B, int c,
-                                                               uint32_t n_groups, G1Xyzz *__restrict__ out) {
-    constexpr int GPW = 64 / LPG;
-    __shared__ uint32_t queue[GPW][128];
-    const int lane = threadIdx.x, sub = lane / LPG, sl = lane % LPG;
-    const uint32_t g = blockIdx.x * GPW + (uint32_t)sub;
-    const bool live = g < n_groups;
-    const uint32_t w = live ? g / (uint32_t)c : 0, bit = live ? g - w * (uint32_t)c : 0;
-    const uint32_t lo = live ? chunk_off[(size_t)w * B] : 0, hi = live ? chunk_off[(size_t)(w + 1) * B] : 0;
-    const uint64_t sub_mask = (LPG == 64 ? ~0ull : ((1ull << LPG) - 1ull)) << (sub * LPG);
-    G1Xyzz28 acc;
-    bool have = false;
-    uint32_t head = 0, tail = 0, base = lo;  // uniform within the group's lanes
-    uint32_t *q = queue[sub];
-    bool done = false;
-    while (!__all(done)) {
-        const bool more = base < hi;
-        const uint32_t e = base + (uint32_t)sl;
-        const bool match = more && e < hi && (((chunk_bucket[e] - w * B + 1) >> bit) & 1u);
-        const uint64_t mm = __ballot(match) & sub_mask;  // this group's matches
-        if (match) q[(tail + (uint32_t)__popcll(mm & ((1ull << lane) - 1ull))) & 127u] = e;
-        tail += (uint32_t)__popcll(mm);
-        if (more) base += LPG;
-        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");  // the wave's own queues: its writes before its reads
-        __builtin_amdgcn_wave_barrier();
-        const uint32_t avail = tail - head;
-        if (avail >= (uint32_t)LPG || (!more && avail > 0)) {
-            const uint32_t take = avail < (uint32_t)LPG ? avail : (uint32_t)LPG;
-            if ((uint32_t)sl < take) {
-                const G1Xyzz v = load_xyzz(&chunk_partial[q[(head + (uint32_t)sl) & 127u]]);
-                xyzz_acc28(acc, have, xyzz28_from(v), !v.is_inf());
-            }
-            head += take;
-        } else if (!more) {
-            done = true;
-        }
-        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-    }
-#pragma unroll 1
-    for (int stride = LPG / 2; stride >= 1; stride >>= 1) {
-        const G1Xyzz28 other = xyzz28_shfl_down(acc, stride);
-        const bool have_other = __shfl_down((int)have, stride, 64) != 0;
-        if (sl < stride) xyzz_acc28(acc, have, other, have_other);
-    }
-    if (sl == 0 && live) store_xyzz(&out[g], have ? xyzz28_store(acc) : G1Xyzz::inf());
-}
-
-// Four groups per 256-lane block: the walk above, one group per wave, then ONE tree for the block through LDS.  A
-// wave on its own pays six full additions for its six tree levels although level k has work for 64 >> k lanes; here
-// level 1 of the four groups fills two waves, level 2 one, and the rest a shrinking part of wave 0: 7 wave-additions
-// per four groups instead of 24, while the other waves sleep at the barrier and leave their SIMDs to other batches.
-// The verifier's pair of MSMs needs 5 376 wave-additions in the one-wave form, 3 200 here; measured: the kernel alone
-// 217 -> 203 us, the streamed verifier +2.5 %.
-// NOT THE DEFAULT (MI_SNARK_BITSUM_LPG=4 selects it): with this kernel in the stream, one `bench.py --steps 400` run in
-// five to ten ended in "Memory access fault by GPU" at a 2 MB-aligned address, in the middle of a stream of identical
-// batches; 14 runs with the one-wave kernel (and every run before this kernel existed) were clean, and so were 17
-// runs in which this kernel served pair passes.  Its index arithmetic, its wave-level queue (also tried with
-// workgroup-scope fences) and its generated code (no scratch, no flat accesses, pointers live where they are used)
-// were checked without finding an out-of-range access.  The LDS footprint alone is not it: the one-wave kernel asking
-// for 60 KB of LDS it never touches (MI_SNARK_BITSUM_LDS_PAD) ran 16 benches clean; nor the undefined accumulator
-// registers that waves without matches put into LDS (zero-initialised: 26 clean runs, then the same fault).  What
-// separates the good from the bad is the number of waves in the block: BS_GROUPS = 1 (this very code, one wave per
-// block, the tree through LDS) ran 30 benches clean; BS_GROUPS = 2 ended its tenth in
-// HSA_STATUS_ERROR_ILLEGAL_INSTRUCTION -- a wave's program counter gone astray, as a 2 MB-aligned fault address also
-// suggests.  It is not the barrier either: a variant in which waves 1..3 post their partials, count themselves in
-// LDS and END while wave 0 runs the whole tree (no wave ever parked at an s_barrier) ended its 17th run the same way.
-// Multi-wave blocks of THIS kernel fail, one-wave blocks of the same code do not; unexplained below that, therefore off.
-// tools/fault_hunt.sh is the bounded reproduction.
-#define BS_GROUPS 4
-__global__ void __launch_bounds__(64 * BS_GROUPS) msm_bit_sums_block_kernel(const G1Xyzz *__restrict__ chunk_partial,
-                                                                            const uint32_t *__restrict__ chunk_off,
-                                                                            const uint32_t *__restrict__ chunk_bucket, uint32_t B, int c,
-                                                                            uint32_t n_groups, G1Xyzz *__restrict__ out) {
-    constexpr int NT = 64 * BS_GROUPS;
-    __shared__ uint32_t queue[BS_GROUPS][128];
-    __shared__ int32_t slot[56][NT];  // word k of lane p's partial at slot[k][p]: conflict-free for consecutive lanes
-    __shared__ uint32_t slot_have[NT];
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const uint32_t g = blockIdx.x * BS_GROUPS + (uint32_t)wv;
-    const bool live = g < n_groups;
-    const uint32_t w = live ? g / (uint32_t)c : 0, bit = g - w * (uint32_t)c;
-    const uint32_t lo = live ? chunk_off[(size_t)w * B] : 0, hi = live ? chunk_off[(size_t)(w + 1) * B] : 0;
-    G1Xyzz28 acc;
-    bool have = false;
-    uint32_t head = 0, tail = 0, base = lo;  // wave-uniform
-    uint32_t *q = queue[wv];
-    while (true) {
-        const bool more = base < hi;
-        if (more) {
-            const uint32_t e = base + lane;
-            const bool match = e < hi && (((chunk_bucket[e] - w * B + 1) >> bit) & 1u);
-            const uint64_t mm = __ballot(match);
-            if (match) q[(tail + (uint32_t)__popcll(mm & ((1ull << lane) - 1ull))) & 127u] = e;
-            tail += (uint32_t)__popcll(mm);
-            base += 64;
-            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");  // the wave's own queue: its writes before its reads
-            __builtin_amdgcn_wave_barrier();
-        }
-        const uint32_t avail = tail - head;
-        if (avail >= 64 || (!more && avail > 0)) {
-            const uint32_t take = avail < 64 ? avail : 64;
-            if ((uint32_t)lane < take) {
-                const G1Xyzz v = load_xyzz(&chunk_partial[q[(head + lane) & 127u]]);
-                xyzz_acc28(acc, have, xyzz28_from(v), !v.is_inf());
-            }
-            head += take;
-            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-        } else if (!more) {
-            break;
-        }
-    }
-    // the block's tree: slot p = 64 * (group in block) + lane
-    auto put = [&](int p, const G1Xyzz28 &v, bool hv) {
-#pragma unroll
-        for (int k = 0; k < 14; k++) {
-            slot[k][p] = v.x.l[k];
-            slot[14 + k][p] = v.y.l[k];
-            slot[28 + k][p] = v.zz.l[k];
-            slot[42 + k][p] = v.zzz.l[k];
-        }
-        slot_have[p] = hv ? 1u : 0u;
-    };
-    auto get = [&](int p, G1Xyzz28 &v) {
-#pragma unroll
-        for (int k = 0; k < 14; k++) {
-            v.x.l[k] = slot[k][p];
-            v.y.l[k] = slot[14 + k][p];
-            v.zz.l[k] = slot[28 + k][p];
-            v.zzz.l[k] = slot[42 + k][p];
-        }
-        return slot_have[p] != 0;
-    };
-    put(tid, acc, have);
-#pragma unroll 1
-    for (int stride = 32; stride >= 1; stride >>= 1) {
-        __syncthreads();
-        if (tid < BS_GROUPS * stride) {
-            const int p = 64 * (tid / stride) + (tid % stride);  // read by this lane alone at this level: no hazard on the write
-            G1Xyzz28 other;
-            have = get(p, acc);
-            const bool have_other = get(p + stride, other);
-            xyzz_acc28(acc, have, other, have_other);
-            if (stride > 1) put(p, acc, have);
-        }
-    }
-    if (tid < BS_GROUPS && blockIdx.x * BS_GROUPS + (uint32_t)tid < n_groups)
-        store_xyzz(&out[blockIdx.x * BS_GROUPS + tid], have ? xyzz28_store(acc) : G1Xyzz::inf());
-}
-
-template <int LPG>  // lanes per group: 64 (one group per wave) or 32 (two: half the tree work, twice the walk)
-__global__ void __launch_bounds__(64) msm_bit_sums_wave_kernel(const G1Xyzz *__restrict__ chunk_partial,
-                                                               const uint32_t *__restrict__ chunk_off,
-                                                               const uint32_t *__restrict__ chunk_bucket, uint32_t B, int c,
-                                                               uint32_t n_groups, G1Xyzz *__restrict__ out) {
-    const int lane = threadIdx.x % LPG;
-    const uint32_t g = blockIdx.x * (64 / LPG) + threadIdx.x / LPG;
-    const bool valid = g < n_groups;
-    const uint32_t gg = valid ? g : 0, w = gg / (uint32_t)c, bit = gg - w * (uint32_t)c;
-    const uint32_t lo = chunk_off[(size_t)w * B], hi = valid ? chunk_off[(size_t)(w + 1) * B] : lo;
-    G1Xyzz acc = G1Xyzz::inf();
-    uint32_t e = lo + lane;
-    for (;;) {
-        while (e < hi && !(((chunk_bucket[e] - w * B + 1) >> bit) & 1u)) e += LPG;
-        if (__ballot(e < hi) == 0ull) break;
-        if (e < hi) {
-            acc = add<true>(acc, load_xyzz(&chunk_partial[e]));  // products inlined: the call overhead of the shared copy doubles an addition
-            e += LPG;
-        }
-    }
-#pragma unroll 1
-    for (int stride = LPG / 2; stride >= 1; stride >>= 1) {
-        G1Xyzz other = xyzz_shfl_down(acc, stride);
-        if (lane < stride) acc = add<true>(acc, other);
-    }
-    if (lane == 0 && valid) store_xyzz(&out[g], acc);
-}
+// (Variants of this reduction were built, measured and REMOVED in round 3: several groups per wave (less work, a longer
+// chain: slower), a strided walk without the queue (slower), and four groups per 256-lane block with one tree through
+// LDS (+2.5 % streamed throughput, but one 400-batch run in five to seventeen ended in a memory fault at a 2 MB-aligned
+// address or an illegal-instruction error whose cause was not found by reading its code, its descriptor or its ISA:
+// DESIGN.md section 3 item 5.  A verifier library does not ship a path with a known fault behind a switch.)
 
 // ---------------------------------------------------------------- large MSMs: tiled histogram in LDS
 // The global histogram atomics run at the memory-side atomic rate (21 G/s: 0.7 ms of a 2^20 MSM, 10.6 ms at 2^24).
@@ -1049,10 +866,6 @@ void msm_enqueue(Context &cx, const G1Affine *d_points, const uint32_t *d_scalar
     if (T < 16) T = 16;
     if (small) {
         T = msm_small_chunk();
-        // four problems in one launch sequence = a pair pass of the streamed verifier, i.e. the device is busy and the
-        // total work counts, not the chain length: MI_SNARK_MSM_SMALL_T4 (experiments)
-        static const int t4 = getenv("MI_SNARK_MSM_SMALL_T4") ? atoi(getenv("MI_SNARK_MSM_SMALL_T4")) : 0;
-        if (problems >= 4 && t4 >= 4 && t4 <= 256) T = (uint32_t)t4;
     }
     const uint32_t HEAVY = 1;  // every bucket with more than one chunk is summed by the heavy kernel (a wave each)
     const size_t max_chunks = nb + (n * (size_t)pl.nwin) / T + 1;
@@ -1117,30 +930,9 @@ void msm_enqueue(Context &cx, const G1Affine *d_points, const uint32_t *d_scalar
         snprintf(pn, sizeof pn, "msm%d.pin%d", slot, pin_parity);
         job->h = (G1Xyzz *)cx.pin_named(pn, sizeof(G1Xyzz) * all_groups);
         cx.prof.begin("msm_bitsums", st, n);
-        static const int lpg = getenv("MI_SNARK_BITSUM_LPG") ? atoi(getenv("MI_SNARK_BITSUM_LPG")) : 0;  // 0: queue-balanced (default)
-        // MI_SNARK_BITSUM_LDS_PAD: dynamic LDS the one-wave kernel asks for and never touches (an experiment on the
-        // fault described at msm_bit_sums_block_kernel: does the LDS footprint alone bring it about?)
-        static const size_t lds_pad = getenv("MI_SNARK_BITSUM_LDS_PAD") ? (size_t)atoi(getenv("MI_SNARK_BITSUM_LDS_PAD")) : 0;
-        // passes that carry several batches (four or more MSMs): groups of `part` lanes, several to a wave
-        static const int part = getenv("MI_SNARK_BITSUM_PART") ? atoi(getenv("MI_SNARK_BITSUM_PART")) : 0;
-        if (lpg == 0 && problems >= 4 && part == 32)
-            hipLaunchKernelGGL(msm_bit_sums_part_kernel<32>, dim3((unsigned)((all_groups + 1) / 2)), dim3(64), 0, st, chunk_partial,
-                               chunk_off, chunk_bucket, pl.B, pl.c, (uint32_t)all_groups, job->h);
-        else if (lpg == 0 && problems >= 4 && part == 16)
-            hipLaunchKernelGGL(msm_bit_sums_part_kernel<16>, dim3((unsigned)((all_groups + 3) / 4)), dim3(64), 0, st, chunk_partial,
-                               chunk_off, chunk_bucket, pl.B, pl.c, (uint32_t)all_groups, job->h);
-        else if (lpg == 0)  // one wave per group, its own six tree levels
-            hipLaunchKernelGGL(msm_bit_sums_queue_kernel, dim3((unsigned)all_groups), dim3(64), lds_pad, st, chunk_partial, chunk_off,
-                               chunk_bucket, pl.B, pl.c, job->h);
-        else if (lpg == 4)  // four groups per block, one tree through LDS: NOT the default, see the kernel's comment
-            hipLaunchKernelGGL(msm_bit_sums_block_kernel, dim3((unsigned)((all_groups + BS_GROUPS - 1) / BS_GROUPS)), dim3(64 * BS_GROUPS), 0,
-                               st, chunk_partial, chunk_off, chunk_bucket, pl.B, pl.c, (uint32_t)all_groups, job->h);
-        else if (lpg == 32)
-            hipLaunchKernelGGL(msm_bit_sums_wave_kernel<32>, dim3((unsigned)((all_groups + 1) / 2)), dim3(64), 0, st, chunk_partial,
-                               chunk_off, chunk_bucket, pl.B, pl.c, (uint32_t)all_groups, job->h);
-        else
-            hipLaunchKernelGGL(msm_bit_sums_wave_kernel<64>, dim3((unsigned)all_groups), dim3(64), 0, st, chunk_partial, chunk_off,
-                               chunk_bucket, pl.B, pl.c, (uint32_t)all_groups, job->h);  // straight into pinned host memory
+        // one wave per group, its own six tree levels, results straight into pinned host memory
+        hipLaunchKernelGGL(msm_bit_sums_queue_kernel, dim3((unsigned)all_groups), dim3(64), 0, st, chunk_partial, chunk_off,
+                           chunk_bucket, pl.B, pl.c, job->h);
         cx.prof.end("msm_bitsums", st);
         result = nullptr;
     } else {
@@ -1276,8 +1068,7 @@ void msm_finish_all(Context &cx, MsmJob *job, hipStream_t st, mi_g1_jac *const *
             InFlight() : others(g_folds_in_flight.fetch_add(1)) {}
             ~InFlight() { g_folds_in_flight.fetch_sub(1); }
         } in_flight;
-        static const int force_k = getenv("MI_SNARK_FOLD_K") ? atoi(getenv("MI_SNARK_FOLD_K")) : 0;  // experiments
-        const int K = force_k ? force_k : (in_flight.others == 0 ? 4 : 2);
+        const int K = in_flight.others == 0 ? 4 : 2;
         std::vector<FoldSplit> f;
         f.reserve(MSM_MAX_PROBLEMS);
         for (int p = 0; p < np; p++) f.emplace_back(h + (size_t)p * job->groups, job->groups, job->groups > 160 ? K : 2);

@@ -1291,10 +1291,8 @@ static void vs_run_derive(Context &cx, VsKeys &v, const void *const *d_proofs, c
         // kernels of the batches in flight then never share a CU.  Their loop body (~70 KB of unrolled products) is
         // larger than the instruction cache; waves of different batches on one CU sit at different places in it and
         // fetch against each other (4 concurrent kernels each ran 2.2x slower before).
-        // (the kernel's two exchange sets are 2 x 43 KB of dynamic LDS: more than half a CU's by themselves;
-        // MI_SNARK_FS_LDS_PAD adds to that for experiments)
-        static const size_t fs_pad = 2 * (size_t)VS_FS_PROOFS_PER_BLOCK * 12 * sizeof(Fq28) +
-                                     (getenv("MI_SNARK_FS_LDS_PAD") ? (size_t)atoi(getenv("MI_SNARK_FS_LDS_PAD")) : 0);
+        // (the kernel's two exchange sets are 2 x 43 KB of dynamic LDS: more than half a CU's by themselves)
+        static const size_t fs_pad = 2 * (size_t)VS_FS_PROOFS_PER_BLOCK * 12 * sizeof(Fq28);
         cx.raise_lds_limit((const void *)vs_fs_poseidon_kernel, (int)fs_pad);
         static_assert(VS_FS_PROOFS_PER_BLOCK % 64 == 0, "VsMore::first_block counts units of 64 proofs");
         hipLaunchKernelGGL(vs_fs_poseidon_kernel, dim3(cdiv(derive_blocks, VS_FS_PROOFS_PER_BLOCK / 64)), dim3(4 * VS_FS_PROOFS_PER_BLOCK), fs_pad, st, d_proofs[0], n,
