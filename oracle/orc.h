@@ -174,9 +174,13 @@ typedef struct {
      * combinations (v_H(alpha) v_H(beta) ...); polynomials 0 and 1 take the plain power */
     uint8_t lc_kind[ORC_VS_EVALS];
     /* per-circuit batch size: a proof covers 1 .. max_instances instances of its circuit (0 / 1: one; records are then
-     * orc_vs_proof2); with more, records are orc_vs_proof3 */
+     * orc_vs_proof2); with more, records are orc_vs_proof3.  lc_kind bit 2 (VarunaShaped-v3): the coefficient is further
+     * multiplied by 1 / (z_beta - z_gamma) */
     uint8_t max_instances;
-    uint8_t pad[2];
+    /* VarunaShaped-v3: a proof covers instances of 1 .. max_circuits distinct circuits (0 / 1: one); with more, records
+     * are orc_vs_proof4 */
+    uint8_t max_circuits;
+    uint8_t pad[1];
 } orc_vs_shape; /* 56 B */
 typedef struct { orc_g1_affine gamma_g; orc_g2_affine shift_h[ORC_VS_MAX_BOUNDS]; } orc_vs_key_ext; /* 480 B */
 typedef struct { orc_vs_proof base; orc_fr random_v[2]; orc_g1_affine shifted[ORC_VS_PROOF_COMMS]; } orc_vs_proof2; /* 3184 B */
@@ -186,6 +190,36 @@ typedef struct { orc_vs_proof base; orc_fr random_v[2]; orc_g1_affine shifted[OR
 #define ORC_VS_MAX_INSTANCES 4
 typedef struct { orc_fr inputs[ORC_VS_INPUTS]; orc_g1_affine comms[2]; orc_fr evals[2]; } orc_vs_instance; /* 768 B */
 typedef struct { orc_vs_proof2 base2; uint32_t n_instances; uint32_t pad[3]; orc_vs_instance extra[ORC_VS_MAX_INSTANCES - 1]; } orc_vs_proof3; /* 5504 B */
+/* VarunaShaped-v3: instances of SEVERAL circuits in one proof (Varuna's keys_to_inputs map).  Every circuit after the
+ * first brings a part: its id (strictly above the previous circuit's), the index of its first instance (strictly
+ * above the previous part's, at least 1, below n_instances) and the evaluations of its 12 polynomials, which open like
+ * the first circuit's with xi^(36 + 12 (d - 1) + k) */
+#define ORC_VS_MAX_CIRCUITS 3
+typedef struct { uint32_t circuit, first_instance, pad[2]; orc_fr vk_evals[ORC_VS_VK_COMMS]; } orc_vs_circuit_part; /* 400 B */
+typedef struct { orc_vs_proof3 base3; uint32_t n_circuits; uint32_t pad[3]; orc_vs_circuit_part more[ORC_VS_MAX_CIRCUITS - 1]; } orc_vs_proof4; /* 6320 B */
+/* records of the shape's kind (orc_vs_proof2 / 3 / 4); n_circuits = circuits of the context (ids are checked against it) */
+void orc_vs4_generate(uint64_t seed, size_t n, size_t n_circuits, uint32_t corrupt_per_1024, const orc_vs_shape *shape,
+                      orc_kzg_vk *vk, orc_vs_key_ext *ext, orc_vs_circuit_vk *circuits, void *records,
+                      uint8_t *randomizers /* n x 48 */, uint8_t *expected);
+/* dec_ok (may be NULL): per-proof flags of a wire decode; a proof whose flag is 0 is invalid */
+void orc_vs4_verify_batch_cpu(const orc_kzg_vk *vk, const orc_vs_key_ext *ext, const orc_vs_shape *shape,
+                              const orc_vs_circuit_vk *circuits, size_t n_circuits, const void *records, size_t n,
+                              const uint8_t *randomizers, const uint8_t *dec_ok, uint8_t *verdicts, int threads);
+int orc_vs4_verify_aggregated(const orc_kzg_vk *vk, const orc_vs_key_ext *ext, const orc_vs_shape *shape,
+                              const orc_vs_circuit_vk *circuits, size_t n_circuits, const void *records, size_t n,
+                              const uint8_t *randomizers, const uint8_t *dec_ok, uint8_t *alg_ok, orc_g1_affine totals[4],
+                              int threads);
+/* ---- the WIRE form of a record (what the node holds inside Transaction bytes: reference
+ * node/router/messages/src/unconfirmed_transaction.rs:25-28, node/bft/events/src/block_response.rs:64-70): every G1
+ * point compressed to 48 bytes (orc_g1_compress), every Fr field canonical little-endian, headers as they are; slots a
+ * record does not use (shifted commitments of unbounded polynomials, instances / circuits beyond the counts) are zero
+ * and are not decoded.  shape == NULL: v1 records (orc_vs_proof).  Sizes: 1728 / 2224 / 4256 / 5072 bytes. */
+size_t orc_vs_record_bytes(const orc_vs_shape *shape);
+size_t orc_vs_wire_bytes(const orc_vs_shape *shape);
+void orc_vs_wire_encode(const orc_vs_shape *shape, const void *records, size_t n, uint8_t *wire);
+/* dec_ok[i] = 0 when a used point is not the encoding of a point of the order-r subgroup or a used Fr field is not
+ * below r (that field is zero / infinity in the record) */
+void orc_vs_wire_decode(const orc_vs_shape *shape, const uint8_t *wire, size_t n, void *records, uint8_t *dec_ok, int threads);
 /* the same three entry points over records of the shape's kind (orc_vs_proof2 when max_instances <= 1, else
  * orc_vs_proof3), given as bytes */
 void orc_vs3_generate(uint64_t seed, size_t n, size_t n_circuits, uint32_t corrupt_per_1024, const orc_vs_shape *shape,

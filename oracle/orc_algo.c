@@ -386,10 +386,21 @@ static void fs_embed(fq_t *r, const void *b, size_t n) {
 }
 /* the e-th of the 73 + 38 m1 absorbed elements (oracle/pyref.py: vs_fs_elements); m1 further instances (768-byte
  * records: 16 inputs, two commitments, two evaluations) sit after C_1 (36 elements each) and at the end (2 each) */
-static void fs_element(fq_t *r, const orc_vs_circuit_vk *cvk, const orc_vs_proof *p, const uint8_t *extra, int m1, int e) {
+/* VarunaShaped-v3: d1 further circuits (parts: 400-byte records {id, first instance, pad, 12 evaluations}) put their
+ * header and digest after the first circuit's digest (2 elements each) and their evaluations at the very end (12 each) */
+typedef struct { const orc_vs_circuit_part *parts; int d1; const orc_vs_circuit_vk *circuits; } vs_parts;
+static const vs_parts VS_NO_PARTS = {NULL, 0, NULL};
+static void fs_element(fq_t *r, const orc_vs_circuit_vk *cvk, const orc_vs_proof *p, const uint8_t *extra, int m1, const vs_parts *pt, int e) {
     const uint8_t *comms = (const uint8_t *)p->comms;
     if (e == 0) { fs_embed(r, VS_TAG, 32); return; }
     if (e == 1) { fs_embed(r, cvk->digest, 32); return; }
+    if (e < 2 + 2 * pt->d1) {
+        const orc_vs_circuit_part *cp = &pt->parts[(e - 2) >> 1];
+        if ((e - 2) & 1) fs_embed(r, pt->circuits[cp->circuit].digest, 32);
+        else fs_embed(r, cp, 16);
+        return;
+    }
+    e -= 2 * pt->d1;
     if (e < 34) { fs_embed(r, (const uint8_t *)&p->inputs[(e - 2) >> 1] + 16 * ((e - 2) & 1), 16); return; }
     if (e < 38) { fs_embed(r, comms + 48 * (e - 34), 48); return; }
     e -= 38;
@@ -405,19 +416,22 @@ static void fs_element(fq_t *r, const orc_vs_circuit_vk *cvk, const orc_vs_proof
     e -= 14;
     if (e < 21) { fs_embed(r, &p->evals[e], 32); return; }
     e -= 21;
-    fs_embed(r, extra + 768 * (e >> 1) + 704 + 32 * (e & 1), 32);
+    if (e < 2 * m1) { fs_embed(r, extra + 768 * (e >> 1) + 704 + 32 * (e & 1), 32); return; }
+    e -= 2 * m1;
+    fs_embed(r, &pt->parts[e / ORC_VS_VK_COMMS].vk_evals[e % ORC_VS_VK_COMMS], 32);
 }
-static void vs_challenges_poseidon(const orc_vs_circuit_vk *cvk, const orc_vs_proof *p, const uint8_t *extra, int m1, fr_t *z_beta,
-                                   fr_t *z_gamma, fr_t *xi) {
+static void vs_challenges_poseidon(const orc_vs_circuit_vk *cvk, const orc_vs_proof *p, const uint8_t *extra, int m1, const vs_parts *pt,
+                                   fr_t *z_beta, fr_t *z_gamma, fr_t *xi) {
     orc_fq st[3];
     memset(st, 0, sizeof st);
-    const int n_el = 73 + 38 * m1, n_blocks = 37 + 19 * m1, b_beta = 21 + 18 * m1, b_gamma = 25 + 18 * m1;
+    const int d1 = pt->d1;
+    const int n_el = 73 + 38 * m1 + 14 * d1, n_blocks = 37 + 19 * m1 + 7 * d1, b_beta = 21 + 18 * m1 + d1, b_gamma = 25 + 18 * m1 + d1;
     for (int b = 0; b < n_blocks; b++) {
         fq_t e;
-        fs_element(&e, cvk, p, extra, m1, 2 * b);
+        fs_element(&e, cvk, p, extra, m1, pt, 2 * b);
         fq_add((fq_t *)&st[1], (fq_t *)&st[1], &e);
         if (2 * b + 1 < n_el) {
-            fs_element(&e, cvk, p, extra, m1, 2 * b + 1);
+            fs_element(&e, cvk, p, extra, m1, pt, 2 * b + 1);
             fq_add((fq_t *)&st[2], (fq_t *)&st[2], &e);
         }
         orc_poseidon_permute(st);
@@ -453,16 +467,20 @@ int orc_vs_proof_is_well_formed(const orc_vs_proof *p) {
 
 /* the transcript with m1 further instances (extra: m1 x 768 bytes): each is chained in after C_1 (inputs and
  * commitments) and after the evaluations (its two) */
+static void vs_challenges_pt(const orc_vs_circuit_vk *cvk, const orc_vs_proof *p, const uint8_t *extra, int m1, const vs_parts *pt,
+                             orc_fr *z_beta, orc_fr *z_gamma, orc_fr *xi);
 static void vs_challenges_ex(const orc_vs_circuit_vk *cvk, const orc_vs_proof *p, const uint8_t *extra, int m1, orc_fr *z_beta,
-                             orc_fr *z_gamma, orc_fr *xi);
+                             orc_fr *z_gamma, orc_fr *xi) {
+    vs_challenges_pt(cvk, p, extra, m1, &VS_NO_PARTS, z_beta, z_gamma, xi);
+}
 void orc_vs_challenges(const orc_vs_circuit_vk *cvk, const orc_vs_proof *p, orc_fr *z_beta, orc_fr *z_gamma,
                        orc_fr *xi) {
     vs_challenges_ex(cvk, p, NULL, 0, z_beta, z_gamma, xi);
 }
-static void vs_challenges_ex(const orc_vs_circuit_vk *cvk, const orc_vs_proof *p, const uint8_t *extra, int m1, orc_fr *z_beta,
-                             orc_fr *z_gamma, orc_fr *xi) {
+static void vs_challenges_pt(const orc_vs_circuit_vk *cvk, const orc_vs_proof *p, const uint8_t *extra, int m1, const vs_parts *pt,
+                             orc_fr *z_beta, orc_fr *z_gamma, orc_fr *xi) {
     if (g_vs_fs_kind) {
-        vs_challenges_poseidon(cvk, p, extra, m1, S(z_beta), S(z_gamma), S(xi));
+        vs_challenges_poseidon(cvk, p, extra, m1, pt, S(z_beta), S(z_gamma), S(xi));
         return;
     }
     uint8_t buf[32 + 21 * 32 + 64], h[32];
@@ -472,6 +490,12 @@ static void vs_challenges_ex(const orc_vs_circuit_vk *cvk, const orc_vs_proof *p
     memcpy(buf + o, p->inputs, sizeof p->inputs); o += sizeof p->inputs;
     memcpy(buf + o, &p->comms[0], 2 * 96); o += 2 * 96;
     orc_sha256(h, buf, o);
+    for (int d = 0; d < pt->d1; d++) { /* every further circuit: its header (id, first instance) and digest */
+        memcpy(buf, h, 32);
+        memcpy(buf + 32, &pt->parts[d], 16);
+        memcpy(buf + 48, pt->circuits[pt->parts[d].circuit].digest, 32);
+        orc_sha256(h, buf, 80);
+    }
     for (int j = 0; j < m1; j++) {
         memcpy(buf, h, 32);
         memcpy(buf + 32, extra + 768 * j, 704);
@@ -493,6 +517,11 @@ static void vs_challenges_ex(const orc_vs_circuit_vk *cvk, const orc_vs_proof *p
         memcpy(buf, h, 32);
         memcpy(buf + 32, extra + 768 * j + 704, 64);
         orc_sha256(h, buf, 32 + 64);
+    }
+    for (int d = 0; d < pt->d1; d++) { /* and the evaluations of every further circuit's polynomials */
+        memcpy(buf, h, 32);
+        memcpy(buf + 32, pt->parts[d].vk_evals, 384);
+        orc_sha256(h, buf, 32 + 384);
     }
     fr_from_u128le(S(xi), h);
 }
@@ -831,8 +860,15 @@ void orc_vs_generate(uint64_t seed, size_t n, size_t n_circuits, uint32_t corrup
  * generator only. */
 /* kap[kind] = (z_beta^16 - 1)^(kind & 1) (z_gamma^16 - 1)^(kind >> 1): the challenge-dependent factors of the shape's
  * linear-combination table */
-static void vs2_lc_factors(fr_t kap[4], const fr_t z[2]) {
-    fr_t v[2], one;
+/* kinds 4..7 (VarunaShaped-v3): the same times 1 / (z_beta - z_gamma).  Returns 0 when the shape uses such a kind and
+ * z_beta == z_gamma (the proof is invalid; kap[4..7] are then zero). */
+static int vs2_shape_needs_inverse(const orc_vs_shape *sh) {
+    for (int k = 0; k < ORC_VS_EVALS; k++)
+        if (sh->lc_kind[k] & 4) return 1;
+    return 0;
+}
+static int vs2_lc_factors(fr_t kap[8], const fr_t z[2], int need_inverse) {
+    fr_t v[2], one, d;
     fr_one(&one);
     for (int q = 0; q < 2; q++) {
         v[q] = z[q];
@@ -843,24 +879,33 @@ static void vs2_lc_factors(fr_t kap[4], const fr_t z[2]) {
     kap[1] = v[0];
     kap[2] = v[1];
     fr_mul(&kap[3], &v[0], &v[1]);
+    for (int k = 4; k < 8; k++) fr_zero(&kap[k]);
+    if (!need_inverse) return 1;
+    fr_sub(&d, &z[0], &z[1]);
+    if (fr_is_zero(&d)) return 0;
+    fr_inv(&d, &d);
+    for (int k = 0; k < 4; k++) fr_mul(&kap[4 + k], &kap[k], &d);
+    return 1;
 }
 /* inst / m1: the further instances of a proof with instances (their scalars r_beta xi^(30 + 2j + c) go to ex_scalar) */
+/* pt / px_scalar: the further circuits of a VarunaShaped-v3 proof (their scalars r_q xi^(36 + 12 d + k) kap go to px_scalar) */
 static void vs2_derive(vs_fr_work *o, fr_t rho[ORC_VS_PROOF_COMMS], fr_t *h_scalar, const orc_vs_shape *sh,
                        const orc_vs_circuit_vk *cvk, const orc_vs_proof2 *p2, const uint8_t *rand3x16,
-                       const orc_vs_instance *inst, int m1, fr_t ex_scalar[][2]) {
+                       const orc_vs_instance *inst, int m1, fr_t ex_scalar[][2], const vs_parts *pt,
+                       fr_t px_scalar[][ORC_VS_VK_COMMS]) {
     const orc_vs_proof *p = &p2->base;
     fr_t z[2], xi, r[3], xip, val[2], t, xhat, znm1;
-    vs_challenges_ex(cvk, p, (const uint8_t *)inst, m1, (orc_fr *)&z[0], (orc_fr *)&z[1], (orc_fr *)&xi);
+    vs_challenges_pt(cvk, p, (const uint8_t *)inst, m1, pt, (orc_fr *)&z[0], (orc_fr *)&z[1], (orc_fr *)&xi);
     for (int k = 0; k < 3; k++) fr_from_u128le(&r[k], rand3x16 + 16 * k);
     fr_one(&xip);
     fr_zero(&val[0]);
     fr_zero(&val[1]);
-    fr_t kap[4];
-    vs2_lc_factors(kap, z);
+    fr_t kap[8];
+    const int inverse_ok = vs2_lc_factors(kap, z, vs2_shape_needs_inverse(sh));
     for (int k = 0; k < ORC_VS_EVALS; k++) {
         const int q = sh->query_of[k] & 1;
         fr_t coef;
-        fr_mul(&coef, &xip, &kap[sh->lc_kind[k] & 3]);
+        fr_mul(&coef, &xip, &kap[sh->lc_kind[k] & 7]);
         fr_mul(&o->poly_scalar[k], &r[q], &coef);
         fr_mul(&t, &coef, S(&p->evals[k]));
         fr_add(&val[q], &val[q], &t);
@@ -877,6 +922,19 @@ static void vs2_derive(vs_fr_work *o, fr_t rho[ORC_VS_PROOF_COMMS], fr_t *h_scal
             fr_add(&val[0], &val[0], &t);
             fr_mul(&xip, &xip, &xi);
         }
+    if (pt->d1) { /* the further circuits' polynomials: xi^(36 + 12 d + k), the first circuit's query and lc tables */
+        for (int j = m1; j < ORC_VS_MAX_INSTANCES - 1; j++) { fr_mul(&xip, &xip, &xi); fr_mul(&xip, &xip, &xi); } /* to xi^36 */
+        for (int d = 0; d < pt->d1; d++)
+            for (int k = 0; k < ORC_VS_VK_COMMS; k++) {
+                const int pp = ORC_VS_PROOF_COMMS + k, q = sh->query_of[pp] & 1;
+                fr_t coef;
+                fr_mul(&coef, &xip, &kap[sh->lc_kind[pp] & 7]);
+                fr_mul(&px_scalar[d][k], &r[q], &coef);
+                fr_mul(&t, &coef, S(&pt->parts[d].vk_evals[k]));
+                fr_add(&val[q], &val[q], &t);
+                fr_mul(&xip, &xip, &xi);
+            }
+    }
     fr_zero(&o->g_scalar);
     fr_zero(h_scalar);
     for (int q = 0; q < 2; q++) {
@@ -906,7 +964,9 @@ static void vs2_derive(vs_fr_work *o, fr_t rho[ORC_VS_PROOF_COMMS], fr_t *h_scal
                  orc_g1_is_on_curve(pt);
         }
     }
-    if (wf && vs_input_eval(&xhat, &znm1, (const fr_t *)p->inputs, &z[0])) {
+    for (int d = 0; d < pt->d1 && wf; d++)
+        for (int k = 0; k < ORC_VS_VK_COMMS && wf; k++) wf = limbs_lt((const uint64_t *)&pt->parts[d].vk_evals[k], ORC_FR_MODULUS, 4);
+    if (wf && inverse_ok && vs_input_eval(&xhat, &znm1, (const fr_t *)p->inputs, &z[0])) {
         fr_mul(&t, &znm1, S(&p->evals[1]));
         fr_add(&t, &t, &xhat);
         o->alg_ok = fr_eq(&t, S(&p->evals[0]));
@@ -920,16 +980,45 @@ static void vs2_derive(vs_fr_work *o, fr_t rho[ORC_VS_PROOF_COMMS], fr_t *h_scal
 }
 /* the record of proof i under the shape: orc_vs_proof2, or orc_vs_proof3 when the shape carries instances; *m1 = its
  * further instances (0 when the count is out of range: the proof is then rejected by vs3_count_ok) */
-static size_t vs3_stride(const orc_vs_shape *sh) { return sh->max_instances > 1 ? sizeof(orc_vs_proof3) : sizeof(orc_vs_proof2); }
+static int vs3_kind(const orc_vs_shape *sh) { return !sh ? 1 : (sh->max_circuits > 1 ? 4 : (sh->max_instances > 1 ? 3 : 2)); }
+static size_t vs3_stride(const orc_vs_shape *sh) {
+    static const size_t bytes[5] = {0, sizeof(orc_vs_proof), sizeof(orc_vs_proof2), sizeof(orc_vs_proof3), sizeof(orc_vs_proof4)};
+    return bytes[vs3_kind(sh)];
+}
+size_t orc_vs_record_bytes(const orc_vs_shape *sh) { return vs3_stride(sh); }
+/* pt: the further circuits (VarunaShaped-v3 records); n_ctx_circuits: circuits of the context.  A record whose instance
+ * or circuit structure is out of range is rejected (count_ok = 0) and keeps its first instance and circuit only. */
 static const orc_vs_proof2 *vs3_record(const orc_vs_shape *sh, const void *records, size_t i, const orc_vs_instance **inst, int *m1,
-                                        int *count_ok) {
+                                        int *count_ok, vs_parts *pt, const orc_vs_circuit_vk *circuits, size_t n_ctx_circuits) {
     const uint8_t *rec = (const uint8_t *)records + vs3_stride(sh) * i;
     *inst = NULL;
     *m1 = 0;
     *count_ok = 1;
-    if (sh->max_instances > 1) {
+    pt->parts = NULL;
+    pt->d1 = 0;
+    pt->circuits = circuits;
+    if (sh->max_instances > 1 || sh->max_circuits > 1) {
         const orc_vs_proof3 *p3 = (const orc_vs_proof3 *)rec;
-        *count_ok = p3->n_instances >= 1 && p3->n_instances <= sh->max_instances && p3->n_instances <= ORC_VS_MAX_INSTANCES;
+        const uint32_t mi = sh->max_instances > 1 ? sh->max_instances : 1;
+        *count_ok = p3->n_instances >= 1 && p3->n_instances <= mi && p3->n_instances <= ORC_VS_MAX_INSTANCES;
+        if (*count_ok && sh->max_circuits > 1) {
+            const orc_vs_proof4 *p4 = (const orc_vs_proof4 *)rec;
+            const uint32_t nc = p4->n_circuits;
+            int ok = nc >= 1 && nc <= sh->max_circuits && nc <= ORC_VS_MAX_CIRCUITS && nc <= p3->n_instances &&
+                     p3->base2.base.circuit < n_ctx_circuits;
+            uint32_t c_prev = p3->base2.base.circuit, f_prev = 0;
+            for (uint32_t d = 0; ok && d + 1 < nc; d++) {
+                const orc_vs_circuit_part *cp = &p4->more[d];
+                ok = cp->circuit > c_prev && cp->circuit < n_ctx_circuits && cp->first_instance > f_prev && cp->first_instance < p3->n_instances;
+                c_prev = cp->circuit;
+                f_prev = cp->first_instance;
+            }
+            *count_ok = ok;
+            if (ok) {
+                pt->parts = p4->more;
+                pt->d1 = (int)nc - 1;
+            }
+        }
         if (*count_ok) {
             *m1 = (int)p3->n_instances - 1;
             *inst = p3->extra;
@@ -940,12 +1029,12 @@ static const orc_vs_proof2 *vs3_record(const orc_vs_shape *sh, const void *recor
 /* the four accumulators of one proof (Jacobian) */
 static void vs2_accumulate_one(orc_g1_jac acc[4], int *alg_ok, const orc_kzg_vk *vk, const orc_vs_key_ext *ext,
                                const orc_vs_shape *sh, const orc_vs_circuit_vk *circuits, const orc_vs_proof2 *p2,
-                               const uint8_t *rand3x16, const orc_vs_instance *inst, int m1) {
+                               const uint8_t *rand3x16, const orc_vs_instance *inst, int m1, const vs_parts *pt) {
     const orc_vs_proof *p = &p2->base;
     const orc_vs_circuit_vk *cvk = &circuits[p->circuit];
     vs_fr_work fw;
-    fr_t rho[ORC_VS_PROOF_COMMS], hs, t, exs[ORC_VS_MAX_INSTANCES][2];
-    vs2_derive(&fw, rho, &hs, sh, cvk, p2, rand3x16, inst, m1, exs);
+    fr_t rho[ORC_VS_PROOF_COMMS], hs, t, exs[ORC_VS_MAX_INSTANCES][2], pxs[ORC_VS_MAX_CIRCUITS][ORC_VS_VK_COMMS];
+    vs2_derive(&fw, rho, &hs, sh, cvk, p2, rand3x16, inst, m1, exs, pt, pxs);
     orc_g1_jac tj;
     for (int k = 0; k < 4; k++) g1_set_inf(&acc[k]);
     for (int k = 0; k < ORC_VS_EVALS; k++) {
@@ -956,6 +1045,11 @@ static void vs2_accumulate_one(orc_g1_jac acc[4], int *alg_ok, const orc_kzg_vk 
     for (int j = 0; j < m1; j++)
         for (int c = 0; c < 2; c++) {
             g1_mul_fr(&tj, &inst[j].comms[c], &exs[j][c]);
+            orc_g1_add(&acc[0], &acc[0], &tj);
+        }
+    for (int d = 0; d < pt->d1; d++)
+        for (int k = 0; k < ORC_VS_VK_COMMS; k++) {
+            g1_mul_fr(&tj, &circuits[pt->parts[d].circuit].comms[k], &pxs[d][k]);
             orc_g1_add(&acc[0], &acc[0], &tj);
         }
     for (int q = 0; q < 2; q++) {
@@ -990,6 +1084,11 @@ static int vs2_product_is_one(const orc_g1_jac acc[4], const orc_g2_prepared *co
 void orc_vs3_verify_batch_cpu(const orc_kzg_vk *vk, const orc_vs_key_ext *ext, const orc_vs_shape *sh,
                               const orc_vs_circuit_vk *circuits, const void *records, size_t n,
                               const uint8_t *randomizers /* n x 48 */, uint8_t *verdicts, int threads) {
+    orc_vs4_verify_batch_cpu(vk, ext, sh, circuits, (size_t)-1, records, n, randomizers, NULL, verdicts, threads);
+}
+void orc_vs4_verify_batch_cpu(const orc_kzg_vk *vk, const orc_vs_key_ext *ext, const orc_vs_shape *sh,
+                              const orc_vs_circuit_vk *circuits, size_t n_circuits, const void *records, size_t n,
+                              const uint8_t *randomizers /* n x 48 */, const uint8_t *dec_ok, uint8_t *verdicts, int threads) {
     orc_g2_prepared *pr = (orc_g2_prepared *)malloc(sizeof(orc_g2_prepared) * 4);
     orc_g2_prepare(&pr[0], &vk->h);
     orc_g2_prepare(&pr[1], &vk->tau_h);
@@ -1001,8 +1100,10 @@ void orc_vs3_verify_batch_cpu(const orc_kzg_vk *vk, const orc_vs_key_ext *ext, c
         orc_g1_jac acc[4];
         int alg, m1, count_ok;
         const orc_vs_instance *inst;
-        const orc_vs_proof2 *p2 = vs3_record(sh, records, i, &inst, &m1, &count_ok);
-        vs2_accumulate_one(acc, &alg, vk, ext, sh, circuits, p2, randomizers + 48 * i, inst, m1);
+        vs_parts pt;
+        const orc_vs_proof2 *p2 = vs3_record(sh, records, i, &inst, &m1, &count_ok, &pt, circuits, n_circuits);
+        if (dec_ok && !dec_ok[i]) { verdicts[i] = 0; continue; }
+        vs2_accumulate_one(acc, &alg, vk, ext, sh, circuits, p2, randomizers + 48 * i, inst, m1, &pt);
         verdicts[i] = (uint8_t)(alg && count_ok && vs2_product_is_one(acc, preps, sh->n_bounds));
     }
     free(pr);
@@ -1019,6 +1120,12 @@ void orc_vs2_verify_batch_cpu(const orc_kzg_vk *vk, const orc_vs_key_ext *ext, c
 int orc_vs3_verify_aggregated(const orc_kzg_vk *vk, const orc_vs_key_ext *ext, const orc_vs_shape *sh,
                               const orc_vs_circuit_vk *circuits, const void *records, size_t n,
                               const uint8_t *randomizers, uint8_t *alg_ok, orc_g1_affine totals[4], int threads) {
+    return orc_vs4_verify_aggregated(vk, ext, sh, circuits, (size_t)-1, records, n, randomizers, NULL, alg_ok, totals, threads);
+}
+int orc_vs4_verify_aggregated(const orc_kzg_vk *vk, const orc_vs_key_ext *ext, const orc_vs_shape *sh,
+                              const orc_vs_circuit_vk *circuits, size_t n_circuits, const void *records, size_t n,
+                              const uint8_t *randomizers, const uint8_t *dec_ok, uint8_t *alg_ok, orc_g1_affine totals[4],
+                              int threads) {
     if (threads < 1) threads = 1;
     orc_g1_jac *part = (orc_g1_jac *)malloc(sizeof(orc_g1_jac) * 4 * (size_t)threads);
     for (int k = 0; k < 4 * threads; k++) g1_set_inf(&part[k]);
@@ -1030,9 +1137,10 @@ int orc_vs3_verify_aggregated(const orc_kzg_vk *vk, const orc_vs_key_ext *ext, c
             orc_g1_jac acc[4];
             int alg, m1, count_ok;
             const orc_vs_instance *inst;
-            const orc_vs_proof2 *p2 = vs3_record(sh, records, i, &inst, &m1, &count_ok);
-            vs2_accumulate_one(acc, &alg, vk, ext, sh, circuits, p2, randomizers + 48 * i, inst, m1);
-            alg_ok[i] = (uint8_t)(alg && count_ok);
+            vs_parts pt;
+            const orc_vs_proof2 *p2 = vs3_record(sh, records, i, &inst, &m1, &count_ok, &pt, circuits, n_circuits);
+            vs2_accumulate_one(acc, &alg, vk, ext, sh, circuits, p2, randomizers + 48 * i, inst, m1, &pt);
+            alg_ok[i] = (uint8_t)(alg && count_ok && (!dec_ok || dec_ok[i]));
             for (int k = 0; k < 4; k++) orc_g1_add(&part[4 * tid + k], &part[4 * tid + k], &acc[k]);
         }
     }
@@ -1062,10 +1170,22 @@ int orc_vs2_verify_aggregated(const orc_kzg_vk *vk, const orc_vs_key_ext *ext, c
 void orc_vs3_generate(uint64_t seed, size_t n, size_t n_circuits, uint32_t corrupt_per_1024, const orc_vs_shape *sh,
                       orc_kzg_vk *vk, orc_vs_key_ext *ext, orc_vs_circuit_vk *circuits, void *records,
                       uint8_t *randomizers /* n x 48 */, uint8_t *expected) {
+    orc_vs4_generate(seed, n, n_circuits, corrupt_per_1024, sh, vk, ext, circuits, records, randomizers, expected);
+}
+/* Shapes without several circuits draw exactly the random stream they always drew (committed fixtures stay reproducible);
+ * with max_circuits > 1 a proof also draws its number of circuits, their ids and first instances (n_circuits of the
+ * context must be at least max_circuits), every further circuit's 12 evaluations are made like the first circuit's,
+ * and a corrupted proof may have a part spoilt. */
+void orc_vs4_generate(uint64_t seed, size_t n, size_t n_circuits, uint32_t corrupt_per_1024, const orc_vs_shape *sh,
+                      orc_kzg_vk *vk, orc_vs_key_ext *ext, orc_vs_circuit_vk *circuits, void *records,
+                      uint8_t *randomizers /* n x 48 */, uint8_t *expected) {
     const size_t stride = vs3_stride(sh);
+    const int MC = sh->max_circuits > 1 ? (sh->max_circuits > ORC_VS_MAX_CIRCUITS ? ORC_VS_MAX_CIRCUITS : sh->max_circuits) : 1;
     const int MI = sh->max_instances > 1 ? (sh->max_instances > ORC_VS_MAX_INSTANCES ? ORC_VS_MAX_INSTANCES : sh->max_instances) : 1;
+    const int need_inv = vs2_shape_needs_inverse(sh);
 #define REC2(i) ((orc_vs_proof2 *)((uint8_t *)records + stride * (i)))
 #define REC3(i) ((orc_vs_proof3 *)((uint8_t *)records + stride * (i)))
+#define REC4(i) ((orc_vs_proof4 *)((uint8_t *)records + stride * (i)))
     const size_t EX = (size_t)(ORC_VS_MAX_INSTANCES - 1) * 2; /* further-instance polynomials per proof */
     smix g = {seed};
     fr_t tau, gam, shf[ORC_VS_MAX_BOUNDS];
@@ -1151,6 +1271,23 @@ void orc_vs3_generate(uint64_t seed, size_t n, size_t n_circuits, uint32_t corru
                     fr_add(&xcval[i * EX + 2 * j + c], &xtau[i * EX + 2 * j + c], &t2);
                 }
             }
+            if (MC > 1) { /* the proof's circuits: ids ascending, each with at least one instance */
+                orc_vs_proof4 *p4 = REC4(i);
+                const uint32_t ni = p3->n_instances;
+                const uint32_t lim = (uint32_t)MC < ni ? (uint32_t)MC : ni;
+                const uint32_t nc = 1 + (uint32_t)(smix_next(&g) % lim);
+                p4->n_circuits = nc;
+                p->circuit = (uint32_t)(smix_next(&g) % (n_circuits - (nc - 1)));
+                uint32_t c_prev = p->circuit, f_prev = 0;
+                for (uint32_t d = 0; d + 1 < nc; d++) {
+                    const uint32_t rem = nc - 2 - d; /* parts still to come after this one */
+                    orc_vs_circuit_part *cp = &p4->more[d];
+                    cp->circuit = c_prev + 1 + (uint32_t)(smix_next(&g) % (n_circuits - 1 - rem - c_prev));
+                    cp->first_instance = f_prev + 1 + (uint32_t)(smix_next(&g) % (ni - 1 - rem - f_prev));
+                    c_prev = cp->circuit;
+                    f_prev = cp->first_instance;
+                }
+            }
         }
     }
     orc_g1_affine *pcomm = (orc_g1_affine *)malloc(sizeof(orc_g1_affine) * n * PC * 2);
@@ -1176,8 +1313,17 @@ void orc_vs3_generate(uint64_t seed, size_t n, size_t n_circuits, uint32_t corru
         const orc_vs_circuit_vk *cvk = &circuits[p->circuit];
         const int m1 = MI > 1 ? (int)REC3(i)->n_instances - 1 : 0;
         orc_vs_instance *inst = MI > 1 ? REC3(i)->extra : NULL;
+        vs_parts pt = {NULL, 0, circuits};
+        if (MC > 1) {
+            pt.parts = REC4(i)->more;
+            pt.d1 = (int)REC4(i)->n_circuits - 1;
+        }
         fr_t z[2], xi, xip, t, num[2], rv[2];
-        vs_challenges_ex(cvk, p, (const uint8_t *)inst, m1, (orc_fr *)&z[0], (orc_fr *)&z[1], (orc_fr *)&xi);
+        vs_challenges_pt(cvk, p, (const uint8_t *)inst, m1, &pt, (orc_fr *)&z[0], (orc_fr *)&z[1], (orc_fr *)&xi);
+        for (int d = 0; d < pt.d1; d++) /* the further circuits' polynomials at their query points */
+            for (int k = 0; k < ORC_VS_VK_COMMS; k++)
+                poly_eval(S(&REC4(i)->more[d].vk_evals[k]), &cpoly[(REC4(i)->more[d].circuit * ORC_VS_VK_COMMS + k) * VS_DEG],
+                          &z[sh->query_of[ORC_VS_PROOF_COMMS + k] & 1]);
         for (int k = 0; k < ORC_VS_EVALS; k++) {
             const int q = sh->query_of[k] & 1;
             const fr_t *poly = k < ORC_VS_PROOF_COMMS ? &ppoly[(i * PC + k) * VS_DEG]
@@ -1199,16 +1345,16 @@ void orc_vs3_generate(uint64_t seed, size_t n, size_t n_circuits, uint32_t corru
                 fr_add(S(&inst[j].evals[0]), &xh, &t);
             }
         }
-        vs_challenges_ex(cvk, p, (const uint8_t *)inst, m1, (orc_fr *)&z[0], (orc_fr *)&z[1], (orc_fr *)&xi);
+        vs_challenges_pt(cvk, p, (const uint8_t *)inst, m1, &pt, (orc_fr *)&z[0], (orc_fr *)&z[1], (orc_fr *)&xi);
         fr_one(&xip);
         for (int q = 0; q < 2; q++) { fr_zero(&num[q]); fr_zero(&rv[q]); }
-        fr_t kap[4];
-        vs2_lc_factors(kap, z);
+        fr_t kap[8];
+        (void)vs2_lc_factors(kap, z, need_inv);
         for (int k = 0; k < ORC_VS_EVALS; k++) {
             const int q = sh->query_of[k] & 1;
             const fr_t *at_tau = k < ORC_VS_PROOF_COMMS ? &ptau[i * PC + k] : &ctau[p->circuit * ORC_VS_VK_COMMS + (k - ORC_VS_PROOF_COMMS)];
             fr_t coef;
-            fr_mul(&coef, &xip, &kap[sh->lc_kind[k] & 3]);
+            fr_mul(&coef, &xip, &kap[sh->lc_kind[k] & 7]);
             fr_sub(&t, at_tau, S(&p->evals[k]));
             fr_mul(&t, &t, &coef);
             fr_add(&num[q], &num[q], &t);
@@ -1227,6 +1373,19 @@ void orc_vs3_generate(uint64_t seed, size_t n, size_t n_circuits, uint32_t corru
                     fr_add(&num[0], &num[0], &t);
                     fr_mul(&t, &xip, &xrho[i * EX + 2 * j + c]);
                     fr_add(&rv[0], &rv[0], &t);
+                    fr_mul(&xip, &xip, &xi);
+                }
+        }
+        if (pt.d1) { /* xip = xi^(30 + 2 m1) -> xi^36, then the further circuits' polynomials (never hiding) */
+            for (int j = m1; j < ORC_VS_MAX_INSTANCES - 1; j++) { fr_mul(&xip, &xip, &xi); fr_mul(&xip, &xip, &xi); }
+            for (int d = 0; d < pt.d1; d++)
+                for (int k = 0; k < ORC_VS_VK_COMMS; k++) {
+                    const int pp = ORC_VS_PROOF_COMMS + k, q = sh->query_of[pp] & 1;
+                    fr_t coef;
+                    fr_mul(&coef, &xip, &kap[sh->lc_kind[pp] & 7]);
+                    fr_sub(&t, &ctau[pt.parts[d].circuit * ORC_VS_VK_COMMS + k], S(&pt.parts[d].vk_evals[k]));
+                    fr_mul(&t, &t, &coef);
+                    fr_add(&num[q], &num[q], &t);
                     fr_mul(&xip, &xip, &xi);
                 }
         }
@@ -1250,6 +1409,17 @@ void orc_vs3_generate(uint64_t seed, size_t n, size_t n_circuits, uint32_t corru
         orc_vs_proof *p = &p2->base;
         fr_t one;
         fr_one(&one);
+        if (MC > 1 && REC4(i)->n_circuits > 1 && (smix_next(&g) & 3) == 0) { /* spoil a further circuit's part instead */
+            orc_vs_circuit_part *cp = &REC4(i)->more[smix_next(&g) % (REC4(i)->n_circuits - 1)];
+            switch ((int)(smix_next(&g) % 4)) {
+            case 0: { int k = (int)(smix_next(&g) % ORC_VS_VK_COMMS); fr_add(S(&cp->vk_evals[k]), S(&cp->vk_evals[k]), &one); break; }
+            case 1: cp->circuit = p->circuit; break;                 /* ids must ascend strictly */
+            case 2: cp->first_instance = REC3(i)->n_instances; break; /* a circuit without an instance */
+            default: REC4(i)->n_circuits = (uint32_t)MC + 1; break;  /* more circuits than the shape allows */
+            }
+            expected[i] = 0;
+            continue;
+        }
         if (MI > 1 && REC3(i)->n_instances > 1 && (smix_next(&g) & 1)) { /* spoil a further instance instead */
             orc_vs_instance *in = &REC3(i)->extra[smix_next(&g) % (REC3(i)->n_instances - 1)];
             switch ((int)(smix_next(&g) % 3)) {
@@ -1283,6 +1453,145 @@ void orc_vs3_generate(uint64_t seed, size_t n, size_t n_circuits, uint32_t corru
     free(xpoly); free(xtau); free(xrho); free(xcval);
 #undef REC2
 #undef REC3
+#undef REC4
+}
+
+/* ------------------------------------------------------------------ wire records (orc.h) */
+/* a record as a run of segments: raw bytes | Fr fields | G1 points, each with the class of slot it sits in */
+enum { SEG_RAW, SEG_FR, SEG_G1 };
+enum { CLS_BASE = 0, CLS_SHIFTED = 1, CLS_INST = 2 /* + j */, CLS_PART = 8 /* + d */ };
+typedef struct { int type, count, cls; } vs_seg;
+static int vs_layout(int kind, vs_seg *seg) {
+    int n = 0;
+    seg[n++] = (vs_seg){SEG_RAW, 16, CLS_BASE};
+    seg[n++] = (vs_seg){SEG_FR, ORC_VS_INPUTS, CLS_BASE};
+    seg[n++] = (vs_seg){SEG_G1, ORC_VS_PROOF_COMMS, CLS_BASE};
+    seg[n++] = (vs_seg){SEG_FR, ORC_VS_EVALS, CLS_BASE};
+    seg[n++] = (vs_seg){SEG_G1, 2, CLS_BASE};
+    if (kind >= 2) {
+        seg[n++] = (vs_seg){SEG_FR, 2, CLS_BASE};
+        seg[n++] = (vs_seg){SEG_G1, ORC_VS_PROOF_COMMS, CLS_SHIFTED};
+    }
+    if (kind >= 3) {
+        seg[n++] = (vs_seg){SEG_RAW, 16, CLS_BASE};
+        for (int j = 0; j < ORC_VS_MAX_INSTANCES - 1; j++) {
+            seg[n++] = (vs_seg){SEG_FR, ORC_VS_INPUTS, CLS_INST + j};
+            seg[n++] = (vs_seg){SEG_G1, 2, CLS_INST + j};
+            seg[n++] = (vs_seg){SEG_FR, 2, CLS_INST + j};
+        }
+    }
+    if (kind >= 4) {
+        seg[n++] = (vs_seg){SEG_RAW, 16, CLS_BASE};
+        for (int d = 0; d < ORC_VS_MAX_CIRCUITS - 1; d++) {
+            seg[n++] = (vs_seg){SEG_RAW, 16, CLS_PART + d};
+            seg[n++] = (vs_seg){SEG_FR, ORC_VS_VK_COMMS, CLS_PART + d};
+        }
+    }
+    return n;
+}
+static size_t vs_wire_bytes_kind(int kind) {
+    vs_seg seg[32] = {{0, 0, 0}};
+    const int ns = vs_layout(kind, seg);
+    size_t b = 0;
+    for (int k = 0; k < ns; k++) b += (size_t)seg[k].count * (seg[k].type == SEG_RAW ? 1 : (seg[k].type == SEG_FR ? 32 : 48));
+    return b;
+}
+size_t orc_vs_wire_bytes(const orc_vs_shape *sh) { return vs_wire_bytes_kind(vs3_kind(sh)); }
+static int vs_slot_used(const orc_vs_shape *sh, int cls, int j, int m1, int d1) {
+    if (cls == CLS_BASE) return 1;
+    if (cls == CLS_SHIFTED) return sh && sh->bound_class[j] >= 0 && sh->bound_class[j] < sh->n_bounds;
+    if (cls >= CLS_PART) return cls - CLS_PART < d1;
+    return cls - CLS_INST < m1;
+}
+/* the counts a record's headers announce, clamped to what the shape allows (out of range: first instance / circuit only) */
+static void vs_counts(const orc_vs_shape *sh, int kind, uint32_t ni, uint32_t nc, int *m1, int *d1) {
+    *m1 = *d1 = 0;
+    if (kind >= 3) {
+        const uint32_t mi = sh->max_instances > 1 ? sh->max_instances : 1;
+        if (ni >= 1 && ni <= mi && ni <= ORC_VS_MAX_INSTANCES) *m1 = (int)ni - 1;
+    }
+    if (kind >= 4 && nc >= 1 && nc <= sh->max_circuits && nc <= ORC_VS_MAX_CIRCUITS) *d1 = (int)nc - 1;
+}
+void orc_vs_wire_encode(const orc_vs_shape *sh, const void *records, size_t n, uint8_t *wire) {
+    const int kind = vs3_kind(sh);
+    vs_seg seg[32] = {{0, 0, 0}};
+    const int ns = vs_layout(kind, seg);
+    const size_t rb = vs3_stride(sh), wb = orc_vs_wire_bytes(sh);
+    for (size_t i = 0; i < n; i++) {
+        const uint8_t *r = (const uint8_t *)records + rb * i;
+        uint8_t *w = wire + wb * i;
+        uint32_t ni = 0, nc = 0;
+        if (kind >= 3) memcpy(&ni, r + sizeof(orc_vs_proof2), 4);
+        if (kind >= 4) memcpy(&nc, r + sizeof(orc_vs_proof3), 4);
+        int m1, d1;
+        vs_counts(sh, kind, ni, nc, &m1, &d1);
+        for (int k = 0; k < ns; k++)
+            for (int j = 0; j < (seg[k].type == SEG_RAW ? 1 : seg[k].count); j++) {
+                const int used = vs_slot_used(sh, seg[k].cls, j, m1, d1);
+                if (seg[k].type == SEG_RAW) {
+                    if (used) memcpy(w, r, (size_t)seg[k].count); else memset(w, 0, (size_t)seg[k].count);
+                    r += seg[k].count;
+                    w += seg[k].count;
+                } else if (seg[k].type == SEG_FR) {
+                    memset(w, 0, 32);
+                    if (used) fr_to_canonical((uint64_t *)w, (const fr_t *)r);
+                    r += 32;
+                    w += 32;
+                } else {
+                    memset(w, 0, 48);
+                    if (used) orc_g1_compress(w, (const orc_g1_affine *)r);
+                    r += 96;
+                    w += 48;
+                }
+            }
+    }
+}
+void orc_vs_wire_decode(const orc_vs_shape *sh, const uint8_t *wire, size_t n, void *records, uint8_t *dec_ok, int threads) {
+    const int kind = vs3_kind(sh);
+    vs_seg seg[32] = {{0, 0, 0}};
+    const int ns = vs_layout(kind, seg);
+    const size_t rb = vs3_stride(sh), wb = orc_vs_wire_bytes(sh);
+    const size_t off_ni = vs_wire_bytes_kind(2), off_nc = vs_wire_bytes_kind(3); /* where the counts sit in the wire record */
+    if (threads < 1) threads = 1;
+#pragma omp parallel for schedule(dynamic, 4) num_threads(threads)
+    for (size_t i = 0; i < n; i++) {
+        const uint8_t *w = wire + wb * i;
+        uint8_t *r = (uint8_t *)records + rb * i;
+        uint32_t ni = 0, nc = 0;
+        if (kind >= 3) memcpy(&ni, w + off_ni, 4);
+        if (kind >= 4) memcpy(&nc, w + off_nc, 4);
+        int m1, d1, ok = 1;
+        vs_counts(sh, kind, ni, nc, &m1, &d1);
+        for (int k = 0; k < ns; k++)
+            for (int j = 0; j < (seg[k].type == SEG_RAW ? 1 : seg[k].count); j++) {
+                const int used = vs_slot_used(sh, seg[k].cls, j, m1, d1);
+                if (seg[k].type == SEG_RAW) {
+                    if (used) memcpy(r, w, (size_t)seg[k].count); else memset(r, 0, (size_t)seg[k].count);
+                    r += seg[k].count;
+                    w += seg[k].count;
+                } else if (seg[k].type == SEG_FR) {
+                    memset(r, 0, 32);
+                    if (used) {
+                        uint64_t c[4];
+                        memcpy(c, w, 32);
+                        if (limbs_lt(c, ORC_FR_MODULUS, 4)) fr_from_canonical((fr_t *)r, c);
+                        else ok = 0;
+                    }
+                    r += 32;
+                    w += 32;
+                } else {
+                    memset(r, 0, 96);
+                    if (used) {
+                        orc_g1_affine pt;
+                        if (orc_g1_decompress(&pt, w, 1)) memcpy(r, &pt, 96);
+                        else ok = 0;
+                    }
+                    r += 96;
+                    w += 48;
+                }
+            }
+        dec_ok[i] = (uint8_t)ok;
+    }
 }
 void orc_vs2_generate(uint64_t seed, size_t n, size_t n_circuits, uint32_t corrupt_per_1024, const orc_vs_shape *sh,
                       orc_kzg_vk *vk, orc_vs_key_ext *ext, orc_vs_circuit_vk *circuits, orc_vs_proof2 *proofs,

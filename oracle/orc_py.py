@@ -365,19 +365,56 @@ VS1_QUERY_OF = [0] * 5 + [1] * 4 + [0] * 6 + [1] * 6
 VS3_PROOF_BYTES, VS_MAX_INSTANCES = 5504, 4
 
 
+VS4_PROOF_BYTES, VS_MAX_CIRCUITS = 6320, 3
+VS_WIRE_BYTES = {1: 1728, 2: 2224, 3: 4256, 4: 5072}
+
+
+def vs2_record_kind(shape):
+    """1: mi_vs_proof (no shape), 2: mi_vs_proof2, 3: mi_vs_proof3 (instances), 4: mi_vs_proof4 (several circuits)"""
+    if shape is None:
+        return 1
+    sh = np.asarray(shape).reshape(-1)
+    return 4 if int(sh[54]) > 1 else (3 if int(sh[53]) > 1 else 2)
+
+
 def vs2_record_bytes(shape):
-    """bytes per proof record under a shape: mi_vs_proof2, or mi_vs_proof3 when the shape carries instances"""
-    return VS3_PROOF_BYTES if int(np.asarray(shape).reshape(-1)[53]) > 1 else VS2_PROOF_BYTES
+    """bytes per proof record under a shape: mi_vs_proof2, mi_vs_proof3 when the shape carries instances, mi_vs_proof4
+    when it carries several circuits"""
+    return {1: VS_PROOF_BYTES, 2: VS2_PROOF_BYTES, 3: VS3_PROOF_BYTES, 4: VS4_PROOF_BYTES}[vs2_record_kind(shape)]
 
 
-def vs2_shape(query_of=None, bound_class=None, hiding=True, n_bounds=2, lc_kind=None, max_instances=1):
+def vs_wire_bytes(shape):
+    return VS_WIRE_BYTES[vs2_record_kind(shape)]
+
+
+def vs_wire_encode(shape, records):
+    """uncompressed records -> wire records (points compressed, Fr canonical); shape None: v1 records"""
+    records = np.ascontiguousarray(records, dtype=np.uint8).reshape(-1)
+    n = records.size // vs2_record_bytes(shape)
+    out = np.zeros(n * vs_wire_bytes(shape), dtype=np.uint8)
+    lib().orc_vs_wire_encode(_p(shape) if shape is not None else None, _p(records), C.c_size_t(n), _p(out))
+    return out
+
+
+def vs_wire_decode(shape, wire, threads=1):
+    """wire records -> (uncompressed records, dec_ok[n])"""
+    wire = np.ascontiguousarray(wire, dtype=np.uint8).reshape(-1)
+    n = wire.size // vs_wire_bytes(shape)
+    out = np.zeros(n * vs2_record_bytes(shape), dtype=np.uint8)
+    ok = np.zeros(n, dtype=np.uint8)
+    lib().orc_vs_wire_decode(_p(shape) if shape is not None else None, _p(wire), C.c_size_t(n), _p(out), _p(ok), C.c_int(threads))
+    return out, ok
+
+
+def vs2_shape(query_of=None, bound_class=None, hiding=True, n_bounds=2, lc_kind=None, max_instances=1, max_circuits=1):
     """56-byte mi_vs_shape / orc_vs_shape: query table, degree-bound classes, hiding flag, linear-combination kinds
-    (0: xi^p; bit 0: times z_beta^16 - 1; bit 1: times z_gamma^16 - 1)"""
+    (0: xi^p; bit 0: times z_beta^16 - 1; bit 1: times z_gamma^16 - 1; bit 2: times 1 / (z_beta - z_gamma)), instances
+    per proof, distinct circuits per proof"""
     q = list(query_of if query_of is not None else VS1_QUERY_OF)
     bc = list(bound_class if bound_class is not None else [-1, -1, -1, -1, -1, 0, 0, 1, 1])
     lc = list(lc_kind if lc_kind is not None else [0] * 21)
     assert len(q) == 21 and len(bc) == 9 and q[0] == 0 and q[1] == 0, "p_0 and p_1 open at the beta query (public-input identity)"
-    assert len(lc) == 21 and lc[0] == 0 and lc[1] == 0 and all(0 <= x <= 3 for x in lc)
+    assert len(lc) == 21 and lc[0] == 0 and lc[1] == 0 and all(0 <= x <= 7 for x in lc)
     out = np.zeros(VS2_SHAPE_BYTES, dtype=np.uint8)
     out[:21] = q
     out[21:30] = np.array(bc, dtype=np.int8).view(np.uint8)
@@ -385,6 +422,8 @@ def vs2_shape(query_of=None, bound_class=None, hiding=True, n_bounds=2, lc_kind=
     out[32:53] = lc
     assert 1 <= max_instances <= VS_MAX_INSTANCES
     out[53] = max_instances
+    assert 1 <= max_circuits <= VS_MAX_CIRCUITS and max_circuits <= max_instances
+    out[54] = max_circuits
     return out
 
 
@@ -401,8 +440,9 @@ class VS2Batch:
         self.proofs = np.zeros(n * self.record_bytes, dtype=np.uint8)
         self.randomizers = np.zeros(n * VS2_RAND_BYTES, dtype=np.uint8)
         self.expected = np.zeros(n, dtype=np.uint8)
+        self.dec_ok = None
         lib().orc_vs_set_transcript(C.c_int(transcript))
-        lib().orc_vs3_generate(C.c_uint64(seed), C.c_size_t(n), C.c_size_t(n_circuits), C.c_uint32(corrupt_per_1024), _p(self.shape),
+        lib().orc_vs4_generate(C.c_uint64(seed), C.c_size_t(n), C.c_size_t(n_circuits), C.c_uint32(corrupt_per_1024), _p(self.shape),
                                _p(self.vk), _p(self.ext), _p(self.circuits), _p(self.proofs), _p(self.randomizers), _p(self.expected))
 
     @classmethod
@@ -414,14 +454,27 @@ class VS2Batch:
         b.randomizers = np.ascontiguousarray(randomizers, dtype=np.uint8).reshape(-1)
         b.record_bytes = vs2_record_bytes(b.shape)
         b.n, b.n_circuits = b.proofs.size // b.record_bytes, b.circuits.size // VS_CIRCUIT_VK_BYTES
-        b.transcript, b.seed, b.expected = transcript, None, None
+        b.transcript, b.seed, b.expected, b.dec_ok = transcript, None, None, None
         return b
+
+    @classmethod
+    def from_wire(cls, vk, ext, shape, circuits, wire, randomizers, transcript=FS_SHA256, threads=1):
+        """the batch a verifier sees when the records arrive in the wire form: decoded (orc_vs_wire_decode), with the
+        per-proof decode flags that every verdict below takes into account"""
+        recs, ok = vs_wire_decode(shape, wire, threads)
+        b = cls.wrap(vk, ext, shape, circuits, recs, randomizers, transcript)
+        b.dec_ok = ok
+        return b
+
+    def wire(self):
+        return vs_wire_encode(self.shape, self.proofs)
 
     def verify_cpu(self, threads=1):
         lib().orc_vs_set_transcript(C.c_int(self.transcript))
         v = np.zeros(self.n, dtype=np.uint8)
-        lib().orc_vs3_verify_batch_cpu(_p(self.vk), _p(self.ext), _p(self.shape), _p(self.circuits), _p(self.proofs), C.c_size_t(self.n),
-                                       _p(self.randomizers), _p(v), C.c_int(threads))
+        lib().orc_vs4_verify_batch_cpu(_p(self.vk), _p(self.ext), _p(self.shape), _p(self.circuits), C.c_size_t(self.n_circuits),
+                                       _p(self.proofs), C.c_size_t(self.n), _p(self.randomizers),
+                                       _p(self.dec_ok) if self.dec_ok is not None else None, _p(v), C.c_int(threads))
         return v
 
     def verify_aggregated(self, threads=1):
@@ -429,8 +482,9 @@ class VS2Batch:
         lib().orc_vs_set_transcript(C.c_int(self.transcript))
         alg = np.zeros(self.n, dtype=np.uint8)
         tot = u64((4, 12))
-        ok = lib().orc_vs3_verify_aggregated(_p(self.vk), _p(self.ext), _p(self.shape), _p(self.circuits), _p(self.proofs),
-                                             C.c_size_t(self.n), _p(self.randomizers), _p(alg), _p(tot), C.c_int(threads))
+        ok = lib().orc_vs4_verify_aggregated(_p(self.vk), _p(self.ext), _p(self.shape), _p(self.circuits), C.c_size_t(self.n_circuits),
+                                             _p(self.proofs), C.c_size_t(self.n), _p(self.randomizers),
+                                             _p(self.dec_ok) if self.dec_ok is not None else None, _p(alg), _p(tot), C.c_int(threads))
         return bool(ok), alg, tot
 
 
