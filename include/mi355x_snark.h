@@ -75,6 +75,29 @@ int32_t mi_device_id(int32_t index);    /* HIP ordinal of list entry `index` (ne
 int32_t mi_shutdown(void);
 const char *mi_error_string(int32_t status);
 int32_t mi_abi_version(void);
+/* What the embedding process should have arranged and has not (a bit set, never an error; the library sets no
+ * environment variable itself: setenv races with a multithreaded caller's getenv).
+ *   MI_HINT_HW_QUEUES: GPU_MAX_HW_QUEUES is unset or below 24.  The streamed verifier keeps ~20 HIP streams busy; HIP
+ *   maps them onto 4 hardware queues unless the variable says otherwise (a 20-batch stream then takes 11 ms instead of
+ *   6).  Set GPU_MAX_HW_QUEUES=32 in the process environment before the first HIP call. */
+#define MI_HINT_HW_QUEUES 1
+int32_t mi_runtime_hints(void);
+/* ---- counters (the build-side analogues of reference node/metrics/src/names.rs:15-48 and of the
+ * block / commit latencies recorded at node/consensus/src/lib.rs:511-528) ----  Monotonic since mi_init, summed over
+ * all devices; read them twice and take differences for rates (proofs_per_sec = d proofs_verified / d t, ...). */
+typedef struct {
+    uint64_t batches_verified;     /* batches whose verdict was produced (any entry point) */
+    uint64_t proofs_verified;      /* proofs in those batches */
+    uint64_t proofs_rejected;      /* proofs named invalid */
+    uint64_t verify_batch_nanos;   /* host wall time inside synchronous verify calls + stream submit-to-verdict latencies */
+    uint64_t msm_calls, msm_points;            /* mi_msm_g1* / mi_kzg_commit* and the verifier's own MSMs */
+    uint64_t ntt_calls, ntt_elements;
+    uint64_t pairing_products, pairing_pairs;
+    uint64_t points_decompressed;  /* mi_g1_decompress* and wire records */
+    uint64_t fallback_batches;     /* batches taken apart proof by proof */
+    uint64_t reserved[4];
+} mi_stats; /* 128 B */
+int32_t mi_stats_read(mi_stats *out);
 
 /* ---- msm::VariableBase::msm ---- */
 int32_t mi_msm_g1(const mi_g1_affine *bases, const mi_bigint256 *scalars, size_t n, mi_g1_jac *out);
@@ -164,8 +187,7 @@ typedef struct {
  *   - records are mi_vs_proof2, 3184 B (mi_vs_proof3, 5504 B, with instances), and THREE 128-bit randomizers per
  *     proof (48 B).
  * A context made by mi_vs_ctx_create_v2 takes such records through every mi_vs_* entry point (proof pointers are then
- * pointers to mi_vs_proof2; the host-pointer prototypes keep their v1 pointer type, cast).  Not in the shape (stated
- * in DESIGN.md): coefficients that need a field inversion of a challenge. */
+ * pointers to mi_vs_proof2; the host-pointer prototypes keep their v1 pointer type, cast). */
 #define MI_VS_MAX_BOUNDS 2
 typedef struct {
     uint8_t query_of[MI_VS_EVALS];         /* 0: the beta query, 1: the gamma query; polynomials 0 and 1 open at beta */
@@ -176,9 +198,14 @@ typedef struct {
      * v_H(alpha) v_H(beta)-style factors; polynomials 0 and 1 (the public-input identity) take the plain power */
     uint8_t lc_kind[MI_VS_EVALS];
     /* per-circuit batch size (Varuna's batch_sizes): a proof covers 1 .. max_instances instances of its circuit.
-     * 0 / 1: one, records are mi_vs_proof2; more: records are mi_vs_proof3 */
+     * 0 / 1: one, records are mi_vs_proof2; more: records are mi_vs_proof3.
+     * VarunaShaped-v3: lc_kind bit 2 -- the coefficient is further multiplied by 1 / (z_beta - z_gamma) (coefficients that
+     * need the inverse of a challenge; z_beta == z_gamma is an invalid proof under a shape that uses the bit) */
     uint8_t max_instances;
-    uint8_t pad[2];
+    /* VarunaShaped-v3: a proof covers instances of 1 .. max_circuits DISTINCT circuits (Varuna's keys_to_inputs map);
+     * 0 / 1: one; more: records are mi_vs_proof4.  max_circuits <= max_instances. */
+    uint8_t max_circuits;
+    uint8_t pad[1];
 } mi_vs_shape; /* 56 B */
 typedef struct { mi_g1_affine gamma_g; mi_g2_affine shift_h[MI_VS_MAX_BOUNDS]; } mi_vs_key_ext; /* 480 B */
 typedef struct { mi_vs_proof base; mi_fr random_v[2]; mi_g1_affine shifted[MI_VS_PROOF_COMMS]; } mi_vs_proof2; /* 3184 B */
@@ -195,6 +222,37 @@ typedef struct {
     uint32_t pad[3];
     mi_vs_instance extra[MI_VS_EXTRA_INSTANCES];
 } mi_vs_proof3; /* 5504 B */
+/* VarunaShaped-v3 (VarunaSNARK::verify_batch takes keys_to_inputs: BTreeMap<&CircuitVerifyingKey,
+ * &[Vec<Fr>]>): one proof over instances of SEVERAL circuits.  Instance 0 belongs to the proof's first circuit
+ * (base.circuit); every further circuit brings a part: its id (strictly above the previous circuit's: a BTreeMap's key
+ * order), the index of its first instance (strictly above the previous part's, >= 1, < n_instances: instances are
+ * grouped by circuit) and the evaluations of its 12 polynomials, which open like the first circuit's (the shape's query
+ * and linear-combination tables at 9 + k) with xi^(36 + 12 (d - 1) + k); its commitments' scalars merge into that
+ * circuit's slots of the aggregate.  Both transcripts absorb every part's header and circuit digest after the first
+ * circuit's digest and its evaluations after the instances' (Poseidon: 14 elements, 7 permutations per part).  A count
+ * or an id out of range is an invalid proof. */
+#define MI_VS_MAX_CIRCUITS 3
+#define MI_VS_EXTRA_CIRCUITS 2 /* MI_VS_MAX_CIRCUITS - 1 */
+typedef struct { uint32_t circuit, first_instance, pad[2]; mi_fr vk_evals[MI_VS_VK_COMMS]; } mi_vs_circuit_part; /* 400 B */
+typedef struct {
+    mi_vs_proof3 base3;
+    uint32_t n_circuits; /* 1 .. min(the shape's max_circuits, n_instances) */
+    uint32_t pad[3];
+    mi_vs_circuit_part more[MI_VS_EXTRA_CIRCUITS];
+} mi_vs_proof4; /* 6320 B */
+/* ---- WIRE records: what the node holds are Transaction bytes (reference
+ * node/bft/ledger-service/src/ledger.rs:326-331, node/router/messages/src/unconfirmed_transaction.rs:25-28,
+ * node/bft/events/src/block_response.rs:64-70) in which every commitment is a 48-byte compressed point and every field
+ * element its canonical little-endian value.  A context created with MI_VS_WIRE takes its records in that form: the
+ * record of its kind (mi_vs_proof / 2 / 3 / 4) with every mi_g1_affine replaced by its compressed encoding
+ * (mi_g1_compress), every mi_fr by the canonical integer, the 16-byte headers as they are: 1728 / 2224 / 4256 / 5072
+ * bytes.  Slots the record does not use (shifted commitments of polynomials without a degree bound, instances and
+ * circuits beyond the record's counts) are zero and are not decoded.  The lane pass decodes on the device ahead of the
+ * transcript (square root in Fq, sign, and the exact subgroup test snarkVM's deserialiser performs; Fr below r); a point
+ * that is not the encoding of a point of the order-r subgroup or a non-canonical Fr makes the proof invalid -- the same
+ * verdict as the oracle's.  mi_vs_strides tells a caller the record and randomizer sizes of a context;
+ * mi_vs_wire_encode (host arithmetic) turns uncompressed records into wire records. */
+#define MI_VS_WIRE 2
 /* one shard's accumulator (592 B); bound[c] is infinity for contexts without that class */
 typedef struct { mi_g1_jac total_c, total_w, bound[MI_VS_MAX_BOUNDS]; uint64_t n_proofs, n_alg_fail; } mi_vs_partial;
 
@@ -206,12 +264,19 @@ int32_t mi_vs_ctx_create(const mi_kzg_vk *vk, const mi_vs_circuit_vk *circuits, 
  * z_gamma, xi = low 128 bits of the first rate element after the 22nd, 26th and 37th permutation), instead of the
  * SHA-256 stand-in of mi_vs_ctx_create.  Proofs are bound to their transcript kind. */
 #define MI_VS_FS_POSEIDON 1
+/* flags may also carry MI_VS_WIRE (above): the context then takes wire records */
 int32_t mi_vs_ctx_create_ex(const mi_kzg_vk *vk, const mi_vs_circuit_vk *circuits, size_t n_circuits, uint32_t flags,
                             uint64_t *ctx_out);
 /* VarunaShaped-v2 context: ext may be NULL when the shape neither hides nor bounds; flags as above */
 int32_t mi_vs_ctx_create_v2(const mi_kzg_vk *vk, const mi_vs_key_ext *ext, const mi_vs_shape *shape,
                             const mi_vs_circuit_vk *circuits, size_t n_circuits, uint32_t flags, uint64_t *ctx_out);
 int32_t mi_vs_ctx_destroy(uint64_t ctx);
+/* bytes per proof record and per proof's randomizers that every mi_vs_* entry point of this context reads (host-pointer
+ * forms copy n * proof_bytes and n * rand_bytes) */
+int32_t mi_vs_strides(uint64_t ctx, size_t *proof_bytes, size_t *rand_bytes);
+/* uncompressed records of the context's kind -> wire records (n * the MI_VS_WIRE stride of that kind); works for
+ * contexts with and without MI_VS_WIRE */
+int32_t mi_vs_wire_encode(uint64_t ctx, const void *records, size_t n, uint8_t *wire_out);
 /* host-pointer form: verdicts[n] (1 = valid) and *all_ok.  randomizers128: n x 2 x 16 bytes. */
 int32_t mi_vs_verify_batch(uint64_t ctx, const mi_vs_proof *proofs, size_t n, const uint8_t *randomizers128,
                            uint8_t *verdicts, uint8_t *all_ok);

@@ -103,45 +103,87 @@ pub fn kzg_batch_check(vk: &mi_kzg_vk, comms: &[G1Affine], points: &[Fr], values
 }
 
 /// One verifier (KZG vk + circuit verifying keys), resident on every device that is handed work for it.
-pub struct BatchVerifier(u64);
+/// The record and randomizer sizes belong to the CONTEXT (v1 2256 / 32 bytes, v2 3184 / 48, with instances 5504, with
+/// several circuits 6320; under `MI_VS_WIRE` the wire strides 1728 / 2224 / 4256 / 5072): they are read back from the
+/// library once (`mi_vs_strides`) and every safe entry point takes BYTES and checks their length against them -- the
+/// library copies `n * proof_bytes`, so a typed slice of the wrong record type would be an out-of-bounds read.
+pub struct BatchVerifier {
+    ctx: u64,
+    proof_bytes: usize,
+    rand_bytes: usize,
+}
 
 impl BatchVerifier {
-    pub fn new(vk: &mi_kzg_vk, circuits: &[mi_vs_circuit_vk]) -> Result<Self, Status> {
+    fn wrap(ctx: u64) -> Result<Self, Status> {
+        let (mut pb, mut rb) = (0usize, 0usize);
+        if let Err(st) = check(unsafe { mi_vs_strides(ctx, &mut pb, &mut rb) }) {
+            unsafe { mi_vs_ctx_destroy(ctx) };
+            return Err(st);
+        }
+        Ok(Self { ctx, proof_bytes: pb, rand_bytes: rb })
+    }
+    /// `wire`: the records are the node's own bytes (48-byte compressed commitments, canonical field elements:
+    /// ledger.rs:326-331), decoded on the device.
+    pub fn new(vk: &mi_kzg_vk, circuits: &[mi_vs_circuit_vk], poseidon: bool, wire: bool) -> Result<Self, Status> {
         let mut h = 0u64;
-        check(unsafe { mi_vs_ctx_create(vk, circuits.as_ptr(), circuits.len(), &mut h) })?;
-        Ok(Self(h))
+        let flags: u32 = (if poseidon { MI_VS_FS_POSEIDON as u32 } else { 0 }) | (if wire { MI_VS_WIRE as u32 } else { 0 });
+        check(unsafe { mi_vs_ctx_create_ex(vk, circuits.as_ptr(), circuits.len(), flags, &mut h) })?;
+        Self::wrap(h)
+    }
+    /// VarunaShaped-v2 / v3 (query-set table, hiding, degree-bound classes, instances, several circuits per proof,
+    /// inverse-challenge coefficients): three 128-bit randomizers per proof.
+    pub fn new_v2(vk: &mi_kzg_vk, ext: Option<&mi_vs_key_ext>, shape: &mi_vs_shape, circuits: &[mi_vs_circuit_vk], poseidon: bool,
+                  wire: bool) -> Result<Self, Status> {
+        let mut h = 0u64;
+        let e = ext.map_or(std::ptr::null(), |x| x as *const mi_vs_key_ext);
+        let flags: u32 = (if poseidon { MI_VS_FS_POSEIDON as u32 } else { 0 }) | (if wire { MI_VS_WIRE as u32 } else { 0 });
+        check(unsafe { mi_vs_ctx_create_v2(vk, e, shape, circuits.as_ptr(), circuits.len(), flags, &mut h) })?;
+        Self::wrap(h)
+    }
+    pub fn proof_bytes(&self) -> usize { self.proof_bytes }
+    pub fn rand_bytes(&self) -> usize { self.rand_bytes }
+    /// number of records in `proofs`, after checking both slices against the context's strides
+    fn count(&self, proofs: &[u8], randomizers128: &[u8]) -> usize {
+        assert!(self.proof_bytes > 0 && proofs.len() % self.proof_bytes == 0, "proofs: not a whole number of this context's records");
+        let n = proofs.len() / self.proof_bytes;
+        assert_eq!(randomizers128.len(), self.rand_bytes * n, "randomizers: rand_bytes per proof");
+        n
     }
     /// The chunk of `VM::check_transactions` (<= 1000 executions): verdict per proof, on the primary device.
-    pub fn verify_batch(&self, proofs: &[mi_vs_proof], randomizers128: &[u8]) -> Result<(bool, Vec<u8>), Status> {
-        assert_eq!(randomizers128.len(), 32 * proofs.len());
-        let (mut verdicts, mut all_ok) = (vec![0u8; proofs.len()], 0u8);
-        check(unsafe { mi_vs_verify_batch(self.0, proofs.as_ptr(), proofs.len(), randomizers128.as_ptr(), verdicts.as_mut_ptr(), &mut all_ok) })?;
+    pub fn verify_batch(&self, proofs: &[u8], randomizers128: &[u8]) -> Result<(bool, Vec<u8>), Status> {
+        let n = self.count(proofs, randomizers128);
+        let (mut verdicts, mut all_ok) = (vec![0u8; n], 0u8);
+        check(unsafe { mi_vs_verify_batch(self.ctx, proofs.as_ptr() as *const mi_vs_proof, n, randomizers128.as_ptr(), verdicts.as_mut_ptr(), &mut all_ok) })?;
         Ok((all_ok != 0, verdicts))
     }
     /// One block over ALL devices of the process: sharded inside the library, partials exchanged over RCCL,
     /// one pairing product (what `Consensus::try_advance_to_next_block` needs: node/consensus/src/lib.rs:499).
-    pub fn verify_block(&self, proofs: &[mi_vs_proof], randomizers128: &[u8]) -> Result<(bool, Vec<u8>), Status> {
-        assert_eq!(randomizers128.len(), 32 * proofs.len());
-        let (mut verdicts, mut all_ok) = (vec![0u8; proofs.len()], 0u8);
-        check(unsafe { mi_vs_verify_block(self.0, proofs.as_ptr(), proofs.len(), randomizers128.as_ptr(), verdicts.as_mut_ptr(), &mut all_ok) })?;
+    pub fn verify_block(&self, proofs: &[u8], randomizers128: &[u8]) -> Result<(bool, Vec<u8>), Status> {
+        let n = self.count(proofs, randomizers128);
+        let (mut verdicts, mut all_ok) = (vec![0u8; n], 0u8);
+        check(unsafe { mi_vs_verify_block(self.ctx, proofs.as_ptr() as *const mi_vs_proof, n, randomizers128.as_ptr(), verdicts.as_mut_ptr(), &mut all_ok) })?;
         Ok((all_ok != 0, verdicts))
     }
-    /// VarunaShaped-v2 (query-set table, hiding, degree-bound classes): records are `mi_vs_proof2`, three 128-bit
-    /// randomizers per proof; every other method takes them through the same entry points (pointer casts).
-    pub fn new_v2(vk: &mi_kzg_vk, ext: Option<&mi_vs_key_ext>, shape: &mi_vs_shape, circuits: &[mi_vs_circuit_vk], poseidon: bool)
-                  -> Result<Self, Status> {
-        let mut h = 0u64;
-        let e = ext.map_or(std::ptr::null(), |x| x as *const mi_vs_key_ext);
-        let flags: u32 = if poseidon { MI_VS_FS_POSEIDON as u32 } else { 0 };
-        check(unsafe { mi_vs_ctx_create_v2(vk, e, shape, circuits.as_ptr(), circuits.len(), flags, &mut h) })?;
-        Ok(Self(h))
+    /// v1 records as a typed slice (contexts made by `new(.., wire = false)` only: checked)
+    pub fn verify_batch_v1(&self, proofs: &[mi_vs_proof], randomizers128: &[u8]) -> Result<(bool, Vec<u8>), Status> {
+        assert_eq!(self.proof_bytes, std::mem::size_of::<mi_vs_proof>(), "not a v1 context");
+        let bytes = unsafe { std::slice::from_raw_parts(proofs.as_ptr() as *const u8, std::mem::size_of_val(proofs)) };
+        self.verify_batch(bytes, randomizers128)
+    }
+    /// uncompressed records of this context's kind -> wire records (host arithmetic)
+    pub fn wire_encode(&self, records: &[u8], record_bytes: usize, wire_bytes: usize) -> Result<Vec<u8>, Status> {
+        assert!(record_bytes > 0 && records.len() % record_bytes == 0);
+        let n = records.len() / record_bytes;
+        let mut out = vec![0u8; n * wire_bytes];
+        check(unsafe { mi_vs_wire_encode(self.ctx, records.as_ptr() as *const c_void, n, out.as_mut_ptr()) })?;
+        Ok(out)
     }
     /// The verdict vector of a chunk already known to fail (a streamed chunk whose `all_ok` came back false), from
     /// its device-resident inputs: no aggregate pass.
     pub unsafe fn identify(&self, d_proofs: *const c_void, n: usize, d_randomizers128: *const c_void, hip_stream: *mut c_void)
                            -> Result<Vec<u8>, Status> {
         let mut verdicts = vec![0u8; n];
-        check(mi_vs_identify_device(self.0, d_proofs, n, d_randomizers128, verdicts.as_mut_ptr(), hip_stream))?;
+        check(mi_vs_identify_device(self.ctx, d_proofs, n, d_randomizers128, verdicts.as_mut_ptr(), hip_stream))?;
         Ok(verdicts)
     }
     /// Several chunks in ONE lane pass (at most `MI_VS_MAX_BATCHES_PER_PASS`; `batches_per_pass` tells how many of a
@@ -152,14 +194,14 @@ impl BatchVerifier {
         let (pr, ns, rn): (Vec<_>, Vec<_>, Vec<_>) = (chunks.iter().map(|c| c.0).collect(), chunks.iter().map(|c| c.1).collect(),
                                                       chunks.iter().map(|c| c.2).collect());
         let mut h = 0u64;
-        check(mi_vs_accumulate_begin_multi(self.0, k as i32, pr.as_ptr(), ns.as_ptr(), rn.as_ptr(), hip_stream, &mut h))?;
+        check(mi_vs_accumulate_begin_multi(self.ctx, k as i32, pr.as_ptr(), ns.as_ptr(), rn.as_ptr(), hip_stream, &mut h))?;
         let mut parts: Vec<mi_vs_partial> = Vec::with_capacity(k);
-        check(mi_vs_accumulate_end_multi(self.0, h, parts.as_mut_ptr(), k as i32))?;
+        check(mi_vs_accumulate_end_multi(self.ctx, h, parts.as_mut_ptr(), k as i32))?;
         parts.set_len(k);
         Ok(parts)
     }
     pub fn batches_per_pass(&self, n: usize) -> Result<usize, Status> {
-        let r = unsafe { mi_vs_batches_per_pass(self.0, n) };
+        let r = unsafe { mi_vs_batches_per_pass(self.ctx, n) };
         if r < 1 { Err(r) } else { Ok(r as usize) }
     }
     /// Streamed chunks (mempool admission, block sync): `exchange` = None on one GPU, or
@@ -168,14 +210,14 @@ impl BatchVerifier {
     pub fn stream(&self, fold_threads: i32, products: i32, lanes: i32, exchange: mi_vs_exchange_fn, user: *mut c_void,
                   exchange_group: i32) -> Result<VerifyStream, Status> {
         let mut s = 0u64;
-        check(unsafe { mi_vs_stream_open(self.0, fold_threads, products, lanes, exchange, user, exchange_group, &mut s) })?;
+        check(unsafe { mi_vs_stream_open(self.ctx, fold_threads, products, lanes, exchange, user, exchange_group, &mut s) })?;
         Ok(VerifyStream(s))
     }
 }
 
 impl Drop for BatchVerifier {
     fn drop(&mut self) {
-        unsafe { mi_vs_ctx_destroy(self.0) };
+        unsafe { mi_vs_ctx_destroy(self.ctx) };
     }
 }
 

@@ -319,8 +319,10 @@ class VarunaShaped:
     """Batch verifier for the synthetic VarunaShaped-v1 proofs; the role of
     VarunaSNARK::verify_batch inside VM::check_transactions."""
 
-    def __init__(self, kzg_vk, circuit_vks, transcript="sha256", shape=None, key_ext=None):
-        """transcript: "sha256" (the round-1 stand-in) or "poseidon" (sponge over Fq with the reference's absorb volume,
+    def __init__(self, kzg_vk, circuit_vks, transcript="sha256", shape=None, key_ext=None, wire=False):
+        """wire: the context takes WIRE records (MI_VS_WIRE: compressed points, canonical Fr), decoded on the device
+        inside the lane pass; `wire_encode` turns uncompressed records into them.
+        transcript: "sha256" (the round-1 stand-in) or "poseidon" (sponge over Fq with the reference's absorb volume,
         mi_vs_ctx_create_ex(..., MI_VS_FS_POSEIDON)); proofs are bound to their transcript kind.
         shape / key_ext: VarunaShaped-v2 (mi_vs_ctx_create_v2): the 56-byte mi_vs_shape (query-set table, degree-bound
         classes, hiding, linear-combination kinds, instances per proof) and the 480-byte mi_vs_key_ext (gamma_g, shift_h[2]);
@@ -332,7 +334,7 @@ class VarunaShaped:
         assert transcript in ("sha256", "poseidon")
         self.n_circuits = cv.size // L.VS_CIRCUIT_VK_BYTES
         h = C.c_uint64(0)
-        flags = L.VS_FS_POSEIDON if transcript == "poseidon" else 0
+        flags = (L.VS_FS_POSEIDON if transcript == "poseidon" else 0) | (L.VS_WIRE if wire else 0)
         self.proof_bytes, self.rand_bytes = L.VS_PROOF_BYTES, 32
         if shape is not None:
             sh = np.ascontiguousarray(shape).view(np.uint8).reshape(-1)
@@ -341,16 +343,33 @@ class VarunaShaped:
             L.check(L.lib().mi_vs_ctx_create_v2(L.ptr(vk), L.ptr(ext), L.ptr(sh), L.ptr(cv), C.c_size_t(self.n_circuits),
                                                 C.c_uint32(flags), C.byref(h)), "mi_vs_ctx_create_v2")
             self.proof_bytes, self.rand_bytes = (L.VS3_PROOF_BYTES if int(sh[53]) > 1 else L.VS2_PROOF_BYTES), 48
+            if int(sh[54]) > 1:
+                self.proof_bytes = L.VS4_PROOF_BYTES
         else:
             L.check(L.lib().mi_vs_ctx_create_ex(L.ptr(vk), L.ptr(cv), C.c_size_t(self.n_circuits), C.c_uint32(flags), C.byref(h)),
                     "mi_vs_ctx_create_ex")
         self.ctx = h.value
+        self.record_bytes = self.proof_bytes  # the uncompressed record of the context's kind
+        pb, rb = C.c_size_t(0), C.c_size_t(0)
+        L.check(L.lib().mi_vs_strides(C.c_uint64(self.ctx), C.byref(pb), C.byref(rb)), "mi_vs_strides")
+        assert rb.value == self.rand_bytes and (wire or pb.value == self.proof_bytes)
+        self.proof_bytes = pb.value  # what every entry point of this context reads per proof (the wire stride under MI_VS_WIRE)
         # accumulation lanes of this context (the library reads the same variable when it creates the context)
         try:
             lanes = int(os.environ.get("MI_SNARK_VS_LANES", L.VS_DEFAULT_LANES))
         except ValueError:
             lanes = L.VS_DEFAULT_LANES
         self.lanes = lanes if 1 <= lanes <= L.VS_MAX_OPEN_ACCUMULATIONS else L.VS_DEFAULT_LANES
+
+    def wire_encode(self, records):
+        """uncompressed records of this context's kind -> wire records (mi_vs_wire_encode, host arithmetic)"""
+        r = np.ascontiguousarray(records).view(np.uint8).reshape(-1)
+        n = r.size // self.record_bytes
+        assert r.size == n * self.record_bytes
+        wb = {L.VS_PROOF_BYTES: 1728, L.VS2_PROOF_BYTES: 2224, L.VS3_PROOF_BYTES: 4256, L.VS4_PROOF_BYTES: 5072}[self.record_bytes]
+        out = np.zeros(n * wb, dtype=np.uint8)
+        L.check(L.lib().mi_vs_wire_encode(C.c_uint64(self.ctx), L.ptr(r), C.c_size_t(n), L.ptr(out)), "mi_vs_wire_encode")
+        return out
 
     def close(self):
         if self.ctx:

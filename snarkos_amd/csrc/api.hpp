@@ -76,6 +76,7 @@ int32_t vs_ctx_create(Context &cx, const mi_kzg_vk *vk, const mi_vs_key_ext *ext
 // record and randomizer strides of a verifier context (v1: 2256 / 32, v2: 3184 / 48); false: no such context
 bool vs_strides(uint64_t id, size_t *proof_bytes, size_t *rand_bytes);
 int32_t vs_ctx_destroy(Context &cx, uint64_t id);
+int32_t vs_wire_encode_host(uint64_t id, const void *records, size_t n, uint8_t *wire_out);
 int32_t vs_accumulate_device(Context &cx, uint64_t id, const void *d_proofs, size_t n, const void *d_rand,
                              mi_vs_partial *out, hipStream_t st);
 int32_t vs_accumulate_begin(Context &cx, uint64_t id, const void *d_proofs, size_t n, const void *d_rand, hipStream_t st,

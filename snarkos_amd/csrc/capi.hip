@@ -209,6 +209,7 @@ __global__ void __launch_bounds__(64) g1_compress_kernel(const G1Affine *__restr
 }
 void g1_decompress_device(Context &cx, const uint8_t *d_in, size_t n, int check_subgroup, G1Affine *d_out, uint8_t *d_ok, hipStream_t st) {
     if (!n) return;
+    stats().points_decompressed += n;
     cx.prof.begin("g1_decompress", st, n);
     hipLaunchKernelGGL(g1_decompress_kernel, dim3(cdiv(n, 64)), dim3(64), 0, st, d_in, n, check_subgroup, d_out, d_ok);
     cx.prof.end("g1_decompress", st);
@@ -361,7 +362,31 @@ const char *mi_error_string(int32_t s) {
     default: return "unknown status";
     }
 }
-int32_t mi_abi_version(void) { return 2; }
+int32_t mi_abi_version(void) { return 3; }
+int32_t mi_runtime_hints(void) {
+    int32_t h = 0;
+    const char *e = getenv("GPU_MAX_HW_QUEUES");
+    if (!e || atoi(e) < 24) h |= MI_HINT_HW_QUEUES;
+    return h;
+}
+int32_t mi_stats_read(mi_stats *out) {
+    if (!out) return MI_ERR_BAD_ARGS;
+    memset(out, 0, sizeof *out);
+    const Stats &s = stats();
+    out->batches_verified = s.batches_verified.load();
+    out->proofs_verified = s.proofs_verified.load();
+    out->proofs_rejected = s.proofs_rejected.load();
+    out->verify_batch_nanos = s.verify_batch_nanos.load();
+    out->msm_calls = s.msm_calls.load();
+    out->msm_points = s.msm_points.load();
+    out->ntt_calls = s.ntt_calls.load();
+    out->ntt_elements = s.ntt_elements.load();
+    out->pairing_products = s.pairing_products.load();
+    out->pairing_pairs = s.pairing_pairs.load();
+    out->points_decompressed = s.points_decompressed.load();
+    out->fallback_batches = s.fallback_batches.load();
+    return MI_OK;
+}
 
 // ------------------------------------------------------------ MSM
 // entries per MSM are indexed with 32 bits (index << 1 | sign; offsets over all windows): n <= 2^27
@@ -857,11 +882,11 @@ int32_t mi_vs_ctx_create(const mi_kzg_vk *vk, const mi_vs_circuit_vk *circuits, 
 }
 int32_t mi_vs_ctx_create_v2(const mi_kzg_vk *vk, const mi_vs_key_ext *ext, const mi_vs_shape *shape, const mi_vs_circuit_vk *circuits,
                             size_t n_circuits, uint32_t flags, uint64_t *ctx_out) {
-    if (!vk || !shape || !circuits || !n_circuits || !ctx_out || (flags & ~(uint32_t)MI_VS_FS_POSEIDON)) return MI_ERR_BAD_ARGS;
+    if (!vk || !shape || !circuits || !n_circuits || !ctx_out || (flags & ~(uint32_t)(MI_VS_FS_POSEIDON | MI_VS_WIRE))) return MI_ERR_BAD_ARGS;
     return guarded([&](Context &cx) -> int32_t { return vs_ctx_create(cx, vk, ext, shape, circuits, n_circuits, flags, ctx_out); });
 }
 int32_t mi_vs_ctx_create_ex(const mi_kzg_vk *vk, const mi_vs_circuit_vk *circuits, size_t n_circuits, uint32_t flags, uint64_t *ctx_out) {
-    if (!vk || !circuits || !n_circuits || !ctx_out || (flags & ~(uint32_t)MI_VS_FS_POSEIDON)) return MI_ERR_BAD_ARGS;
+    if (!vk || !circuits || !n_circuits || !ctx_out || (flags & ~(uint32_t)(MI_VS_FS_POSEIDON | MI_VS_WIRE))) return MI_ERR_BAD_ARGS;
     return guarded([&](Context &cx) -> int32_t { return vs_ctx_create(cx, vk, nullptr, nullptr, circuits, n_circuits, flags, ctx_out); });
 }
 int32_t mi_vs_ctx_destroy(uint64_t c) {
@@ -872,6 +897,18 @@ int32_t mi_vs_ctx_destroy(uint64_t c) {
         if (s != MI_OK) st = s;
     }
     return st;
+}
+int32_t mi_vs_strides(uint64_t c, size_t *proof_bytes, size_t *rand_bytes) {
+    if (!proof_bytes || !rand_bytes) return MI_ERR_BAD_ARGS;
+    return vs_strides(c, proof_bytes, rand_bytes) ? MI_OK : MI_ERR_BAD_ARGS;
+}
+int32_t mi_vs_wire_encode(uint64_t c, const void *records, size_t n, uint8_t *wire_out) {
+    if (!records || !wire_out) return MI_ERR_BAD_ARGS;
+    try {
+        return vs_wire_encode_host(c, records, n, wire_out);
+    } catch (...) {
+        return MI_ERR_KERNEL;
+    }
 }
 int32_t mi_vs_verify_batch(uint64_t c, const mi_vs_proof *proofs, size_t n, const uint8_t *randomizers128,
                            uint8_t *verdicts, uint8_t *all_ok) {

@@ -779,6 +779,8 @@ void msm_enqueue(Context &cx, const G1Affine *d_points, const uint32_t *d_scalar
         return ws;
     };
     MsmPlan pl = msm_plan(n, scalar_bits, force_c);
+    stats().msm_calls++;
+    stats().msm_points += n;
     job->c = pl.c;
     job->nwin = pl.nwin;
     // A small MSM is latency bound (one mixed addition is ~10k instructions; its ~17 dependent launches cost more

@@ -369,6 +369,8 @@ static void ntt_launch_lds_pass(Context &cx, const Fr *in, Fr *out, const Fr *tw
 
 // in place on d_data (device pointer, 2^log_n elements)
 void ntt_device(Context &cx, Fr *d_data, uint32_t log_n, bool inverse, bool coset, hipStream_t st) {
+    stats().ntt_calls++;
+    stats().ntt_elements += (uint64_t)1 << log_n;
     const size_t n = (size_t)1 << log_n;
     if (coset) ntt_get_coset_tables(cx, st);
     if (coset && !inverse)

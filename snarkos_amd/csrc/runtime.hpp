@@ -8,6 +8,7 @@
 #include <deque>
 #include <functional>
 #include <future>
+#include <atomic>
 #include <chrono>
 #include <map>
 #include <memory>
@@ -124,6 +125,24 @@ struct HostSpan {
         auto &a = host_prof().acc[name];
         a.s += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
         a.n++;
+    }
+};
+
+// Process-wide counters behind mi_stats_read (the build-side analogues of the reference's
+// prometheus metrics).  Relaxed atomics: any thread adds, the reader takes a snapshot.
+struct Stats {
+    std::atomic<uint64_t> batches_verified{0}, proofs_verified{0}, proofs_rejected{0}, verify_batch_nanos{0}, msm_calls{0},
+        msm_points{0}, ntt_calls{0}, ntt_elements{0}, pairing_products{0}, pairing_pairs{0}, points_decompressed{0},
+        fallback_batches{0};
+};
+inline Stats &stats() {
+    static Stats s;
+    return s;
+}
+struct StatTimer {  // adds its lifetime to verify_batch_nanos
+    std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+    ~StatTimer() {
+        stats().verify_batch_nanos += (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count();
     }
 };
 

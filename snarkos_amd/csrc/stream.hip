@@ -17,6 +17,7 @@
 #include <thread>
 #include <vector>
 #include "../../include/mi355x_snark.h"
+#include "runtime.hpp"  // the process-wide counters only: the driver itself runs on the public entry points
 
 namespace {
 
@@ -34,6 +35,8 @@ struct Stream {
     std::deque<int32_t> results;                        // 0 / 1 verdicts, or a negative status
     struct Sub { const void *proofs; size_t n; const void *rand; };
     std::deque<Sub> pending;                            // submitted batches whose verdict has not been taken, oldest first
+    std::vector<size_t> sizes;                          // every submitted batch's size, in order (counters)
+    size_t published = 0;                               // verdicts handed to `results` so far
     uint64_t submitted = 0, open = 0;                   // batches submitted; accumulations begun and not yet folded
     // Under load consecutive batches share one lane pass (mi_vs_accumulate_begin_multi): a batch submitted while
     // `pair_at` or more passes are open is HELD until `per_pass` batches are together -- or until a pass ends, the
@@ -191,6 +194,11 @@ struct Stream {
             const int32_t st = mi_vs_finalize_wait_multi(ctx, tk.first, ok, tk.second);
             std::lock_guard<std::mutex> lk(mu);
             for (int k = 0; k < tk.second; k++) results.push_back(st == MI_OK ? (int32_t)ok[k] : st);
+            if (st == MI_OK) {  // counters: the batches these verdicts belong to are the oldest unpublished ones
+                mi::stats().batches_verified += (uint64_t)tk.second;
+                for (int k = 0; k < tk.second && published + (size_t)k < sizes.size(); k++) mi::stats().proofs_verified += sizes[published + (size_t)k];
+            }
+            published += (size_t)tk.second;
             inflight--;
             cv.notify_all();
         }
@@ -331,6 +339,7 @@ int32_t mi_vs_stream_submit(uint64_t stream, const void *d_proofs, size_t n, con
     {
         std::lock_guard<std::mutex> lk(s->mu);
         if (s->finished) return MI_ERR_BAD_ARGS;
+        s->sizes.push_back(n);  // one submitting thread per stream: submission order is batch order
         join = !s->held.empty() && s->held_stream == hip_stream && s->held.front().n == n;
         ask = s->per_pass == 0;
     }

@@ -17,6 +17,7 @@
 #include "tower.hpp"
 #include "pairing_wg.hpp"
 #include "glv.hpp"
+#include "codec.hpp"
 
 namespace mi {
 
@@ -143,7 +144,85 @@ struct VsConsts {
     uint32_t inst_slot;            // first of the 2 (max_inst - 1) H-side slots of the further instances' commitments
     int8_t bound_class[MI_VS_PROOF_COMMS];
     uint8_t _pad[2];
+    // ---- VarunaShaped-v3
+    uint32_t max_circ;             // 1 .. MI_VS_MAX_CIRCUITS distinct circuits per proof (records: mi_vs_proof4)
+    uint32_t need_inv;             // some lc_kind carries bit 2: 1 / (z_beta - z_gamma)
+    uint32_t wire;                 // records arrive in the wire form (MI_VS_WIRE) and are decoded ahead of the transcript
+    uint32_t wire_bytes;           // their stride
 };
+// The wire form of the context's record kind (include/mi355x_snark.h, MI_VS_WIRE) as the decode kernels walk it: runs of
+// raw bytes and of Fr fields, and the point slots the SHAPE uses (shifted commitments of unbounded polynomials are left
+// out here; instances and circuits beyond a record's own counts are decided per record).  cls: 0 always used, 2 + j
+// the j-th further instance, 8 + d the d-th further circuit.
+struct VsWireMap {
+    uint32_t n_pts, n_runs;
+    uint32_t off_ni, off_nc;       // wire offsets of n_instances / n_circuits (0: the kind has none)
+    uint32_t rec_bytes, wire_bytes, max_inst, max_circ;
+    uint16_t pt_wire[32], pt_rec[32];
+    uint8_t pt_cls[32];
+    struct Run { uint16_t wire, rec, count; uint8_t type, cls; } run[24];  // type 0: raw bytes (count = bytes), 1: Fr fields
+};
+// terms / chains of one proof in the per-proof fallback (see vs_terms_kernel): its own H-side points, the commitments of
+// up to max_circ circuits, G (and gamma_g), the two witnesses on the tau-H side, the class accumulators' points
+__host__ __device__ __forceinline__ uint32_t vs_terms_of(uint32_t per_proof, uint32_t hiding, uint32_t n_bounded, uint32_t max_circ) {
+    return per_proof + MI_VS_VK_COMMS * max_circ + 1 + hiding + 2 + n_bounded;
+}
+__host__ __device__ __forceinline__ uint32_t vs_chains_of(uint32_t per_proof, uint32_t hiding, uint32_t n_bounded, uint32_t max_circ) {
+    return 2 * vs_terms_of(per_proof, hiding, n_bounded, max_circ) - 2;
+}
+// the wire layout of the context's record kind (v1 records when the context has no shape)
+static void vs_build_wire_map(VsWireMap &m, const VsConsts &hc, bool has_shape) {
+    memset(&m, 0, sizeof m);
+    const int kind = !has_shape ? 1 : (hc.max_circ > 1 ? 4 : (hc.max_inst > 1 ? 3 : 2));
+    uint32_t w = 0, r = 0;
+    auto raw = [&](uint32_t bytes, uint8_t cls) {
+        m.run[m.n_runs++] = VsWireMap::Run{(uint16_t)w, (uint16_t)r, (uint16_t)bytes, 0, cls};
+        w += bytes;
+        r += bytes;
+    };
+    auto frs = [&](uint32_t count, uint8_t cls) {
+        m.run[m.n_runs++] = VsWireMap::Run{(uint16_t)w, (uint16_t)r, (uint16_t)count, 1, cls};
+        w += 32 * count;
+        r += 32 * count;
+    };
+    auto pts = [&](uint32_t count, uint8_t cls, const int8_t *bound_class) {
+        for (uint32_t j = 0; j < count; j++) {
+            const bool used = !bound_class || (bound_class[j] >= 0 && bound_class[j] < (int)hc.n_bounds);
+            if (used) {
+                m.pt_wire[m.n_pts] = (uint16_t)w;
+                m.pt_rec[m.n_pts] = (uint16_t)r;
+                m.pt_cls[m.n_pts] = cls;
+                m.n_pts++;
+            }
+            w += 48;
+            r += 96;
+        }
+    };
+    raw(16, 0); frs(MI_VS_INPUTS, 0); pts(MI_VS_PROOF_COMMS, 0, nullptr); frs(MI_VS_EVALS, 0); pts(2, 0, nullptr);
+    if (kind >= 2) { frs(2, 0); pts(MI_VS_PROOF_COMMS, 0, hc.bound_class); }
+    if (kind >= 3) {
+        m.off_ni = w;
+        raw(16, 0);
+        for (uint32_t j = 0; j < MI_VS_EXTRA_INSTANCES; j++) {
+            const uint8_t cls = (uint8_t)(2 + j);
+            if (j + 1 < hc.max_inst) { frs(MI_VS_INPUTS, cls); pts(2, cls, nullptr); frs(2, cls); }
+            else { w += 32 * MI_VS_INPUTS + 96 + 64; r += sizeof(mi_vs_instance); }  // beyond the shape: never used, stays zero
+        }
+    }
+    if (kind >= 4) {
+        m.off_nc = w;
+        raw(16, 0);
+        for (uint32_t d = 0; d + 1 < MI_VS_MAX_CIRCUITS; d++) {
+            const uint8_t cls = (uint8_t)(8 + d);
+            if (d + 1 < hc.max_circ) { raw(16, cls); frs(MI_VS_VK_COMMS, cls); }
+            else { w += sizeof(mi_vs_circuit_part); r += sizeof(mi_vs_circuit_part); }
+        }
+    }
+    m.wire_bytes = w;
+    m.rec_bytes = r;
+    m.max_inst = hc.max_inst;
+    m.max_circ = hc.max_circ;
+}
 // where one proof's operands go (device pointers into the lane's workspace)
 struct VsOut {
     G1Affine *pts1, *pts2, *ptsb[MI_VS_MAX_BOUNDS];
@@ -151,6 +230,7 @@ struct VsOut {
     Fr *vk_scal, *g_scal, *h_scal;
     uint8_t *alg_ok;
     uint32_t *circuit_of;
+    const uint8_t *dec_ok;  // wire records: per-proof decode flags
 };
 // A lane pass over SEVERAL batches (mi_vs_accumulate_begin_multi): the blocks from b[k].first_block on serve further
 // batch k (block ranges ascend with k)
@@ -197,14 +277,17 @@ struct VsCtx {
     G2Prepared h_prep, tauh_prep;  // prepared once on the host (as the reference prepares prepared_h / prepared_beta_h)
     G2Prepared shift_prep[MI_VS_MAX_BOUNDS];  // v2: the G2 partners of the degree-bound classes (prepared_shift_power)
     VsConsts consts;
+    VsWireMap wire_map;
 };
 struct VsKeys {  // one device's copy
-    DevBuf circuits, h_prep, tauh_prep, consts, shift_prep[MI_VS_MAX_BOUNDS];
+    DevBuf circuits, h_prep, tauh_prep, consts, shift_prep[MI_VS_MAX_BOUNDS], wire_map;
+    VsWireMap wm;  // host copy
     size_t n_circuits = 0;
     bool fs_poseidon = false;
     VsConsts shape;  // host copy of what consts holds
     ~VsKeys() {
         circuits.release();
+        wire_map.release();
         h_prep.release();
         tauh_prep.release();
         consts.release();
@@ -322,9 +405,52 @@ static std::shared_ptr<VsCtx> vs_find(uint64_t id) {
 bool vs_strides(uint64_t id, size_t *proof_bytes, size_t *rand_bytes) {
     std::shared_ptr<VsCtx> v = vs_find(id);
     if (!v) return false;
-    *proof_bytes = (size_t)v->consts.proof_words * 4;
+    *proof_bytes = v->consts.wire ? (size_t)v->consts.wire_bytes : (size_t)v->consts.proof_words * 4;
     *rand_bytes = v->consts.rand_bytes;
     return true;
+}
+// records of the context's kind -> wire records, on the host (the inverse of the decode kernels; tests, benches and a
+// caller that holds decoded records use it)
+int32_t vs_wire_encode_host(uint64_t id, const void *records, size_t n, uint8_t *wire_out) {
+    std::shared_ptr<VsCtx> v = vs_find(id);
+    if (!v) return MI_ERR_BAD_ARGS;
+    const VsWireMap &wm = v->wire_map;
+    memset(wire_out, 0, (size_t)wm.wire_bytes * n);
+    for (size_t i = 0; i < n; i++) {
+        const uint8_t *r = (const uint8_t *)records + (size_t)wm.rec_bytes * i;
+        uint8_t *w = wire_out + (size_t)wm.wire_bytes * i;
+        uint32_t m1 = 0, d1 = 0;
+        if (wm.off_ni) {
+            uint32_t ni;
+            memcpy(&ni, r + sizeof(mi_vs_proof2), 4);
+            if (ni >= 1 && ni <= wm.max_inst) m1 = ni - 1;
+        }
+        if (wm.off_nc) {
+            uint32_t nc;
+            memcpy(&nc, r + sizeof(mi_vs_proof3), 4);
+            if (nc >= 1 && nc <= wm.max_circ) d1 = nc - 1;
+        }
+        auto used = [&](uint32_t cls) { return cls == 0 || (cls >= 8 ? cls - 8 < d1 : cls - 2 < m1); };
+        for (uint32_t k = 0; k < wm.n_runs; k++) {
+            const VsWireMap::Run &run = wm.run[k];
+            if (!used(run.cls)) continue;
+            if (run.type == 0) memcpy(w + run.wire, r + run.rec, run.count);
+            else
+                for (uint32_t j = 0; j < run.count; j++) {
+                    Fr x;
+                    memcpy(&x, r + run.rec + 32 * j, 32);
+                    x = from_mont(x);
+                    memcpy(w + run.wire + 32 * j, &x, 32);
+                }
+        }
+        for (uint32_t k = 0; k < wm.n_pts; k++) {
+            if (!used(wm.pt_cls[k])) continue;
+            G1Affine pt;
+            memcpy(&pt, r + wm.pt_rec[k], sizeof pt);
+            g1_compress_one(pt, w + wm.pt_wire[k]);
+        }
+    }
+    return MI_OK;
 }
 void verify_release_keys() {
     std::lock_guard<std::mutex> lk(g_vs_mu);
@@ -345,6 +471,8 @@ static VsKeys &vs_keys(Context &cx, const VsCtx &v) {
     MI_HIP(hipMemcpyAsync(k->tauh_prep.get(sizeof(G2Prepared)), &v.tauh_prep, sizeof(G2Prepared), hipMemcpyHostToDevice, st));
     MI_HIP(hipMemcpyAsync(k->consts.get(sizeof(VsConsts)), &v.consts, sizeof(VsConsts), hipMemcpyHostToDevice, st));
     k->shape = v.consts;
+    k->wm = v.wire_map;
+    MI_HIP(hipMemcpyAsync(k->wire_map.get(sizeof(VsWireMap)), &v.wire_map, sizeof(VsWireMap), hipMemcpyHostToDevice, st));
     for (uint32_t c = 0; c < v.consts.n_bounds; c++)
         MI_HIP(hipMemcpyAsync(k->shift_prep[c].get(sizeof(G2Prepared)), &v.shift_prep[c], sizeof(G2Prepared), hipMemcpyHostToDevice, st));
     MI_HIP(hipStreamSynchronize(st));  // sources are the master's members: alive, but later users run on other streams
@@ -361,10 +489,12 @@ int32_t vs_ctx_create(Context &cx, const mi_kzg_vk *vk, const mi_vs_key_ext *ext
         if (shape->n_bounds > MI_VS_MAX_BOUNDS || shape->hiding > 1 || (shape->query_of[0] & 1) || (shape->query_of[1] & 1)) return MI_ERR_BAD_ARGS;
         if (shape->lc_kind[0] || shape->lc_kind[1]) return MI_ERR_BAD_ARGS;  // the public-input identity reads p_0, p_1 as they are
         for (int p = 0; p < MI_VS_EVALS; p++)
-            if (shape->lc_kind[p] > 3) return MI_ERR_BAD_ARGS;
+            if (shape->lc_kind[p] > 7) return MI_ERR_BAD_ARGS;
         if ((shape->hiding || shape->n_bounds) && !ext) return MI_ERR_BAD_ARGS;
         if (shape->max_instances > MI_VS_MAX_INSTANCES) return MI_ERR_BAD_ARGS;
+        if (shape->max_circuits > MI_VS_MAX_CIRCUITS || (shape->max_circuits > 1 && shape->max_circuits > shape->max_instances)) return MI_ERR_BAD_ARGS;
     }
+    if ((flags & MI_VS_WIRE) && !shape) {}  // v1 records have a wire form too
     std::shared_ptr<VsCtx> v(new VsCtx());
     v->n_circuits = n_circuits;
     v->flags = flags;
@@ -389,6 +519,11 @@ int32_t vs_ctx_create(Context &cx, const mi_kzg_vk *vk, const mi_vs_key_ext *ext
     memcpy(hc.tag_elem.l, TAG, 32);
     hc.fs_kind = flags & MI_VS_FS_POSEIDON;
     memset(hc._pad, 0, sizeof hc._pad);
+    hc.max_circ = 1;
+    hc.need_inv = 0;
+    hc.wire = (flags & MI_VS_WIRE) ? 1 : 0;
+    hc.wire_bytes = 0;
+    memset(hc.lc_kind, 0, sizeof hc.lc_kind);
     hc.gamma_g = G1Affine::inf();
     // ---- the shape: v1 = the fixed query table, nothing hidden, nothing bounded, 2256-byte records, two randomizers
     hc.proof_words = sizeof(mi_vs_proof) / 4;
@@ -422,6 +557,14 @@ int32_t vs_ctx_create(Context &cx, const mi_kzg_vk *vk, const mi_vs_key_ext *ext
     hc.inst_slot = MI_VS_PROOF_COMMS + 2 + hc.n_bounded;
     hc.per_proof = hc.inst_slot + 2 * (hc.max_inst - 1);
     if (hc.max_inst > 1) hc.proof_words = sizeof(mi_vs_proof3) / 4;
+    hc.max_circ = shape && shape->max_circuits > 1 ? shape->max_circuits : 1;
+    if (hc.max_circ > 1) hc.proof_words = sizeof(mi_vs_proof4) / 4;
+    for (int p = 0; p < MI_VS_EVALS; p++)
+        if (hc.lc_kind[p] & 4) hc.need_inv = 1;
+    // the per-proof fallback sums a proof's chains in one workgroup of at most 128 lanes per proof (vs_sums_kernel)
+    if (vs_chains_of(hc.per_proof, hc.hiding, hc.n_bounded, hc.max_circ) > 128) return MI_ERR_BAD_ARGS;
+    vs_build_wire_map(v->wire_map, hc, shape != nullptr);
+    hc.wire_bytes = v->wire_map.wire_bytes;
     {
         std::lock_guard<std::mutex> lk(g_vs_mu);
         v->id = g_vs_next++;
@@ -488,6 +631,46 @@ __device__ __attribute__((noinline)) bool vs_point_ok(const uint32_t *__restrict
     return sqrq(y) == add(mulq(sqrq(x), x), Fq::one());
 }
 
+// The instance / circuit structure a record announces: m1 further instances, d1 further circuits (ids into pcirc), or --
+// when a count or an id is out of range -- an invalid proof that keeps its first instance and circuit only (the oracle's
+// vs3_record).  pw: the record's words; parts sit 4 words behind the n_circuits header, 100 words each.
+#define VS_PART_WORDS (sizeof(mi_vs_circuit_part) / 4)
+__device__ __forceinline__ bool vs_record_counts(const uint32_t *__restrict__ pw, const VsConsts *__restrict__ kc, size_t n_circuits,
+                                                 uint32_t &m1, uint32_t &d1, uint32_t pcirc[MI_VS_MAX_CIRCUITS - 1]) {
+    const uint32_t MI = kc->max_inst, MC = kc->max_circ;
+    m1 = d1 = 0;
+#pragma unroll
+    for (int d = 0; d < MI_VS_MAX_CIRCUITS - 1; d++) pcirc[d] = 0xffffffffu;
+    bool count_ok = true;
+    uint32_t ni = 1;
+    if (MI > 1) {
+        ni = pw[sizeof(mi_vs_proof2) / 4];
+        count_ok = ni >= 1 && ni <= MI;
+    }
+    if (MC > 1) {
+        const uint32_t nc = pw[sizeof(mi_vs_proof3) / 4];
+        const uint32_t *parts = pw + sizeof(mi_vs_proof3) / 4 + 4;
+        bool ok = count_ok && nc >= 1 && nc <= MC && nc <= ni && pw[0] < n_circuits;
+        uint32_t c_prev = pw[0], f_prev = 0;
+        for (uint32_t d = 0; d + 1 < MC; d++)
+            if (ok && d + 1 < nc) {
+                const uint32_t c = parts[VS_PART_WORDS * d], f = parts[VS_PART_WORDS * d + 1];
+                ok = c > c_prev && c < n_circuits && f > f_prev && f < ni;
+                c_prev = c;
+                f_prev = f;
+                pcirc[d] = c;
+            }
+        count_ok = ok;
+        d1 = ok ? nc - 1 : 0;
+        if (!ok) {
+#pragma unroll
+            for (int d = 0; d < MI_VS_MAX_CIRCUITS - 1; d++) pcirc[d] = 0xffffffffu;
+        }
+    }
+    if (count_ok) m1 = ni - 1;
+    return count_ok;
+}
+
 // FS = 0: the SHA-256 transcript is walked here; FS = 1: the challenges come from `chal` (n x 3 x 128 bits: z_beta,
 // z_gamma, xi), written by vs_fs_poseidon_kernel
 template <int FS>
@@ -497,6 +680,7 @@ __global__ void __launch_bounds__(128) vs_derive_kernel(const void *__restrict__
                                                         const VsConsts *__restrict__ kc, VsOut o, const uint32_t *__restrict__ chal,
                                                         VsMore more) {
     __shared__ uint32_t zb_lds[64][4];
+    __shared__ uint32_t inv_ok_lds[64];
     const int lane = threadIdx.x & 63, role = threadIdx.x >> 6;  // role 0: transcript + scalars, role 1: points + check
     uint32_t block = blockIdx.x;
     const int mb = more.of_block(block);
@@ -510,6 +694,7 @@ __global__ void __launch_bounds__(128) vs_derive_kernel(const void *__restrict__
     }
     const size_t i = (size_t)block * 64 + lane;
     const bool live = i < n;
+    const uint8_t *const dec_ok = o.dec_ok;  // wire records: the decode kernels' per-proof flags (nullptr otherwise)
     const uint32_t PW = kc->proof_words, PP = kc->per_proof, RB = kc->rand_bytes, NB = kc->n_bounds;
     const bool v2 = PW != sizeof(mi_vs_proof) / 4;
     const uint32_t *pw = reinterpret_cast<const uint32_t *>(proofs) + (live ? i : 0) * (size_t)PW;
@@ -527,15 +712,13 @@ __global__ void __launch_bounds__(128) vs_derive_kernel(const void *__restrict__
     const uint32_t *evals = comms + 216;             // 21 x 8 words
     // records with instances (mi_vs_proof3): the count, then MI_VS_EXTRA_INSTANCES x {16 inputs, 2 commitments, 2
     // evaluations} = 192 words each.  A count out of range fails the proof and leaves only its first instance.
-    const uint32_t MI = kc->max_inst, ISLOT = kc->inst_slot;
+    // records of several circuits (mi_vs_proof4): the count, then MI_VS_MAX_CIRCUITS - 1 parts {id, first instance, pad,
+    // 12 evaluations} = 100 words each
+    const uint32_t MI = kc->max_inst, ISLOT = kc->inst_slot, MC = kc->max_circ;
     const uint32_t *xinst = pw + sizeof(mi_vs_proof2) / 4 + 4;
-    uint32_t m1 = 0;
-    bool count_ok = true;
-    if (MI > 1) {
-        const uint32_t ni = pw[sizeof(mi_vs_proof2) / 4];
-        count_ok = ni >= 1 && ni <= MI;
-        m1 = count_ok ? ni - 1 : 0;
-    }
+    const uint32_t *parts = pw + sizeof(mi_vs_proof3) / 4 + 4;
+    uint32_t m1, d1, pcirc[MI_VS_MAX_CIRCUITS - 1];
+    const bool count_ok = vs_record_counts(pw, kc, n_circuits, m1, d1, pcirc);
     uint32_t h[8], zw[2][4], xw[4];
     bool well_formed = true;
     if (role == 0) {
@@ -544,6 +727,8 @@ __global__ void __launch_bounds__(128) vs_derive_kernel(const void *__restrict__
 #pragma unroll
             for (int k = 0; k < 8; k++) tag[k] = kc->tag[k];
             sha256_prefixed(h, tag, digest, 8, inputs, 128 + 48);
+            for (uint32_t d = 0; d < d1; d++)  // every further circuit: its header (id, first instance) and digest
+                sha256_prefixed(h, h, parts + VS_PART_WORDS * d, 4, reinterpret_cast<const uint32_t *>(circuits[pcirc[d]].digest), 8);
             for (uint32_t j = 0; j < m1; j++) sha256_prefixed(h, h, xinst + 192 * j, 176, nullptr, 0);  // inputs, A_j, B_j
             sha256_prefixed(h, h, comms + 48, 72, nullptr, 0);
 #pragma unroll
@@ -568,13 +753,17 @@ __global__ void __launch_bounds__(128) vs_derive_kernel(const void *__restrict__
             for (int k = 0; k < MI_VS_INPUTS; k++) well_formed = well_formed && vs_limbs_below(x + 8 * k, FrP::MOD, 8);
             for (int c = 0; c < 2; c++) well_formed = well_formed && vs_point_ok(x + 128 + 24 * c) && vs_limbs_below(x + 176 + 8 * c, FrP::MOD, 8);
         }
+        for (uint32_t d = 0; d < d1; d++)
+            for (int k = 0; k < MI_VS_VK_COMMS; k++) well_formed = well_formed && vs_limbs_below(parts + VS_PART_WORDS * d + 4 + 8 * k, FrP::MOD, 8);
+        if (dec_ok) well_formed = well_formed && dec_ok[i] != 0;
         for (uint32_t j = 0; j + 1 < MI; j++)  // the further instances' commitments: their H-side slots (infinity when absent)
             for (uint32_t c = 0; c < 2; c++) {
                 G1Affine pt = G1Affine::inf();
                 if (j < m1) copy_g1(&pt, reinterpret_cast<const G1Affine *>(xinst + 192 * j + 128 + 24 * c));
                 copy_g1(pts1 + i * PP + ISLOT + 2 * j + c, &pt);
             }
-        circuit_of[i] = circuit;
+        circuit_of[i * MC] = circuit;
+        for (uint32_t d = 0; d + 1 < MC; d++) circuit_of[i * MC + 1 + d] = pcirc[d];  // 0xffffffff: no such circuit in this proof
         // ---- points into MSM order, randomizers as the tau-H side's scalars
         const G1Affine *pc = reinterpret_cast<const G1Affine *>(comms);
         for (int k = 0; k < MI_VS_PROOF_COMMS; k++) copy_g1(pts1 + i * PP + k, pc + k);
@@ -602,14 +791,15 @@ __global__ void __launch_bounds__(128) vs_derive_kernel(const void *__restrict__
         for (int k = 0; k < 4; k++) { os[k] = rw[k]; os[4 + k] = 0; os[8 + k] = rw[4 + k]; os[12 + k] = 0; }
     }
     __syncthreads();
-    if (!live) return;
-    if (role == 0) {
+    bool ok = false;  // role 1: the proof's algebraic verdict
+    if (role == 0 && live) {
         if (FS == 0) {
             sha256_prefixed(h, h, comms + 120, 96, nullptr, 0);
 #pragma unroll
             for (int k = 0; k < 4; k++) zw[1][k] = __builtin_bswap32(h[k]);
             sha256_prefixed(h, h, evals, 168, nullptr, 0);
             for (uint32_t j = 0; j < m1; j++) sha256_prefixed(h, h, xinst + 192 * j + 176, 16, nullptr, 0);  // a_j, b_j
+            for (uint32_t d = 0; d < d1; d++) sha256_prefixed(h, h, parts + VS_PART_WORDS * d + 4, 96, nullptr, 0);  // its 12 evaluations
 #pragma unroll
             for (int k = 0; k < 4; k++) xw[k] = __builtin_bswap32(h[k]);
         } else {
@@ -635,14 +825,28 @@ __global__ void __launch_bounds__(128) vs_derive_kernel(const void *__restrict__
         kap1 = sub(kap1, Fr::one());
         kap2 = sub(kap2, Fr::one());
         const Fr kap3 = mul(kap1, kap2);
+        // VarunaShaped-v3, kinds with bit 2: times 1 / (z_beta - z_gamma).  Every lane of the wave inverts its own
+        // difference in lockstep (Pornin's binary GCD, branch-free): 64 inversions for the time of one; a Montgomery
+        // batch across the pass's waves would add a launch and a grid-wide chain to save 0.1 % of the pass's work.
+        Fr kinv = Fr::one();
+        if (kc->need_inv) {  // uniform
+            const Fr dz = sub(z[0], z[1]);
+            inv_ok_lds[lane] = dz.is_zero() ? 0u : 1u;  // z_beta == z_gamma: the coefficient does not exist, the proof is invalid
+            kinv = invr(dz);
+        }
+        auto lc_coef = [&](const Fr &power, uint32_t kind) {
+            Fr coef = power;
+            const uint32_t k3 = kind & 3u;
+            if (k3) coef = mul(power, k3 == 1 ? kap1 : (k3 == 2 ? kap2 : kap3));
+            if (kind & 4u) coef = mul(coef, kinv);
+            return coef;
+        };
         for (int k = 0; k < MI_VS_EVALS; k++) {
             const int q = kc->query_of[k] & 1;
-            const uint32_t kind = kc->lc_kind[k] & 3u;  // uniform
-            Fr coef = xip;
-            if (kind) coef = mul(xip, kind == 1 ? kap1 : (kind == 2 ? kap2 : kap3));
+            const Fr coef = lc_coef(xip, kc->lc_kind[k] & 7u);  // uniform kind
             Fr s = mul(q ? r[1] : r[0], coef);
             if (k < MI_VS_PROOF_COMMS) fr_store(sc1 + (i * PP + k) * 8, from_mont(s));
-            else fr_store(vk_scal + i * MI_VS_VK_COMMS + (k - MI_VS_PROOF_COMMS), s);
+            else fr_store(vk_scal + (i * MC) * MI_VS_VK_COMMS + (k - MI_VS_PROOF_COMMS), s);
             const Fr tv = mul(coef, fr_load(evals + 8 * k));
             if (q) val[1] = add(val[1], tv);
             else val[0] = add(val[0], tv);
@@ -678,6 +882,24 @@ __global__ void __launch_bounds__(128) vs_derive_kernel(const void *__restrict__
                     fr_store(sc1 + (i * PP + ISLOT + 2 * j + c) * 8, from_mont(s));
                 }
         }
+        if (MC > 1) {  // the further circuits' polynomials: xi^(36 + 12 d + k), the first circuit's query and lc tables
+            for (uint32_t j = 0; j < MI_VS_EXTRA_INSTANCES; j++)
+                if (j >= m1) xip = mul(mul(xip, xi), xi);  // past the absent instances' powers: xi^36
+            for (uint32_t d = 0; d + 1 < MC; d++)
+                for (int k = 0; k < MI_VS_VK_COMMS; k++) {
+                    const int pp = MI_VS_PROOF_COMMS + k, q = kc->query_of[pp] & 1;
+                    Fr s = Fr::zero();
+                    if (d < d1) {
+                        const Fr coef = lc_coef(xip, kc->lc_kind[pp] & 7u);
+                        s = mul(q ? r[1] : r[0], coef);
+                        const Fr tv = mul(coef, fr_load(parts + VS_PART_WORDS * d + 4 + 8 * k));
+                        if (q) val[1] = add(val[1], tv);
+                        else val[0] = add(val[0], tv);
+                        xip = mul(xip, xi);
+                    }
+                    fr_store(vk_scal + (i * MC + 1 + d) * MI_VS_VK_COMMS + k, s);
+                }
+        }
         Fr gs = Fr::zero(), hs = Fr::zero();
 #pragma unroll
         for (int q = 0; q < 2; q++) {
@@ -687,8 +909,8 @@ __global__ void __launch_bounds__(128) vs_derive_kernel(const void *__restrict__
         }
         fr_store(g_scal + i, gs);
         if (kc->hiding) fr_store(o.h_scal + i, hs);
-        return;
     }
+    if (role == 1 && live) {
     // ---- role 1: public-input consistency, inversion-free.  With d_k = z - w^k and prod_k d_k = z^16 - 1:
     //   v_0 = x_hat(z) + (z^16-1) v_1,  x_hat(z) = (z^16-1)/16 * sum_k in_k w^k / d_k
     //   <=>  16 (v_0 - (z^16-1) v_1) = sum_k in_k w^k prod_{j != k} d_j          (for z^16 != 1)
@@ -707,7 +929,7 @@ __global__ void __launch_bounds__(128) vs_derive_kernel(const void *__restrict__
 #pragma unroll
     for (int k = 0; k < 4; k++) zn = sqr(zn);
     Fr znm1 = sub(zn, Fr::one());
-    bool ok = !znm1.is_zero() && !bad_circuit && well_formed && count_ok;  // z^16 = 1 rejects, as in the oracle
+    ok = !znm1.is_zero() && !bad_circuit && well_formed && count_ok;  // z^16 = 1 rejects, as in the oracle
     Fr pre[MI_VS_INPUTS], acc = Fr::one();
     for (int k = 0; k < MI_VS_INPUTS; k++) {  // pre[k] = prod_{j < k} d_j
         pre[k] = acc;
@@ -727,7 +949,12 @@ __global__ void __launch_bounds__(128) vs_derive_kernel(const void *__restrict__
         for (int k = 0; k < 4; k++) lhs = dbl(lhs);  // * 16
         ok = ok && (lhs == rhs);
     }
-    alg_ok[i] = ok ? 1 : 0;
+    }
+    if (kc->need_inv) {  // uniform: the scalar wave's "z_beta != z_gamma" reaches the checking wave
+        __syncthreads();
+        if (role == 1 && live) ok = ok && inv_ok_lds[lane] != 0;
+    }
+    if (role == 1 && live) alg_ok[i] = ok ? 1 : 0;
 }
 
 // ---------------------------------------------------------------- Poseidon Fiat-Shamir transcript (row A9 on the path)
@@ -753,12 +980,31 @@ __device__ __forceinline__ Fq28 f28_sel(bool c, const Fq28 &a, const Fq28 &b) {
 // element e of the transcript of a proof with m1 further instances (73 + 38 m1 elements; oracle: fs_element): a run
 // of 16 / 32 / 48 bytes of the record taken as Montgomery limbs (zero-extended).  xinst: the further instances (192
 // words each: 16 inputs, two commitments, two evaluations); they sit after C_1 (36 elements each) and at the end (2).
+// VarunaShaped-v3: d1 further circuits put {header, digest} after the first circuit's digest (2 elements each) and
+// their 12 evaluations at the very end; parts: 100 words each, pcirc: their ids.
 __device__ __forceinline__ Fq vs_fs_element(const mi_vs_proof *__restrict__ p, const uint32_t *__restrict__ digest,
-                                            const VsConsts *__restrict__ kc, const uint32_t *__restrict__ xinst, int m1, int e) {
+                                            const VsConsts *__restrict__ kc, const uint32_t *__restrict__ xinst, int m1, int e,
+                                            int d1, const uint32_t *__restrict__ parts, const uint32_t *pcirc,
+                                            const mi_vs_circuit_vk *__restrict__ circuits) {
     const uint32_t *pw = reinterpret_cast<const uint32_t *>(p);
-    const uint32_t *src;
-    int words;
-    if (e == 0) { src = kc->tag_elem.l; words = 8; }
+    const uint32_t *src = kc->tag_elem.l;
+    int words = 8;
+    if (e >= 2 && e < 2 + 2 * d1) {
+        const int d = (e - 2) >> 1;
+        if ((e - 2) & 1) { src = reinterpret_cast<const uint32_t *>(circuits[pcirc[d]].digest); words = 8; }
+        else { src = parts + VS_PART_WORDS * d; words = 4; }
+        e = -1;
+    } else if (e >= 2 + 2 * d1) {
+        e -= 2 * d1;
+        if (e >= 73 + 38 * m1) {  // the further circuits' evaluations
+            const int f = e - 73 - 38 * m1;
+            src = parts + VS_PART_WORDS * (f / MI_VS_VK_COMMS) + 4 + 8 * (f % MI_VS_VK_COMMS);
+            words = 8;
+            e = -1;
+        }
+    }
+    if (e < 0) {}
+    else if (e == 0) { src = kc->tag_elem.l; words = 8; }
     else if (e == 1) { src = digest; words = 8; }
     else if (e < 34) { src = pw + 4 + 4 * (e - 2); words = 4; }      // halves of the 16 inputs
     else if (e < 38) { src = pw + 132 + 12 * (e - 34); words = 12; }  // coordinates of C_0, C_1
@@ -831,22 +1077,23 @@ __global__ void __launch_bounds__(4 * VS_FS_PROOFS_PER_BLOCK) vs_fs_poseidon_ker
     }
     // further instances (mi_vs_proof3): every proof absorbs 38 more elements per instance; the block walks the shape's
     // maximum number of permutations (the barriers are block-wide), a proof stops absorbing and squeezing at its own end
-    const uint32_t MI = kc->max_inst;
+    // (several circuits, mi_vs_proof4: 14 more per further circuit)
+    const uint32_t MI = kc->max_inst, MC = kc->max_circ;
     const uint32_t *xinst = reinterpret_cast<const uint32_t *>(p) + sizeof(mi_vs_proof2) / 4 + 4;
-    int m1 = 0;
-    if (MI > 1) {
-        const uint32_t ni = reinterpret_cast<const uint32_t *>(p)[sizeof(mi_vs_proof2) / 4];
-        m1 = (ni >= 1 && ni <= MI) ? (int)ni - 1 : 0;
-    }
-    const int n_el = VS_FS_ELEMS + 38 * m1, my_blocks = VS_FS_BLOCKS + 19 * m1, all_blocks = VS_FS_BLOCKS + 19 * ((int)MI - 1);
-    const int b_beta = 21 + 18 * m1, b_gamma = 25 + 18 * m1;
+    const uint32_t *parts = reinterpret_cast<const uint32_t *>(p) + sizeof(mi_vs_proof3) / 4 + 4;
+    uint32_t um1, ud1, pcirc[MI_VS_MAX_CIRCUITS - 1];
+    (void)vs_record_counts(reinterpret_cast<const uint32_t *>(p), kc, n_circuits, um1, ud1, pcirc);
+    const int m1 = (int)um1, d1 = (int)ud1;
+    const int n_el = VS_FS_ELEMS + 38 * m1 + 14 * d1, my_blocks = VS_FS_BLOCKS + 19 * m1 + 7 * d1,
+              all_blocks = VS_FS_BLOCKS + 19 * ((int)MI - 1) + 7 * ((int)MC - 1);
+    const int b_beta = 21 + 18 * m1 + d1, b_gamma = 25 + 18 * m1 + d1;
     Fq28 s;
 #pragma unroll
     for (int k = 0; k < 14; k++) s.l[k] = 0;
     for (int b = 0; b < all_blocks; b++) {
         // ---- absorb: lane 1 takes element 2b, lane 2 element 2b + 1 (the last block holds one)
         const int e = 2 * b + (l == 2 ? 1 : 0);
-        if ((l == 1 || l == 2) && e < n_el) s = add28(s, load28(vs_fs_element(p, digest, kc, xinst, m1, e)));
+        if ((l == 1 || l == 2) && e < n_el) s = add28(s, load28(vs_fs_element(p, digest, kc, xinst, m1, e, d1, parts, pcirc, circuits)));
         // ---- permutation
         for (int r = 0; r < MI_POSEIDON_ROUNDS; r++) {
             s = normalise28(add28(s, load28(pc->ark[r][lc])));
@@ -915,8 +1162,9 @@ __global__ void __launch_bounds__(256) vs_merge_kernel(const Fr *__restrict__ vk
     Fr acc = Fr::zero();
     if (slot < n_vk_slots) {
         const uint32_t c = (uint32_t)(slot / MI_VS_VK_COMMS), k = (uint32_t)(slot % MI_VS_VK_COMMS);
-        for (size_t i = t; i < n; i += 256)
-            if (circuit_of[i] == c) acc = add(acc, fr_load(vk_scal + i * MI_VS_VK_COMMS + k));
+        const size_t MC = kc->max_circ;  // a proof's scalars for circuit c sit in the slot of whichever of its circuits that is
+        for (size_t e = t; e < n * MC; e += 256)
+            if (circuit_of[e] == c) acc = add(acc, fr_load(vk_scal + e * MI_VS_VK_COMMS + k));
     } else {
         const Fr *src = slot == n_vk_slots ? g_scal : h_scal;
         for (size_t i = t; i < n; i += 256) acc = add(acc, fr_load(src + i));
@@ -955,8 +1203,8 @@ __global__ void __launch_bounds__(256) vs_merge_kernel(const Fr *__restrict__ vk
 //                         exit at once).
 // Terms of a proof, in order (PP = per_proof, H = hiding):
 //   [0, PP)            its own H-side points (commitments, witnesses times z, shifted commitments) with sc1
-//   [PP, PP + 12)      the circuit's commitments with vk_scal
-//   PP + 12            G with g_scal;   PP + 13 (if H): gamma_g with h_scal
+//   [PP, PP + 12 MC)   the commitments of the proof's circuits (MC = the shape's max_circuits; unused slots: infinity) with vk_scal
+//   PP + 12 MC         G with g_scal;   the next (if H): gamma_g with h_scal
 //   next 2             W_q with r_q (the tau-H side, 128-bit scalars: one chain each)
 //   then               the class accumulators' C_j with rho_j, class 0 first
 // and its chains: 2 per term (s1 P, s2 phi(P)) except the two 128-bit ones.
@@ -968,17 +1216,11 @@ struct VsTermsIn {
     const Fr *vk_scal, *g_scal, *h_scal;
     const uint32_t *circuit_of;
 };
-__host__ __device__ __forceinline__ uint32_t vs_terms_of(uint32_t per_proof, uint32_t hiding, uint32_t n_bounded) {
-    return per_proof + MI_VS_VK_COMMS + 1 + hiding + 2 + n_bounded;
-}
-__host__ __device__ __forceinline__ uint32_t vs_chains_of(uint32_t per_proof, uint32_t hiding, uint32_t n_bounded) {
-    return 2 * vs_terms_of(per_proof, hiding, n_bounded) - 2;
-}
 __global__ void __launch_bounds__(256) vs_terms_kernel(size_t n, VsTermsIn in, const mi_vs_circuit_vk *__restrict__ circuits,
                                                       const VsConsts *__restrict__ kc, G1Affine *__restrict__ tables,
                                                       G1Xyzz *__restrict__ terms) {
-    const uint32_t PP = kc->per_proof, H = kc->hiding, CH = vs_chains_of(PP, H, kc->n_bounded);
-    const uint32_t n_c = PP + MI_VS_VK_COMMS + 1 + H;
+    const uint32_t PP = kc->per_proof, H = kc->hiding, MC = kc->max_circ, CH = vs_chains_of(PP, H, kc->n_bounded, MC);
+    const uint32_t NVK = MI_VS_VK_COMMS * MC, n_c = PP + NVK + 1 + H;
     size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= n * CH) return;
     const size_t i = t / CH;
@@ -992,14 +1234,18 @@ __global__ void __launch_bounds__(256) vs_terms_kernel(size_t n, VsTermsIn in, c
     if (k < PP) {
         copy_g1(&P, in.pts1 + i * PP + k);
         v = fr_load(in.sc1 + (i * PP + k) * 8);
-    } else if (k < PP + MI_VS_VK_COMMS) {
-        const uint32_t kk = k - PP;
-        copy_g1(&P, reinterpret_cast<const G1Affine *>(circuits[in.circuit_of[i]].comms) + kk);
-        v = from_mont(fr_load(in.vk_scal + i * MI_VS_VK_COMMS + kk));
-    } else if (k == PP + MI_VS_VK_COMMS) {
+    } else if (k < PP + NVK) {
+        const uint32_t kk = k - PP, circ = in.circuit_of[i * MC + kk / MI_VS_VK_COMMS];
+        P = G1Affine::inf();  // a circuit slot the proof does not use (0xffffffff)
+        v = Fr::zero();
+        if (circ != 0xffffffffu) {
+            copy_g1(&P, reinterpret_cast<const G1Affine *>(circuits[circ].comms) + kk % MI_VS_VK_COMMS);
+            v = from_mont(fr_load(in.vk_scal + i * NVK + kk));
+        }
+    } else if (k == PP + NVK) {
         copy_g1(&P, &kc->g);
         v = from_mont(fr_load(in.g_scal + i));
-    } else if (H && k == PP + MI_VS_VK_COMMS + 1) {
+    } else if (H && k == PP + NVK + 1) {
         copy_g1(&P, &kc->gamma_g);
         v = from_mont(fr_load(in.h_scal + i));
     } else if (k < n_c + 2) {
@@ -1049,8 +1295,8 @@ __global__ void __launch_bounds__(VS_GROUP * LP) vs_sums_kernel(size_t n, const 
     uint32_t *shf = reinterpret_cast<uint32_t *>(sh + VS_GROUP * LP);
     const uint32_t pl = threadIdx.x / LP, l = threadIdx.x % LP;
     const size_t first = (size_t)blockIdx.x * VS_GROUP, i = first + pl;
-    const uint32_t PP = kc->per_proof, H = kc->hiding, CH = vs_chains_of(PP, H, kc->n_bounded);
-    const uint32_t n_c = PP + MI_VS_VK_COMMS + 1 + H;
+    const uint32_t PP = kc->per_proof, H = kc->hiding, CH = vs_chains_of(PP, H, kc->n_bounded, kc->max_circ);
+    const uint32_t n_c = PP + MI_VS_VK_COMMS * kc->max_circ + 1 + H;
     const uint32_t lo1 = 2 * n_c, lo2 = lo1 + 2, lo3 = lo2 + 2 * kc->class_count[0];
     uint32_t seg, lo, hi;
     if (l < lo1) { seg = 0; lo = 0; hi = lo1; }
@@ -1177,6 +1423,87 @@ __global__ void __launch_bounds__(PW_THREADS) vs_proof_check_kernel(const G1Affi
     }
 }
 
+// ---------------------------------------------------------------- wire records -> records (MI_VS_WIRE)
+// The batches of a pass, as the decode kernels see them: batch k's wire records, where its decoded records and flags
+// go, and the index of its first proof among all proofs of the pass.
+struct VsWireJobs {
+    int count = 0;
+    struct B { const uint8_t *wire; uint8_t *rec; uint8_t *dec_ok; uint32_t n, first; } b[MI_VS_MAX_BATCHES_PER_PASS];
+    __device__ __forceinline__ int of(uint32_t g) const {
+        int k = 0;
+        for (int j = 1; j < count; j++)
+            if (g >= b[j].first) k = j;
+        return k;
+    }
+};
+__device__ __forceinline__ void vs_wire_counts(const uint8_t *__restrict__ w, const VsWireMap *__restrict__ wm, uint32_t &m1, uint32_t &d1) {
+    m1 = d1 = 0;
+    if (wm->off_ni) {
+        const uint32_t ni = *reinterpret_cast<const uint32_t *>(w + wm->off_ni);
+        if (ni >= 1 && ni <= wm->max_inst) m1 = ni - 1;
+    }
+    if (wm->off_nc) {
+        const uint32_t nc = *reinterpret_cast<const uint32_t *>(w + wm->off_nc);
+        if (nc >= 1 && nc <= wm->max_circ) d1 = nc - 1;
+    }
+}
+__device__ __forceinline__ bool vs_wire_used(uint32_t cls, uint32_t m1, uint32_t d1) {
+    return cls == 0 || (cls >= 8 ? cls - 8 < d1 : cls - 2 < m1);
+}
+// a lane per proof: headers as they are, Fr fields canonical -> Montgomery (not below r: the proof's flag is cleared and
+// the field stays zero).  The decoded records were zeroed beforehand: unused slots are not written.
+__global__ void __launch_bounds__(64) vs_wire_fields_kernel(VsWireJobs jobs, uint32_t n_all, const VsWireMap *__restrict__ wm) {
+    const uint32_t g = blockIdx.x * 64 + threadIdx.x;
+    if (g >= n_all) return;
+    const VsWireJobs::B &jb = jobs.b[jobs.of(g)];
+    const uint32_t i = g - jb.first;
+    const uint8_t *w = jb.wire + (size_t)i * wm->wire_bytes;
+    uint8_t *r = jb.rec + (size_t)i * wm->rec_bytes;
+    uint32_t m1, d1;
+    vs_wire_counts(w, wm, m1, d1);
+    bool ok = true;
+    for (uint32_t k = 0; k < wm->n_runs; k++) {
+        const VsWireMap::Run run = wm->run[k];
+        if (!vs_wire_used(run.cls, m1, d1)) continue;
+        if (run.type == 0) {
+            for (uint32_t b = 0; b < run.count; b += 16)
+                *reinterpret_cast<uint4 *>(r + run.rec + b) = *reinterpret_cast<const uint4 *>(w + run.wire + b);
+        } else {
+            for (uint32_t j = 0; j < run.count; j++) {
+                const Fr c = fr_load(w + run.wire + 32 * j);
+                if (vs_limbs_below(c.l, FrP::MOD, 8)) fr_store(r + run.rec + 32 * j, to_mont(c));
+                else ok = false;
+            }
+        }
+    }
+    jb.dec_ok[i] = ok ? 1 : 0;
+}
+// a lane per (proof, point slot of the shape): 48 bytes -> the affine point (square root, sign, exact subgroup test:
+// codec.hpp); anything that is not the encoding of a subgroup point clears the proof's flag and leaves infinity
+__global__ void __launch_bounds__(64) vs_wire_points_kernel(VsWireJobs jobs, uint32_t n_all, const VsWireMap *__restrict__ wm) {
+    const uint32_t g = blockIdx.x * 64 + threadIdx.x, NP = wm->n_pts;
+    if (g >= n_all * NP) return;
+    const uint32_t gp = g / NP, slot = g - gp * NP;
+    const VsWireJobs::B &jb = jobs.b[jobs.of(gp)];
+    const uint32_t i = gp - jb.first;
+    const uint8_t *w = jb.wire + (size_t)i * wm->wire_bytes;
+    uint32_t m1, d1;
+    vs_wire_counts(w, wm, m1, d1);
+    if (!vs_wire_used(wm->pt_cls[slot], m1, d1)) return;
+    uint8_t b[48];
+    const uint4 *src = reinterpret_cast<const uint4 *>(w + wm->pt_wire[slot]);  // record strides and offsets are multiples of 16
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        const uint4 v = src[k];
+        const uint32_t ww[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int j = 0; j < 16; j++) b[16 * k + j] = (uint8_t)(ww[j >> 2] >> (8 * (j & 3)));
+    }
+    G1Affine pt;
+    if (g1_decompress_one(b, true, pt)) copy_g1(reinterpret_cast<G1Affine *>(jb.rec + (size_t)i * wm->rec_bytes + wm->pt_rec[slot]), &pt);
+    else jb.dec_ok[i] = 0;  // only ever cleared here; the fields kernel (earlier on the stream) set it
+}
+
 // ---------------------------------------------------------------- host drivers
 struct VsWork {
     VsOut o;
@@ -1217,7 +1544,7 @@ static int vs_max_per_pass(const VsKeys &v, size_t n) {
 
 // derive (+ merge) of the pass's batches, one launch each for all of them: the further batches' operands follow the
 // first's in the lane's operand arrays, so all their MSMs are one launch sequence.  ws[k] describes batch k.
-static void vs_run_derive(Context &cx, VsKeys &v, const void *const *d_proofs, const size_t *ns, const void *const *d_rand, int count,
+static void vs_run_derive(Context &cx, VsKeys &v, const void *const *d_proofs_in, const size_t *ns, const void *const *d_rand, int count,
                           hipStream_t st, int lane, VsWork *ws) {
     const VsConsts &hc = v.shape;
     // every operand array exists once per lane: several passes are in flight on different streams
@@ -1253,15 +1580,41 @@ static void vs_run_derive(Context &cx, VsKeys &v, const void *const *d_proofs, c
         at += vs_work_total(x);
         char nn[24];
         snprintf(nn, sizeof nn, "vk_scal%s", suffix[k]);
-        o.vk_scal = (Fr *)cx.buf(W(nn), sizeof(Fr) * cap * MI_VS_VK_COMMS);
+        o.vk_scal = (Fr *)cx.buf(W(nn), sizeof(Fr) * cap * MI_VS_VK_COMMS * hc.max_circ);
         snprintf(nn, sizeof nn, "g_scal%s", suffix[k]);
         o.g_scal = (Fr *)cx.buf(W(nn), sizeof(Fr) * 2 * cap);
         o.h_scal = o.g_scal + cap;
         snprintf(nn, sizeof nn, "alg_ok%s", suffix[k]);
         o.alg_ok = (uint8_t *)cx.buf(W(nn), cap);
         snprintf(nn, sizeof nn, "circuit_of%s", suffix[k]);
-        o.circuit_of = (uint32_t *)cx.buf(W(nn), 4 * cap);
+        o.circuit_of = (uint32_t *)cx.buf(W(nn), 4 * cap * hc.max_circ);
+        o.dec_ok = nullptr;
     }
+    // wire records: decoded into the lane's record buffer ahead of everything else (one launch each for all batches)
+    const void *recs[MI_VS_MAX_BATCHES_PER_PASS];
+    for (int k = 0; k < count; k++) recs[k] = d_proofs_in[k];
+    if (hc.wire) {
+        const VsWireMap &wm = v.wm;
+        uint8_t *exp = (uint8_t *)cx.buf(W("records"), (size_t)wm.rec_bytes * n_all);
+        uint8_t *dok = (uint8_t *)cx.buf(W("dec_ok"), n_all);
+        VsWireJobs jobs;
+        jobs.count = count;
+        size_t first = 0;
+        for (int k = 0; k < count; k++) {
+            jobs.b[k] = VsWireJobs::B{(const uint8_t *)d_proofs_in[k], exp + first * wm.rec_bytes, dok + first, (uint32_t)ns[k], (uint32_t)first};
+            recs[k] = jobs.b[k].rec;
+            ws[k].o.dec_ok = jobs.b[k].dec_ok;
+            first += ns[k];
+        }
+        cx.prof.begin("vs_wire_decode", st, n_all);
+        MI_HIP(hipMemsetAsync(exp, 0, (size_t)wm.rec_bytes * n_all, st));
+        hipLaunchKernelGGL(vs_wire_fields_kernel, dim3((unsigned)cdiv(n_all, 64)), dim3(64), 0, st, jobs, (uint32_t)n_all, (const VsWireMap *)v.wire_map.p);
+        hipLaunchKernelGGL(vs_wire_points_kernel, dim3((unsigned)cdiv(n_all * wm.n_pts, 64)), dim3(64), 0, st, jobs, (uint32_t)n_all,
+                           (const VsWireMap *)v.wire_map.p);
+        cx.prof.end("vs_wire_decode", st);
+        stats().points_decompressed += n_all * wm.n_pts;
+    }
+    const void *const *d_proofs = recs;
     VsOut &o = ws[0].o;
     VsMore more;
     more.count = count - 1;
@@ -1648,6 +2001,8 @@ int32_t vs_finalize(Context &cx, uint64_t id, const mi_vs_partial *parts, size_t
     const int K = vs_g2_keys(v, qs);
     Fq12 f;
     pairing_product_prepared(cx, ps, qs, K, &f, st);
+    stats().pairing_products++;
+    stats().pairing_pairs += (uint64_t)K;
     *all_ok = (f.is_one() && fails == 0) ? 1 : 0;
     return MI_OK;
 }
@@ -1690,6 +2045,8 @@ int32_t vs_finalize_async_multi(Context &cx, uint64_t id, const mi_vs_partial *p
     const G2Prepared *qs[MI_MAX_PAIRS];
     const int K = vs_g2_keys(v, qs);
     pairing_launch_multi(cx, ps, qs, K, count, sl.h_out, sl.stream, slot);  // the kernels store their results in pinned host memory
+    stats().pairing_products += (uint64_t)count;
+    stats().pairing_pairs += (uint64_t)count * (uint64_t)K;
     MI_HIP(hipEventRecord(sl.done, sl.stream));
     sl.ticket = tk;
     sl.busy = true;
@@ -1716,7 +2073,7 @@ int32_t vs_finalize_wait(Context &cx, uint64_t id, uint64_t ticket, uint8_t *all
 // on the lane's stream and workspaces (the lane is still held by the caller); one wait at the end
 static void vs_identify(Context &cx, VsKeys &v, const VsWork &w, size_t n, int lane, hipStream_t st, uint8_t *verdicts) {
     char nm[32];
-    const uint32_t CH = vs_chains_of(v.shape.per_proof, v.shape.hiding, v.shape.n_bounded);
+    const uint32_t CH = vs_chains_of(v.shape.per_proof, v.shape.hiding, v.shape.n_bounded, v.shape.max_circ);
     const size_t n_groups = cdiv(n, VS_GROUP);
     snprintf(nm, sizeof nm, "vs%d.terms", lane);
     G1Xyzz *terms = (G1Xyzz *)cx.buf(nm, sizeof(G1Xyzz) * n * CH);
@@ -1776,12 +2133,15 @@ static void vs_identify(Context &cx, VsKeys &v, const VsWork &w, size_t n, int l
         MI_HIP(hipStreamSynchronize(st));
     }
     memcpy(verdicts, h, n);
+    stats().fallback_batches++;
+    for (size_t i = 0; i < n; i++) stats().proofs_rejected += h[i] ? 0 : 1;
 }
 
 int32_t vs_verify_batch_device(Context &cx, uint64_t id, const void *d_proofs, size_t n, const void *d_rand,
                                uint8_t *verdicts, uint8_t *all_ok, hipStream_t st) {
     std::shared_ptr<VsCtx> vc = vs_find(id);
     if (!vc) return MI_ERR_BAD_ARGS;
+    StatTimer timer;
     mi_vs_partial part;
     VsWork w;
     uint64_t hd;
@@ -1796,6 +2156,8 @@ int32_t vs_verify_batch_device(Context &cx, uint64_t id, const void *d_proofs, s
         if (s == MI_OK) {
             if (*all_ok) memset(verdicts, 1, n);
             else vs_identify(cx, vs_keys(cx, *vc), w, n, (int)(hd & 0xff), a.st, verdicts);  // aggregate check failed
+            stats().batches_verified++;
+            stats().proofs_verified += n;
         }
     } catch (...) {
         vs_release_lane(cx, a);
@@ -1889,7 +2251,7 @@ int32_t vs_verify_block(uint64_t id, const void *const *proofs, const void *cons
             const void *dp = j.proofs, *dr = j.rand;
             hipStream_t st = cx.stream;
             if (!device_ptrs) {
-                const size_t pb = (size_t)vc->consts.proof_words * 4, rb = vc->consts.rand_bytes;
+                const size_t pb = vc->consts.wire ? (size_t)vc->consts.wire_bytes : (size_t)vc->consts.proof_words * 4, rb = vc->consts.rand_bytes;
                 void *p = cx.buf("blk.in_proofs", pb * j.n);
                 void *r = cx.buf("blk.in_rand", rb * j.n);
                 MI_HIP(hipMemcpyAsync(p, j.proofs, pb * j.n, hipMemcpyHostToDevice, st));

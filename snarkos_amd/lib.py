@@ -33,12 +33,15 @@ VS_MAX_TICKETS = 16  # compile-time cap; a device has MI_SNARK_VS_SLOTS (default
 VS_FS_POSEIDON = 1  # mi_vs_ctx_create_ex flag: Poseidon Fiat-Shamir transcript
 VS2_PROOF_BYTES = 3184  # mi_vs_proof2
 VS3_PROOF_BYTES = 5504  # mi_vs_proof3 (shapes with max_instances > 1)
+VS4_PROOF_BYTES = 6320  # mi_vs_proof4 (shapes with max_circuits > 1)
+VS_WIRE = 2  # mi_vs_ctx_create_* flag: records arrive in the wire form (compressed points, canonical Fr)
 VS2_KEY_EXT_BYTES = 480
 VS2_SHAPE_BYTES = 56
 
 # every symbol include/mi355x_snark.h declares
 EXPORTS = [
-    "mi_init", "mi_device_count", "mi_device_id", "mi_shutdown", "mi_error_string", "mi_abi_version",
+    "mi_init", "mi_device_count", "mi_device_id", "mi_shutdown", "mi_error_string", "mi_abi_version", "mi_runtime_hints", "mi_stats_read",
+    "mi_vs_strides", "mi_vs_wire_encode",
     "mi_msm_g1", "mi_msm_g1_device", "mi_g1_sum", "mi_bases_register", "mi_bases_release", "mi_msm_g1_h",
     "mi_ntt_fr", "mi_ntt_fr_device", "mi_kzg_commit_h", "mi_kzg_commit_h_device", "mi_kzg_open_h", "mi_poly_mul_fr",
     "mi_kzg_commit_hiding_h", "mi_kzg_open_hiding_h", "mi_kzg_commit_lagrange_h",
@@ -181,6 +184,21 @@ def comm_destroy(comm):
 
 def shutdown():
     check(lib().mi_shutdown(), "mi_shutdown")
+
+
+STATS_FIELDS = ("batches_verified", "proofs_verified", "proofs_rejected", "verify_batch_nanos", "msm_calls", "msm_points", "ntt_calls",
+                "ntt_elements", "pairing_products", "pairing_pairs", "points_decompressed", "fallback_batches")
+
+
+def stats_read():
+    """mi_stats_read -> dict of the monotonic counters"""
+    buf = np.zeros(16, dtype=np.uint64)
+    check(lib().mi_stats_read(ptr(buf)), "mi_stats_read")
+    return {k: int(buf[i]) for i, k in enumerate(STATS_FIELDS)}
+
+
+def runtime_hints():
+    return int(lib().mi_runtime_hints())
 
 
 def prof_enable(level=1):

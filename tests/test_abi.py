@@ -23,7 +23,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(l, name), name
     assert sorted(L.EXPORTS) == declared
-    assert l.mi_abi_version() == 2
+    assert l.mi_abi_version() == 3
 
 
 def test_struct_sizes_match_header():

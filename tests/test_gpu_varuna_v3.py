@@ -1,0 +1,233 @@
+"""-m gpu: VarunaShaped-v3 through the C ABI against the CPU oracle (oracle/orc_algo.c, itself checked against
+oracle/pyref.py in tests/test_oracle_golden.py::test_varuna_shaped_v3_against_pyref / ::test_wire_records_against_pyref):
+  (a) WIRE records (MI_VS_WIRE): 48-byte compressed commitments and canonical Fr, decoded inside the lane pass -- what
+      the node holds (reference node/bft/ledger-service/src/ledger.rs:319-347,
+      node/router/messages/src/unconfirmed_transaction.rs:25-28, node/bft/events/src/block_response.rs:64-70);
+  (b) proofs over instances of SEVERAL circuits (Varuna's keys_to_inputs map);
+  (c) linear-combination coefficients with the inverse of a challenge, 1 / (z_beta - z_gamma).
+Partials are compared bit for bit, verdict vectors proof by proof; the encoding is [RECALL]: parity unpinned."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+V3_LC = [0, 0, 1, 4, 3, 0, 5, 3, 6] + [7, 1, 0, 4] * 3
+R4 = 6320
+
+
+def _ctx(mi, b, transcript="sha256", wire=False):
+    return mi.VarunaShaped(b.vk, b.circuits, transcript=transcript, shape=b.shape, key_ext=b.ext, wire=wire)
+
+
+def _v3_shape(orc, **kw):
+    args = dict(lc_kind=V3_LC, max_instances=4, max_circuits=3)
+    args.update(kw)
+    return orc.vs2_shape(None, None, True, 2, **args)
+
+
+@pytest.mark.parametrize("transcript", ["sha256", "poseidon"])
+def test_several_circuits_partial_bit_exact_and_verdicts(orc, mi, transcript):
+    import torch
+    tr = orc.FS_POSEIDON if transcript == "poseidon" else orc.FS_SHA256
+    sh = _v3_shape(orc)
+    good = orc.VS2Batch(0x30A1, 96, 6, 0, shape=sh, transcript=tr)
+    ncs = good.proofs.view(np.uint32).reshape(96, R4 // 4)[:, 5504 // 4]
+    assert {1, 2, 3} <= set(int(x) for x in ncs)
+    v = _ctx(mi, good, transcript)
+    try:
+        ok, verdicts = v.verify_batch(good.proofs, good.randomizers)
+        assert ok and verdicts.all()
+        whole = v.accumulate(torch.from_numpy(good.proofs).cuda(), torch.from_numpy(good.randomizers).cuda())
+        assert (np.frombuffer(whole.tobytes(), dtype=np.uint8) == orc.vs_partial_from_oracle(good, 8)).all()
+        assert v.finalize([whole])
+    finally:
+        v.close()
+    bad = orc.VS2Batch(0x30A2, 96, 6, 160, shape=sh, transcript=tr)
+    assert 0 < bad.expected.sum() < bad.n
+    vb = _ctx(mi, bad, transcript)
+    try:
+        ok, verdicts = vb.verify_batch(bad.proofs, bad.randomizers)
+        assert not ok and (verdicts == bad.expected).all() and (verdicts == bad.verify_cpu(8)).all()
+        # the aggregate of a batch with invalid proofs is still the oracle's, flag for flag
+        whole = vb.accumulate(torch.from_numpy(bad.proofs).cuda(), torch.from_numpy(bad.randomizers).cuda())
+        assert (np.frombuffer(whole.tobytes(), dtype=np.uint8) == orc.vs_partial_from_oracle(bad, 8)).all()
+    finally:
+        vb.close()
+
+
+def test_circuit_structure_out_of_range_is_an_invalid_proof(orc, mi):
+    sh = _v3_shape(orc)
+    good = orc.VS2Batch(0x30A3, 32, 5, 0, shape=sh)
+    w32 = good.proofs.view(np.uint32).reshape(32, R4 // 4)
+    multi = [i for i in range(32) if w32[i, 5504 // 4] >= 2]
+    assert len(multi) >= 5
+    bad = good.proofs.copy()
+    b32 = bad.view(np.uint32).reshape(32, R4 // 4)
+    a, c, d, e, f = multi[:5]
+    b32[a, 5504 // 4] = 4                       # more circuits than the shape allows
+    b32[c, 5520 // 4] = b32[c, 0]               # the second circuit's id equals the first's
+    b32[d, 5524 // 4] = 0                       # the second circuit starts at instance 0
+    b32[e, 5520 // 4] = 99                      # an id beyond the context's circuits
+    b32[f, 5504 // 4] = b32[f, 3184 // 4] + 1   # more circuits than instances
+    want = np.ones(32, dtype=np.uint8)
+    want[[a, c, d, e, f]] = 0
+    cpu = orc.VS2Batch.wrap(good.vk, good.ext, sh, good.circuits, bad, good.randomizers)
+    assert (cpu.verify_cpu(8) == want).all()
+    v = _ctx(mi, good)
+    try:
+        ok, verdicts = v.verify_batch(bad, good.randomizers)
+        assert not ok and (verdicts == want).all()
+        # flipping one bit of a further circuit's evaluation turns exactly that proof invalid
+        bad2 = good.proofs.copy()
+        bad2[a * R4 + 5520 + 16 + 32 * 7 + 3] ^= 1
+        ok, verdicts = v.verify_batch(bad2, good.randomizers)
+        w2 = np.ones(32, dtype=np.uint8); w2[a] = 0
+        assert not ok and (verdicts == w2).all()
+        assert (orc.VS2Batch.wrap(good.vk, good.ext, sh, good.circuits, bad2, good.randomizers).verify_cpu(8) == w2).all()
+    finally:
+        v.close()
+
+
+def test_inverse_challenge_coefficients_on_v2_records(orc, mi):
+    import torch
+    sh = orc.vs2_shape(None, None, True, 2, lc_kind=V3_LC)
+    for tr, name in ((orc.FS_SHA256, "sha256"), (orc.FS_POSEIDON, "poseidon")):
+        b = orc.VS2Batch(0x30A4, 72, 4, 100, shape=sh, transcript=tr)
+        assert 0 < b.expected.sum() < b.n
+        v = _ctx(mi, b, name)
+        try:
+            ok, verdicts = v.verify_batch(b.proofs, b.randomizers)
+            assert not ok and (verdicts == b.expected).all()
+        finally:
+            v.close()
+        g = orc.VS2Batch(0x30A5, 72, 4, 0, shape=sh, transcript=tr)
+        vg = _ctx(mi, g, name)
+        try:
+            whole = vg.accumulate(torch.from_numpy(g.proofs).cuda(), torch.from_numpy(g.randomizers).cuda())
+            assert (np.frombuffer(whole.tobytes(), dtype=np.uint8) == orc.vs_partial_from_oracle(g, 8)).all()
+            assert vg.finalize([whole])
+        finally:
+            vg.close()
+
+
+def _off_subgroup_encoding():
+    d = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "g1_compressed.json")))
+    (c,) = [c for c in d["points"] if c["ok_unchecked"] and not c["ok"]]
+    return np.frombuffer(bytes.fromhex(c["bytes"]), dtype=np.uint8)
+
+
+@pytest.mark.parametrize("kind", [2, 3, 4])
+def test_wire_records_partial_bit_exact_and_damage_rejected_alike(orc, mi, kind):
+    """records in the wire form: the encoder agrees with the oracle's byte for byte, a valid batch's partial is the
+    oracle's, and every way an encoding can be wrong (a non-residue x, a curve point outside the subgroup, an x >= q,
+    the sign flag on the infinity encoding, a non-canonical Fr) makes exactly that proof invalid -- in the oracle and here"""
+    import torch
+    sh = {2: orc.vs2_shape(None, None, True, 2, lc_kind=V3_LC), 3: orc.vs2_shape(None, None, False, 1, max_instances=3),
+          4: _v3_shape(orc)}[kind]
+    b = orc.VS2Batch(0x30B0 + kind, 48, 5, 0, shape=sh)
+    v = _ctx(mi, b, wire=True)
+    try:
+        wire = v.wire_encode(b.proofs)
+        assert (wire == orc.vs_wire_encode(sh, b.proofs)).all()
+        wb = orc.vs_wire_bytes(sh)
+        assert v.proof_bytes == wb and wire.size == 48 * wb
+        ok, verdicts = v.verify_batch(wire, b.randomizers)
+        assert ok and verdicts.all()
+        ob = orc.VS2Batch.from_wire(b.vk, b.ext, sh, b.circuits, wire, b.randomizers, threads=8)
+        whole = v.accumulate(torch.from_numpy(wire).cuda(), torch.from_numpy(b.randomizers).cuda())
+        assert (np.frombuffer(whole.tobytes(), dtype=np.uint8) == orc.vs_partial_from_oracle(ob, 8)).all()
+        assert v.finalize([whole])
+        bad = wire.copy()
+        c0 = 16 + 512  # the first commitment of a wire record
+        bad[3 * wb + c0 + 48 * 2 + 7] ^= 0x10                                    # C_2: another x (non-residue or off the subgroup)
+        bad[5 * wb + c0 + 48 * 4:5 * wb + c0 + 48 * 5] = _off_subgroup_encoding()  # C_4: on the curve, outside the subgroup
+        bad[7 * wb + c0 + 48 * 1:7 * wb + c0 + 48 * 2] = 0xFF                      # C_1: x >= q (and both flags)
+        bad[9 * wb + c0 + 48 * 6:9 * wb + c0 + 48 * 7] = 0
+        bad[9 * wb + c0 + 48 * 6 + 47] = 0xC0                                     # C_6: infinity with the sign flag
+        bad[11 * wb + 16 + 32 * 5:11 * wb + 16 + 32 * 6] = 0xFF                    # input 5: not below r
+        bad[13 * wb + c0 + 432 + 32 * 9 + 31] |= 0x80                             # evaluation 9: not below r
+        ob = orc.VS2Batch.from_wire(b.vk, b.ext, sh, b.circuits, bad, b.randomizers, threads=8)
+        want = np.ones(48, dtype=np.uint8)
+        want[[3, 5, 7, 9, 11, 13]] = 0
+        assert (ob.dec_ok == want).all() and (ob.verify_cpu(8) == want).all()
+        ok, verdicts = v.verify_batch(bad, b.randomizers)
+        assert not ok and (verdicts == want).all()
+        whole = v.accumulate(torch.from_numpy(bad).cuda(), torch.from_numpy(b.randomizers).cuda())
+        assert (np.frombuffer(whole.tobytes(), dtype=np.uint8) == orc.vs_partial_from_oracle(ob, 8)).all()
+        # an infinity commitment is a valid encoding: the relation then fails, the decoder does not
+        inf = wire.copy()
+        inf[2 * wb + c0 + 48 * 3:2 * wb + c0 + 48 * 4] = 0
+        inf[2 * wb + c0 + 48 * 3 + 47] = 0x40
+        ob = orc.VS2Batch.from_wire(b.vk, b.ext, sh, b.circuits, inf, b.randomizers, threads=8)
+        assert ob.dec_ok.all()
+        w2 = np.ones(48, dtype=np.uint8); w2[2] = 0
+        ok, verdicts = v.verify_batch(inf, b.randomizers)
+        assert not ok and (verdicts == w2).all() and (ob.verify_cpu(8) == w2).all()
+    finally:
+        v.close()
+
+
+def test_wire_v1_records_and_stream(orc, mi):
+    """v1 records (no shape) in the wire form through the streaming driver: good, damaged, good"""
+    import torch
+    b = orc.VSBatch(0x30C1, 64, 4, 0)
+    v = mi.VarunaShaped(b.vk, b.circuits, wire=True)
+    try:
+        wire = v.wire_encode(b.proofs)
+        assert (wire == orc.vs_wire_encode(None, b.proofs)).all() and v.proof_bytes == 1728
+        back, dec = orc.vs_wire_decode(None, wire, 8)
+        assert dec.all() and (back == b.proofs).all()
+        ok, verdicts = v.verify_batch(wire, b.randomizers)
+        assert ok and verdicts.all()
+        bad = wire.copy()
+        bad[17 * 1728 + 16 + 512 + 48 * 9 + 672 + 3] ^= 4   # a witness
+        recs, dec = orc.vs_wire_decode(None, bad, 8)
+        cpu = orc.VSArrays(b.vk, b.circuits, recs, b.randomizers).verify_cpu(8) & dec
+        ok, verdicts = v.verify_batch(bad, b.randomizers)
+        assert not ok and (verdicts == cpu).all() and verdicts.sum() == 63 and verdicts[17] == 0
+        rnd = torch.from_numpy(b.randomizers).cuda()
+        g, x = (torch.from_numpy(wire).cuda(), rnd), (torch.from_numpy(bad).cuda(), rnd)
+        assert list(v.verify_stream(iter([g, x, g, g]))) == [True, False, True, True]
+    finally:
+        v.close()
+
+
+def test_wire_batches_share_a_pass(orc, mi):
+    """two wire batches in one lane pass (one decode launch for both): partials byte-identical to single passes"""
+    import torch
+    sh = orc.vs2_shape(None, [-1] * 9, False, 0)
+    a = orc.VS2Batch(0x30D1, 336, 4, 0, shape=sh)  # one key set: the first 200 proofs are batch a, the last 136 batch b
+    v = _ctx(mi, a, wire=True)
+    try:
+        w = v.wire_encode(a.proofs)
+        wb = v.proof_bytes
+        ta, tra = torch.from_numpy(w[:200 * wb].copy()).cuda(), torch.from_numpy(a.randomizers[:200 * 48].copy()).cuda()
+        tb, trb = torch.from_numpy(w[200 * wb:].copy()).cuda(), torch.from_numpy(a.randomizers[200 * 48:].copy()).cuda()
+        one_a, one_b = v.accumulate(ta, tra), v.accumulate(tb, trb)
+        if v.batches_per_pass(200) >= 2:
+            h = v.accumulate_begin_pair(ta, tra, tb, trb)
+            pa, pb = v.accumulate_end_pair(h)
+            assert (pa == one_a).all() and (pb == one_b).all()
+        assert v.finalize([one_a]) and v.finalize([one_b])
+    finally:
+        v.close()
+
+
+def test_counters_move(orc, mi):
+    from snarkos_amd import lib as L
+    b = orc.VS2Batch(0x30E1, 16, 2, 0, shape=orc.vs2_shape(None, [-1] * 9, False, 0))
+    v = _ctx(mi, b, wire=True)
+    try:
+        s0 = L.stats_read()
+        ok, _ = v.verify_batch(v.wire_encode(b.proofs), b.randomizers)
+        s1 = L.stats_read()
+        assert ok
+        assert s1["batches_verified"] == s0["batches_verified"] + 1 and s1["proofs_verified"] == s0["proofs_verified"] + 16
+        assert s1["points_decompressed"] == s0["points_decompressed"] + 16 * 11
+        assert s1["msm_calls"] > s0["msm_calls"] and s1["pairing_products"] == s0["pairing_products"] + 1
+        assert s1["verify_batch_nanos"] > s0["verify_batch_nanos"]
+    finally:
+        v.close()
