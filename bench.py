@@ -582,6 +582,14 @@ def extras(dev, verifier, proofs, rnd):
         ex["g1_decompress_batch_commitments"] = codec
     except Exception as e:  # noqa: BLE001
         ex["g1_decompress_batch_commitments"] = {"error": str(e)}
+    # --- VarunaShaped-v3, the records as the node holds them (MI_VS_WIRE): the headline batch with every commitment a
+    # 48-byte compressed point and every field element canonical, decoded INSIDE the timed stream's lane passes
+    try:
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import wire_one
+        ex["batch_1024_v3_compressed"] = wire_one.measure(dev)
+    except Exception as e:  # noqa: BLE001
+        ex["batch_1024_v3_compressed"] = {"error": str(e)}
     # --- the 1024-proof batch under the Poseidon Fiat-Shamir transcript (row A9 on the path: 37 permutations per proof)
     try:
         dp = np.load(os.path.join(ROOT, "tests", "golden", "vs_batch_1024_poseidon.npz"))

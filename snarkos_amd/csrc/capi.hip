@@ -6,7 +6,7 @@
 #include "api.hpp"
 #include "field28.hpp"
 #include "tower.hpp"
-#include "codec.hpp"
+#include "codec28.hpp"
 
 extern "C" int mi_host_cpu_ok(void);  // cpu_probe.cpp (built without the x86-64-v3 / ADX flags)
 
@@ -181,24 +181,17 @@ __device__ __attribute__((noinline)) void poseidon_permute(Fq st[3], const Posei
         for (int i = 0; i < 3; i++) st[i] = o[i];
     }
 }
-// a lane per point; the data-dependent loops of the square root run in lockstep over the wave (worst lane decides)
-__global__ void __launch_bounds__(64) g1_decompress_kernel(const uint8_t *__restrict__ in, size_t n, int check_subgroup,
-                                                           G1Affine *__restrict__ out, uint8_t *__restrict__ ok) {
-    const size_t i = (size_t)blockIdx.x * 64 + threadIdx.x;
-    if (i >= n) return;
-    uint8_t b[48];
-    const uint4 *src = reinterpret_cast<const uint4 *>(in + 48 * i);  // 48 i is a multiple of 16
-#pragma unroll
-    for (int k = 0; k < 3; k++) {
-        const uint4 v = src[k];
-        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-        for (int j = 0; j < 16; j++) b[16 * k + j] = (uint8_t)(w[j >> 2] >> (8 * (j & 3)));
-    }
+// two waves per 64 points (codec28.hpp): one takes the square root, the other runs the subgroup test beside it
+__global__ void __launch_bounds__(128) g1_decompress_kernel(const uint8_t *__restrict__ in, size_t n, int check_subgroup,
+                                                            G1Affine *__restrict__ out, uint8_t *__restrict__ ok, SqrtDev T) {
+    extern __shared__ int32_t c28_lds[];  // C28_LDS_BYTES
+    const size_t i = (size_t)blockIdx.x * 64 + (threadIdx.x & 63);
     G1Affine p;
-    const bool good = g1_decompress_one(b, check_subgroup != 0, p);
-    out[i] = p;
-    ok[i] = good ? 1 : 0;
+    const bool good = g1_decode28(i < n ? in + 48 * i : nullptr, check_subgroup != 0, T, c28_lds, p);  // 48 i is a multiple of 16
+    if (threadIdx.x < 64 && i < n) {
+        out[i] = p;
+        ok[i] = good ? 1 : 0;
+    }
 }
 __global__ void __launch_bounds__(64) g1_compress_kernel(const G1Affine *__restrict__ in, size_t n, uint8_t *__restrict__ out) {
     const size_t i = (size_t)blockIdx.x * 64 + threadIdx.x;
@@ -211,7 +204,8 @@ void g1_decompress_device(Context &cx, const uint8_t *d_in, size_t n, int check_
     if (!n) return;
     stats().points_decompressed += n;
     cx.prof.begin("g1_decompress", st, n);
-    hipLaunchKernelGGL(g1_decompress_kernel, dim3(cdiv(n, 64)), dim3(64), 0, st, d_in, n, check_subgroup, d_out, d_ok);
+    hipLaunchKernelGGL(g1_decompress_kernel, dim3(cdiv(n, 64)), dim3(128), C28_LDS_BYTES, st, d_in, n, check_subgroup, d_out, d_ok,
+                       sqrt_tables(cx, st));
     cx.prof.end("g1_decompress", st);
     MI_HIP(hipGetLastError());
 }

@@ -17,7 +17,7 @@
 #include "tower.hpp"
 #include "pairing_wg.hpp"
 #include "glv.hpp"
-#include "codec.hpp"
+#include "codec28.hpp"
 
 namespace mi {
 
@@ -1478,30 +1478,32 @@ __global__ void __launch_bounds__(64) vs_wire_fields_kernel(VsWireJobs jobs, uin
     }
     jb.dec_ok[i] = ok ? 1 : 0;
 }
-// a lane per (proof, point slot of the shape): 48 bytes -> the affine point (square root, sign, exact subgroup test:
-// codec.hpp); anything that is not the encoding of a subgroup point clears the proof's flag and leaves infinity
-__global__ void __launch_bounds__(64) vs_wire_points_kernel(VsWireJobs jobs, uint32_t n_all, const VsWireMap *__restrict__ wm) {
-    const uint32_t g = blockIdx.x * 64 + threadIdx.x, NP = wm->n_pts;
-    if (g >= n_all * NP) return;
-    const uint32_t gp = g / NP, slot = g - gp * NP;
-    const VsWireJobs::B &jb = jobs.b[jobs.of(gp)];
-    const uint32_t i = gp - jb.first;
-    const uint8_t *w = jb.wire + (size_t)i * wm->wire_bytes;
-    uint32_t m1, d1;
-    vs_wire_counts(w, wm, m1, d1);
-    if (!vs_wire_used(wm->pt_cls[slot], m1, d1)) return;
-    uint8_t b[48];
-    const uint4 *src = reinterpret_cast<const uint4 *>(w + wm->pt_wire[slot]);  // record strides and offsets are multiples of 16
-#pragma unroll
-    for (int k = 0; k < 3; k++) {
-        const uint4 v = src[k];
-        const uint32_t ww[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-        for (int j = 0; j < 16; j++) b[16 * k + j] = (uint8_t)(ww[j >> 2] >> (8 * (j & 3)));
+// TWO waves per 64 (proof, point slot of the shape) pairs: 48 bytes -> the affine point (codec28.hpp: one wave takes
+// the square root, the other runs the exact subgroup test beside it, both on 28-bit limbs); anything that is not the
+// encoding of a subgroup point clears the proof's flag and leaves infinity
+__global__ void __launch_bounds__(128) vs_wire_points_kernel(VsWireJobs jobs, uint32_t n_all, const VsWireMap *__restrict__ wm, SqrtDev T) {
+    extern __shared__ int32_t c28_lds[];  // C28_LDS_BYTES
+    const uint32_t g = blockIdx.x * 64 + (threadIdx.x & 63), NP = wm->n_pts;
+    const uint8_t *src = nullptr;
+    uint32_t i = 0, slot = 0;
+    int k = 0;
+    if (g < n_all * NP) {
+        const uint32_t gp = g / NP;
+        slot = g - gp * NP;
+        k = jobs.of(gp);
+        i = gp - jobs.b[k].first;
+        const uint8_t *w = jobs.b[k].wire + (size_t)i * wm->wire_bytes;
+        uint32_t m1, d1;
+        vs_wire_counts(w, wm, m1, d1);
+        if (vs_wire_used(wm->pt_cls[slot], m1, d1)) src = w + wm->pt_wire[slot];  // record strides and offsets are multiples of 16
     }
     G1Affine pt;
-    if (g1_decompress_one(b, true, pt)) copy_g1(reinterpret_cast<G1Affine *>(jb.rec + (size_t)i * wm->rec_bytes + wm->pt_rec[slot]), &pt);
-    else jb.dec_ok[i] = 0;  // only ever cleared here; the fields kernel (earlier on the stream) set it
+    const bool ok = g1_decode28(src, true, T, c28_lds, pt);
+    if (threadIdx.x < 64 && src) {  // the root wave holds the verdict and the point
+        const VsWireJobs::B &jb = jobs.b[k];
+        if (ok) copy_g1(reinterpret_cast<G1Affine *>(jb.rec + (size_t)i * wm->rec_bytes + wm->pt_rec[slot]), &pt);
+        else jb.dec_ok[i] = 0;  // only ever cleared here; the fields kernel (earlier on the stream) set it
+    }
 }
 
 // ---------------------------------------------------------------- host drivers
@@ -1609,8 +1611,8 @@ static void vs_run_derive(Context &cx, VsKeys &v, const void *const *d_proofs_in
         cx.prof.begin("vs_wire_decode", st, n_all);
         MI_HIP(hipMemsetAsync(exp, 0, (size_t)wm.rec_bytes * n_all, st));
         hipLaunchKernelGGL(vs_wire_fields_kernel, dim3((unsigned)cdiv(n_all, 64)), dim3(64), 0, st, jobs, (uint32_t)n_all, (const VsWireMap *)v.wire_map.p);
-        hipLaunchKernelGGL(vs_wire_points_kernel, dim3((unsigned)cdiv(n_all * wm.n_pts, 64)), dim3(64), 0, st, jobs, (uint32_t)n_all,
-                           (const VsWireMap *)v.wire_map.p);
+        hipLaunchKernelGGL(vs_wire_points_kernel, dim3((unsigned)cdiv(n_all * wm.n_pts, 64)), dim3(128), C28_LDS_BYTES, st, jobs, (uint32_t)n_all,
+                           (const VsWireMap *)v.wire_map.p, sqrt_tables(cx, st));
         cx.prof.end("vs_wire_decode", st);
         stats().points_decompressed += n_all * wm.n_pts;
     }
