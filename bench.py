@@ -138,7 +138,9 @@ def main():
         comm = native_comm(rank, world, dev if args.backend == "nccl" else "cpu")
         if comm is None and args.exchange == "native":
             raise SystemExit("native RCCL exchange requested but not available on every rank")
-    exchange_kind = "native-rccl" if comm is not None else ("torch.distributed" if dist_on else "none")
+    # (the transport behind a native communicator is the library's decision, taken by all ranks at mi_comm_init_rank:
+    # RCCL when it comes up everywhere, the shared-memory all-gather between the node's processes otherwise)
+    exchange_kind = ("native-" + L.comm_transport(comm)) if comm is not None else ("torch.distributed" if dist_on else "none")
     stamps = []
 
     def run(k, stamp=False):
@@ -159,10 +161,12 @@ def main():
     # ---- timed region: exactly K batches, no profiling hooks
     L.prof_enable(0)
     sync_all(dist_on)
+    st0 = L.stats_read()
     t0 = time.perf_counter()
     run(args.steps)
     sync_all(dist_on)
     dt = time.perf_counter() - t0
+    st1 = L.stats_read()
     if dist_on:
         t = torch.tensor([dt], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
@@ -237,7 +241,12 @@ def main():
         "config": {"workload": "configs[3]: batch verify of 1024 synthetic VarunaShaped-v1 proofs per GPU "
                                "(KZG open + pairing check); N GPUs = one %d-proof block sharded, partials all-gathered over RCCL" % (world * PROOFS_PER_GPU),
                    "proofs_per_gpu": PROOFS_PER_GPU, "circuits": 8, "all_valid": True, "parallelism": "shard%d" % world,
-                   "exchange": exchange_kind,
+                   "exchange": exchange_kind, "exchange_group": args.exchange_group,
+                   # the all-gathers of the timed region on rank 0's finisher thread (native transports; the torch callback is
+                   # outside the library's counters): how long a group's exchange held the thread that launches products
+                   "exchange_calls": st1["exchange_calls"] - st0["exchange_calls"],
+                   "exchange_wait_ms_per_group": (1e-6 * (st1["exchange_nanos"] - st0["exchange_nanos"]) / (st1["exchange_calls"] - st0["exchange_calls"])
+                                                  if st1["exchange_calls"] > st0["exchange_calls"] else None),
                    "pipeline": "batches streamed: %d accumulation lanes, %d pairing products in flight, %d host fold threads"
                                % (args.acc_depth, args.products, args.fold_threads)},
         "roofline": roofline, "alu": alu_view(kernels), "kernels": kernels,

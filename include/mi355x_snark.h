@@ -95,7 +95,8 @@ typedef struct {
     uint64_t pairing_products, pairing_pairs;
     uint64_t points_decompressed;  /* mi_g1_decompress* and wire records */
     uint64_t fallback_batches;     /* batches taken apart proof by proof */
-    uint64_t reserved[4];
+    uint64_t exchange_calls, exchange_nanos; /* all-gathers of partials (any transport) and the host wall time inside them */
+    uint64_t reserved[2];
 } mi_stats; /* 128 B */
 int32_t mi_stats_read(mi_stats *out);
 
@@ -386,7 +387,10 @@ int32_t mi_vs_stream_close(uint64_t stream); /* finishes, drains and joins the t
 /* ---- the exchange itself, native: RCCL called from the library (librccl is dlopen'ed on first use) ----
  * One process per GPU: rank 0 calls mi_comm_unique_id, the 128 bytes reach the other ranks over the caller's own
  * transport, every rank calls mi_comm_init_rank (collective).  mi_vs_exchange_rccl is an mi_vs_exchange_fn: pass it to
- * mi_vs_stream_open with user = (void *)(uintptr_t)comm.  MI_ERR_NO_DEVICE: no usable RCCL (keep your own exchange).
+ * mi_vs_stream_open with user = (void *)(uintptr_t)comm.  The transport is the LIBRARY's decision, taken by all ranks
+ * together at mi_comm_init_rank: RCCL over xGMI when it comes up on every rank; otherwise (two ranks rehearsing on one
+ * device, no librccl, an init that fails somewhere, MI_SNARK_EXCHANGE=host) a shared-memory all-gather between the
+ * node's processes -- the ranks of SURVEY.md 8e share one node.  mi_comm_transport tells which.
  * One process, all GPUs: mi_comm_init_local (ncclCommInitAll over the library's device list; what mi_vs_verify_block
  * uses by itself). */
 #define MI_COMM_ID_BYTES 128
@@ -394,6 +398,9 @@ int32_t mi_comm_unique_id(uint8_t *id_out /* MI_COMM_ID_BYTES */);
 int32_t mi_comm_init_rank(const uint8_t *id, int32_t rank, int32_t world, uint64_t *comm_out);
 int32_t mi_comm_init_local(uint64_t *comm_out);
 int32_t mi_comm_world(uint64_t comm); /* ranks, or a negative status */
+#define MI_COMM_RCCL 1
+#define MI_COMM_HOST 2
+int32_t mi_comm_transport(uint64_t comm); /* MI_COMM_RCCL / MI_COMM_HOST, or a negative status */
 int32_t mi_comm_destroy(uint64_t comm);
 /* all-gather of one `bytes`-sized host record per rank: all[rank * bytes ...] (rank-per-process communicators) */
 int32_t mi_comm_all_gather(uint64_t comm, const void *mine, size_t bytes, void *all);

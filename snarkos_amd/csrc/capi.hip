@@ -379,6 +379,8 @@ int32_t mi_stats_read(mi_stats *out) {
     out->pairing_pairs = s.pairing_pairs.load();
     out->points_decompressed = s.points_decompressed.load();
     out->fallback_batches = s.fallback_batches.load();
+    out->exchange_calls = s.exchange_calls.load();
+    out->exchange_nanos = s.exchange_nanos.load();
     return MI_OK;
 }
 

@@ -14,8 +14,14 @@
 // keeps its own exchange (in one process the partials are host values anyway: mi_vs_verify_block falls back to adding
 // them directly).  Pure host code: no kernels here.
 #include <dlfcn.h>
+#include <fcntl.h>
 #include <rccl/rccl.h>
+#include <sched.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
 #include <atomic>
+#include <chrono>
 #include <map>
 #include <memory>
 #include <mutex>
@@ -74,6 +80,89 @@ static int32_t nccl_status(ncclResult_t r, const char *what) {
         if (_s != MI_OK) return _s;                   \
     } while (0)
 
+// ---------------------------------------------------------------- the host transport (same node, no RCCL)
+// One process per GPU on ONE node is the shape of SURVEY.md 8e, so when RCCL cannot serve a communicator -- two ranks
+// rehearsing on one device ("invalid usage"), no librccl, an init that fails on some rank -- the ranks still share the
+// node's memory: a POSIX shared-memory segment named after the communicator's unique id carries the all-gather.  It is
+// also where the ranks AGREE on the transport (every rank publishes whether RCCL came up; one failure sends all of them
+// here), so the decision is the library's, not a watchdog's in the caller.
+// Protocol (round s, parity p = s & 1): wait until every rank has read round s - 2 (the slot about to be overwritten),
+// write the own slot, publish written = s + 1 (release); wait for every rank's written >= s + 1 (acquire), copy all
+// slots, publish read = s + 1.  A fresh segment is zero-filled: that is the valid initial state, nobody initialises it.
+#define SHM_MAX_RANKS 64
+#define SHM_SLOT_BYTES 8192  // a group of up to 8 partials (8 x 592) per rank and round
+struct ShmSeg {
+    std::atomic<uint32_t> attached, rccl_votes, rccl_failed, pad;
+    std::atomic<uint64_t> device_key[SHM_MAX_RANKS];  // PCI location + 1 of every rank's device (0: not yet published)
+    std::atomic<uint64_t> written[SHM_MAX_RANKS], read[SHM_MAX_RANKS];
+    uint8_t slot[2][SHM_MAX_RANKS][SHM_SLOT_BYTES];
+};
+struct Shm {
+    ShmSeg *seg = nullptr;
+    char name[64] = {0};
+    int rank = 0, world = 1;
+    uint64_t round = 0;
+    ~Shm() {
+        if (seg) munmap(seg, sizeof(ShmSeg));
+    }
+};
+static bool shm_wait(const std::function<bool()> &ready, double seconds) {
+    const auto t0 = std::chrono::steady_clock::now();
+    for (uint32_t spin = 0; !ready(); spin++) {
+        if (spin < 2000) continue;  // ~ microseconds: the peers are usually there already
+        sched_yield();
+        if ((spin & 1023) == 0 && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > seconds) return false;
+    }
+    return true;
+}
+static std::unique_ptr<Shm> shm_attach(const uint8_t *id, int rank, int world) {
+    if (world > SHM_MAX_RANKS) return nullptr;
+    std::unique_ptr<Shm> s(new Shm());
+    uint64_t h = 0xcbf29ce484222325ull;  // FNV-1a over the 128 id bytes
+    for (int i = 0; i < MI_COMM_ID_BYTES; i++) h = (h ^ id[i]) * 0x100000001b3ull;
+    snprintf(s->name, sizeof s->name, "/mi355x_snark_%016llx", (unsigned long long)h);
+    const int fd = shm_open(s->name, O_CREAT | O_RDWR, 0600);
+    if (fd < 0) return nullptr;
+    if (ftruncate(fd, sizeof(ShmSeg)) != 0) {
+        close(fd);
+        return nullptr;
+    }
+    void *p = mmap(nullptr, sizeof(ShmSeg), PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+    close(fd);
+    if (p == MAP_FAILED) return nullptr;
+    s->seg = (ShmSeg *)p;
+    s->rank = rank;
+    s->world = world;
+    s->seg->attached.fetch_add(1);
+    ShmSeg *seg = s->seg;
+    if (!shm_wait([=] { return seg->attached.load() >= (uint32_t)world; }, 120.0)) return nullptr;
+    if (rank == 0) shm_unlink(s->name);  // everybody holds a mapping: the name has done its work
+    return s;
+}
+static int32_t shm_all_gather(Shm &s, const void *mine, size_t bytes, void *all) {
+    if (bytes > SHM_SLOT_BYTES) return MI_ERR_BAD_ARGS;
+    ShmSeg *seg = s.seg;
+    const uint64_t r = s.round++;
+    const int par = (int)(r & 1), world = s.world;
+    if (r >= 2 && !shm_wait([=] {
+            for (int k = 0; k < world; k++)
+                if (seg->read[k].load(std::memory_order_acquire) + 1 < r) return false;
+            return true;
+        }, 120.0))
+        return MI_ERR_KERNEL;
+    memcpy(seg->slot[par][s.rank], mine, bytes);
+    seg->written[s.rank].store(r + 1, std::memory_order_release);
+    if (!shm_wait([=] {
+            for (int k = 0; k < world; k++)
+                if (seg->written[k].load(std::memory_order_acquire) < r + 1) return false;
+            return true;
+        }, 120.0))
+        return MI_ERR_KERNEL;
+    for (int k = 0; k < world; k++) memcpy((uint8_t *)all + (size_t)k * bytes, seg->slot[par][k], bytes);
+    seg->read[s.rank].store(r + 1, std::memory_order_release);
+    return MI_OK;
+}
+
 // One member per device this process contributes: its communicator, a stream of its own and staging buffers.
 struct CommMember {
     Context *cx = nullptr;
@@ -87,6 +176,8 @@ struct Comm {
     std::mutex mu;  // one collective at a time per communicator (RCCL's own requirement for a given comm)
     int world = 1;  // ranks over all processes
     std::vector<CommMember> members;
+    std::unique_ptr<Shm> shm;  // rank-per-process communicators: the agreement channel, and the transport when RCCL is not used
+    bool use_rccl = true;
 };
 static std::mutex g_comm_mu;
 static std::map<uint64_t, std::shared_ptr<Comm>> g_comms;
@@ -144,6 +235,8 @@ void comm_release_all() {
 int32_t comm_all_gather(Comm &c, const void *const *mine, size_t bytes, void *const *all) {
     RcclApi &api = rccl();
     std::lock_guard<std::mutex> lk(c.mu);
+    StatExchange timer;
+    if (!c.use_rccl) return c.shm ? shm_all_gather(*c.shm, mine[0], bytes, all[0]) : MI_ERR_NO_DEVICE;
     try {
         for (size_t i = 0; i < c.members.size(); i++) {
             CommMember &m = c.members[i];
@@ -228,39 +321,90 @@ extern "C" {
 
 int32_t mi_comm_unique_id(uint8_t *id_out) {
     if (!id_out) return MI_ERR_BAD_ARGS;
-    if (!rccl().ok) return MI_ERR_NO_DEVICE;
-    ncclUniqueId id;
-    MI_NCCL(rccl().GetUniqueId(&id));
-    static_assert(sizeof id == MI_COMM_ID_BYTES, "ncclUniqueId size");
-    memcpy(id_out, &id, sizeof id);
+    static_assert(sizeof(ncclUniqueId) == MI_COMM_ID_BYTES, "ncclUniqueId size");
+    if (rccl().ok) {
+        ncclUniqueId id;
+        if (rccl().GetUniqueId(&id) == ncclSuccess) {
+            memcpy(id_out, &id, sizeof id);
+            return MI_OK;
+        }
+    }
+    // no RCCL: the id only has to name the host transport's segment
+    memset(id_out, 0, MI_COMM_ID_BYTES);
+    const int fd = open("/dev/urandom", O_RDONLY);
+    if (fd < 0 || read(fd, id_out, 32) != 32) {
+        if (fd >= 0) close(fd);
+        return MI_ERR_KERNEL;
+    }
+    close(fd);
     return MI_OK;
 }
 
+// Collective over the ranks.  RCCL when it comes up on EVERY rank (the ranks vote through the shared segment; ranks
+// that share a device do not try: ncclCommInitRank refuses that), the host transport otherwise.  MI_SNARK_EXCHANGE=host
+// in the environment of every rank skips RCCL.
 int32_t mi_comm_init_rank(const uint8_t *id, int32_t rank, int32_t world, uint64_t *comm_out) {
     if (!id || !comm_out || world < 1 || rank < 0 || rank >= world) return MI_ERR_BAD_ARGS;
-    if (!rccl().ok) return MI_ERR_NO_DEVICE;
-    const int32_t st = ensure_init();
-    if (st != MI_OK) return st;
+    const bool have_device = ensure_init() == MI_OK;  // without a device the communicator still serves host records (tests)
     std::shared_ptr<Comm> c(new Comm());
     c->world = world;
     c->members.resize(1);
     CommMember &m = c->members[0];
-    m.cx = &primary();  // one process per GPU: this process's device
-    ncclUniqueId uid;
-    memcpy(&uid, id, sizeof uid);
-    try {
-        MI_HIP(hipSetDevice(m.cx->device));
-        const int32_t s = nccl_status(rccl().CommInitRank(&m.comm, world, uid, rank), "ncclCommInitRank");
-        if (s != MI_OK) return s;
-        MI_HIP(hipStreamCreateWithFlags(&m.st, hipStreamNonBlocking));
-    } catch (const HipError &h) {
-        member_free(m);
-        return status_of(h);
+    m.cx = have_device ? &primary() : nullptr;  // one process per GPU: this process's device
+    c->shm = shm_attach(id, rank, world);
+    if (!c->shm) return MI_ERR_NO_DEVICE;
+    ShmSeg *seg = c->shm->seg;
+    // ---- may RCCL be tried at all?  every rank publishes its device; two ranks on one device rule it out for all
+    char bus[64] = {0};
+    uint64_t key = 1000 + (uint64_t)rank;  // no device: a key of its own
+    if (have_device && hipDeviceGetPCIBusId(bus, sizeof bus, m.cx->device) == hipSuccess) {
+        key = 1;
+        for (const char *q = bus; *q; q++) key = key * 131 + (uint8_t)*q;
+    }
+    seg->device_key[rank].store(key | 1ull << 63);
+    if (!shm_wait([=] {
+            for (int k = 0; k < world; k++)
+                if (!seg->device_key[k].load()) return false;
+            return true;
+        }, 120.0))
+        return MI_ERR_KERNEL;
+    bool shared_device = false;
+    for (int a = 0; a < world; a++)
+        for (int b = 0; b < a; b++)
+            if (seg->device_key[a].load() == seg->device_key[b].load()) shared_device = true;
+    const char *e = getenv("MI_SNARK_EXCHANGE");
+    bool try_rccl = have_device && rccl().ok && !shared_device && !(e && !strcmp(e, "host"));
+    bool mine_ok = false;
+    if (try_rccl) {
+        ncclUniqueId uid;
+        memcpy(&uid, id, sizeof uid);
+        try {
+            MI_HIP(hipSetDevice(m.cx->device));
+            mine_ok = nccl_status(rccl().CommInitRank(&m.comm, world, uid, rank), "ncclCommInitRank") == MI_OK;
+            if (mine_ok) MI_HIP(hipStreamCreateWithFlags(&m.st, hipStreamNonBlocking));
+        } catch (const HipError &h) {
+            (void)status_of(h);
+            mine_ok = false;
+        }
+    }
+    // ---- the vote: one rank without RCCL sends every rank to the host transport
+    if (!mine_ok) seg->rccl_failed.fetch_add(1);
+    seg->rccl_votes.fetch_add(1);
+    if (!shm_wait([=] { return seg->rccl_votes.load() >= (uint32_t)world; }, 120.0)) return MI_ERR_KERNEL;
+    c->use_rccl = seg->rccl_failed.load() == 0;
+    if (!c->use_rccl && m.comm) {
+        (void)rccl().CommDestroy(m.comm);
+        m.comm = nullptr;
     }
     std::lock_guard<std::mutex> lk(g_comm_mu);
     *comm_out = g_comm_next++;
     g_comms[*comm_out] = c;
     return MI_OK;
+}
+int32_t mi_comm_transport(uint64_t comm) {
+    std::shared_ptr<Comm> c = comm_find(comm);
+    if (!c) return MI_ERR_BAD_ARGS;
+    return c->use_rccl ? MI_COMM_RCCL : MI_COMM_HOST;
 }
 
 int32_t mi_comm_init_local(uint64_t *comm_out) {

@@ -133,7 +133,7 @@ struct HostSpan {
 struct Stats {
     std::atomic<uint64_t> batches_verified{0}, proofs_verified{0}, proofs_rejected{0}, verify_batch_nanos{0}, msm_calls{0},
         msm_points{0}, ntt_calls{0}, ntt_elements{0}, pairing_products{0}, pairing_pairs{0}, points_decompressed{0},
-        fallback_batches{0};
+        fallback_batches{0}, exchange_calls{0}, exchange_nanos{0};
 };
 inline Stats &stats() {
     static Stats s;
@@ -143,6 +143,14 @@ struct StatTimer {  // adds its lifetime to verify_batch_nanos
     std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
     ~StatTimer() {
         stats().verify_batch_nanos += (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count();
+    }
+};
+
+struct StatExchange {  // one all-gather of partials (any transport): call count and host wall time
+    std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+    ~StatExchange() {
+        stats().exchange_calls++;
+        stats().exchange_nanos += (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count();
     }
 };
 

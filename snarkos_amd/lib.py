@@ -52,7 +52,7 @@ EXPORTS = [
     "mi_vs_accumulate_device", "mi_vs_accumulate_begin", "mi_vs_accumulate_end", "mi_vs_accumulate_begin_pair", "mi_vs_accumulate_end_pair", "mi_vs_accumulate_begin_multi", "mi_vs_accumulate_end_multi", "mi_vs_batches_per_pass", "mi_g1_decompress", "mi_g1_decompress_device", "mi_g1_compress", "mi_vs_finalize", "mi_vs_finalize_async", "mi_vs_finalize_wait", "mi_vs_finalize_async_multi", "mi_vs_finalize_wait_multi",
     "mi_vs_verify_block", "mi_vs_verify_block_device",
     "mi_vs_stream_open", "mi_vs_stream_submit", "mi_vs_stream_finish", "mi_vs_stream_next", "mi_vs_stream_next_verdicts", "mi_vs_stream_close",
-    "mi_comm_unique_id", "mi_comm_init_rank", "mi_comm_init_local", "mi_comm_world", "mi_comm_destroy", "mi_comm_all_gather",
+    "mi_comm_unique_id", "mi_comm_init_rank", "mi_comm_init_local", "mi_comm_world", "mi_comm_transport", "mi_comm_destroy", "mi_comm_all_gather",
     "mi_vs_exchange_rccl",
     "mi_dbg_fq_mul", "mi_dbg_fq_mul28", "mi_dbg_g1_add28", "mi_dbg_fr_mul", "mi_dbg_g1_add", "mi_dbg_fq_mul_throughput", "mi_dbg_gen_points_device",
     "mi_prof_enable", "mi_prof_read",
@@ -106,6 +106,7 @@ def lib():
         l.mi_comm_init_rank.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.POINTER(C.c_uint64)]
         l.mi_comm_init_local.argtypes = [C.POINTER(C.c_uint64)]
         l.mi_comm_world.argtypes = [C.c_uint64]
+        l.mi_comm_transport.argtypes = [C.c_uint64]
         l.mi_comm_destroy.argtypes = [C.c_uint64]
         l.mi_comm_all_gather.argtypes = [C.c_uint64, C.c_void_p, C.c_size_t, C.c_void_p]
         l.mi_vs_verify_block.argtypes = [C.c_uint64, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p]
@@ -178,6 +179,14 @@ def comm_init_rank(uid, rank, world):
     return h.value
 
 
+def comm_transport(comm):
+    """"rccl" or "host" (shared memory between the node's ranks): decided by all ranks together at comm_init_rank"""
+    t = lib().mi_comm_transport(C.c_uint64(comm))
+    if t < 0:
+        raise MiError(t, "mi_comm_transport")
+    return {1: "rccl", 2: "host"}[t]
+
+
 def comm_destroy(comm):
     check(lib().mi_comm_destroy(C.c_uint64(comm)), "mi_comm_destroy")
 
@@ -187,7 +196,7 @@ def shutdown():
 
 
 STATS_FIELDS = ("batches_verified", "proofs_verified", "proofs_rejected", "verify_batch_nanos", "msm_calls", "msm_points", "ntt_calls",
-                "ntt_elements", "pairing_products", "pairing_pairs", "points_decompressed", "fallback_batches")
+                "ntt_elements", "pairing_products", "pairing_pairs", "points_decompressed", "fallback_batches", "exchange_calls", "exchange_nanos")
 
 
 def stats_read():

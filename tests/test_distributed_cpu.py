@@ -50,3 +50,16 @@ def test_sharded_batch_with_a_bad_proof():
 
 def test_sharded_msm():
     _run(3, -2)  # points split 101/100/100 across three ranks, 144-byte partial sums all-gathered
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_host_transport_all_gather(world, tmp_path):
+    """the library's own exchange between rank-per-process communicators when RCCL does not serve them (here: no GPU):
+    mi_comm_unique_id / mi_comm_init_rank / mi_comm_all_gather over the shared-memory transport, 60 rounds of 1..8
+    partials with stragglers"""
+    idf = str(tmp_path / "comm.id")
+    procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "comm_worker.py"), str(r), str(world), idf, "60"],
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(world)]
+    outs = [p.communicate(timeout=300)[0] for p in procs]
+    for p, o in zip(procs, outs):
+        assert p.returncode == 0, o
