@@ -140,6 +140,10 @@ def main():
             raise SystemExit("native RCCL exchange requested but not available on every rank")
     # (the transport behind a native communicator is the library's decision, taken by all ranks at mi_comm_init_rank:
     # RCCL when it comes up everywhere, the shared-memory all-gather between the node's processes otherwise)
+    if not dist_on and args.exchange == "native":
+        # one rank with the exchange path switched on (a communicator of world 1): what the grouped exchange of the
+        # streaming driver costs by itself, apart from what several ranks do to each other
+        comm = L.comm_init_rank(L.comm_unique_id(), 0, 1)
     exchange_kind = ("native-" + L.comm_transport(comm)) if comm is not None else ("torch.distributed" if dist_on else "none")
     stamps = []
 

@@ -13,6 +13,30 @@ def test_pairing_value_matches_oracle(orc, mi):
     assert (mi.Bls12_377.pairing(p, q) == orc.pairing(p, q)).all()
 
 
+def test_pairing_value_golden_vector_and_random_pairs(orc, mi):
+    """the pairing VALUE (cube of the reduced ate pairing, every coefficient): the pyref-generated golden vector
+    tests/golden/pairing.json through the HIP library, a handful of random (P, Q) against the C oracle, bilinearity in
+    both arguments on the device's own values, and the points at infinity"""
+    import golden_util as G
+    d = G.load("pairing.json")
+    p, q = orc.g1_from_ints(G.pt(d["p"])), orc.g2_from_ints(G.g2_pt(d["q"]))
+    got = mi.Bls12_377.pairing(p, q)
+    assert orc.fq12_to_power_basis(got) == [G.h(c) for c in d["e_cubed_power_basis"]]
+    rng = P.SplitMix64(0xE0E0)
+    g, h = orc.g1_generator(), orc.g2_generator()
+    for _ in range(6):
+        a, b = rng.below(P.R, 5), rng.below(P.R, 5)
+        pa, qb = orc.g1_mul(g, a), orc.g2_mul(h, b)
+        e = mi.Bls12_377.pairing(pa, qb)
+        assert (e == orc.pairing(pa, qb)).all()
+        # e(aG, bH) == e(abG, H) == e(G, abH): three different Miller loops, one value
+        ab = a * b % P.R
+        assert (mi.Bls12_377.pairing(orc.g1_mul(g, ab), h) == e).all() and (mi.Bls12_377.pairing(g, orc.g2_mul(h, ab)) == e).all()
+    one = mi.Bls12_377.pairing(np.zeros(12, dtype=np.uint64), h)
+    assert (one == mi.Bls12_377.pairing(g, np.zeros(24, dtype=np.uint64))).all()
+    assert orc.fq12_to_power_basis(one) == [1] + [0] * 11
+
+
 def test_pairing_product(orc, mi):
     g, h = orc.g1_generator(), orc.g2_generator()
     a, b = 1234577, 99991
