@@ -42,6 +42,7 @@ PROOFS_PER_GPU = 1024
 # algorithmic bytes per unit of each profiled kernel (DESIGN.md "Measurement")
 ALG_BYTES = {
     "msm_accumulate": 128.0,        # per (point, scalar) pair: 96 B affine point + 32 B scalar
+    "msm_bitsums": 192.0,           # per chunk partial read (XYZZ, 4 x 48 B); units are the launch's points: see chip_alu_view
     "vs_derive": 2256.0 + 32.0,     # per proof: the proof record + its two 128-bit randomizers
     "pairing": 96.0 + 13264.0,      # per pair: one G1 point + one prepared G2 line table
     "ntt_pass": 64.0,               # per element per pass: 32 B read + 32 B written
@@ -212,7 +213,7 @@ def main():
             torch.distributed.destroy_process_group()
         return
 
-    dom = max((k for k in kernels if k in ALG_BYTES), key=lambda k: kernels[k]["total_ms"])
+    dom = max((k for k in kernels if k in ALG_BYTES and k != "msm_bitsums"), key=lambda k: kernels[k]["total_ms"])
     pmc_path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     traffic = None
     if os.path.exists(pmc_path):
@@ -253,8 +254,9 @@ def main():
                                                   if st1["exchange_calls"] > st0["exchange_calls"] else None),
                    "pipeline": "batches streamed: %d accumulation lanes, %d pairing products in flight, %d host fold threads"
                                % (args.acc_depth, args.products, args.fold_threads)},
-        "roofline": roofline, "alu": alu_view(kernels), "kernels": kernels,
+        "roofline": roofline, "alu": alu_view(kernels), "alu_chip": chip_alu_view(kernels, steady), "kernels": kernels,
     }
+    roofline["traffic_source"] = "profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of tools/profile_round.sh, committed; not measured in this run)"
     if world == 1:
         trace("one batch on its own")
         verifier.verify_batch(d_proofs, d_rnd)
@@ -304,6 +306,66 @@ def alu_view(kernels):
             "note": "one workgroup (3 waves, one CU) per product (its 21-workgroup line launch is bracketed separately); a launch carries "
                     "one to four products (a workgroup each: same duration, work and waves scale together, so the fraction is per "
                     "product); several launches run side by side in the streamed region, so avg_us includes their mutual slowdown"}
+
+
+# ---- chip-level ALU view of the streamed steady state: how much of the device's integer throughput a batch uses.
+# Work per batch in Fq-product equivalents on 28-bit limbs (one product = 14 x 14 v_mad_i64_i32 + reduction), counted from
+# the launch's own numbers (points per pass from the profiler's units, window width / windows / chunk length from the
+# library's plan):
+#   accumulate  one mixed addition (8 products + 2 squarings) per non-zero digit: points x windows x (1 - 2^-c); the
+#               128-bit randomizer side has ceil(129 / c) live windows
+#   bit sums    per (window, bit) group one wave: ceil(matches / 64) queue additions + 6 tree levels, each a full XYZZ
+#               addition (12 products + 2 squarings) on 64 lanes; matches = half the window's chunks
+#   derive      ~165 products per proof on 32-bit limbs (11 curve checks, ~250 Fr products, the SHA-256 transcript)
+#   pairing     450 rounds x 192 lanes x 179 limb products / 288 per product, on 32-bit limbs
+# against the rates tools/ubench.hip measures for a tight loop over the whole chip (8 waves/SIMD): 79.9 G products/s and
+# 96.7 G squarings/s on 28-bit limbs, 60 G products/s on 32-bit limbs.
+CHIP_RATE_28, CHIP_SQR_28, CHIP_RATE_32 = 79.9e9, 96.7e9, 60.0e9
+
+
+def chip_alu_view(kernels, steady_ms):
+    import ctypes as C
+    if "msm_accumulate" not in kernels or "vs_derive" not in kernels:
+        return None
+    pts = kernels["msm_accumulate"]["units_per_launch"]        # points of all MSMs of a lane pass
+    proofs = kernels["vs_derive"]["units_per_launch"]          # proofs of a lane pass (one or two batches)
+    batches = proofs / PROOFS_PER_GPU
+    c, nwin, chunk, small = C.c_int32(0), C.c_int32(0), C.c_int32(0), C.c_int32(0)
+    L.check(L.lib().mi_dbg_msm_plan(C.c_size_t(int(round(pts))), C.c_int32(254), C.byref(c), C.byref(nwin), C.byref(chunk), C.byref(small)), "mi_dbg_msm_plan")
+    c, nwin, chunk = c.value, nwin.value, chunk.value
+    n_w = 2.0 * proofs                                           # the tau-H side: two witnesses per proof, 128-bit scalars
+    n_h = pts - n_w
+    nwin_w = -(-129 // c)
+    live = 1.0 - 2.0 ** -c
+    sq = CHIP_RATE_28 / CHIP_SQR_28                              # a squaring in product equivalents
+    adds = (n_h * nwin + n_w * nwin_w) * live
+    acc = adds * (8 + 2 * sq)
+    buckets = 2 ** (c - 1)
+    def groups_work(n_points, windows):                          # per problem of ONE batch
+        per_bucket = n_points * live / buckets
+        chunks = buckets * max(1.0, per_bucket / chunk + 0.5)
+        wave_adds = -(-(chunks / 2) // 64) + 6
+        return windows * c * wave_adds * 64 * (12 + 2 * sq)
+    bits = batches * (groups_work(n_h / batches, nwin) + groups_work(n_w / batches, nwin_w))
+    derive = 165.0 * proofs * CHIP_RATE_28 / CHIP_RATE_32
+    pairing = batches * PAIRING_LIMB_PRODUCTS / 288.0 * CHIP_RATE_28 / CHIP_RATE_32
+    per_batch = (acc + bits + derive + pairing) / batches
+    out = {"unit": "Fq products/s (28-bit-limb equivalents)", "work_per_batch": per_batch,
+           "split_per_batch": {"msm_accumulate": acc / batches, "msm_bit_sums": bits / batches, "vs_derive": derive / batches, "pairing": pairing / batches},
+           "plan": {"points_per_pass": pts, "batches_per_pass": batches, "c": c, "windows": nwin, "chunk": chunk},
+           "steady_state_ms_per_batch": steady_ms, "achieved": per_batch / (steady_ms * 1e-3), "peak": CHIP_RATE_28,
+           "frac": per_batch / (steady_ms * 1e-3) / CHIP_RATE_28,
+           "note": "the whole chip over the middle of the stream; counts are analytic (formulas above chip_alu_view in bench.py), the "
+                   "host fold of the bit sums is not GPU work"}
+    ka = kernels["msm_accumulate"]
+    out["msm_accumulate_in_stream"] = {"avg_us": ka["avg_us"], "products_per_launch": acc, "achieved": acc / (ka["avg_us"] * 1e-6),
+                                       "note": "several passes share the device: this launch's own rate, not a fraction of the chip"}
+    if "msm_bitsums" in kernels:
+        kb = kernels["msm_bitsums"]
+        out["msm_bit_sums_in_stream"] = {"avg_us": kb["avg_us"], "products_per_launch": bits, "achieved": bits / (kb["avg_us"] * 1e-6),
+                                         "waves": bits / (64 * (12 + 2 * sq)) / (-(-(1) // 1)) and None}
+        out["msm_bit_sums_in_stream"].pop("waves")
+    return out
 
 
 def native_comm(rank, world, flag_device):

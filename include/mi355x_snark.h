@@ -436,6 +436,9 @@ int32_t mi_dbg_g1_add(const mi_g1_affine *a, const mi_g1_affine *b, mi_g1_affine
 int32_t mi_dbg_fq_mul28(const mi_fq *a, const mi_fq *b, mi_fq *out, size_t n);
 int32_t mi_dbg_g1_add28(const mi_g1_affine *a, const mi_g1_affine *b, mi_g1_affine *out, size_t n);
 int32_t mi_dbg_fq_mul_throughput(size_t n_threads, uint32_t iters, double *gmul_per_s);
+/* the plan an MSM of n points with scalars of scalar_bits (254 / 128) runs on: window width c, windows, chunk length, and
+ * whether it takes the latency-bound small path (work counts of the benchmark's ALU view) */
+int32_t mi_dbg_msm_plan(size_t n, int32_t scalar_bits, int32_t *c, int32_t *nwin, int32_t *chunk, int32_t *small_path);
 /* synthetic inputs made on the device: out[i] = k_i * G with k_i = splitmix64(seed + i) (distinct, in-subgroup) */
 int32_t mi_dbg_gen_points_device(uint64_t seed, size_t n, void *d_out, void *stream);
 

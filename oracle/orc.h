@@ -241,6 +241,27 @@ int orc_vs2_verify_aggregated(const orc_kzg_vk *vk, const orc_vs_key_ext *ext, c
                               const orc_vs_circuit_vk *circuits, const orc_vs_proof2 *proofs, size_t n,
                               const uint8_t *randomizers, uint8_t *alg_ok, orc_g1_affine totals[4], int threads);
 
+/* ---- Schnorr signatures over Edwards-BLS12 (orc_schnorr.c; pyref "Schnorr signatures") ----
+ * twisted Edwards -x^2 + y^2 = 1 + 3021 x^2 y^2 over Fr; subgroup order s (251 bits), cofactor 4; coordinates Montgomery Fr,
+ * scalars canonical integers below s */
+typedef struct { orc_fr x, y; } orc_ed_affine; /* 64 B; the identity is (0, 1) */
+typedef struct {
+    orc_ed_affine address;   /* the signer */
+    orc_fr message;          /* one field element: the batch id a certificate's signers sign */
+    uint64_t challenge[4], response[4];
+    orc_ed_affine pk_sig, pr_sig;
+} orc_sig_record; /* 288 B */
+void orc_ed_generator(orc_ed_affine *g);
+void orc_ed_order(uint64_t s[4]);
+int orc_ed_on_curve(const orc_ed_affine *p);
+void orc_ed_add(orc_ed_affine *r, const orc_ed_affine *p, const orc_ed_affine *q);
+void orc_ed_mul(orc_ed_affine *r, const orc_ed_affine *p, const uint64_t k[4]);
+void orc_ed_poseidon_permute(orc_fr *state, int width /* 5 or 9 */);
+void orc_ed_hash_to_scalar(uint64_t out[4], const orc_fr *inputs, int n, int rate /* 4 or 8 */);
+int orc_schnorr_verify_one(const orc_sig_record *r);
+void orc_schnorr_verify_batch(const orc_sig_record *recs, size_t n, uint8_t *verdicts, int threads);
+void orc_schnorr_generate(uint64_t seed, size_t n, size_t n_signers, uint32_t corrupt_per_1024, orc_sig_record *recs, uint8_t *expected);
+
 int orc_self_test(void);
 
 #ifdef __cplusplus

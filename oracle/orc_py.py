@@ -20,7 +20,7 @@ KZG_VK_BYTES = 480
 
 def build(force=False):
     so = os.path.join(_HERE, "liboracle.so")
-    srcs = [os.path.join(_HERE, f) for f in ("orc_core.c", "orc_algo.c", "orc.h", "orc_internal.h", "mont_tmpl.h", "constants.h")]
+    srcs = [os.path.join(_HERE, f) for f in ("orc_core.c", "orc_algo.c", "orc_schnorr.c", "orc.h", "orc_internal.h", "mont_tmpl.h", "constants.h")]
     if force or not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs if os.path.exists(s)):
         subprocess.check_call(["make", "-C", _HERE, "-B", "liboracle.so"], stdout=subprocess.DEVNULL)
     return so
@@ -565,3 +565,53 @@ class VSArrays(VSBatch):
         self.n_circuits = self.circuits.size // VS_CIRCUIT_VK_BYTES
         self.expected = expected
         self.seed = None
+
+
+# ----------------------------------------------------------------------------- Schnorr signatures over Edwards-BLS12 (8f row 4)
+SIG_RECORD_BYTES = 288
+
+
+def ed_generator():
+    g = u64(8)
+    lib().orc_ed_generator(_p(g))
+    return g
+
+
+def ed_to_ints(p):
+    p = np.asarray(p, dtype=np.uint64).reshape(8)
+    return fr_to_ints(p[:4])[0], fr_to_ints(p[4:])[0]
+
+
+def ed_from_ints(pt):
+    return np.concatenate([fr_from_ints([pt[0]])[0], fr_from_ints([pt[1]])[0]])
+
+
+def ed_mul(p, k):
+    out = u64(8)
+    lib().orc_ed_mul(_p(out), _p(np.ascontiguousarray(p, dtype=np.uint64)), _p(int_to_limbs(k, 4)))
+    return out
+
+
+def ed_hash_to_scalar(inputs_mont, rate):
+    """inputs: (n, 4) Montgomery Fr -> the 250-bit scalar"""
+    out = u64(4)
+    a = np.ascontiguousarray(inputs_mont, dtype=np.uint64).reshape(-1, 4)
+    lib().orc_ed_hash_to_scalar(_p(out), _p(a), C.c_int(len(a)), C.c_int(rate))
+    return limbs_to_int(out)
+
+
+class SigBatch:
+    """synthetic certificate signatures: record i is signer i % n_signers over message i // n_signers"""
+
+    def __init__(self, seed, n, n_signers=8, corrupt_per_1024=0):
+        self.n = n
+        self.records = np.zeros(n * SIG_RECORD_BYTES, dtype=np.uint8)
+        self.expected = np.zeros(n, dtype=np.uint8)
+        lib().orc_schnorr_generate(C.c_uint64(seed), C.c_size_t(n), C.c_size_t(n_signers), C.c_uint32(corrupt_per_1024), _p(self.records),
+                                   _p(self.expected))
+
+    def verify_cpu(self, threads=1, records=None):
+        r = self.records if records is None else np.ascontiguousarray(records, dtype=np.uint8).reshape(-1)
+        v = np.zeros(r.size // SIG_RECORD_BYTES, dtype=np.uint8)
+        lib().orc_schnorr_verify_batch(_p(r), C.c_size_t(len(v)), _p(v), C.c_int(threads))
+        return v

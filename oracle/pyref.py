@@ -1043,3 +1043,142 @@ def poseidon_hash(inputs, n_out, params=None):
         if len(out) < n_out:
             st = poseidon_permute(st, params)
     return out
+
+
+# ----------------------------------------------------------------------------- Schnorr signatures over Edwards-BLS12
+# What the BFT layer verifies per batch certificate: reference node/bft/src/helpers/storage.rs:465 (check_certificate ->
+# every signer's signature over the batch id), node/bft/src/gateway.rs:1391 (handshake, verify_bytes), account/src/lib.rs:76-88.
+# The scheme is snarkVM's console::account::Signature [RECALL: the crate is not in /root/reference; PARITY UNPINNED]:
+#   curve      twisted Edwards  a x^2 + y^2 = 1 + d x^2 y^2  over Fr of BLS12-377, a = -1, d = 3021; #E = 4 s with s the
+#              251-bit prime below (machine-checked here: s prime, 4 s in the Hasse interval, 4 s P = O for random P;
+#              a is a square and d is not, so the addition law is complete)
+#   keys       pk_sig = sk_sig G, pr_sig = r_sig G, sk_prf = H4(pk_sig.x, pr_sig.x), address = pk_sig + pr_sig + sk_prf G
+#   signature  (challenge c, response s, pk_sig, pr_sig) with s = k - c sk_sig for a nonce k, c = H8(kG.x, pk_sig.x, pr_sig.x,
+#              address.x, message...)
+#   verify     g_r = s G + c pk_sig;  c == H8(g_r.x, pk_sig.x, pr_sig.x, address.x, message...)  and the address identity.
+# H4 / H8: hash-to-scalar by a Poseidon sponge over Fr of rate 4 / 8 (width 5 / 9, x^17, 8 + 31 rounds), one permutation
+# for these input counts, the first rate element truncated to 250 bits.  snarkVM's generator, Poseidon constants and domain
+# separators are not available offline: the generator is derived below, the constants by the procedure of poseidon_params
+# over Fr -- same shape and cost, different numbers.
+ED_A, ED_D = R - 1, 3021
+ED_S = 2111115437357092606062206234695386632838870926408408195193685246394721360383  # subgroup order (251 bits); cofactor 4
+ED_ID = (0, 1)
+
+
+def ed_on_curve(p):
+    x, y = p
+    return (ED_A * x * x + y * y - 1 - ED_D * x * x * y * y) % R == 0
+
+
+def ed_add(p, q):
+    x1, y1 = p
+    x2, y2 = q
+    t = ED_D * x1 * x2 * y1 * y2 % R
+    return ((x1 * y2 + y1 * x2) * inv((1 + t) % R, R) % R, (y1 * y2 - ED_A * x1 * x2) * inv((1 - t) % R, R) % R)
+
+
+def ed_mul(p, k):
+    acc = ED_ID
+    for bit in bin(k)[2:] if k else "":
+        acc = ed_add(acc, acc)
+        if bit == "1":
+            acc = ed_add(acc, p)
+    return acc
+
+
+def fr_sqrt(v):
+    """a square root of v mod R (Tonelli-Shanks over the 2^47-th roots of unity), or None"""
+    v %= R
+    if v == 0:
+        return 0
+    if pow(v, (R - 1) // 2, R) != 1:
+        return None
+    s, t = FR_TWO_ADICITY, (R - 1) >> FR_TWO_ADICITY
+    m, c, x, b = s, pow(FR_GENERATOR, t, R), pow(v, (t + 1) // 2, R), pow(v, t, R)
+    while b != 1:
+        i, b2 = 0, b
+        while b2 != 1:
+            b2, i = b2 * b2 % R, i + 1
+        g = pow(c, 1 << (m - i - 1), R)
+        m, c, x, b = i, g * g % R, x * g % R, b * g * g % R
+    return x
+
+
+def ed_generator():
+    """4 (x, y) for the smallest x >= 2 that is the abscissa of a curve point, y the smaller root: a generator of the
+    order-s subgroup (own constant; snarkVM's is not available offline)"""
+    x = 2
+    while True:
+        y = fr_sqrt((1 - ED_A * x * x) * inv((1 - ED_D * x * x) % R, R) % R)
+        if y is not None:
+            g = ed_mul((x, min(y, R - y)), 4)
+            if g != ED_ID:
+                assert ed_mul(g, ED_S) == ED_ID
+                return g
+        x += 1
+
+
+ED_POSEIDON_TAG = b"MI355X-Poseidon-BLS12-377-Fr-v1"
+
+
+def ed_poseidon_params(width):
+    rounds = POSEIDON_RF + POSEIDON_RP
+    ark = [[int.from_bytes(sha256(ED_POSEIDON_TAG + bytes([width, r, i]) + b"\x00") + sha256(ED_POSEIDON_TAG + bytes([width, r, i]) + b"\x01"), "little") % R
+            for i in range(width)] for r in range(rounds)]
+    mds = [[inv((i + width + j) % R, R) for j in range(width)] for i in range(width)]
+    return ark, mds
+
+
+_ED_PARAMS = {}
+
+
+def ed_poseidon_permute(state):
+    w = len(state)
+    if w not in _ED_PARAMS:
+        _ED_PARAMS[w] = ed_poseidon_params(w)
+    ark, mds = _ED_PARAMS[w]
+    st = list(state)
+    half = POSEIDON_RF // 2
+    for r in range(POSEIDON_RF + POSEIDON_RP):
+        st = [(x + c) % R for x, c in zip(st, ark[r])]
+        if r < half or r >= half + POSEIDON_RP:
+            st = [pow(x, POSEIDON_ALPHA, R) for x in st]
+        else:
+            st[0] = pow(st[0], POSEIDON_ALPHA, R)
+        st = [sum(mds[i][j] * st[j] for j in range(w)) % R for i in range(w)]
+    return st
+
+
+def ed_hash_to_scalar(inputs, rate):
+    """one permutation of the width rate + 1 sponge: capacity = 2^64 * rate + number of inputs (domain separation), the
+    inputs in the rate part; the first rate element's low 250 bits"""
+    assert len(inputs) <= rate
+    st = [((rate << 64) + len(inputs)) % R] + [x % R for x in inputs] + [0] * (rate - len(inputs))
+    return ed_poseidon_permute(st)[1] & ((1 << 250) - 1)
+
+
+def schnorr_keygen(sk_sig, r_sig, g=None):
+    g = g or ed_generator()
+    pk_sig, pr_sig = ed_mul(g, sk_sig % ED_S), ed_mul(g, r_sig % ED_S)
+    sk_prf = ed_hash_to_scalar([pk_sig[0], pr_sig[0]], 4)
+    return pk_sig, pr_sig, ed_add(ed_add(pk_sig, pr_sig), ed_mul(g, sk_prf))
+
+
+def schnorr_sign(sk_sig, r_sig, nonce, message, g=None):
+    g = g or ed_generator()
+    pk_sig, pr_sig, address = schnorr_keygen(sk_sig, r_sig, g)
+    g_r = ed_mul(g, nonce % ED_S)
+    c = ed_hash_to_scalar([g_r[0], pk_sig[0], pr_sig[0], address[0]] + list(message), 8)
+    return {"challenge": c, "response": (nonce - c * sk_sig) % ED_S, "pk_sig": pk_sig, "pr_sig": pr_sig}, address
+
+
+def schnorr_verify(address, message, sig, g=None):
+    g = g or ed_generator()
+    c, s, pk_sig, pr_sig = sig["challenge"], sig["response"], sig["pk_sig"], sig["pr_sig"]
+    if c >= ED_S or s >= ED_S or not (ed_on_curve(pk_sig) and ed_on_curve(pr_sig) and ed_on_curve(address)):
+        return False
+    g_r = ed_add(ed_mul(g, s), ed_mul(pk_sig, c))
+    if ed_hash_to_scalar([g_r[0], pk_sig[0], pr_sig[0], address[0]] + list(message), 8) != c:
+        return False
+    sk_prf = ed_hash_to_scalar([pk_sig[0], pr_sig[0]], 4)
+    return ed_add(ed_add(pk_sig, pr_sig), ed_mul(g, sk_prf)) == address

@@ -43,6 +43,7 @@ void msm_finish(Context &cx, MsmJob *job, hipStream_t st, mi_g1_jac *out, mi_g1_
 // all problems' results: outs[p] may be null (result not wanted), n_outs <= MSM_MAX_PROBLEMS
 void msm_finish_all(Context &cx, MsmJob *job, hipStream_t st, mi_g1_jac *const *outs, int n_outs);
 size_t msm_small_limit();  // largest n on the latency-bound small path (the only one that takes a split)
+void msm_plan_query(size_t n, int scalar_bits, int *c, int *nwin, int *chunk, int *small);
 void msm_device(Context &cx, const G1Affine *d_points, const uint32_t *d_scalars, size_t n, mi_g1_jac *out,
                 hipStream_t st, int scalar_bits = 254, int force_c = 0);
 

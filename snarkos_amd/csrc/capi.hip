@@ -1099,6 +1099,16 @@ int32_t mi_dbg_gen_points_device(uint64_t seed, size_t n, void *d_out, void *str
     });
 }
 
+int32_t mi_dbg_msm_plan(size_t n, int32_t scalar_bits, int32_t *c, int32_t *nwin, int32_t *chunk, int32_t *small_path) {
+    if (!n || !c || !nwin || !chunk || !small_path) return MI_ERR_BAD_ARGS;
+    int a, b, t, s;
+    msm_plan_query(n, scalar_bits, &a, &b, &t, &s);
+    *c = a;
+    *nwin = b;
+    *chunk = t;
+    *small_path = s;
+    return MI_OK;
+}
 int32_t mi_prof_enable(int32_t on) {
     return guarded([&](Context &cx) -> int32_t {
         cx.prof.level = on < 0 ? 0 : (on > 2 ? 2 : on);

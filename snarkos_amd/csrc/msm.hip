@@ -105,6 +105,17 @@ static MsmPlan msm_plan(size_t n, int scalar_bits, int force_c) {
     return p;
 }
 
+// the plan an MSM of n points would run on (diagnostics: bench.py's work counts)
+void msm_plan_query(size_t n, int scalar_bits, int *c, int *nwin, int *chunk, int *small) {
+    const MsmPlan p = msm_plan(n, scalar_bits, 0);
+    *c = p.c;
+    *nwin = p.nwin;
+    *small = n <= msm_small_limit() ? 1 : 0;
+    uint32_t T = (uint32_t)(2 * ((n + p.B - 1) / p.B));
+    if (T < 16) T = 16;
+    *chunk = *small ? (int)msm_small_chunk() : (int)T;
+}
+
 // ---------------------------------------------------------------- K1: signed digits + histogram
 template <int C, int BITS>
 __global__ void __launch_bounds__(256) msm_digits_kernel(const uint32_t *__restrict__ scalars, size_t n,

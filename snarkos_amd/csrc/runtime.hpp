@@ -251,7 +251,7 @@ struct Profiler {
     std::vector<hipEvent_t> pool;  // recycled events: creating one costs microseconds
     static bool headline(const char *name) {
         return !strcmp(name, "pairing") || !strcmp(name, "msm_accumulate") || !strcmp(name, "vs_derive") ||
-               !strcmp(name, "ntt_pass") || !strcmp(name, "msm_total");
+               !strcmp(name, "ntt_pass") || !strcmp(name, "msm_total") || !strcmp(name, "msm_bitsums") || !strcmp(name, "vs_wire_decode");
     }
     bool active(const char *name) const { return level >= 2 || (level == 1 && headline(name)); }
     hipEvent_t get() {

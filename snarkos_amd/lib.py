@@ -54,7 +54,7 @@ EXPORTS = [
     "mi_vs_stream_open", "mi_vs_stream_submit", "mi_vs_stream_finish", "mi_vs_stream_next", "mi_vs_stream_next_verdicts", "mi_vs_stream_close",
     "mi_comm_unique_id", "mi_comm_init_rank", "mi_comm_init_local", "mi_comm_world", "mi_comm_transport", "mi_comm_destroy", "mi_comm_all_gather",
     "mi_vs_exchange_rccl",
-    "mi_dbg_fq_mul", "mi_dbg_fq_mul28", "mi_dbg_g1_add28", "mi_dbg_fr_mul", "mi_dbg_g1_add", "mi_dbg_fq_mul_throughput", "mi_dbg_gen_points_device",
+    "mi_dbg_fq_mul", "mi_dbg_fq_mul28", "mi_dbg_g1_add28", "mi_dbg_fr_mul", "mi_dbg_g1_add", "mi_dbg_fq_mul_throughput", "mi_dbg_gen_points_device", "mi_dbg_msm_plan",
     "mi_prof_enable", "mi_prof_read",
 ]
 
