@@ -665,6 +665,31 @@ def extras(dev, verifier, proofs, rnd):
         ex["batch_1024_v3_compressed"] = wire_one.measure(dev)
     except Exception as e:  # noqa: BLE001
         ex["batch_1024_v3_compressed"] = {"error": str(e)}
+    # --- the signatures of a subdag's batch certificates (100 certificates x 67 signers: the quorum of a
+    # 100-validator committee), Schnorr over Edwards-BLS12, one call; the oracle on the host cores beside it
+    try:
+        sys.path.insert(0, os.path.join(ROOT, "oracle"))
+        import orc_py as O
+        nsig = 6700
+        sb = O.SigBatch(0xA1E00005, nsig, 100, 0)
+        d_sig = torch.from_numpy(sb.records).to(dev)
+        outv = A.SchnorrBatch.verify(d_sig)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(5):
+            outv = A.SchnorrBatch.verify(d_sig)
+        torch.cuda.synchronize()
+        dts = (time.perf_counter() - t0) / 5
+        cores = usable_cores()
+        t0 = time.perf_counter()
+        cpu_v = sb.verify_cpu(cores, sb.records[:1024 * 288])
+        dtc = time.perf_counter() - t0
+        ex["schnorr_certificate_signatures"] = {"signatures": nsig, "ms": 1e3 * dts, "signatures_per_s": nsig / dts,
+                                                "all_valid": bool(outv.all().item()) and bool(cpu_v.all()),
+                                                "cpu_signatures_per_s": 1024 / dtc, "cpu_cores": cores,
+                                                "note": "100 certificates x 67 signers; [RECALL] scheme, own generator / Poseidon constants: parity unpinned"}
+    except Exception as e:  # noqa: BLE001
+        ex["schnorr_certificate_signatures"] = {"error": str(e)}
     # --- the 1024-proof batch under the Poseidon Fiat-Shamir transcript (row A9 on the path: 37 permutations per proof)
     try:
         dp = np.load(os.path.join(ROOT, "tests", "golden", "vs_batch_1024_poseidon.npz"))

@@ -419,6 +419,29 @@ int32_t mi_g1_decompress(const uint8_t *compressed48, size_t n, int32_t check_su
 int32_t mi_g1_decompress_device(const void *d_compressed48, size_t n, int32_t check_subgroup, void *d_out, void *d_ok, void *stream);
 int32_t mi_g1_compress(const mi_g1_affine *points, size_t n, uint8_t *compressed48_out);
 
+/* ---- batch-certificate signatures: Schnorr over Edwards-BLS12, many at once ----
+ * Replaces the per-signature `signature.verify(&address, &[batch_id])` loop over a certificate's signers (reference
+ * node/bft/src/helpers/storage.rs:465 check_certificate, node/bft/src/gateway.rs:1391 verify_bytes, account/src/lib.rs:76-88),
+ * i.e. snarkVM's console::account::Signature::verify [RECALL: the crate is not in /root/reference -- parity unpinned]:
+ *   g_r = response G + challenge pk_sig;  challenge == H8(g_r.x, pk_sig.x, pr_sig.x, address.x, message)  and
+ *   address == pk_sig + pr_sig + H4(pk_sig.x, pr_sig.x) G
+ * on the twisted Edwards curve -x^2 + y^2 = 1 + 3021 x^2 y^2 over Fr (subgroup order s of 251 bits, cofactor 4), H4 / H8 =
+ * one permutation of a Poseidon sponge over Fr of rate 4 / 8 truncated to 250 bits.  The generator and the Poseidon
+ * constants are this library's own (tools/gen_constants.py; snarkVM's are not available offline).  Coordinates and the
+ * message are Montgomery Fr, the scalars canonical integers below s.  verdicts[i] = 1: valid.  Checked per record: fields
+ * below r, scalars below s, the three points on the curve; NOT checked: membership of the points in the order-s subgroup
+ * (snarkVM's deserialiser guarantees it for what it hands out).  Records here carry affine points; the 32-byte
+ * x-coordinate encoding is a next step. */
+typedef struct { mi_fr x, y; } mi_ed_affine; /* 64 B; the identity is (0, 1) */
+typedef struct {
+    mi_ed_affine address;
+    mi_fr message;                 /* one field element: the batch id a certificate's signers sign */
+    mi_bigint256 challenge, response;
+    mi_ed_affine pk_sig, pr_sig;   /* the signature's compute key */
+} mi_sig_record; /* 288 B */
+int32_t mi_schnorr_verify_batch(const mi_sig_record *recs, size_t n, uint8_t *verdicts);
+int32_t mi_schnorr_verify_batch_device(const void *d_recs, size_t n, void *d_verdicts, void *stream);
+
 /* ---- crypto_hash::PoseidonSponge<Fq, 2, 1>, many independent sponges at once ----
  * Structure as snarkVM's (width 3, S-box x^17, 8 full + 31 partial rounds); the round constants and MDS matrix
  * are this library's own (tools/gen_constants.py): snarkVM's are not available offline, so this is the kernel a

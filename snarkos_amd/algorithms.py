@@ -281,6 +281,28 @@ class G1Codec:
         return out
 
 
+class SchnorrBatch:
+    """Batch-certificate signatures: Schnorr over Edwards-BLS12, a certificate's (or a subdag's)
+    signatures verified in one call; the role of `signature.verify(&address, &[batch_id])` over the signers in
+    Storage::check_certificate (reference node/bft/src/helpers/storage.rs:465)."""
+
+    @staticmethod
+    def verify(records, stream=None):
+        """records: n x 288 bytes (mi_sig_record), host array or CUDA tensor -> uint8[n] verdicts (tensor in, tensor out)"""
+        if _is_torch_cuda(records):
+            import torch
+            n = records.numel() * records.element_size() // L.SIG_RECORD_BYTES
+            out = torch.empty(n, dtype=torch.uint8, device=records.device)
+            L.check(L.lib().mi_schnorr_verify_batch_device(L.dptr(records), C.c_size_t(n), L.dptr(out), L.stream_ptr(stream)),
+                    "mi_schnorr_verify_batch_device")
+            return out
+        r = np.ascontiguousarray(records).view(np.uint8).reshape(-1)
+        n = r.size // L.SIG_RECORD_BYTES
+        out = np.zeros(n, dtype=np.uint8)
+        L.check(L.lib().mi_schnorr_verify_batch(L.ptr(r), C.c_size_t(n), L.ptr(out)), "mi_schnorr_verify_batch")
+        return out
+
+
 class KZG10:
     """snarkvm_algorithms::polycommit::kzg10::KZG10"""
 

@@ -15,7 +15,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(CSRC, "_obj")
 LIB = os.path.join(HERE, "libmi355x_snark.so")
-UNITS = ["capi", "msm", "ntt", "pairing", "verify", "stream", "comm"]
+UNITS = ["capi", "msm", "ntt", "pairing", "verify", "stream", "comm", "schnorr"]
 PLAIN_UNITS = ["cpu_probe"]  # host-only C++ built WITHOUT the x86-64-v3 / ADX flags (it is what checks for them)
 # host side: x86-64-v3 (BMI2 mulx) + ADX for the 64-bit-limb host products; every MI355X host CPU has them
 FLAGS = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", "-march=x86-64-v3", "-madx"]

@@ -37,6 +37,7 @@ VS4_PROOF_BYTES = 6320  # mi_vs_proof4 (shapes with max_circuits > 1)
 VS_WIRE = 2  # mi_vs_ctx_create_* flag: records arrive in the wire form (compressed points, canonical Fr)
 VS2_KEY_EXT_BYTES = 480
 VS2_SHAPE_BYTES = 56
+SIG_RECORD_BYTES = 288  # mi_sig_record
 
 # every symbol include/mi355x_snark.h declares
 EXPORTS = [
@@ -47,7 +48,7 @@ EXPORTS = [
     "mi_kzg_commit_hiding_h", "mi_kzg_open_hiding_h", "mi_kzg_commit_lagrange_h",
     "mi_ntt_divide_by_vanishing_on_coset", "mi_ntt_divide_by_vanishing_on_coset_device",
     "mi_pairing_product_is_one", "mi_pairing", "mi_kzg_batch_check", "mi_kzg_batch_check_hiding",
-    "mi_poseidon_fq_hash_many", "mi_poseidon_fq_hash_many_device",
+    "mi_poseidon_fq_hash_many", "mi_poseidon_fq_hash_many_device", "mi_schnorr_verify_batch", "mi_schnorr_verify_batch_device",
     "mi_vs_ctx_create", "mi_vs_ctx_create_ex", "mi_vs_ctx_create_v2", "mi_vs_ctx_destroy", "mi_vs_verify_batch", "mi_vs_verify_batch_device", "mi_vs_identify_device",
     "mi_vs_accumulate_device", "mi_vs_accumulate_begin", "mi_vs_accumulate_end", "mi_vs_accumulate_begin_pair", "mi_vs_accumulate_end_pair", "mi_vs_accumulate_begin_multi", "mi_vs_accumulate_end_multi", "mi_vs_batches_per_pass", "mi_g1_decompress", "mi_g1_decompress_device", "mi_g1_compress", "mi_vs_finalize", "mi_vs_finalize_async", "mi_vs_finalize_wait", "mi_vs_finalize_async_multi", "mi_vs_finalize_wait_multi",
     "mi_vs_verify_block", "mi_vs_verify_block_device",

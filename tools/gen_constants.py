@@ -209,8 +209,95 @@ def emit(prefix, static_kw):
     return "\n".join(o) + "\n"
 
 
+# ---- Edwards-BLS12 (Schnorr signatures of batch certificates): twisted Edwards a = -1, d = 3021 over
+# Fr [RECALL for the parameters; checked below], subgroup order s, cofactor 4.  The generator and the Poseidon constants
+# over Fr are this repo's own (snarkVM's are not available offline): same derivation as oracle/pyref.py, written again.
+ED_D = 3021
+ED_S = 2111115437357092606062206234695386632838870926408408195193685246394721360383
+assert is_probable_prime(ED_S) and abs(4 * ED_S - (R + 1)) <= 2 * int(R ** 0.5) + 2
+assert pow(R - 1, (R - 1) // 2, R) == 1 and pow(ED_D, (R - 1) // 2, R) == R - 1  # a square, d not: complete addition law
+
+
+def _ed_add(p, q):
+    (x1, y1), (x2, y2) = p, q
+    t = ED_D * x1 * x2 * y1 * y2 % R
+    return ((x1 * y2 + y1 * x2) * pow(1 + t, -1, R) % R, (y1 * y2 + x1 * x2) * pow(1 - t, -1, R) % R)
+
+
+def _ed_mul(p, k):
+    acc = (0, 1)
+    while k:
+        if k & 1:
+            acc = _ed_add(acc, p)
+        p = _ed_add(p, p)
+        k >>= 1
+    return acc
+
+
+def _fr_sqrt(v):
+    if pow(v, (R - 1) // 2, R) != 1:
+        return None
+    t = (R - 1) >> 47
+    m, c, x, b = 47, pow(22, t, R), pow(v, (t + 1) // 2, R), pow(v, t, R)
+    while b != 1:
+        i, b2 = 0, b
+        while b2 != 1:
+            b2, i = b2 * b2 % R, i + 1
+        g = pow(c, 1 << (m - i - 1), R)
+        m, c, x, b = i, g * g % R, x * g % R, b * g * g % R
+    return x
+
+
+def _ed_generator():
+    x = 2
+    while True:
+        y = _fr_sqrt((1 + x * x) * pow(1 - ED_D * x * x, -1, R) % R)
+        if y is not None:
+            g = _ed_mul((x, min(y, R - y)), 4)
+            if g != (0, 1):
+                assert _ed_mul(g, ED_S) == (0, 1)
+                return g
+        x += 1
+
+
+ED_GEN = _ed_generator()
+ED_TAG = b"MI355X-Poseidon-BLS12-377-Fr-v1"
+
+
+def _ed_ark(width):
+    return [[int.from_bytes(hashlib.sha256(ED_TAG + bytes([width, r, i]) + b"\x00").digest()
+                            + hashlib.sha256(ED_TAG + bytes([width, r, i]) + b"\x01").digest(), "little") % R
+             for i in range(width)] for r in range(POSEIDON_ROUNDS)]
+
+
+def emit_ed():
+    o = []
+    a = o.append
+    a("/* GENERATED by tools/gen_constants.py -- do not edit.  Edwards-BLS12 over Fr of BLS12-377: -x^2 + y^2 = 1 + d x^2 y^2. */")
+    a("#pragma once")
+    a("#include <stdint.h>")
+    a("static const uint64_t MI_ED_D[4] = %s; /* 3021, Montgomery */" % fr(ED_D))
+    a("static const uint64_t MI_ED_2D[4] = %s;" % fr(2 * ED_D))
+    a("static const uint64_t MI_ED_ORDER[4] = %s; /* the subgroup order s (251 bits), canonical */" % arr(ED_S, 4))
+    a("static const uint64_t MI_ED_GEN[2][4] = {%s, %s}; /* own generator: 4 (x, y), smallest x >= 2 on the curve */" % (fr(ED_GEN[0]), fr(ED_GEN[1])))
+    for w in (5, 9):
+        ark = _ed_ark(w)
+        a("/* Poseidon over Fr, width %d (rate %d): x^17, 4 + 31 + 4 rounds, own constants (Montgomery) */" % (w, w - 1))
+        a("static const uint64_t MI_ED_ARK%d[39][%d][4] = {" % (w, w))
+        for r in range(POSEIDON_ROUNDS):
+            a("  {" + ", ".join(fr(ark[r][i]) for i in range(w)) + "},")
+        a("};")
+        a("static const uint64_t MI_ED_MDS%d[%d][%d][4] = {" % (w, w, w))
+        for i in range(w):
+            a("  {" + ", ".join(fr(pow(i + w + j, -1, R)) for j in range(w)) + "},")
+        a("};")
+    return "\n".join(o) + "\n"
+
+
 def main():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with open(os.path.join(root, "snarkos_amd", "csrc", "ed_constants.hpp"), "w") as f:
+        f.write(emit_ed())
     with open(os.path.join(root, "oracle", "constants.h"), "w") as f:
         f.write(emit("ORC_", "static const"))
     os.makedirs(os.path.join(root, "snarkos_amd", "csrc"), exist_ok=True)
