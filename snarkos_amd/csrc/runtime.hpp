@@ -1,6 +1,7 @@
 // Device context, workspace cache and error plumbing shared by every entry point.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <sched.h>
 #include <stdint.h>
 #include <stdio.h>
 #include <string.h>
@@ -85,8 +86,39 @@ class WorkerPool {
     std::condition_variable cv_;
     bool stop_ = false;
 };
+// Workers: what the process may run on (its affinity mask) less the driver's own threads (submitter, folders, finisher,
+// publisher), between 4 and 16; MI_SNARK_POOL overrides.  A burst of a dozen lane passes ends with a dozen folds of 8
+// tasks each at about the same time: with 8 workers that queue was the tail of a short stream.
+inline int worker_pool_size() {
+    if (const char *e = getenv("MI_SNARK_POOL")) {
+        const int x = atoi(e);
+        if (x >= 1 && x <= 64) return x;
+    }
+    int cores = (int)std::thread::hardware_concurrency();
+    cpu_set_t set;
+    CPU_ZERO(&set);
+    if (sched_getaffinity(0, sizeof set, &set) == 0) {
+        const int c = CPU_COUNT(&set);
+        if (c > 0 && (cores <= 0 || c < cores)) cores = c;
+    }
+    {   // a container's CPU quota counts, not the host's core count (cgroup v2: "max" or "<quota> <period>")
+        FILE *f = fopen("/sys/fs/cgroup/cpu.max", "r");
+        if (f) {
+            long long q = 0, per = 0;
+            if (fscanf(f, "%lld %lld", &q, &per) == 2 && q > 0 && per > 0) {
+                const int c = (int)(q / per);
+                if (c > 0 && c < cores) cores = c;
+            }
+            fclose(f);
+        }
+    }
+    int n = cores - 4;
+    if (n < 4) n = 4;
+    if (n > 16) n = 16;
+    return n;
+}
 inline WorkerPool &worker_pool() {
-    static WorkerPool p(8);
+    static WorkerPool p(worker_pool_size());
     return p;
 }
 
