@@ -161,6 +161,9 @@ struct VsWireMap {
     uint16_t pt_wire[32], pt_rec[32];
     uint8_t pt_cls[32];
     struct Run { uint16_t wire, rec, count; uint8_t type, cls; } run[24];  // type 0: raw bytes (count = bytes), 1: Fr fields
+    // parts of the record that no run and no point slot covers (slots the shape never uses): the decode zeroes them
+    uint32_t n_gaps;
+    struct Gap { uint16_t rec, bytes; } gap[16];
 };
 // terms / chains of one proof in the per-proof fallback (see vs_terms_kernel): its own H-side points, the commitments of
 // up to max_circ circuits, G (and gamma_g), the two witnesses on the tau-H side, the class accumulators' points
@@ -222,6 +225,22 @@ static void vs_build_wire_map(VsWireMap &m, const VsConsts &hc, bool has_shape) 
     m.rec_bytes = r;
     m.max_inst = hc.max_inst;
     m.max_circ = hc.max_circ;
+    // what is left uncovered (16-byte granules: every field is a multiple of 16 bytes at a multiple of 16)
+    std::vector<uint8_t> covered(r / 16, 0);
+    for (uint32_t k = 0; k < m.n_runs; k++) {
+        const uint32_t bytes = m.run[k].type ? 32u * m.run[k].count : m.run[k].count;
+        for (uint32_t b = 0; b < bytes; b += 16) covered[(m.run[k].rec + b) / 16] = 1;
+    }
+    for (uint32_t k = 0; k < m.n_pts; k++)
+        for (uint32_t b = 0; b < 96; b += 16) covered[(m.pt_rec[k] + b) / 16] = 1;
+    for (uint32_t g = 0; g < covered.size();) {
+        if (covered[g]) { g++; continue; }
+        uint32_t e = g;
+        while (e < covered.size() && !covered[e]) e++;
+        if (m.n_gaps >= 16) throw std::runtime_error("wire map: too many gaps");
+        m.gap[m.n_gaps++] = VsWireMap::Gap{(uint16_t)(16 * g), (uint16_t)(16 * (e - g))};
+        g = e;
+    }
 }
 // where one proof's operands go (device pointers into the lane's workspace)
 struct VsOut {
@@ -1451,7 +1470,8 @@ __device__ __forceinline__ bool vs_wire_used(uint32_t cls, uint32_t m1, uint32_t
     return cls == 0 || (cls >= 8 ? cls - 8 < d1 : cls - 2 < m1);
 }
 // a lane per proof: headers as they are, Fr fields canonical -> Montgomery (not below r: the proof's flag is cleared and
-// the field stays zero).  The decoded records were zeroed beforehand: unused slots are not written.
+// the field is zero).  Every byte of the decoded record is written by this kernel or the points kernel (runs the record
+// does not use and the gaps of the map are zeroed here): no memset of the record buffer is needed.
 __global__ void __launch_bounds__(64) vs_wire_fields_kernel(VsWireJobs jobs, uint32_t n_all, const VsWireMap *__restrict__ wm) {
     const uint32_t g = blockIdx.x * 64 + threadIdx.x;
     if (g >= n_all) return;
@@ -1462,20 +1482,27 @@ __global__ void __launch_bounds__(64) vs_wire_fields_kernel(VsWireJobs jobs, uin
     uint32_t m1, d1;
     vs_wire_counts(w, wm, m1, d1);
     bool ok = true;
+    const uint4 zero4 = make_uint4(0, 0, 0, 0);
     for (uint32_t k = 0; k < wm->n_runs; k++) {
         const VsWireMap::Run run = wm->run[k];
-        if (!vs_wire_used(run.cls, m1, d1)) continue;
+        const bool used = vs_wire_used(run.cls, m1, d1);
         if (run.type == 0) {
             for (uint32_t b = 0; b < run.count; b += 16)
-                *reinterpret_cast<uint4 *>(r + run.rec + b) = *reinterpret_cast<const uint4 *>(w + run.wire + b);
+                *reinterpret_cast<uint4 *>(r + run.rec + b) = used ? *reinterpret_cast<const uint4 *>(w + run.wire + b) : zero4;
         } else {
             for (uint32_t j = 0; j < run.count; j++) {
-                const Fr c = fr_load(w + run.wire + 32 * j);
-                if (vs_limbs_below(c.l, FrP::MOD, 8)) fr_store(r + run.rec + 32 * j, to_mont(c));
-                else ok = false;
+                Fr v = Fr::zero();
+                if (used) {
+                    const Fr c = fr_load(w + run.wire + 32 * j);
+                    if (vs_limbs_below(c.l, FrP::MOD, 8)) v = to_mont(c);
+                    else ok = false;
+                }
+                fr_store(r + run.rec + 32 * j, v);
             }
         }
     }
+    for (uint32_t k = 0; k < wm->n_gaps; k++)
+        for (uint32_t b = 0; b < wm->gap[k].bytes; b += 16) *reinterpret_cast<uint4 *>(r + wm->gap[k].rec + b) = zero4;
     jb.dec_ok[i] = ok ? 1 : 0;
 }
 // TWO waves per 64 (proof, point slot of the shape) pairs: 48 bytes -> the affine point (codec28.hpp: one wave takes
@@ -1487,7 +1514,8 @@ __global__ void __launch_bounds__(128) vs_wire_points_kernel(VsWireJobs jobs, ui
     const uint8_t *src = nullptr;
     uint32_t i = 0, slot = 0;
     int k = 0;
-    if (g < n_all * NP) {
+    const bool in_range = g < n_all * NP;
+    if (in_range) {
         const uint32_t gp = g / NP;
         slot = g - gp * NP;
         k = jobs.of(gp);
@@ -1499,10 +1527,10 @@ __global__ void __launch_bounds__(128) vs_wire_points_kernel(VsWireJobs jobs, ui
     }
     G1Affine pt;
     const bool ok = g1_decode28(src, true, T, c28_lds, pt);
-    if (threadIdx.x < 64 && src) {  // the root wave holds the verdict and the point
+    if (threadIdx.x < 64 && in_range) {  // the root wave holds the verdict and the point (infinity when there is none)
         const VsWireJobs::B &jb = jobs.b[k];
-        if (ok) copy_g1(reinterpret_cast<G1Affine *>(jb.rec + (size_t)i * wm->rec_bytes + wm->pt_rec[slot]), &pt);
-        else jb.dec_ok[i] = 0;  // only ever cleared here; the fields kernel (earlier on the stream) set it
+        copy_g1(reinterpret_cast<G1Affine *>(jb.rec + (size_t)i * wm->rec_bytes + wm->pt_rec[slot]), &pt);
+        if (src && !ok) jb.dec_ok[i] = 0;  // only ever cleared here; the fields kernel (earlier on the stream) set it
     }
 }
 
@@ -1609,7 +1637,6 @@ static void vs_run_derive(Context &cx, VsKeys &v, const void *const *d_proofs_in
             first += ns[k];
         }
         cx.prof.begin("vs_wire_decode", st, n_all);
-        MI_HIP(hipMemsetAsync(exp, 0, (size_t)wm.rec_bytes * n_all, st));
         hipLaunchKernelGGL(vs_wire_fields_kernel, dim3((unsigned)cdiv(n_all, 64)), dim3(64), 0, st, jobs, (uint32_t)n_all, (const VsWireMap *)v.wire_map.p);
         hipLaunchKernelGGL(vs_wire_points_kernel, dim3((unsigned)cdiv(n_all * wm.n_pts, 64)), dim3(128), C28_LDS_BYTES, st, jobs, (uint32_t)n_all,
                            (const VsWireMap *)v.wire_map.p, sqrt_tables(cx, st));

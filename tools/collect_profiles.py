@@ -18,7 +18,7 @@ import shutil
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
 src = os.path.join(ROOT, "gpurun_out", tag)
 dst = os.path.join(ROOT, "profiles")
 os.makedirs(dst, exist_ok=True)
@@ -43,7 +43,9 @@ for pat, out in (("stats/*/*_kernel_stats.csv", "%s_rocprofv3_kernel_stats.csv" 
                  ("stats_bench.json", "%s_bench_under_rocprofv3.json" % tag),
                  ("msm20_stats/*/*_kernel_stats.csv", "%s_msm20_kernel_stats.csv" % tag),
                  ("ntt22_stats/*/*_kernel_stats.csv", "%s_ntt22_kernel_stats.csv" % tag),
-                 ("batch_stats/*/*_kernel_stats.csv", "%s_one_batch_kernel_stats.csv" % tag)):
+                 ("batch_stats/*/*_kernel_stats.csv", "%s_one_batch_kernel_stats.csv" % tag),
+                 ("wire_stats/*/*_kernel_stats.csv", "%s_wire_batch_kernel_stats.csv" % tag), ("wire.json", "%s_wire_batch.json" % tag),
+                 ("schnorr_stats/*/*_kernel_stats.csv", "%s_schnorr_kernel_stats.csv" % tag)):
     f = newest(pat)
     if f:
         shutil.copy(f, os.path.join(dst, out))
