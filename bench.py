@@ -26,6 +26,8 @@ import time
 # streams of this process (torch's, 8 accumulation lanes, 8 in-flight pairing products) should not share
 # hardware queues: a 3 ms pairing kernel must not sit in front of the next batch's MSM kernels
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "32")
+# RCCL prints a version banner on stdout at init when NCCL_DEBUG asks for it: the driver reads ONE JSON line from there
+os.environ["NCCL_DEBUG"] = os.environ.get("MI_BENCH_NCCL_DEBUG", "WARN")
 
 import numpy as np  # noqa: E402
 import torch  # noqa: E402

@@ -351,7 +351,11 @@ struct VsPipe {
     hipEvent_t acc_ev[VS_ACC_DEPTH] = {};
     VsSlot slots[VS_SLOTS];  // pairing products run on the slots' streams, beside the next batches' accumulation
     uint64_t next_acc = 2, next_ticket = 1;
-    bool primed = false;  // every lane has run one accumulation (workspaces, pinned buffers, hardware queues exist)
+    // every lane has run one accumulation of at least this footprint (workspaces, pinned buffers, hardware queues exist):
+    // the MSM points and the record bytes of the largest pass primed so far.  A later context with a larger shape (or
+    // larger batches) primes again, once, instead of growing each lane's ~25 workspaces in mid-stream (every regrow
+    // drains the device: ADVICE r2).
+    size_t primed_points = 0, primed_bytes = 0;
     VsPipe() {  // the device is current (Context::mod is only called under guarded_on)
         if (const char *e = getenv("MI_SNARK_VS_LANES")) {
             const int x = atoi(e);
@@ -1797,11 +1801,30 @@ static int32_t vs_accumulate_begin_impl(Context &cx, const VsCtx &vc, const void
         if (!tl_ctx_lock) return MI_ERR_AGAIN;
         cx.lane_cv.wait(*tl_ctx_lock);  // ends (any thread) and context destruction signal it
     }
-    if (!pp.primed) {
+    const int per_pass_prime = vs_max_per_pass(v, n);
+    size_t need_points = 0, need_bytes = 0;
+    {
+        VsWork wq;
+        vs_work_sizes(v, n, wq);
+        need_points = vs_work_total(wq) * (size_t)per_pass_prime;
+        need_bytes = (size_t)v.shape.proof_words * 4 * n * (size_t)per_pass_prime;
+        if (multi) {
+            size_t tot = 0, nb = 0;
+            for (int k = 0; k < bt.count; k++) {
+                vs_work_sizes(v, bt.n[k], wq);
+                tot += vs_work_total(wq);
+                nb += (size_t)v.shape.proof_words * 4 * bt.n[k];
+            }
+            if (tot > need_points) need_points = tot;
+            if (nb > need_bytes) need_bytes = nb;
+        }
+    }
+    if (need_points > pp.primed_points || need_bytes > pp.primed_bytes) {
         // The first batch a device sees runs once on EVERY lane (results discarded): each lane's ~25 workspaces, its
         // pinned result buffers and its events then exist, sized for this batch shape, before the pipeline fills --
         // otherwise the first dozen batches of a stream each pay the allocations of the lane they land on.
-        pp.primed = true;
+        if (need_points > pp.primed_points) pp.primed_points = need_points;
+        if (need_bytes > pp.primed_bytes) pp.primed_bytes = need_bytes;
         HostSpan hs("begin.prime");
         for (int p = 0; p < pp.lanes; p++) {
             if (pp.acc[p].open) continue;  // the lane this call takes is primed too: its real pass follows on the same stream
@@ -1810,7 +1833,7 @@ static int32_t vs_accumulate_begin_impl(Context &cx, const VsCtx &vc, const void
             MI_HIP(hipStreamWaitEvent(sp, pp.acc_ev[p], 0));
             // a shape that may run passes of several batches is primed with the largest (the batch repeated): the
             // larger workspaces exist before a stream under load starts sharing passes
-            const int per_pass = vs_max_per_pass(v, n);
+            const int per_pass = per_pass_prime;
             VsBatches rep;
             rep.count = per_pass;
             for (int k = 0; k < per_pass; k++) {
