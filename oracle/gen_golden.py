@@ -136,6 +136,15 @@ def main():
     bad_inf = bytearray(P.g1_compress(None))
     bad_inf[3] = 1
     comp.append({"bytes": bytes(bad_inf).hex(), "ok": False, "ok_unchecked": False, "point": pt(None)})
+    # y = 0 (x^3 = -1, here x = q - 1): the point of order two.  Its only encoding has the sign flag clear; with the flag
+    # set it is non-canonical (the flag has nothing to select) and rejected even without the subgroup check
+    x2 = P.Q - 1
+    assert (x2 ** 3 + 1) % P.Q == 0
+    comp.append({"bytes": x2.to_bytes(48, "little").hex(), "ok": False, "ok_unchecked": True, "point": pt((x2, 0))})
+    flagged = bytearray(x2.to_bytes(48, "little"))
+    flagged[47] |= 0x80
+    assert P.g1_decompress(bytes(flagged), check_subgroup=False) == (False, None)
+    comp.append({"bytes": bytes(flagged).hex(), "ok": False, "ok_unchecked": False, "point": pt(None)})
     roots = [{"a": hx(a), "root": hx(P.fq_sqrt(a)) if P.fq_sqrt(a) is not None else None}
              for a in [0, 1, 4, 15, P.Q - 1] + [rng.below(P.Q, 11 + i) for i in range(6)]]
     json.dump({"points": comp, "sqrt": roots}, open(os.path.join(OUT, "g1_compressed.json"), "w"), indent=0)

@@ -96,6 +96,13 @@ def test_struct_layouts_match_the_python_loader_and_the_header():
     assert size["mi_g1_affine"] == 96 and size["mi_g1_jac"] == 144 and size["mi_g2_affine"] == 192 and size["mi_fq12"] == 576
     assert size["mi_kzg_vk"] == L.KZG_VK_BYTES and size["mi_vs_circuit_vk"] == L.VS_CIRCUIT_VK_BYTES
     assert size["mi_vs_proof"] == L.VS_PROOF_BYTES and size["mi_vs_partial"] == L.VS_PARTIAL_BYTES
+    # the record kinds a v2 / v3 context reads (the safe layer sizes its slices by these), signatures, counters
+    assert size["mi_vs_proof2"] == L.VS2_PROOF_BYTES == 3184 and size["mi_vs_proof3"] == L.VS3_PROOF_BYTES == 5504
+    assert size["mi_vs_proof4"] == L.VS4_PROOF_BYTES == 6320 and size["mi_vs_circuit_part"] == 400
+    assert size["mi_vs_shape"] == L.VS2_SHAPE_BYTES and size["mi_vs_key_ext"] == L.VS2_KEY_EXT_BYTES
+    assert size["mi_sig_record"] == L.SIG_RECORD_BYTES == 288 and size["mi_stats"] == 128
+    rs = open(os.path.join(ROOT, "integration", "snarkvm-algorithms-hip", "src", "lib.rs")).read()
+    assert "mi_vs_strides" in rs and "proofs: &[u8]" in rs and "fn count(&self, proofs: &[u8], randomizers128: &[u8])" in rs
     src = open(FFI).read()
     for name, fields in structs:
         body = re.search(r"pub struct %s \{(.*?)\n\}" % name, src, flags=re.S).group(1)
