@@ -148,6 +148,42 @@ def main():
     roots = [{"a": hx(a), "root": hx(P.fq_sqrt(a)) if P.fq_sqrt(a) is not None else None}
              for a in [0, 1, 4, 15, P.Q - 1] + [rng.below(P.Q, 11 + i) for i in range(6)]]
     json.dump({"points": comp, "sqrt": roots}, open(os.path.join(OUT, "g1_compressed.json"), "w"), indent=0)
+    # --- Schnorr over Edwards-BLS12: the derived generator, Poseidon-over-Fr permutations of widths 5
+    # and 9, hash-to-scalar, and signatures made by pyref's signer -- valid ones and each way of spoiling one
+    g = P.ed_generator()
+    perms = []
+    for w in (5, 9):
+        st = [rng.below(P.R, 5) for _ in range(w)]
+        perms.append({"width": w, "in": [hx(x) for x in st], "out": [hx(x) for x in P.ed_poseidon_permute(st)]})
+    h2s = []
+    for rate, m in ((4, 2), (8, 5), (8, 8), (4, 0)):
+        ins = [rng.below(P.R, 5) for _ in range(m)]
+        h2s.append({"rate": rate, "inputs": [hx(x) for x in ins], "scalar": hx(P.ed_hash_to_scalar(ins, rate))})
+    sigs = []
+    for k in range(4):
+        sk, rs, nonce, msg = rng.below(P.ED_S, 5), rng.below(P.ED_S, 5), rng.below(P.ED_S, 5), rng.below(P.R, 5)
+        sig, addr = P.schnorr_sign(sk, rs, nonce, [msg], g)
+        assert P.schnorr_verify(addr, [msg], sig, g)
+        rec = {"address": pt(addr), "message": hx(msg), "challenge": hx(sig["challenge"]), "response": hx(sig["response"]),
+               "pk_sig": pt(sig["pk_sig"]), "pr_sig": pt(sig["pr_sig"]), "valid": True}
+        sigs.append(rec)
+        spoil = dict(rec)
+        if k == 0:
+            spoil["response"] = hx((sig["response"] + 1) % P.ED_S)
+        elif k == 1:
+            spoil["message"] = hx((msg + 1) % P.R)
+        elif k == 2:
+            spoil["pr_sig"] = pt(g)  # another point of the curve: the address identity and the challenge both break
+        else:
+            spoil["challenge"] = hx(sig["challenge"] ^ 2)
+        spoil["valid"] = False
+        bad_sig = {"challenge": int(spoil["challenge"], 16), "response": int(spoil["response"], 16),
+                   "pk_sig": tuple(int(c, 16) for c in spoil["pk_sig"]), "pr_sig": tuple(int(c, 16) for c in spoil["pr_sig"])}
+        assert not P.schnorr_verify(addr, [int(spoil["message"], 16)], bad_sig, g)
+        sigs.append(spoil)
+    json.dump({"curve": {"a": hx(P.ED_A), "d": hx(P.ED_D), "order": hx(P.ED_S)}, "generator": pt(g),
+               "mul": [[hx(k), pt(P.ed_mul(g, k))] for k in (1, 2, 3, P.ED_S - 1, rng.below(P.ED_S, 5))],
+               "poseidon_fr": perms, "hash_to_scalar": h2s, "signatures": sigs}, open(os.path.join(OUT, "schnorr.json"), "w"), indent=0)
     print("golden vectors written to", OUT)
 
 

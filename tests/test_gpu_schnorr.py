@@ -50,3 +50,12 @@ def test_device_entry_point_and_a_subdag_sized_batch(orc, mi):
     torch.cuda.synchronize()
     assert (out.cpu().numpy() == b.expected).all()
     assert mi.SchnorrBatch.verify(b.records[:RB].copy())[0] == b.expected[0]   # a batch of one
+
+
+def test_golden_signatures_from_pyref(orc, mi):
+    """tests/golden/schnorr.json: signatures made and judged by the Python big-integer restatement, through the C ABI"""
+    import golden_util as G
+    from test_oracle_golden import _sig_records_from_golden
+    d = G.load("schnorr.json")
+    recs = _sig_records_from_golden(orc, d["signatures"])
+    assert list(mi.SchnorrBatch.verify(recs)) == [int(s["valid"]) for s in d["signatures"]]

@@ -231,3 +231,50 @@ def test_counters_move(orc, mi):
         assert s1["verify_batch_nanos"] > s0["verify_batch_nanos"]
     finally:
         v.close()
+
+
+def test_pyref_fixture_verdicts_and_wire(orc, mi):
+    """tests/golden/vs3_wire_24.npz: verdicts, wire bytes and decode flags as the Python big-integer restatement gave
+    them (oracle/gen_vs3_fixture.py), through the C ABI -- uncompressed records and wire records"""
+    d = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "vs3_wire_24.npz"))
+    v = mi.VarunaShaped(d["vk"], d["circuits"], shape=d["shape"], key_ext=d["ext"])
+    try:
+        ok, verdicts = v.verify_batch(d["proofs"], d["randomizers"])
+        assert not ok and (verdicts == d["pyref_verdicts"]).all()
+        assert (v.wire_encode(d["proofs"]) == d["pyref_wire"]).all()
+    finally:
+        v.close()
+    w = mi.VarunaShaped(d["vk"], d["circuits"], shape=d["shape"], key_ext=d["ext"], wire=True)
+    try:
+        ok, verdicts = w.verify_batch(d["pyref_wire"], d["randomizers"])
+        assert not ok and (verdicts == d["pyref_verdicts"]).all()
+        # the damaged copy: proofs 2 and 7 fail to decode (pyref's flags); proof 11 decodes to another point and fails the relation
+        ok, verdicts = w.verify_batch(d["damaged_wire"], d["randomizers"])
+        want = d["pyref_verdicts"] & d["pyref_dec_ok"]
+        want[11] = 0
+        cpu = orc.VS2Batch.from_wire(d["vk"], d["ext"], d["shape"], d["circuits"], d["damaged_wire"], d["randomizers"], threads=8).verify_cpu(8)
+        assert (cpu == want).all() and not ok and (verdicts == want).all()
+    finally:
+        w.close()
+
+
+@pytest.mark.parametrize("n", [1, 65, 129])
+def test_wire_ragged_sizes_and_stream_verdict_vectors(orc, mi, n):
+    """batch sizes that are not multiples of a wave, and the verdict vector of a failed STREAMED wire batch (the stream
+    keeps no per-proof state: mi_vs_stream_next_verdicts decodes and takes the batch apart again)"""
+    import torch
+    sh = orc.vs2_shape(None, None, True, 1, bound_class=[-1, -1, 0, -1, -1, -1, 0, -1, -1], max_instances=2)
+    b = orc.VS2Batch(0x30F0 + n, n, 3, 0, shape=sh)
+    v = _ctx(mi, b, wire=True)
+    try:
+        wire = v.wire_encode(b.proofs)
+        ok, verdicts = v.verify_batch(wire, b.randomizers)
+        assert ok and verdicts.all() and len(verdicts) == n
+        bad = wire.copy()
+        bad[(n - 1) * v.proof_bytes + 16 + 512 + 48 * 4 + 2] ^= 1   # the last proof's C_4
+        want = np.ones(n, dtype=np.uint8); want[n - 1] = 0
+        tg, tb, tr = torch.from_numpy(wire).cuda(), torch.from_numpy(bad).cuda(), torch.from_numpy(b.randomizers).cuda()
+        res = list(v.verify_stream(iter([(tg, tr), (tb, tr), (tg, tr)]), verdicts=True))
+        assert [r[0] for r in res] == [True, False, True] and res[0][1] is None and (res[1][1] == want).all()
+    finally:
+        v.close()
