@@ -263,7 +263,7 @@ def test_wire_ragged_sizes_and_stream_verdict_vectors(orc, mi, n):
     """batch sizes that are not multiples of a wave, and the verdict vector of a failed STREAMED wire batch (the stream
     keeps no per-proof state: mi_vs_stream_next_verdicts decodes and takes the batch apart again)"""
     import torch
-    sh = orc.vs2_shape(None, None, True, 1, bound_class=[-1, -1, 0, -1, -1, -1, 0, -1, -1], max_instances=2)
+    sh = orc.vs2_shape(None, [-1, -1, 0, -1, -1, -1, 0, -1, -1], True, 1, max_instances=2)
     b = orc.VS2Batch(0x30F0 + n, n, 3, 0, shape=sh)
     v = _ctx(mi, b, wire=True)
     try:
