@@ -1,11 +1,9 @@
 #!/bin/bash
-# one rank with the exchange path switched on (communicator of world 1): cost of the grouped exchange in the streaming driver
-for x in host rccl; do for g in 1 4; do
-  MI_SNARK_EXCHANGE=$([ $x = host ] && echo host || echo auto) timeout -k 10 200 python bench.py --steps ${1:-200} --warmup 5 --exchange native --exchange-group $g --no-extra --no-cpu-baseline 2>/dev/null | grep '^{"metric"' | python -c "
+# one rank with the exchange path switched on (a communicator of world 1): what the grouped exchange of the streaming
+# driver costs by itself, per transport (auto = RCCL, host = shared memory), exchange group, lanes and product slots
+for cfg in "auto 4 8 6" "auto 4 10 6" "auto 8 8 6" "host 4 8 6" "host 4 12 8"; do set -- $cfg
+  MI_SNARK_EXCHANGE=$1 timeout -k 10 200 python bench.py --steps 200 --warmup 5 --exchange native --exchange-group $2 --acc-depth $3 --products $4 --no-extra --no-cpu-baseline 2>/dev/null | grep '^{"metric"' | python -c "
 import json,sys
 d=json.loads(sys.stdin.read()); c=d['config']
-print('$x group $g', round(d['value']), 'ms/step %.3f steady %.3f' % (d['ms_per_step'], d['steady_state_ms_per_step']), c['exchange'], c['exchange_calls'], c['exchange_wait_ms_per_group'])"
-done; done
-timeout -k 10 200 python bench.py --steps ${1:-200} --warmup 5 --no-extra --no-cpu-baseline 2>/dev/null | grep '^{"metric"' | python -c "
-import json,sys
-d=json.loads(sys.stdin.read()); print('no exchange', round(d['value']), 'ms/step %.3f steady %.3f' % (d['ms_per_step'], d['steady_state_ms_per_step']))"
+print('$cfg', round(d['value']), 'ms/step %.3f steady %.3f' % (d['ms_per_step'], d['steady_state_ms_per_step']), c['exchange'], c['exchange_calls'], c['exchange_wait_ms_per_group'])"
+done
