@@ -353,6 +353,10 @@ int32_t mi_vs_finalize_wait(uint64_t ctx, uint64_t ticket, uint8_t *all_ok);
 int32_t mi_vs_finalize_async_multi(uint64_t ctx, const mi_vs_partial *partials, size_t n_partials_each, int32_t count,
                                    uint64_t *ticket_out);
 int32_t mi_vs_finalize_wait_multi(uint64_t ctx, uint64_t ticket, uint8_t *all_ok, int32_t count);
+/* After MI_ERR_AGAIN from mi_vs_finalize_async[_multi]: MI_OK as soon as a product slot of the device is free (somebody's
+ * mi_vs_finalize_wait ended), MI_ERR_AGAIN if none was within timeout_ms.  For callers whose tickets in flight are not
+ * the ones holding the slots (two drivers, or a driver and a caller of the split entry points, on one device). */
+int32_t mi_vs_wait_product_slot(uint64_t ctx, int32_t timeout_ms);
 
 /* ---- native streaming driver over the split entry points above (what rayon workers would otherwise hand-roll) ----
  * One driver owns host threads: `fold_threads` wait for accumulations and fold them, one finisher turns partials into

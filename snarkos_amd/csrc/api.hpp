@@ -92,6 +92,7 @@ int32_t vs_finalize_async(Context &cx, uint64_t id, const mi_vs_partial *parts, 
 int32_t vs_finalize_wait(Context &cx, uint64_t id, uint64_t ticket, uint8_t *all_ok);
 int32_t vs_finalize_async_multi(Context &cx, uint64_t id, const mi_vs_partial *parts, size_t np, int count, uint64_t *ticket);
 int32_t vs_finalize_wait_multi(Context &cx, uint64_t id, uint64_t ticket, uint8_t *all_ok, int count);
+int32_t vs_wait_product_slot(Context &cx, int timeout_ms);
 int32_t vs_identify_device(Context &cx, uint64_t id, const void *d_proofs, size_t n, const void *d_rand, uint8_t *verdicts,
                            hipStream_t st);
 int32_t vs_verify_batch_device(Context &cx, uint64_t id, const void *d_proofs, size_t n, const void *d_rand,

@@ -1041,6 +1041,10 @@ int32_t mi_vs_finalize_wait_multi(uint64_t c, uint64_t ticket, uint8_t *all_ok, 
     return guarded_on(context_at((int)((ticket >> 8) & 0xff)),
                       [&](Context &cx) -> int32_t { return vs_finalize_wait_multi(cx, c, ticket, all_ok, count); });
 }
+int32_t mi_vs_wait_product_slot(uint64_t c, int32_t timeout_ms) {
+    (void)c;  // slots belong to the device the context's passes run on: the primary one
+    return guarded([&](Context &cx) -> int32_t { return vs_wait_product_slot(cx, timeout_ms); });
+}
 int32_t mi_vs_finalize_wait(uint64_t c, uint64_t ticket, uint8_t *all_ok) {
     if (!all_ok) return MI_ERR_BAD_ARGS;
     if (ensure_init() != MI_OK) return MI_ERR_NO_DEVICE;

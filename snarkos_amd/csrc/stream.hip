@@ -49,6 +49,7 @@ struct Stream {
     void *held_stream = nullptr;
     bool launching = false;                             // somebody is between taking the held batch and queueing its pass
     bool finished = false;                              // no more submissions
+    bool closing = false;                               // mi_vs_stream_close: verdicts not yet started are given up
     bool finisher_done = false;
     int32_t error = MI_OK;                              // first failure inside the pipeline
 
@@ -261,13 +262,12 @@ struct Stream {
                 }
                 uint64_t tk = 0;
                 int32_t st = mi_vs_finalize_async_multi(ctx, one.data(), world, m, &tk);
-                while (st == MI_ERR_AGAIN) {  // fewer product slots than `products` (MI_SNARK_VS_SLOTS), or another stream holds them
+                while (st == MI_ERR_AGAIN) {  // fewer product slots than `products` (MI_SNARK_VS_SLOTS), or other drivers and callers hold them
                     {
-                        std::unique_lock<std::mutex> lk(mu);
-                        if (inflight == 0) break;  // none of ours to wait for: the failure stands
-                        const int before = inflight;
-                        cv.wait(lk, [&] { return inflight < before; });
+                        std::lock_guard<std::mutex> lk(mu);
+                        if (error != MI_OK || closing) break;  // nobody is going to take the verdict: the status stands
                     }
+                    (void)mi_vs_wait_product_slot(ctx, 20);  // our publisher's waits free slots too: one wait covers both cases
                     st = mi_vs_finalize_async_multi(ctx, one.data(), world, m, &tk);
                 }
                 std::lock_guard<std::mutex> lk(mu);
@@ -446,6 +446,7 @@ int32_t mi_vs_stream_close(uint64_t stream) {
     {
         std::lock_guard<std::mutex> lk(s->mu);
         s->finished = true;
+        s->closing = true;
         s->cv.notify_all();
     }
     (void)s->flush_held(true);

@@ -2115,7 +2115,21 @@ int32_t vs_finalize_wait_multi(Context &cx, uint64_t id, uint64_t ticket, uint8_
     if ((ticket & 0xff) >= VS_SLOTS || (int)((ticket >> 8) & 0xff) != cx.index) return MI_ERR_BAD_ARGS;
     VsSlot &sl = vs_pipe(cx).slots[ticket & 0xff];
     if (!sl.busy || sl.ticket != ticket) return MI_ERR_BAD_ARGS;
-    return vs_slot_wait(sl, all_ok, count);
+    const int32_t st = vs_slot_wait(sl, all_ok, count);
+    cx.lane_cv.notify_all();  // vs_wait_product_slot
+    return st;
+}
+// MI_OK as soon as one of the device's product slots is free, MI_ERR_AGAIN when none was for timeout_ms: what a driver
+// whose mi_vs_finalize_async came back MI_ERR_AGAIN waits on when the tickets in flight are not its own (another
+// stream, or a caller of the split entry points, on the same device)
+int32_t vs_wait_product_slot(Context &cx, int timeout_ms) {
+    VsPipe &pp = vs_pipe(cx);
+    const auto until = std::chrono::steady_clock::now() + std::chrono::milliseconds(timeout_ms < 0 ? 0 : timeout_ms);
+    for (;;) {
+        for (int i = 0; i < pp.nslots; i++)
+            if (!pp.slots[i].busy) return MI_OK;
+        if (!tl_ctx_lock || cx.lane_cv.wait_until(*tl_ctx_lock, until) == std::cv_status::timeout) return MI_ERR_AGAIN;
+    }
 }
 int32_t vs_finalize_wait(Context &cx, uint64_t id, uint64_t ticket, uint8_t *all_ok) {
     return vs_finalize_wait_multi(cx, id, ticket, all_ok, 1);

@@ -1,4 +1,5 @@
 """-m gpu: VarunaShaped-v1 batch verification, verdict-for-verdict against the CPU oracle."""
+import ctypes as C
 import os
 
 import numpy as np
@@ -685,3 +686,49 @@ def test_two_pairing_streams_and_a_synchronous_caller(orc, mi, monkeypatch):
             assert out[name][0] == out[name][1], name
     finally:
         v.close()
+
+
+@pytest.mark.gpu
+def test_stream_waits_for_product_slots_held_by_others(orc, mi):
+    """every product slot of the device is taken through the split entry points (tickets not yet waited for) when a
+    stream starts: the stream's products WAIT for slots (mi_vs_wait_product_slot) instead of failing with MI_ERR_AGAIN,
+    and finish once the tickets are collected"""
+    import threading
+    import time
+    import torch
+    from snarkos_amd import lib as L
+    good = orc.VSBatch(0x5107, 24, 3, 0)
+    v = _ctx(mi, good)
+    try:
+        gp, gr = torch.from_numpy(good.proofs).cuda(), torch.from_numpy(good.randomizers).cuda()
+        part = v.accumulate(gp, gr)
+        tickets = []
+        while True:  # take them all
+            try:
+                tickets.append(v.finalize_async(part))
+            except L.MiError as e:
+                assert e.status == L.MI_ERR_AGAIN
+                break
+            assert len(tickets) <= 16
+        assert len(tickets) >= 1
+        assert L.lib().mi_vs_wait_product_slot(C.c_uint64(v.ctx), C.c_int32(5)) == L.MI_ERR_AGAIN
+        out, errs = [], []
+
+        def stream():
+            try:
+                out.extend(v.verify_stream(iter([(gp, gr)] * 6)))
+            except BaseException as e:  # noqa: BLE001
+                errs.append(e)
+
+        t = threading.Thread(target=stream)
+        t.start()
+        time.sleep(0.3)
+        assert t.is_alive() and not errs and not out  # waiting, not failed
+        assert all(v.finalize_wait(tk) for tk in tickets)
+        t.join(60)
+        assert not t.is_alive() and not errs
+        assert out == [True] * 6
+        assert L.lib().mi_vs_wait_product_slot(C.c_uint64(v.ctx), C.c_int32(5)) == L.MI_OK
+    finally:
+        v.close()
+
