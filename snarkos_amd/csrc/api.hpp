@@ -51,12 +51,14 @@ void msm_device(Context &cx, const G1Affine *d_points, const uint32_t *d_scalars
 void ntt_device(Context &cx, Fr *d_data, uint32_t log_n, bool inverse, bool coset, hipStream_t st);
 Fr host_omega(uint32_t log_n);
 
-// pairing.hip
+// pairing.hip.  verdict_only: the result is one exactly when the product is, and otherwise merely not one (the final
+// exponentiation without its inversion in Fq: pairing_wg.hpp pw_final_exp); false: the value of the product
 void pairing_product_prepared(Context &cx, const G1Affine *ps, const G2Prepared *const *d_qs, size_t n, Fq12 *out_host,
-                              hipStream_t st);
+                              hipStream_t st, bool verdict_only);
 void pairing_product_host_args(Context &cx, const G1Affine *ps, const G2Affine *qs, size_t n, Fq12 *out_host,
-                               hipStream_t st);
-void pairing_launch(Context &cx, const G1Affine *ps, const G2Prepared *const *d_qs, size_t n, Fq12 *d_out, hipStream_t st, int unit);
+                               hipStream_t st, bool verdict_only);
+void pairing_launch(Context &cx, const G1Affine *ps, const G2Prepared *const *d_qs, size_t n, Fq12 *d_out, hipStream_t st, int unit,
+                    bool verdict_only);
 void pairing_launch_multi(Context &cx, const G1Affine *ps, const G2Prepared *const *d_qs, size_t n, int count, Fq12 *d_out, hipStream_t st,
                           int unit);
 const PairingConsts *pairing_consts(Context &cx, hipStream_t st);

@@ -786,7 +786,7 @@ int32_t mi_pairing_product_is_one(const mi_g1_affine *ps, const mi_g2_affine *qs
     if (!ps || !qs || !is_one || n == 0 || n > MI_MAX_PAIRS) return MI_ERR_BAD_ARGS;
     return guarded([&](Context &cx) -> int32_t {
         Fq12 f;
-        pairing_product_host_args(cx, (const G1Affine *)ps, (const G2Affine *)qs, n, &f, cx.stream);
+        pairing_product_host_args(cx, (const G1Affine *)ps, (const G2Affine *)qs, n, &f, cx.stream, true);
         *is_one = f.is_one() ? 1 : 0;
         return MI_OK;
     });
@@ -795,7 +795,7 @@ int32_t mi_pairing(const mi_g1_affine *p, const mi_g2_affine *q, mi_fq12 *out) {
     if (!p || !q || !out) return MI_ERR_BAD_ARGS;
     return guarded([&](Context &cx) -> int32_t {
         Fq12 f;
-        pairing_product_host_args(cx, (const G1Affine *)p, (const G2Affine *)q, 1, &f, cx.stream);
+        pairing_product_host_args(cx, (const G1Affine *)p, (const G2Affine *)q, 1, &f, cx.stream, false);  // the VALUE
         memcpy(out, &f, sizeof f);
         return MI_OK;
     });

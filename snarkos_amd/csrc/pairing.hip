@@ -12,6 +12,7 @@ struct PairingArgs {
     G1Affine p[MI_MAX_PAIRS];
     const G2Prepared *q[MI_MAX_PAIRS];
     int n;
+    int verdict_only;  // the caller asks "is the product one?" only: pw_final_exp's form without the inversion in Fq
 };
 
 // one workgroup of 192 lanes per pairing product (pairing_wg.hpp); merged: the Miller factors of pairing_lines_kernel
@@ -19,7 +20,7 @@ __global__ void __launch_bounds__(PW_THREADS) pairing_product_kernel(PairingArgs
                                                                      Fq12 *out, const Fq *merged) {
     extern __shared__ uint4 pw_lds[];  // PW_LDS_BYTES
     LShared &S = *(LShared *)pw_lds;
-    pw_pairing_product(S, args.p, args.q, args.n, pc, out, merged);
+    pw_pairing_product(S, args.p, args.q, args.n, pc, out, merged, args.verdict_only != 0);
 }
 // first launch of the two-launch form: workgroup (g, couple) computes the couple's merged Miller factor of steps
 // 3g .. 3g + 2 (pw_miller_group) into merged[couple][g][12]
@@ -45,7 +46,7 @@ __global__ void __launch_bounds__(PW_THREADS) pairing_product_multi_kernel(Pairi
     extern __shared__ uint4 pw_lds[];  // PW_LDS_BYTES
     LShared &S = *(LShared *)pw_lds;
     const PairingArgs &a = args.a[blockIdx.x];
-    pw_pairing_product(S, a.p, a.q, a.n, pc, out + blockIdx.x, merged ? merged + blockIdx.x * merged_stride : nullptr);
+    pw_pairing_product(S, a.p, a.q, a.n, pc, out + blockIdx.x, merged ? merged + blockIdx.x * merged_stride : nullptr, a.verdict_only != 0);
 }
 __global__ void __launch_bounds__(PW_THREADS) pairing_lines_multi_kernel(PairingArgsN args, const PairingConsts *__restrict__ pc, Fq *merged,
                                                                          size_t merged_stride) {
@@ -109,10 +110,12 @@ const PairingConsts *pairing_consts(Context &cx, hipStream_t st) {
 // verifier, where eight products are in flight, the product kernel runs 0.78 ms instead of 0.93 and the throughput is
 // the same within noise (tools/ab_pairing_launches.sh).  unit names the caller's product slot (its workspace for the
 // factors; -1: the synchronous path).  MI_SNARK_PAIRING_LAUNCHES=1 forces the one-launch form.
-void pairing_launch(Context &cx, const G1Affine *ps, const G2Prepared *const *d_qs, size_t n, Fq12 *d_out, hipStream_t st, int unit) {
+void pairing_launch(Context &cx, const G1Affine *ps, const G2Prepared *const *d_qs, size_t n, Fq12 *d_out, hipStream_t st, int unit,
+                    bool verdict_only) {
     PairingArgs a;
     memset(&a, 0, sizeof a);
     a.n = (int)n;
+    a.verdict_only = verdict_only ? 1 : 0;
     for (size_t i = 0; i < n; i++) { a.p[i] = ps[i]; a.q[i] = d_qs[i]; }
     const PairingConsts *pc = pairing_consts(cx, st);
     static const int force = getenv("MI_SNARK_PAIRING_LAUNCHES") ? atoi(getenv("MI_SNARK_PAIRING_LAUNCHES")) : 0;
@@ -136,16 +139,18 @@ void pairing_launch(Context &cx, const G1Affine *ps, const G2Prepared *const *d_
 }
 
 // `count` products at once: product k pairs ps[k * MI_MAX_PAIRS + i] with d_qs[i], i < n (the same prepared G2 points and
-// the same number of pairs for all: one verifier context); results in d_out[0 .. count)
+// the same number of pairs for all: one verifier context); results in d_out[0 .. count): one, or something that is not
+// (verdict form: nobody reads these values for anything but is_one)
 void pairing_launch_multi(Context &cx, const G1Affine *ps, const G2Prepared *const *d_qs, size_t n, int count, Fq12 *d_out, hipStream_t st,
                           int unit) {
-    if (count == 1) return pairing_launch(cx, ps, d_qs, n, d_out, st, unit);
+    if (count == 1) return pairing_launch(cx, ps, d_qs, n, d_out, st, unit, true);
     if (count < 1 || count > MI_VS_MAX_PRODUCTS_PER_TICKET || n == 0) throw HipError{hipErrorInvalidValue, "pairing_launch_multi", __LINE__};
     PairingArgsN a;
     memset(&a, 0, sizeof a);
     a.count = count;
     for (int k = 0; k < count; k++) {
         a.a[k].n = (int)n;
+        a.a[k].verdict_only = 1;
         for (size_t i = 0; i < n; i++) {
             a.a[k].p[i] = ps[(size_t)k * MI_MAX_PAIRS + i];
             a.a[k].q[i] = d_qs[i];
@@ -170,9 +175,9 @@ void pairing_launch_multi(Context &cx, const G1Affine *ps, const G2Prepared *con
 }
 
 void pairing_product_prepared(Context &cx, const G1Affine *ps, const G2Prepared *const *d_qs, size_t n, Fq12 *out_host,
-                                     hipStream_t st) {
+                                     hipStream_t st, bool verdict_only) {
     Fq12 *d_out = (Fq12 *)cx.buf("pairing.out", sizeof(Fq12));
-    pairing_launch(cx, ps, d_qs, n, d_out, st, -1);
+    pairing_launch(cx, ps, d_qs, n, d_out, st, -1, verdict_only);
     Fq12 *h = (Fq12 *)cx.pin(sizeof(Fq12));
     MI_HIP(hipMemcpyAsync(h, d_out, sizeof(Fq12), hipMemcpyDeviceToHost, st));
     MI_HIP(hipStreamSynchronize(st));
@@ -181,7 +186,7 @@ void pairing_product_prepared(Context &cx, const G1Affine *ps, const G2Prepared 
 
 // arbitrary G2 points given on the host: prepare (host), upload, run
 void pairing_product_host_args(Context &cx, const G1Affine *ps, const G2Affine *qs, size_t n, Fq12 *out_host,
-                                      hipStream_t st) {
+                                      hipStream_t st, bool verdict_only) {
     std::vector<G2Prepared> prep(n);
     for (size_t i = 0; i < n; i++) g2_prepare_host(prep[i], qs[i]);
     G2Prepared *d = (G2Prepared *)cx.buf("pairing.adhoc_q", sizeof(G2Prepared) * n);
@@ -189,7 +194,7 @@ void pairing_product_host_args(Context &cx, const G1Affine *ps, const G2Affine *
     MI_HIP(hipStreamSynchronize(st));
     const G2Prepared *dq[MI_MAX_PAIRS];
     for (size_t i = 0; i < n; i++) dq[i] = d + i;
-    pairing_product_prepared(cx, ps, dq, n, out_host, st);
+    pairing_product_prepared(cx, ps, dq, n, out_host, st, verdict_only);
 }
 
 }  // namespace mi

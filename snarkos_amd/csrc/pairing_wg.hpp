@@ -298,7 +298,8 @@ __device__ __attribute__((noinline)) void pb_exp_by_x(LShared &S, LPB *out, cons
 // inversion in Fq on a single lane.  With U = A frob1(A) frob2(A) (e = 0,1,2) and P2 = A frob1(A):
 //   W = U * frob3(U) * frob6(U) * frob9(P2)   covers e = 0..10,   Abar = frob1(W),   frob6 = conj, frob9 = conj o frob3.
 // Uses S.x, S.y, S.c, S.d as scratch (callers invert before they use those).
-__device__ __attribute__((noinline)) void pb_inv(LShared &S, LPB *out, const LPB *A, const PairingConsts *pc) {
+// unscaled: out = Abar = N A^-1 only -- no norm, no inversion in Fq (pw_final_exp's verdict form).
+__device__ __attribute__((noinline)) void pb_inv(LShared &S, LPB *out, const LPB *A, const PairingConsts *pc, bool unscaled = false) {
     pb_frob(S, &S.x, A, pc->frob[0]);         // x = frob1(A)
     pb_mul(S, &S.c, A, &S.x);                 // c = P2 = A frob1(A)
     pb_frob(S, &S.x, A, pc->frob[1]);         // x = frob2(A)
@@ -311,6 +312,10 @@ __device__ __attribute__((noinline)) void pb_inv(LShared &S, LPB *out, const LPB
     pb_conj(S, &S.x, &S.x);                   // x = frob9(P2)
     pb_mul(S, &S.y, &S.y, &S.x);              // y = W
     pb_frob(S, &S.x, &S.y, pc->frob[0]);      // x = Abar
+    if (unscaled) {                           // uniform
+        pb_copy(S, out, &S.x);
+        return;
+    }
     pb_mul(S, &S.y, A, &S.x);                 // y = N (coefficient 0; the others vanish)
     const int t = threadIdx.x;
     if (t == 0) {
@@ -472,9 +477,15 @@ __device__ __attribute__((noinline)) void pw_miller_merged(LShared &S, const Fq 
 }
 
 // S.f <- S.f ^ (3 (q^12 - 1) / r)
-__device__ __attribute__((noinline)) void pw_final_exp(LShared &S, const PairingConsts *pc) {
+// verdict_only: S.f <- s * that value for some s in Fq* -- the same chain WITHOUT the inversion in Fq.  The easy part
+// takes f^-1 as Abar / N with N = Norm(f) in Fq; leaving 1/N out scales the value by N, an element of Fq*, and every
+// later step keeps "unitary value times an Fq* scalar" in that shape: Frobenius and conjugation fix Fq, products and
+// powers multiply the scalars, and where the chain uses conj(t) for t^-1 the scaled conj(c t) = c t^-1 is c^2 times the
+// inverse.  With z = f^(3 (q^12 - 1) / r) in mu_r and gcd(r, q - 1) = 1:  s z lies in Fq  <=>  z = 1, so the caller's
+// test "is one" becomes "coefficients 1..11 vanish and coefficient 0 does not" (pw_pairing_product writes one / not one).
+__device__ __attribute__((noinline)) void pw_final_exp(LShared &S, const PairingConsts *pc, bool verdict_only) {
     // easy part
-    pb_inv(S, &S.a, &S.f, pc);
+    pb_inv(S, &S.a, &S.f, pc, verdict_only);
     pb_conj(S, &S.t, &S.f);
     pb_mul(S, &S.t, &S.t, &S.a);
     pb_frob(S, &S.a, &S.t, pc->frob[1]);
@@ -522,8 +533,10 @@ __device__ __forceinline__ int pw_live_pairs(LShared &S, const G1Affine *ps, con
 }
 // full product over the live pairs; result (tower order) to out.  merged: the couples' merged Miller factors from
 // pw_miller_group (the two-launch form), or null: everything in this workgroup.
+// verdict_only: *out is one exactly when the product is one, and otherwise SOME value that is not one (pw_final_exp).
 __device__ __forceinline__ void pw_pairing_product(LShared &S, const G1Affine *ps, const G2Prepared *const *qs, int n,
-                                                   const PairingConsts *pc, Fq12 *out, const Fq *merged = nullptr) {
+                                                   const PairingConsts *pc, Fq12 *out, const Fq *merged = nullptr,
+                                                   bool verdict_only = false) {
     __shared__ const G2Prepared *live_q[MI_MAX_PAIRS];
     __shared__ int live_n_s;
     const int t = threadIdx.x;
@@ -540,13 +553,20 @@ __device__ __forceinline__ void pw_pairing_product(LShared &S, const G1Affine *p
             if (c > 0) pb_mul(S, &S.f, &S.f, &S.b);
         }
     }
-    pw_final_exp(S, pc);
+    pw_final_exp(S, pc, verdict_only);
+    Fq res = Fq::zero();
+    if (t < 12) {
+        res = lds_load(&S.f.c[t]);
+        reduce_once(res);  // rounds leave values in [0, 2q)
+    }
+    if (verdict_only && t < 64) {  // wave 0 holds all twelve coefficients: s in Fq* (times one) becomes one
+        const uint64_t nz = __ballot(t < 12 && !res.is_zero());
+        if ((nz & 0xfffull) == 1ull) res = t == 0 ? Fq::one() : Fq::zero();
+    }
     if (t < 12) {
         // tower index (i, j, b) holds the coefficient of w^(i + 2j + 6b)
         const int b = t / 6, rem = t - 6 * b, j = rem >> 1, i = rem & 1;
         Fq *o = &out->c0.c0.c0;
-        Fq res = lds_load(&S.f.c[t]);
-        reduce_once(res);  // rounds leave values in [0, 2q)
         o[(i * 3 + j) * 2 + b] = res;
     }
     __syncthreads();

@@ -1407,7 +1407,7 @@ __global__ void __launch_bounds__(PW_THREADS) vs_group_check_kernel(size_t n, co
             qs[tid] = keys.q[tid];
         }
         __syncthreads();
-        pw_pairing_product(S, ps, qs, K, pc, &result);
+        pw_pairing_product(S, ps, qs, K, pc, &result, nullptr, true);
         __syncthreads();
         ok = result.is_one();
     }
@@ -1439,7 +1439,7 @@ __global__ void __launch_bounds__(PW_THREADS) vs_proof_check_kernel(const G1Affi
             qs[tid] = keys.q[tid];
         }
         __syncthreads();
-        pw_pairing_product(S, ps, qs, K, pc, &result);
+        pw_pairing_product(S, ps, qs, K, pc, &result, nullptr, true);
         __syncthreads();
         if (tid == 0) verdicts[i] = result.is_one() ? 1 : 0;
         __syncthreads();
@@ -2052,7 +2052,7 @@ int32_t vs_finalize(Context &cx, uint64_t id, const mi_vs_partial *parts, size_t
     const G2Prepared *qs[MI_MAX_PAIRS];
     const int K = vs_g2_keys(v, qs);
     Fq12 f;
-    pairing_product_prepared(cx, ps, qs, K, &f, st);
+    pairing_product_prepared(cx, ps, qs, K, &f, st, true);
     stats().pairing_products++;
     stats().pairing_pairs += (uint64_t)K;
     *all_ok = (f.is_one() && fails == 0) ? 1 : 0;
@@ -2451,7 +2451,7 @@ int32_t kzg_batch_check_host(Context &cx, const mi_kzg_vk *vk, const mi_g1_affin
     memcpy(&qs[0], &vk->h, sizeof(G2Affine));
     memcpy(&qs[1], &vk->tau_h, sizeof(G2Affine));
     Fq12 f;
-    pairing_product_host_args(cx, ps, qs, 2, &f, st);
+    pairing_product_host_args(cx, ps, qs, 2, &f, st, true);
     *ok_out = f.is_one() ? 1 : 0;
     return MI_OK;
 }
