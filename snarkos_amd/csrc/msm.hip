@@ -29,6 +29,7 @@
 #include <map>
 #include <thread>
 #include "api.hpp"
+#include "hostfold.hpp"
 #include "field28.hpp"
 
 namespace mi {
@@ -985,21 +986,12 @@ void msm_enqueue(Context &cx, const G1Affine *d_points, const uint32_t *d_scalar
 // dirty -- stale pointers and an unzeroed histogram turn into out-of-range scatter writes.  DESIGN.md "Workspace lifetime".)
 
 // wait for the job's stream, fold on the host (Horner over windows or bit positions), normalise to z = 1
-// Horner over the per-bit sums h[lo..hi): sum_g 2^(g-lo) h[g]
-static G1Xyzz fold_bits(const G1Xyzz *h, size_t lo, size_t hi) {
-    G1Xyzz acc = G1Xyzz::inf();
-    for (size_t g = hi; g-- > lo;) {
-        acc = dbl(acc);
-        if (!h[g].is_inf()) acc = add(acc, h[g]);
-    }
-    return acc;
-}
 // One problem's per-bit sums -> its point, as K independent parts: part k folds the bit positions [at[k], at[k+1])
-// (a doubling and an addition each) and is then shifted down by at[k] doublings; the boundaries balance the parts
-// (9-product doublings against 14-product additions: the top part is the shortest).  The parts of all problems of a job
-// run side by side on the pool (no task waits for another).  K = 2 when several folds share the pool (the streamed
-// verifier: throughput, least total work), K = 4 when this fold has it to itself (one batch on its own: the critical
-// path drops from ~3 600 to ~2 600 field products).
+// (a doubling and an addition each) and is then shifted up by at[k] doublings; the boundaries balance the parts with the
+// measured costs of hostfold.hpp (a folded bit ~2.7 shift doublings: the top part is the shortest).  The parts of all
+// problems of a job run side by side on the pool (no task waits for another).  K = 2 when several folds share the pool
+// (the streamed verifier: throughput, least total work), K = 4 when this fold has it to itself (one batch on its own:
+// the critical path drops by a quarter).
 struct FoldSplit {
     static constexpr int KMAX = 4;
     const G1Xyzz *h;
@@ -1011,13 +1003,13 @@ struct FoldSplit {
         while (G > 0 && h[G - 1].is_inf()) G--;  // short scalars leave the top positions empty
         if (K < 1) K = 1;
         if (K > KMAX) K = KMAX;
-        // equal cost C per part: len_k (9 + 14) + at[k] 9 = C; bisect C so that the lengths add up to G
-        double lo = 0, hi = 23.0 * (double)G + 1;
+        // equal cost C per part: len_k 27 + at[k] 10 = C; bisect C so that the lengths add up to G
+        double lo = 0, hi = 27.0 * (double)G + 1;
         for (int it = 0; it < 50; it++) {
             const double C = 0.5 * (lo + hi);
             double a = 0, tot = 0;
             for (int k = 0; k < K; k++) {
-                double len = (C - 9.0 * a) / 23.0;
+                double len = (C - 10.0 * a) / 27.0;
                 if (len < 0) len = 0;
                 tot += len;
                 a += len;
@@ -1027,7 +1019,7 @@ struct FoldSplit {
         double a = 0;
         at[0] = 0;
         for (int k = 0; k < K; k++) {
-            double len = (hi - 9.0 * a) / 23.0;
+            double len = (hi - 10.0 * a) / 27.0;
             if (len < 0) len = 0;
             a += len;
             size_t e = (size_t)(a + 0.5);
@@ -1037,12 +1029,7 @@ struct FoldSplit {
         }
         for (int k = 0; k < K; k++) part[k] = G1Xyzz::inf();
     }
-    void run(int k) {
-        G1Xyzz p = fold_bits(h, at[k], at[k + 1]);
-        if (!p.is_inf())
-            for (size_t j = 0; j < at[k]; j++) p = dbl(p);
-        part[k] = p;
-    }
+    void run(int k) { part[k] = hostfold::xyzz(hostfold::shift(hostfold::fold_bits(h, at[k], at[k + 1]), at[k])); }
     G1Jac result() const {
         G1Xyzz acc = part[0];
         for (int k = 1; k < K; k++) acc = add(acc, part[k]);
@@ -1094,19 +1081,24 @@ void msm_finish_all(Context &cx, MsmJob *job, hipStream_t st, mi_g1_jac *const *
             }
         }
         std::exception_ptr err;
-        try {
-            f[0].run(0);
-        } catch (...) {
-            err = std::current_exception();
-        }
-        for (auto &t : tasks) {
+        {
+            HostSpan hs_parts("finish.fold.parts");
             try {
-                t.get();
+                HostSpan hs_own("finish.fold.own_part");
+                f[0].run(0);
             } catch (...) {
-                if (!err) err = std::current_exception();
+                err = std::current_exception();
+            }
+            for (auto &t : tasks) {
+                try {
+                    t.get();
+                } catch (...) {
+                    if (!err) err = std::current_exception();
+                }
             }
         }
         if (err) std::rethrow_exception(err);
+        HostSpan hs_norm("finish.fold.normalise");
         G1Jac r[MSM_MAX_PROBLEMS];
         tasks.clear();
         for (int p = 1; p < np; p++) {
@@ -1120,12 +1112,9 @@ void msm_finish_all(Context &cx, MsmJob *job, hipStream_t st, mi_g1_jac *const *
             if (outs[p]) memcpy(outs[p], &r[p], sizeof r[p]);
         return;
     }
-    G1Xyzz acc = h[job->nwin - 1];
-    for (int w = job->nwin - 2; w >= 0; w--) {
-        for (int k = 0; k < job->c; k++) acc = dbl(acc);
-        acc = add(acc, h[w]);
-    }
-    res = affine_to_jac(to_affine(acc));
+    hostfold::PX acc = hostfold::px(h[job->nwin - 1]);
+    for (int w = job->nwin - 2; w >= 0; w--) acc = hostfold::add(hostfold::shift(acc, (size_t)job->c), hostfold::px(h[w]));
+    res = affine_to_jac(to_affine(hostfold::xyzz(acc)));
     memcpy(out, &res, sizeof res);
 }
 

@@ -1,10 +1,12 @@
 // Host build (plain g++, no HIP) of the product's shared host/device arithmetic headers, so the
 // CPU test tier can pin snarkos_amd/csrc/{field,curve,tower}.hpp against the oracle without a GPU.
 // Test infrastructure: compiled by tests/test_host_arith.py into tests/hostlib/libhostcheck.so.
+#include <vector>
 #include <string.h>
 #include "../../snarkos_amd/csrc/tower.hpp"
 #include "../../snarkos_amd/csrc/glv.hpp"
 #include "../../snarkos_amd/csrc/codec.hpp"
+#include "../../snarkos_amd/csrc/hostfold.hpp"
 
 using namespace mi;
 
@@ -84,6 +86,25 @@ void hc_glv_digits(int w, const uint32_t *v4, int *out) {  // out[NW]
 }
 void hc_glv_mul(int w, const G1Affine *p, const uint32_t *k8, G1Affine *o) { *o = w == 3 ? glv_mul_host<3>(*p, k8) : glv_mul_host<4>(*p, k8); }
 void hc_fq_sqr(const Fq *a, Fq *o) { *o = sqr(*a); }
+// csrc/hostfold.hpp: what msm_finish_all folds with (64-bit limbs, the BMI2/ADX product when the CPU has it)
+void hc_hf_mul(const Fq *a, const Fq *b, Fq *o) { *o = hostfold::fq(hostfold::mul(hostfold::h6(*a), hostfold::h6(*b))); }
+void hc_hf_add(const Fq *a, const Fq *b, Fq *o) { *o = hostfold::fq(hostfold::add(hostfold::h6(*a), hostfold::h6(*b))); }
+void hc_hf_sub(const Fq *a, const Fq *b, Fq *o) { *o = hostfold::fq(hostfold::sub(hostfold::h6(*a), hostfold::h6(*b))); }
+int hc_hf_has_adx() {
+#if defined(MI_HOSTFOLD_ADX)
+    return hostfold::have_adx() ? 1 : 0;
+#else
+    return 0;
+#endif
+}
+// sum_g 2^g h[g] over n per-bit sums given as affine points ((0,0): none), split at `cut`: low part + shifted high part
+void hc_hf_fold(const G1Affine *h, int n, int cut, G1Affine *o) {
+    std::vector<G1Xyzz> v((size_t)n);
+    for (int i = 0; i < n; i++) v[(size_t)i] = G1Xyzz::from_affine(h[i]);
+    const hostfold::PX lo = hostfold::fold_bits(v.data(), 0, (size_t)cut);
+    const hostfold::PX hi = hostfold::shift(hostfold::fold_bits(v.data(), (size_t)cut, (size_t)n), (size_t)cut);
+    *o = to_affine(hostfold::xyzz(hostfold::add(lo, hi)));
+}
 int hc_fq_sqrt(const Fq *a, Fq *o) { return fq_sqrt(*a, *o) ? 1 : 0; }
 int hc_g1_decompress(const uint8_t *in, int check, G1Affine *o) { return g1_decompress_one(in, check != 0, *o) ? 1 : 0; }
 void hc_g1_compress(const G1Affine *p, uint8_t *out) { g1_compress_one(*p, out); }

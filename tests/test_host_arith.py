@@ -121,6 +121,39 @@ def test_g1_group_law(hc, orc):
     assert (out == orc.g1_mul(a[6], orc.limbs_to_int(k))).all()
 
 
+def test_host_fold_arithmetic(hc, orc):
+    """csrc/hostfold.hpp (the host fold of a small MSM's per-bit sums): its Fq product / sum / difference on 64-bit
+    limbs against the oracle, and the fold itself -- Horner over per-bit sums, split into a low part and a shifted high
+    part (Jacobian doublings) -- against big-integer arithmetic"""
+    rs = np.random.RandomState(99)
+    vals = [orc.fq_from_int(int.from_bytes(rs.bytes(48), "little") % P.Q) for _ in range(200)]
+    vals += [np.zeros(6, dtype=np.uint64), orc.fq_from_int(1), orc.fq_from_int(P.Q - 1), orc.fq_from_int(P.Q - 2)]
+    out, want = np.zeros(6, dtype=np.uint64), np.zeros(6, dtype=np.uint64)
+    for i in range(len(vals)):
+        a = np.ascontiguousarray(vals[i]); b = np.ascontiguousarray(vals[(i * 5 + 1) % len(vals)] if i % 9 else vals[i])
+        for name in ("mul", "add", "sub"):
+            getattr(hc, "hc_hf_" + name)(_p(a), _p(b), _p(out))
+            getattr(orc.lib(), "orc_fq_" + name)(_p(want), _p(a), _p(b))
+            assert (out == want).all(), (name, i)
+    assert hc.hc_hf_has_adx() in (0, 1)
+    pts = rng_points(17, 40)
+    pts[3] = 0; pts[11] = 0; pts[39] = 0   # empty bit positions, the top one too
+    pts[7] = pts[6]                        # equal neighbours: 2 S + S
+    total = None
+    for g in range(39, -1, -1):
+        total = P.g1_add(total, total) if total is not None else None
+        pg = orc.g1_to_ints(pts[g])
+        if pg is not None:
+            total = P.g1_add(total, pg) if total is not None else pg
+    o = np.zeros(12, dtype=np.uint64)
+    for cut in (0, 1, 13, 39, 40):
+        hc.hc_hf_fold(_p(np.ascontiguousarray(pts)), C.c_int(40), C.c_int(cut), _p(o))
+        assert orc.g1_to_ints(o) == total, cut
+    # nothing but empty positions
+    hc.hc_hf_fold(_p(np.zeros((5, 12), dtype=np.uint64)), C.c_int(5), C.c_int(2), _p(o))
+    assert not o.any()
+
+
 def test_glv_scalar_multiplication(hc, orc):
     """glv.hpp, the per-proof fallback's scalar multiplication: s = s1 + lambda s2 with both halves below 2^127, signed
     window digits that recompose the value, and the whole chain (endomorphism, Jacobian doubling / mixed addition)
