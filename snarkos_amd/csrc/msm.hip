@@ -989,9 +989,9 @@ void msm_enqueue(Context &cx, const G1Affine *d_points, const uint32_t *d_scalar
 // One problem's per-bit sums -> its point, as K independent parts: part k folds the bit positions [at[k], at[k+1])
 // (a doubling and an addition each) and is then shifted up by at[k] doublings; the boundaries balance the parts with the
 // measured costs of hostfold.hpp (a folded bit ~2.7 shift doublings: the top part is the shortest).  The parts of all
-// problems of a job run side by side on the pool (no task waits for another).  K = 2 when several folds share the pool
-// (the streamed verifier: throughput, least total work), K = 4 when this fold has it to itself (one batch on its own:
-// the critical path drops by a quarter).
+// problems of a job run side by side on the pool (no task waits for another).  K = 3 when several folds share the pool
+// (the streamed verifier), K = 4 when this fold has it to itself (one batch on its own: the critical path drops by a
+// quarter; 6 buys nothing more).
 struct FoldSplit {
     static constexpr int KMAX = 4;
     const G1Xyzz *h;
@@ -1068,10 +1068,10 @@ void msm_finish_all(Context &cx, MsmJob *job, hipStream_t st, mi_g1_jac *const *
             InFlight() : others(g_folds_in_flight.fetch_add(1)) {}
             ~InFlight() { g_folds_in_flight.fetch_sub(1); }
         } in_flight;
-        const int K = in_flight.others == 0 ? 4 : 2;
+        const int K = in_flight.others == 0 ? 4 : 3;  // measured (tools/foldk.sh): busy 1 / 2 / 3 within noise of each other, 3 ahead on both rates
         std::vector<FoldSplit> f;
         f.reserve(MSM_MAX_PROBLEMS);
-        for (int p = 0; p < np; p++) f.emplace_back(h + (size_t)p * job->groups, job->groups, job->groups > 160 ? K : 2);
+        for (int p = 0; p < np; p++) f.emplace_back(h + (size_t)p * job->groups, job->groups, job->groups > 160 ? K : (K < 2 ? K : 2));
         std::vector<std::future<void>> tasks;
         for (int p = 0; p < np; p++) {
             FoldSplit *fp = &f[p];

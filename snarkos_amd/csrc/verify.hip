@@ -83,8 +83,26 @@ __device__ void sha256_prefixed(uint32_t out[8], const uint32_t prefix[8], const
     const uint32_t total = 8 + na + nb;                 // message words
     const uint32_t nblocks = (total + 1 + 2 + 15) / 16;  // + 0x80 word + 64-bit length
     // a / b are 16-byte aligned and na / nb multiples of 4 (asserted by the callers' layout): the message is read four
-    // words at a time (one 16-byte load per lane instead of four scattered 4-byte ones; lanes are 2256 bytes apart)
+    // words at a time (one 16-byte load per lane instead of four scattered 4-byte ones; lanes are 2256 bytes apart), and
+    // a block's four loads are issued BEFORE the previous block is compressed: every block is a new cache line for
+    // every lane, and the ~1 400 instructions of a compression hide its latency
+    auto fetch = [&](uint32_t blk, int q) -> uint4 {
+        const uint32_t base = blk * 16 + 4 * (uint32_t)q;
+        if (base >= 8 && base < 8 + na) return *reinterpret_cast<const uint4 *>(a + (base - 8));
+        if (base >= 8 + na && base < total) return *reinterpret_cast<const uint4 *>(b + (base - 8 - na));
+        return make_uint4(0, 0, 0, 0);
+    };
+    uint4 nxt[4];
+#pragma unroll
+    for (int q = 0; q < 4; q++) nxt[q] = fetch(0, q);
     for (uint32_t blk = 0; blk < nblocks; blk++) {
+        uint4 cur[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) cur[q] = nxt[q];
+        if (blk + 1 < nblocks) {
+#pragma unroll
+            for (int q = 0; q < 4; q++) nxt[q] = fetch(blk + 1, q);
+        }
         uint32_t w[16];
 #pragma unroll
         for (int q = 0; q < 4; q++) {
@@ -93,11 +111,8 @@ __device__ void sha256_prefixed(uint32_t out[8], const uint32_t prefix[8], const
             if (blk == 0 && q < 2) {
 #pragma unroll
                 for (int t = 0; t < 4; t++) v[t] = prefix[4 * q + t];
-            } else if (base < 8 + na) {
-                const uint4 x = *reinterpret_cast<const uint4 *>(a + (base - 8));
-                v[0] = __builtin_bswap32(x.x); v[1] = __builtin_bswap32(x.y); v[2] = __builtin_bswap32(x.z); v[3] = __builtin_bswap32(x.w);
             } else if (base < total) {
-                const uint4 x = *reinterpret_cast<const uint4 *>(b + (base - 8 - na));
+                const uint4 x = cur[q];
                 v[0] = __builtin_bswap32(x.x); v[1] = __builtin_bswap32(x.y); v[2] = __builtin_bswap32(x.z); v[3] = __builtin_bswap32(x.w);
             } else {
 #pragma unroll
