@@ -22,17 +22,16 @@ __global__ void __launch_bounds__(PW_THREADS) pairing_product_kernel(PairingArgs
     LShared &S = *(LShared *)pw_lds;
     pw_pairing_product(S, args.p, args.q, args.n, pc, out, merged, args.verdict_only != 0);
 }
-// first launch of the two-launch form: workgroup (g, couple) computes the couple's merged Miller factor of steps
-// 3g .. 3g + 2 (pw_miller_group) into merged[couple][g][12]
+// first launch of the two-launch form: workgroup g computes the merged Miller factor of steps 3g .. 3g + 2 over all
+// the pairs (pw_miller_group) into merged[g][12]
 __global__ void __launch_bounds__(PW_THREADS) pairing_lines_kernel(PairingArgs args, const PairingConsts *__restrict__ pc, Fq *merged) {
     extern __shared__ uint4 pw_lds[];  // PW_LDS_BYTES
     LShared &S = *(LShared *)pw_lds;
     __shared__ const G2Prepared *live_q[MI_MAX_PAIRS];
     __shared__ int live_n_s;
     const int live_n = pw_live_pairs(S, args.p, args.q, args.n, live_q, &live_n_s, pc);
-    const int couple = blockIdx.y, p0 = 2 * couple;
-    if (p0 >= live_n) return;  // uniform
-    pw_miller_group(S, live_q, p0, live_n - p0 >= 2 ? 2 : 1, blockIdx.x, merged + ((size_t)couple * PW_MILLER_GROUPS + blockIdx.x) * 12);
+    if (live_n == 0) return;  // uniform: the product kernel sets one itself
+    pw_miller_group(S, live_q, live_n, blockIdx.x, merged + (size_t)blockIdx.x * 12);
 }
 
 // Several independent products in ONE launch each (a workgroup per product; the line launch adds a grid dimension):
@@ -54,12 +53,10 @@ __global__ void __launch_bounds__(PW_THREADS) pairing_lines_multi_kernel(Pairing
     LShared &S = *(LShared *)pw_lds;
     __shared__ const G2Prepared *live_q[MI_MAX_PAIRS];
     __shared__ int live_n_s;
-    const PairingArgs &a = args.a[blockIdx.z];
+    const PairingArgs &a = args.a[blockIdx.y];
     const int live_n = pw_live_pairs(S, a.p, a.q, a.n, live_q, &live_n_s, pc);
-    const int couple = blockIdx.y, p0 = 2 * couple;
-    if (p0 >= live_n) return;  // uniform
-    pw_miller_group(S, live_q, p0, live_n - p0 >= 2 ? 2 : 1, blockIdx.x,
-                    merged + blockIdx.z * merged_stride + ((size_t)couple * PW_MILLER_GROUPS + blockIdx.x) * 12);
+    if (live_n == 0) return;  // uniform
+    pw_miller_group(S, live_q, live_n, blockIdx.x, merged + blockIdx.y * merged_stride + (size_t)blockIdx.x * 12);
 }
 
 struct PairingState {  // per device (Context::mod)
@@ -120,16 +117,15 @@ void pairing_launch(Context &cx, const G1Affine *ps, const G2Prepared *const *d_
     const PairingConsts *pc = pairing_consts(cx, st);
     static const int force = getenv("MI_SNARK_PAIRING_LAUNCHES") ? atoi(getenv("MI_SNARK_PAIRING_LAUNCHES")) : 0;
     const bool two_launches = force != 1;
-    const int couples = (int)((n + 1) / 2);
     Fq *merged = nullptr;
     cx.raise_lds_limit((const void *)pairing_product_kernel, (int)PW_LDS_BYTES);
     if (two_launches && n > 0) {
         char nm[32];
         snprintf(nm, sizeof nm, "pairing.m%d", unit < 0 ? 99 : unit);
-        merged = (Fq *)cx.buf(nm, sizeof(Fq) * 12 * PW_MILLER_GROUPS * (MI_MAX_PAIRS / 2));
+        merged = (Fq *)cx.buf(nm, sizeof(Fq) * 12 * PW_MILLER_GROUPS);
         cx.raise_lds_limit((const void *)pairing_lines_kernel, (int)PW_LDS_BYTES);
         cx.prof.begin("pairing_lines", st, n);
-        hipLaunchKernelGGL(pairing_lines_kernel, dim3(PW_MILLER_GROUPS, couples), dim3(PW_THREADS), PW_LDS_BYTES, st, a, pc, merged);
+        hipLaunchKernelGGL(pairing_lines_kernel, dim3(PW_MILLER_GROUPS), dim3(PW_THREADS), PW_LDS_BYTES, st, a, pc, merged);
         cx.prof.end("pairing_lines", st);
     }
     cx.prof.begin("pairing", st, n);  // the product kernel alone (what the kernel trace calls pairing_product_kernel)
@@ -157,15 +153,14 @@ void pairing_launch_multi(Context &cx, const G1Affine *ps, const G2Prepared *con
         }
     }
     const PairingConsts *pc = pairing_consts(cx, st);
-    const int couples = (int)((n + 1) / 2);
-    const size_t stride = (size_t)12 * PW_MILLER_GROUPS * (MI_MAX_PAIRS / 2);  // Fq per product
+    const size_t stride = (size_t)12 * PW_MILLER_GROUPS;  // Fq per product
     char nm[32];
     snprintf(nm, sizeof nm, "pairing.mm%d", unit < 0 ? 99 : unit);
     Fq *merged = (Fq *)cx.buf(nm, sizeof(Fq) * stride * MI_VS_MAX_PRODUCTS_PER_TICKET);
     cx.raise_lds_limit((const void *)pairing_product_multi_kernel, (int)PW_LDS_BYTES);
     cx.raise_lds_limit((const void *)pairing_lines_multi_kernel, (int)PW_LDS_BYTES);
     cx.prof.begin("pairing_lines", st, n * count);
-    hipLaunchKernelGGL(pairing_lines_multi_kernel, dim3(PW_MILLER_GROUPS, couples, count), dim3(PW_THREADS), PW_LDS_BYTES, st, a, pc, merged,
+    hipLaunchKernelGGL(pairing_lines_multi_kernel, dim3(PW_MILLER_GROUPS, count), dim3(PW_THREADS), PW_LDS_BYTES, st, a, pc, merged,
                        stride);
     cx.prof.end("pairing_lines", st);
     cx.prof.begin("pairing", st, n * count);

@@ -354,7 +354,8 @@ __device__ const uint8_t PW_LL_TABLE[12][4] = {
 // its P (four per line and pair, a lane each), then the line products l_1 l_2 (twelve coefficients per line: up to four
 // Montgomery products each, a lane per coefficient) into S.lprod[0 .. count).  A single pair (np = 1) runs as a couple
 // whose second line is the constant 1.
-__device__ __forceinline__ void pw_line_products(LShared &S, const G2Prepared *const *qs, int p0, int np, int lo, int count) {
+// at: where the products go, S.lprod[at .. at + count) (and the line coefficients S.lines2[at ..]).
+__device__ __forceinline__ void pw_line_products(LShared &S, const G2Prepared *const *qs, int p0, int np, int lo, int count, int at = 0) {
     const int t = threadIdx.x;
     for (int item = t; item < count * 8; item += PW_THREADS) {
         const int idx = item >> 3, p = (item >> 2) & 1, role = item & 3;
@@ -366,7 +367,7 @@ __device__ __forceinline__ void pw_line_products(LShared &S, const G2Prepared *c
             else if (role == 2) v = mul(ln->c1.c1, lds_load(&S.px[p0 + p]));  // w^7
             else v = ln->c3.c1;                                                // w^9
         }
-        lds_store(&S.lines2[idx][p][role], v);
+        lds_store(&S.lines2[at + idx][p][role], v);
     }
     if (t == 12) lds_store(&S.one, Fq::one());
     __syncthreads();
@@ -379,10 +380,10 @@ __device__ __forceinline__ void pw_line_products(LShared &S, const G2Prepared *c
             const uint32_t code = PW_LL_TABLE[k][e];
             if (!(code & 0x80u)) break;
             const uint32_t i = code & 7u, j = (code >> 3) & 7u;
-            const Fq p = mul(lds_load(i == 0 ? y1 : &S.lines2[idx][0][i - 1]), lds_load(j == 0 ? y2 : &S.lines2[idx][1][j - 1]));
+            const Fq p = mul(lds_load(i == 0 ? y1 : &S.lines2[at + idx][0][i - 1]), lds_load(j == 0 ? y2 : &S.lines2[at + idx][1][j - 1]));
             acc = (code & 0x40u) ? sub(acc, mul5(p)) : add(acc, p);  // w^12 = -5
         }
-        lds_store(&S.lprod[idx][k], acc);
+        lds_store(&S.lprod[at + idx][k], acc);
     }
     __syncthreads();
 }
@@ -411,13 +412,15 @@ __device__ __attribute__((noinline)) void pw_miller2(LShared &S, const G2Prepare
 
 // ---- the Miller loop in two launches (pairing.hip): f_(i+1) = f_i^2 X_i with X_i the step's line product (times the
 // addition step's where x has a bit), so three steps are f^8 (X_a^4 X_b^2 X_c).  The merged factors M_g = X_a^4 X_b^2 X_c
-// do not depend on f: a first launch computes the 21 of every couple on 21 workgroups side by side, the product
-// kernel then runs 3 squarings + one multiplication per couple and group: 84 rounds instead of 132 for one couple,
-// 105 instead of 264 for two.
+// do not depend on f: a first launch computes the 21 factors on 21 workgroups side by side (over all the couples of
+// pairs at once: pw_miller_group), the product kernel then runs 3 squarings + one multiplication per group: 80 rounds
+// instead of 132 for one couple and of 264 for two.
 #define PW_MILLER_GROUPS 21
 static_assert(3 * PW_MILLER_GROUPS == 63, "63 doubling steps in triples");
-// workgroup (g, couple): M_g of the couple (p0, p0 + 1) -> out[12] (plain coefficients in [0, 2q))
-__device__ __forceinline__ void pw_miller_group(LShared &S, const G2Prepared *const *qs, int p0, int np, int g, Fq *out) {
+// workgroup g: M_g of ALL the live pairs (one or two couples) -> out[12] (plain coefficients in [0, 2q)).  With two
+// couples every step's line products are multiplied together first, X_i = (l_1 l_2)(l_3 l_4) -- at most five more
+// rounds here, spread over the 21 workgroups -- so that the product kernel multiplies ONE factor per group.
+__device__ __forceinline__ void pw_miller_group(LShared &S, const G2Prepared *const *qs, int live_n, int g, Fq *out) {
     // line indices of the group's steps: step s (bit 62 - s of x) has its doubling line at s + (addition steps before s)
     int lo = 0;
     for (int s = 0; s < 3 * g; s++) lo += 1 + (int)((MI_BLS_X >> (62 - s)) & 1);
@@ -426,52 +429,64 @@ __device__ __forceinline__ void pw_miller_group(LShared &S, const G2Prepared *co
         nadd[k] = (int)((MI_BLS_X >> (62 - (3 * g + k))) & 1);
         count += 1 + nadd[k];
     }
-    pw_line_products(S, qs, p0, np, lo, count);
+    constexpr int SECOND = 8;  // count <= 6: the second couple's products sit at S.lprod[8 ..]
+    pw_line_products(S, qs, 0, live_n >= 2 ? 2 : 1, lo, count, 0);
+    if (live_n > 2) pw_line_products(S, qs, 2, live_n - 2 >= 2 ? 2 : 1, lo, count, SECOND);
     const int t = threadIdx.x;
     const PwFold fc = pw_fold_consts(S);
-    // acc = X_a; then twice: acc = acc^2 X_next.  X_k = lprod[dbl] (* lprod[add]); products keep the running value as
-    // operand B (a PB with its twin) and the line product as operand A (plain)
+    // X[i]: the step's factor as operand A of a round (plain coefficients)
+    LPB *const merged[6] = {&S.t, &S.a, &S.b, &S.c, &S.d, &S.z};
+    const LFq *X[6];
+    for (int i = 0; i < count; i++) X[i] = S.lprod[i];
+    if (live_n > 2) {
+        for (int i = 0; i < count; i++) {
+            if (t < 12) pb_put(&S.x, t, lds_load(&S.lprod[SECOND + i][t]));
+            __syncthreads();
+            pb_round_impl<true>(S, merged[i], S.lprod[i], &S.x, fc.d0, fc.d1, fc.d2, fc.d3);
+            X[i] = merged[i]->c;
+        }
+    }
+    // acc = X_a; then twice: acc = acc^2 X_next.  X_k = X[dbl] (* X[add]); products keep the running value as operand B
+    // (a PB with its twin) and the factor as operand A (plain)
     LPB *cur = &S.f, *alt = &S.g;
     int idx = 0;
-    if (t < 12) pb_put(cur, t, lds_load(&S.lprod[0][t]));
+    if (t < 12) pb_put(cur, t, lds_load(&X[0][t]));
     __syncthreads();
     idx = 1;
     if (nadd[0]) {
-        pb_round_impl<true>(S, alt, S.lprod[idx], cur, fc.d0, fc.d1, fc.d2, fc.d3);
+        pb_round_impl<true>(S, alt, X[idx], cur, fc.d0, fc.d1, fc.d2, fc.d3);
         idx++;
         LPB *sw = cur; cur = alt; alt = sw;
     }
     for (int k = 1; k < 3; k++) {
-        pb_round_impl<true>(S, alt, cur->c, cur, fc.d0, fc.d1, fc.d2, fc.d3);        // alt = cur^2
-        pb_round_impl<true>(S, cur, S.lprod[idx], alt, fc.d0, fc.d1, fc.d2, fc.d3);  // cur = X_k alt
+        pb_round_impl<true>(S, alt, cur->c, cur, fc.d0, fc.d1, fc.d2, fc.d3);  // alt = cur^2
+        pb_round_impl<true>(S, cur, X[idx], alt, fc.d0, fc.d1, fc.d2, fc.d3);  // cur = X_k alt
         idx++;
         if (nadd[k]) {
-            pb_round_impl<true>(S, alt, S.lprod[idx], cur, fc.d0, fc.d1, fc.d2, fc.d3);
+            pb_round_impl<true>(S, alt, X[idx], cur, fc.d0, fc.d1, fc.d2, fc.d3);
             idx++;
             LPB *sw = cur; cur = alt; alt = sw;
         }
     }
     if (t < 12) out[t] = lds_load(&cur->c[t]);
 }
-// S.f = the Miller value of `couples` couples from their merged factors m[couple][group][12] (global memory)
-__device__ __attribute__((noinline)) void pw_miller_merged(LShared &S, const Fq *m, int couples) {
+// S.f = the Miller value of all the pairs from their merged factors m[group][12] (global memory)
+__device__ __attribute__((noinline)) void pw_miller_merged(LShared &S, const Fq *m) {
     const int t = threadIdx.x;
-    for (int item = t; item < couples * PW_MILLER_GROUPS * 12; item += PW_THREADS) lds_store(&S.lprod[item / 12][item % 12], m[item]);
-    pb_set_one(&S.f);
+    for (int item = t; item < PW_MILLER_GROUPS * 12; item += PW_THREADS) lds_store(&S.lprod[item / 12][item % 12], m[item]);
     __syncthreads();
+    // f = M_0, then per group three squarings and the group's factor
     LPB *cur = &S.f, *alt = &S.g;
+    if (t < 12) pb_put(cur, t, lds_load(&S.lprod[0][t]));
+    __syncthreads();
     const PwFold fc = pw_fold_consts(S);
-    for (int g = 0; g < PW_MILLER_GROUPS; g++) {
-        if (g) {  // f = 1 before the first group
-            for (int k = 0; k < 3; k++) {
-                pb_round_impl<true>(S, alt, cur->c, cur, fc.d0, fc.d1, fc.d2, fc.d3);
-                LPB *sw = cur; cur = alt; alt = sw;
-            }
-        }
-        for (int c = 0; c < couples; c++) {
-            pb_round_impl<true>(S, alt, S.lprod[c * PW_MILLER_GROUPS + g], cur, fc.d0, fc.d1, fc.d2, fc.d3);
+    for (int g = 1; g < PW_MILLER_GROUPS; g++) {
+        for (int k = 0; k < 3; k++) {
+            pb_round_impl<true>(S, alt, cur->c, cur, fc.d0, fc.d1, fc.d2, fc.d3);
             LPB *sw = cur; cur = alt; alt = sw;
         }
+        pb_round_impl<true>(S, alt, S.lprod[g], cur, fc.d0, fc.d1, fc.d2, fc.d3);
+        LPB *sw = cur; cur = alt; alt = sw;
     }
     if (cur != &S.f) pb_copy(S, &S.f, cur);
 }
@@ -545,7 +560,7 @@ __device__ __forceinline__ void pw_pairing_product(LShared &S, const G1Affine *p
         pb_set_one(&S.f);
         __syncthreads();
     } else if (merged) {
-        pw_miller_merged(S, merged, (live_n + 1) / 2);
+        pw_miller_merged(S, merged);
     } else {
         for (int c = 0; c < live_n; c += 2) {
             if (c > 0) pb_copy(S, &S.b, &S.f);  // the couples before this one
