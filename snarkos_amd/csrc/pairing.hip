@@ -15,7 +15,7 @@ struct PairingArgs {
     int verdict_only;  // the caller asks "is the product one?" only: pw_final_exp's form without the inversion in Fq
 };
 
-// one workgroup of 192 lanes per pairing product (pairing_wg.hpp); merged: the Miller factors of pairing_lines_kernel
+// one workgroup of PW_THREADS lanes per pairing product (pairing_wg.hpp); merged: the Miller factors of pairing_lines_kernel
 __global__ void __launch_bounds__(PW_THREADS) pairing_product_kernel(PairingArgs args, const PairingConsts *__restrict__ pc,
                                                                      Fq12 *out, const Fq *merged) {
     extern __shared__ uint4 pw_lds[];  // PW_LDS_BYTES

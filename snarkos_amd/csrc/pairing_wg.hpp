@@ -1,4 +1,5 @@
-// Workgroup-cooperative pairing product for gfx950: 192 lanes (3 waves) share one Fq12 value in LDS.
+// Workgroup-cooperative pairing product for gfx950: 256 lanes share one Fq12 value in LDS (three waves carry its twelve
+// coefficients, the fourth the value's scale: struct PB).
 //
 // A pairing product is one long dependency chain (63 squarings + 69 line multiplications per couple of pairs in the
 // Miller loop, ~350 more Fq12 operations in the final exponentiation), so one lane per pairing is purely latency
@@ -28,11 +29,16 @@
 
 namespace mi {
 
-constexpr int PW_THREADS = 192;
+constexpr int PW_THREADS = 256;  // rows 0..11: the coefficients (three waves); row 12, in the fourth wave: the scale (below)
 
+// A value also carries a SCALE s in Fq* (c[12]; c5[12] = 2q - s, its negative): the value stands for s times a unitary
+// element.  Products multiply the scales (a thirteenth row of the round, on the fourth wave: no time), Frobenius and
+// conjugation keep them.  The cyclotomic squaring round needs it -- the Granger-Scott formulas hold for unitary
+// elements, and for c = s u they read (s u)^2 = 3 A'^2 - 2 s conj(A') ... with the scale in the linear terms -- because the
+// verdict form of the final exponentiation (pw_final_exp) runs on scaled values.  Exact products carry s = 1.
 struct alignas(16) PB {
-    Fq c[12];   // coefficient of w^k, in [0, 2q)
-    Fq c5[12];  // its twin 10q - 5 c_k (= -5 c_k mod q, in (0, 10q]): what a wrapped term of the next round multiplies by
+    Fq c[13];   // coefficient of w^k, in [0, 2q); c[12]: the scale
+    Fq c5[13];  // its twin 10q - 5 c_k (= -5 c_k mod q, in (0, 10q]): what a wrapped term of the next round multiplies by
 };
 
 struct alignas(16) PwShared {
@@ -97,6 +103,20 @@ __device__ __forceinline__ Fq pw_twin(const Fq &v) {
     return r;
 }
 
+// the scale's partner: 2q - s in (0, 2q] for s in [0, 2q)
+__device__ __forceinline__ Fq pw_neg2q(const Fq &v) {
+    constexpr Q12 q10 = pw_make_q10();  // unused limbs fold away; 2q built from the modulus
+    uint32_t bw = 0, c = 0;
+    Fq r;
+    (void)q10;
+#pragma unroll
+    for (int j = 0; j < 12; j++) {
+        const uint32_t q2 = addc32(FqP::MOD[j], FqP::MOD[j], c, &c);
+        r.l[j] = subc32(q2, v.l[j], bw, &bw);
+    }
+    return r;
+}
+
 // x += (x of the quad lane named by the permutation), N limbs with carry: DPP fused into the add instructions
 #define PW_DPP_ADD16(ctrl)                                                                                              \
     asm volatile("s_nop 1\n\t"                                                                                          \
@@ -152,31 +172,13 @@ __device__ __forceinline__ Fq pw_twin(const Fq &v) {
         if (threadIdx.x == 0) prof[i] += now_ - stamp_;               \
         stamp_ = now_;                                                \
     }
-template <bool NOALIAS, bool PROF = false>
-__device__ __forceinline__ void pb_round_impl(LShared &S, LPB *out, const LFq *A, const LPB *B, const Fq &d0, const Fq &d1,
-                                              const Fq &d2, const Fq &d3, uint64_t *prof = nullptr) {
+// everything after the lane's partial product P: quad sum, distributed Montgomery fold, row sum, Barrett, twin, store
+template <bool NOALIAS, bool PROF>
+__device__ __forceinline__ void pb_round_finish(uint32_t (&P)[16], LPB *out, const Fq &d0, const Fq &d1, const Fq &d2, const Fq &d3,
+                                                uint64_t *prof, uint64_t &stamp_) {
     constexpr uint32_t MU0 = 0x54234331u, MU1 = 0x98u;  // floor(2^416 / q)
-    const int t = threadIdx.x, k = t >> 4, L = t & 15, j = L >> 2, g = L & 3;
-    uint64_t stamp_ = PROF ? __builtin_amdgcn_s_memtime() : 0;
-    Fq a[3];
-    uint32_t b[3][3];
-#pragma unroll
-    for (int tt = 0; tt < 3; tt++) {
-        const int s = 3 * g + tt;
-        int i = k - s;
-        const bool wrap = i < 0;
-        if (wrap) i += 12;
-        a[tt] = lds_load(&A[i]);
-        const PW_LDS uint32_t *bl = (wrap ? B->c5[s].l : B->c[s].l) + 3 * j;
-        b[tt][0] = bl[0];
-        b[tt][1] = bl[1];
-        b[tt][2] = bl[2];
-    }
-    if (PROF) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    PW_STAMP(0)
-    uint32_t P[16];
-    pr_qprod(P, a[0], a[1], a[2], b[0], b[1], b[2]);
-    PW_STAMP(1)
+    const int t = threadIdx.x, k = t >> 4, L = t & 15, g = L & 3;
+    const bool scale_wave = __builtin_amdgcn_readfirstlane(t >> 6) == 3;  // scalar: the compiler branches, no exec masks
     // the quad's sum Q_j (limb offset 3j), in all four lanes
     PW_DPP_ADD16("quad_perm:[1,0,3,2]");
     PW_DPP_ADD16("quad_perm:[2,3,0,1]");
@@ -208,13 +210,117 @@ __device__ __forceinline__ void pb_round_impl(LShared &S, LPB *out, const LFq *A
     uint32_t bw = 0;
 #pragma unroll
     for (int i = 0; i < 12; i++) c.l[i] = subc32(F[i], r[i], bw, &bw);
-    const Fq c5 = pw_twin(c);
+    Fq c5;
+    if (!scale_wave) c5 = pw_twin(c);
+    else c5 = pw_neg2q(c);  // the scale's partner is its negative
     PW_STAMP(5)
     if (!NOALIAS) __syncthreads();
-    if (L == 0) lds_store(&out->c[k], c);
-    if (L == 1) lds_store(&out->c5[k], c5);
+    if (k <= 12) {  // rows 13..15 of the scale's wave are idle
+        if (L == 0) lds_store(&out->c[k], c);
+        if (L == 1) lds_store(&out->c5[k], c5);
+    }
     __syncthreads();
     PW_STAMP(6)
+}
+// As: the scale of operand A (&A->c[12]) or nullptr (A is a line product / merged factor: scale one)
+template <bool NOALIAS, bool PROF = false>
+__device__ __forceinline__ void pb_round_impl(LShared &S, LPB *out, const LFq *A, const LPB *B, const Fq &d0, const Fq &d1,
+                                              const Fq &d2, const Fq &d3, uint64_t *prof = nullptr, const LFq *As = nullptr) {
+    const int t = threadIdx.x, k = t >> 4, L = t & 15, j = L >> 2, g = L & 3;
+    uint64_t stamp_ = PROF ? __builtin_amdgcn_s_memtime() : 0;
+    Fq a[3];
+    uint32_t b[3][3];
+    if (__builtin_amdgcn_readfirstlane(t >> 6) != 3) {  // scalar
+#pragma unroll
+        for (int tt = 0; tt < 3; tt++) {
+            const int s = 3 * g + tt;
+            int i = k - s;
+            const bool wrap = i < 0;
+            if (wrap) i += 12;
+            a[tt] = lds_load(&A[i]);
+            const PW_LDS uint32_t *bl = (wrap ? B->c5[s].l : B->c[s].l) + 3 * j;
+            b[tt][0] = bl[0];
+            b[tt][1] = bl[1];
+            b[tt][2] = bl[2];
+        }
+    } else {  // the scale's row (and the three idle rows of its wave, which store nothing): s_A s_B on the lanes g = 0
+        const PW_LDS uint32_t *bl = B->c[12].l + 3 * j;
+        a[0] = As ? lds_load(As) : Fq::one();
+        a[1] = a[2] = Fq::zero();
+#pragma unroll
+        for (int tt = 0; tt < 3; tt++) b[tt][0] = b[tt][1] = b[tt][2] = 0;
+        if (g == 0) {
+            b[0][0] = bl[0];
+            b[0][1] = bl[1];
+            b[0][2] = bl[2];
+        }
+    }
+    if (PROF) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    PW_STAMP(0)
+    uint32_t P[16];
+    pr_qprod(P, a[0], a[1], a[2], b[0], b[1], b[2]);
+    PW_STAMP(1)
+    pb_round_finish<NOALIAS, PROF>(P, out, d0, d1, d2, d3, prof, stamp_);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// The cyclotomic squaring round: out = B^2 for B = s u, u in the cyclotomic subgroup (u^(q^4 - q^2 + 1) = 1: everything
+// after the easy part of the final exponentiation), s = B's scale.  Granger-Scott, in this basis: with W = w^3 (W^4 = -5),
+//   B = A + B w + C w^2,   A = sum_i c_(3i) W^i,  B = sum_i c_(3i+1) W^i,  C = sum_i c_(3i+2) W^i,   X~ = sum (-1)^i x_i W^i:
+//   B^2 = (3 A^2 - 2 s A~) + (3 W C^2 + 2 s B~) w + (3 B^2 - 2 s C~) w^2                 (tools/model_pround.py checks it)
+// A square in Fq[W]/(W^4 + 5) is ten products, so an output coefficient is two or three products of coefficients (times
+// 3 or 6, times -5 through the twin where W^4 wraps) and one product with the scale: one term per lane g of the quad
+// instead of the general round's three -- 12 limb products to scale the operand and 36 for the product against 108.
+// Table entry: a | b << 4 | twin << 8 | multiplier << 9 (0: no term); b = 12: the scale (twin: its negative).
+#define PW_CS(a, b, tw, m) (uint16_t)((a) | ((b) << 4) | ((tw) << 8) | ((m) << 9))
+__device__ const uint16_t PW_CSQR_TABLE[13][4] = {
+    // A-rows k = 3i: 3 [A^2]_i - 2 s (-1)^i c_k; x_m = c_(3m)
+    /* 0 */ {PW_CS(0, 0, 0, 3), PW_CS(6, 6, 1, 3), PW_CS(3, 9, 1, 6), PW_CS(0, 12, 1, 2)},
+    // C-rows k = 3i + 1: 3 [W C^2]_i + 2 s (-1)^i c_k; x_m = c_(3m+2); [W C^2]_0 = -5 [C^2]_3, [W C^2]_i = [C^2]_(i-1)
+    /* 1 */ {PW_CS(2, 11, 1, 6), PW_CS(5, 8, 1, 6), 0, PW_CS(1, 12, 0, 2)},
+    // B-rows k = 3i + 2: 3 [B^2]_i - 2 s (-1)^i c_k; x_m = c_(3m+1)
+    /* 2 */ {PW_CS(1, 1, 0, 3), PW_CS(7, 7, 1, 3), PW_CS(4, 10, 1, 6), PW_CS(2, 12, 1, 2)},
+    /* 3 */ {PW_CS(0, 3, 0, 6), PW_CS(6, 9, 1, 6), 0, PW_CS(3, 12, 0, 2)},
+    /* 4 */ {PW_CS(2, 2, 0, 3), PW_CS(8, 8, 1, 3), PW_CS(5, 11, 1, 6), PW_CS(4, 12, 1, 2)},
+    /* 5 */ {PW_CS(1, 4, 0, 6), PW_CS(7, 10, 1, 6), 0, PW_CS(5, 12, 0, 2)},
+    /* 6 */ {PW_CS(0, 6, 0, 6), PW_CS(3, 3, 0, 3), PW_CS(9, 9, 1, 3), PW_CS(6, 12, 1, 2)},
+    /* 7 */ {PW_CS(2, 5, 0, 6), PW_CS(8, 11, 1, 6), 0, PW_CS(7, 12, 0, 2)},
+    /* 8 */ {PW_CS(1, 7, 0, 6), PW_CS(4, 4, 0, 3), PW_CS(10, 10, 1, 3), PW_CS(8, 12, 1, 2)},
+    /* 9 */ {PW_CS(0, 9, 0, 6), PW_CS(3, 6, 0, 6), 0, PW_CS(9, 12, 0, 2)},
+    /* 10 */ {PW_CS(2, 8, 0, 6), PW_CS(5, 5, 0, 3), PW_CS(11, 11, 1, 3), PW_CS(10, 12, 1, 2)},
+    /* 11 */ {PW_CS(1, 10, 0, 6), PW_CS(4, 7, 0, 6), 0, PW_CS(11, 12, 0, 2)},
+    /* 12: the scale */ {PW_CS(12, 12, 0, 1), 0, 0, 0},
+};
+#undef PW_CS
+// this lane's term (it depends on the lane only: loops keep it in a register)
+__device__ __forceinline__ uint32_t pw_csqr_entry() {
+    const int k = threadIdx.x >> 4, g = threadIdx.x & 3;
+    return k <= 12 ? PW_CSQR_TABLE[k][g] : 0u;  // rows 13..15: idle (zero product, nothing stored)
+}
+template <bool PROF = false>
+__device__ __forceinline__ void pb_csqr_impl(LShared &S, LPB *out, const LPB *B, uint32_t e, const Fq &d0, const Fq &d1, const Fq &d2,
+                                             const Fq &d3, uint64_t *prof = nullptr) {
+    const int L = threadIdx.x & 15, j = L >> 2;
+    uint64_t stamp_ = PROF ? __builtin_amdgcn_s_memtime() : 0;
+    const uint32_t mult = e >> 9;
+    const Fq av = lds_load(&B->c[e & 15u]);
+    const PW_LDS uint32_t *bl = ((e & 0x100u) ? B->c5[(e >> 4) & 15u].l : B->c[(e >> 4) & 15u].l) + 3 * j;
+    const uint32_t b[3] = {bl[0], bl[1], bl[2]};
+    // the operand times its multiplier: < 6 * 2q < 2^381, twelve limbs
+    Fq a;
+    uint64_t carry = 0;
+#pragma unroll
+    for (int i = 0; i < 12; i++) {
+        carry += (uint64_t)av.l[i] * mult;
+        a.l[i] = (uint32_t)carry;
+        carry >>= 32;
+    }
+    if (PROF) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    PW_STAMP(0)
+    uint32_t P[16];
+    pr_qprod1(P, a, b);
+    PW_STAMP(1)
+    pb_round_finish<true, PROF>(P, out, d0, d1, d2, d3, prof, stamp_);
 }
 #undef PW_STAMP
 #undef PW_DPP_ADD16
@@ -229,27 +335,34 @@ __device__ __forceinline__ PwFold pw_fold_consts(LShared &S) {
     return PwFold{lds_load(dt), lds_load(dt + 4), lds_load(dt + 8), lds_load(dt + 12)};
 }
 template <bool NOALIAS>
-__device__ __attribute__((noinline)) void pb_round(LShared &S, LPB *out, const LFq *A, const LPB *B) {
+__device__ __attribute__((noinline)) void pb_round(LShared &S, LPB *out, const LFq *A, const LPB *B, const LFq *As) {
     const PwFold fc = pw_fold_consts(S);
-    pb_round_impl<NOALIAS>(S, out, A, B, fc.d0, fc.d1, fc.d2, fc.d3);
+    pb_round_impl<NOALIAS>(S, out, A, B, fc.d0, fc.d1, fc.d2, fc.d3, nullptr, As);
 }
 
-__device__ __forceinline__ void pb_mul(LShared &S, LPB *out, const LPB *A, const LPB *B) { pb_round<false>(S, out, A->c, B); }
+__device__ __forceinline__ void pb_mul(LShared &S, LPB *out, const LPB *A, const LPB *B) { pb_round<false>(S, out, A->c, B, &A->c[12]); }
 // out must not be A or B
-__device__ __forceinline__ void pb_mul_na(LShared &S, LPB *out, const LPB *A, const LPB *B) { pb_round<true>(S, out, A->c, B); }
+__device__ __forceinline__ void pb_mul_na(LShared &S, LPB *out, const LPB *A, const LPB *B) { pb_round<true>(S, out, A->c, B, &A->c[12]); }
 
 // store coefficient t of a value computed by lanes t < 12, with its twin
 __device__ __forceinline__ void pb_put(LPB *out, int t, const Fq &v) {
     lds_store(&out->c[t], v);
     lds_store(&out->c5[t], pw_twin(v));
 }
+// the value's scale (one lane), with its negative
+__device__ __forceinline__ void pb_put_scale(LPB *out, const Fq &s) {
+    lds_store(&out->c[12], s);
+    lds_store(&out->c5[12], pw_neg2q(s));
+}
 // out = frobenius^e(A): c_k *= gamma_e^k
 __device__ __forceinline__ void pb_frob(LShared &S, LPB *out, const LPB *A, const Fq *gamma /* global, 12 */) {
     const int t = threadIdx.x;
     Fq v;
     if (t < 12) v = mul(lds_load(&A->c[t]), gamma[t]);
+    if (t == 12) v = lds_load(&A->c[12]);  // Fq is fixed
     __syncthreads();
     if (t < 12) pb_put(out, t, v);
+    if (t == 12) pb_put_scale(out, v);
     __syncthreads();
 }
 // out = conj(A): negate the odd coefficients
@@ -261,33 +374,37 @@ __device__ __forceinline__ void pb_conj(LShared &S, LPB *out, const LPB *A) {
         reduce_once(v);  // rounds leave values in [0, 2q)
         if (t & 1) v = neg(v);
     }
+    if (t == 12) v = lds_load(&A->c[12]);
     __syncthreads();
     if (t < 12) pb_put(out, t, v);
+    if (t == 12) pb_put_scale(out, v);
     __syncthreads();
 }
 __device__ __forceinline__ void pb_copy(LShared &S, LPB *out, const LPB *A) {
     const int t = threadIdx.x;
     Fq v;
-    if (t < 24) v = lds_load(t < 12 ? &A->c[t] : &A->c5[t - 12]);
+    if (t < 26) v = lds_load(t < 13 ? &A->c[t] : &A->c5[t - 13]);
     __syncthreads();
-    if (t < 24) lds_store(t < 12 ? &out->c[t] : &out->c5[t - 12], v);
+    if (t < 26) lds_store(t < 13 ? &out->c[t] : &out->c5[t - 13], v);
     __syncthreads();
 }
 __device__ __forceinline__ void pb_set_one(LPB *out) {  // followed by the caller's barrier
     const int t = threadIdx.x;
     if (t < 12) pb_put(out, t, t == 0 ? Fq::one() : Fq::zero());
+    if (t == 12) pb_put_scale(out, Fq::one());
 }
-// out = A^x (x = BLS seed)
+// out = A^x (x = BLS seed), A = s u with u in the cyclotomic subgroup: 63 cyclotomic squarings, 6 products
 __device__ __attribute__((noinline)) void pb_exp_by_x(LShared &S, LPB *out, const LPB *A) {
     // ping-pong between S.y and S.z so that no round writes an operand (one barrier per round); A is neither
     LPB *cur = &S.y, *alt = &S.z;
     pb_copy(S, cur, A);
     const PwFold fc = pw_fold_consts(S);  // in registers across the 69 rounds (a round that reloads them: 1.74 vs 1.44 us)
+    const uint32_t entry = pw_csqr_entry();
     for (int i = 62; i >= 0; i--) {
-        pb_round_impl<true>(S, alt, cur->c, cur, fc.d0, fc.d1, fc.d2, fc.d3);
+        pb_csqr_impl(S, alt, cur, entry, fc.d0, fc.d1, fc.d2, fc.d3);
         LPB *sw = cur; cur = alt; alt = sw;
         if ((MI_BLS_X >> i) & 1) {
-            pb_round_impl<true>(S, alt, cur->c, A, fc.d0, fc.d1, fc.d2, fc.d3);
+            pb_round_impl<true>(S, alt, cur->c, A, fc.d0, fc.d1, fc.d2, fc.d3, nullptr, &cur->c[12]);
             sw = cur; cur = alt; alt = sw;
         }
     }
@@ -298,7 +415,7 @@ __device__ __attribute__((noinline)) void pb_exp_by_x(LShared &S, LPB *out, cons
 // inversion in Fq on a single lane.  With U = A frob1(A) frob2(A) (e = 0,1,2) and P2 = A frob1(A):
 //   W = U * frob3(U) * frob6(U) * frob9(P2)   covers e = 0..10,   Abar = frob1(W),   frob6 = conj, frob9 = conj o frob3.
 // Uses S.x, S.y, S.c, S.d as scratch (callers invert before they use those).
-// unscaled: out = Abar = N A^-1 only -- no norm, no inversion in Fq (pw_final_exp's verdict form).
+// unscaled: out = Abar = N A^-1 with scale N -- no inversion in Fq (pw_final_exp's verdict form).
 __device__ __attribute__((noinline)) void pb_inv(LShared &S, LPB *out, const LPB *A, const PairingConsts *pc, bool unscaled = false) {
     pb_frob(S, &S.x, A, pc->frob[0]);         // x = frob1(A)
     pb_mul(S, &S.c, A, &S.x);                 // c = P2 = A frob1(A)
@@ -312,12 +429,18 @@ __device__ __attribute__((noinline)) void pb_inv(LShared &S, LPB *out, const LPB
     pb_conj(S, &S.x, &S.x);                   // x = frob9(P2)
     pb_mul(S, &S.y, &S.y, &S.x);              // y = W
     pb_frob(S, &S.x, &S.y, pc->frob[0]);      // x = Abar
-    if (unscaled) {                           // uniform
-        pb_copy(S, out, &S.x);
-        return;
-    }
     pb_mul(S, &S.y, A, &S.x);                 // y = N (coefficient 0; the others vanish)
     const int t = threadIdx.x;
+    if (unscaled) {  // uniform: out = Abar = N A^-1, and says so: scale N (A's own scale is one: a Miller value)
+        Fq v;
+        if (t < 12) v = lds_load(&S.x.c[t]);
+        if (t == 12) v = lds_load(&S.y.c[0]);
+        __syncthreads();
+        if (t < 12) pb_put(out, t, v);
+        if (t == 12) pb_put_scale(out, v);
+        __syncthreads();
+        return;
+    }
     if (t == 0) {
         Fq nrm = lds_load(&S.y.c[0]);
         reduce_once(nrm);  // rounds leave values in [0, 2q)
@@ -328,6 +451,7 @@ __device__ __attribute__((noinline)) void pb_inv(LShared &S, LPB *out, const LPB
     if (t < 12) v = mul(lds_load(&S.x.c[t]), lds_load(&S.y.c[1]));
     __syncthreads();
     if (t < 12) pb_put(out, t, v);
+    if (t == 12) pb_put_scale(out, Fq::one());
     __syncthreads();
 }
 
@@ -441,6 +565,7 @@ __device__ __forceinline__ void pw_miller_group(LShared &S, const G2Prepared *co
     if (live_n > 2) {
         for (int i = 0; i < count; i++) {
             if (t < 12) pb_put(&S.x, t, lds_load(&S.lprod[SECOND + i][t]));
+            if (t == 12) pb_put_scale(&S.x, Fq::one());
             __syncthreads();
             pb_round_impl<true>(S, merged[i], S.lprod[i], &S.x, fc.d0, fc.d1, fc.d2, fc.d3);
             X[i] = merged[i]->c;
@@ -451,6 +576,7 @@ __device__ __forceinline__ void pw_miller_group(LShared &S, const G2Prepared *co
     LPB *cur = &S.f, *alt = &S.g;
     int idx = 0;
     if (t < 12) pb_put(cur, t, lds_load(&X[0][t]));
+    if (t == 12) pb_put_scale(cur, Fq::one());
     __syncthreads();
     idx = 1;
     if (nadd[0]) {
@@ -478,6 +604,7 @@ __device__ __attribute__((noinline)) void pw_miller_merged(LShared &S, const Fq 
     // f = M_0, then per group three squarings and the group's factor
     LPB *cur = &S.f, *alt = &S.g;
     if (t < 12) pb_put(cur, t, lds_load(&S.lprod[0][t]));
+    if (t == 12) pb_put_scale(cur, Fq::one());
     __syncthreads();
     const PwFold fc = pw_fold_consts(S);
     for (int g = 1; g < PW_MILLER_GROUPS; g++) {

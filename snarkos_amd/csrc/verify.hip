@@ -1394,7 +1394,7 @@ __global__ void __launch_bounds__(VS_GROUP * LP) vs_sums_kernel(size_t n, const 
     }
 }
 
-// The pairing products of the fallback, workgroup-cooperative (192 lanes), over 2 + n_bounds pairs.
+// The pairing products of the fallback, workgroup-cooperative (PW_THREADS lanes), over 2 + n_bounds pairs.
 struct VsG2Keys {
     const G2Prepared *q[MI_MAX_PAIRS];  // h, tau h, shift_h[0], shift_h[1]
 };

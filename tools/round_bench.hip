@@ -20,6 +20,10 @@ __global__ void __launch_bounds__(RB_THREADS) rounds_kernel(int n, Fq *out) {
         pb_put(&S.f, t, v);
         pb_put(&S.t, t, v);
     }
+    if (t == 12) {
+        pb_put_scale(&S.f, Fq::one());
+        pb_put_scale(&S.t, Fq::one());
+    }
     if (t >= 64 && t < 64 + 25) {  // any constants below q do for timing
         Fq v = Fq::one();
         v.l[2] ^= t;
@@ -50,6 +54,20 @@ __global__ void __launch_bounds__(RB_THREADS) rounds_kernel(int n, Fq *out) {
         if (t < 12) out[t] = lds_load(&cur->c[t]);
         return;
     }
+    if (MODE == 5 || MODE == 6) {  // the cyclotomic squaring round (timing only: the values are no subgroup members)
+        __shared__ uint64_t prof[8];
+        if (t < 8) prof[t] = 0;
+        __syncthreads();
+        const PwFold fc = pw_fold_consts(S);
+        const uint32_t entry = pw_csqr_entry();
+        for (int i = 0; i < n; i++) {
+            pb_csqr_impl<MODE == 6>(S, alt, cur, entry, fc.d0, fc.d1, fc.d2, fc.d3, prof);
+            LPB *sw = cur; cur = alt; alt = sw;
+        }
+        if (MODE == 6 && t < 8) ((uint64_t *)out)[80 + t] = prof[t];
+        if (t < 12) out[t] = lds_load(&cur->c[t]);
+        return;
+    }
     if (MODE == 4) {  // ping-pong rounds with the fold constants kept in registers
         const PwFold fc = pw_fold_consts(S);
         for (int i = 0; i < n; i++) {
@@ -75,14 +93,17 @@ int main() {
     hipMemset(d, 0, sizeof(Fq) * 12 + 1024);
     hipEvent_t e0, e1;
     hipEventCreate(&e0); hipEventCreate(&e1);
-    const char *names[5] = {"dense round, in place (2 barriers)", "dense round, ping-pong (1 barrier)", "Fq inversion on one lane",
-                            "ping-pong round with stage stamps", "ping-pong round, fold constants in registers"};
+    const char *names[7] = {"dense round, in place (2 barriers)", "dense round, ping-pong (1 barrier)", "Fq inversion on one lane",
+                            "ping-pong round with stage stamps", "ping-pong round, fold constants in registers",
+                            "cyclotomic squaring round", "cyclotomic squaring round with stage stamps"};
+    hipFuncSetAttribute((const void *)rounds_kernel<5>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)PW_LDS_BYTES);
+    hipFuncSetAttribute((const void *)rounds_kernel<6>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)PW_LDS_BYTES);
     hipFuncSetAttribute((const void *)rounds_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)PW_LDS_BYTES);
     hipFuncSetAttribute((const void *)rounds_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)PW_LDS_BYTES);
     hipFuncSetAttribute((const void *)rounds_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)PW_LDS_BYTES);
     hipFuncSetAttribute((const void *)rounds_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)PW_LDS_BYTES);
     hipFuncSetAttribute((const void *)rounds_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)PW_LDS_BYTES);
-    for (int mode = 0; mode < 5; mode++) {
+    for (int mode = 0; mode < 7; mode++) {
         const int N = mode == 2 ? 50 : 2000;
         for (int rep = 0; rep < 2; rep++) {
             hipEventRecord(e0, 0);
@@ -90,13 +111,15 @@ int main() {
             else if (mode == 1) hipLaunchKernelGGL(rounds_kernel<1>, dim3(1), dim3(RB_THREADS), PW_LDS_BYTES, 0, N, d);
             else if (mode == 2) hipLaunchKernelGGL(rounds_kernel<2>, dim3(1), dim3(RB_THREADS), PW_LDS_BYTES, 0, N, d);
             else if (mode == 3) hipLaunchKernelGGL(rounds_kernel<3>, dim3(1), dim3(RB_THREADS), PW_LDS_BYTES, 0, N, d);
-            else hipLaunchKernelGGL(rounds_kernel<4>, dim3(1), dim3(RB_THREADS), PW_LDS_BYTES, 0, N, d);
+            else if (mode == 4) hipLaunchKernelGGL(rounds_kernel<4>, dim3(1), dim3(RB_THREADS), PW_LDS_BYTES, 0, N, d);
+            else if (mode == 5) hipLaunchKernelGGL(rounds_kernel<5>, dim3(1), dim3(RB_THREADS), PW_LDS_BYTES, 0, N, d);
+            else hipLaunchKernelGGL(rounds_kernel<6>, dim3(1), dim3(RB_THREADS), PW_LDS_BYTES, 0, N, d);
             hipEventRecord(e1, 0);
             hipEventSynchronize(e1);
             float ms = 0;
             hipEventElapsedTime(&ms, e0, e1);
             if (rep) printf("%s: %.3f us each\n", names[mode], ms * 1e3 / N);
-            if (rep && mode == 3) {
+            if (rep && (mode == 3 || mode == 6)) {
                 uint64_t h[8];
                 hipMemcpy(h, (char *)d + 80 * 8, sizeof h, hipMemcpyDeviceToHost);
                 const char *st[7] = {"loads", "product", "quad reduction", "fold", "row reduction", "Barrett + twin", "stores + barrier"};
