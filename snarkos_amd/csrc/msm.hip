@@ -117,45 +117,119 @@ void msm_plan_query(size_t n, int scalar_bits, int *c, int *nwin, int *chunk, in
     *chunk = *small ? (int)msm_small_chunk() : (int)T;
 }
 
+// ---------------------------------------------------------------- signed digit of one window, without the windows below
+// carry_w = [ k mod 2^(c w)  >  H_w ],  H_w = sum_{j < w} 2^(c j + c - 1)   (the recoding d = raw + carry > 2^(c-1) ? raw +
+// carry - 2^c : raw + carry, by induction on w): one comparison instead of the carry chain through the lower windows.
+__device__ __forceinline__ int32_t msm_digit_at(const uint32_t (&s)[8], int c, int w, const uint32_t *__restrict__ hw) {
+    // carry into window w (uniform w: every branch below is wave-uniform)
+    uint32_t carry = 0;
+    const int nbits = c * w;
+    if (w > 0) {
+        bool gt = false, decided = false;
+#pragma unroll
+        for (int j = 7; j >= 0; j--) {
+            uint32_t limb = 0;
+            if (32 * j < nbits) limb = 32 * (j + 1) <= nbits ? s[j] : (s[j] & ((1u << (nbits - 32 * j)) - 1u));
+            const uint32_t h = hw[j];
+            if (!decided && limb != h) {
+                gt = limb > h;
+                decided = true;
+            }
+        }
+        carry = gt ? 1u : 0u;
+    }
+    const int li = nbits >> 5, off = nbits & 31;
+    uint32_t lo = 0, hi = 0;
+    switch (li) {
+    case 0: lo = s[0]; hi = s[1]; break;
+    case 1: lo = s[1]; hi = s[2]; break;
+    case 2: lo = s[2]; hi = s[3]; break;
+    case 3: lo = s[3]; hi = s[4]; break;
+    case 4: lo = s[4]; hi = s[5]; break;
+    case 5: lo = s[5]; hi = s[6]; break;
+    case 6: lo = s[6]; hi = s[7]; break;
+    case 7: lo = s[7]; hi = 0; break;
+    default: break;
+    }
+    const uint32_t mask = (1u << c) - 1u, B = 1u << (c - 1);
+    const uint32_t raw = ((uint32_t)((((uint64_t)hi << 32) | lo) >> off) & mask) + carry;
+    return raw > B ? (int32_t)raw - (int32_t)(1u << c) : (int32_t)raw;
+}
+// the limbs of H_w for a compile-time width: the bits at positions = C - 1 mod C, below C w (w uniform: scalar code)
+template <int C>
+__device__ __forceinline__ void msm_half_limbs(int w, uint32_t (&hw)[8]) {
+    const int top = C * w;  // bits below this position
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        uint32_t pat = 0;  // compile-time constant per (C, j)
+#pragma unroll
+        for (int b = 0; b < 32; b++)
+            if ((32 * j + b) % C == C - 1) pat |= 1u << b;
+        const int room = top - 32 * j;
+        hw[j] = room >= 32 ? pat : (room <= 0 ? 0u : (pat & ((1u << room) - 1u)));
+    }
+}
+
 // ---------------------------------------------------------------- K1: signed digits + histogram
-template <int C, int BITS>
-__global__ void __launch_bounds__(256) msm_digits_kernel(const uint32_t *__restrict__ scalars, size_t n,
-                                                         int32_t *__restrict__ digits, uint32_t *__restrict__ ranks,
-                                                         uint32_t *__restrict__ counts_all, MsmSplits splits) {
+// One thread per (scalar, window): blockIdx.y is the window, a workgroup takes MSM_DIGITS_THREADS consecutive scalars.  (One thread per
+// scalar walking its 32 windows was a chain of 32 returning global atomics: 56 us of the 1024-proof batch's latency for
+// microseconds of work, and n x windows atomics at the memory-side rate.)  A thread takes its window's carry from one
+// comparison (msm_digit_at), counts its digit in the workgroup's LDS histogram, which
+// also numbers it among the workgroup's entries of that bucket; one global atomic per (workgroup, live bucket) then
+// reserves the workgroup's range of ranks.  Buckets of several problems (split points inside the workgroup's range of
+// scalars) sit side by side in LDS.  Window widths whose histogram does not fit (c > 10: never the small path's) count
+// in global memory directly, hot buckets of a wave through one atomic.
+template <int C, int BITS, int MSM_DIGITS_THREADS>
+__global__ void __launch_bounds__(MSM_DIGITS_THREADS) msm_digits_kernel(const uint32_t *__restrict__ scalars, size_t n,
+                                                                        int32_t *__restrict__ digits, uint32_t *__restrict__ ranks,
+                                                                        uint32_t *__restrict__ counts_all, MsmSplits splits) {
     constexpr int NWIN = (BITS + C - 1) / C;
     constexpr uint32_t B = 1u << (C - 1);
-    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    // several problems in one launch: the points past each split point use a further set of NWIN windows
-    const uint32_t pbase = splits.problem_of(i) * (uint32_t)NWIN * B;
-    const int lane = threadIdx.x & 63;
-    const uint4 *sp = reinterpret_cast<const uint4 *>(scalars + i * 8);
-    uint4 lo = sp[0], hi = sp[1];
-    uint32_t s[9] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w, 0u};
-    uint32_t carry = 0;
-#pragma unroll
-    for (int w = 0; w < NWIN; w++) {
-        constexpr uint32_t MASK = (1u << C) - 1u;
-        const int bit = w * C, limb = bit >> 5, off = bit & 31;
-        uint64_t v = (limb < 8 ? (uint64_t)s[limb] : 0ull) | ((limb + 1 < 9 ? (uint64_t)s[limb + 1] : 0ull) << 32);
-        uint32_t raw = ((uint32_t)(v >> off) & MASK) + carry;
-        int32_t d;
-        if (raw > B) {
-            d = (int32_t)raw - (int32_t)(1u << C);
-            carry = 1;
-        } else {
-            d = (int32_t)raw;
-            carry = 0;
-        }
+    constexpr bool IN_LDS = C <= 10;
+    __shared__ uint32_t hist[IN_LDS ? B * MSM_MAX_PROBLEMS : 1];
+    const size_t first = (size_t)blockIdx.x * MSM_DIGITS_THREADS, i = first + threadIdx.x;
+    const bool live_thread = i < n;
+    const int w = (int)blockIdx.y;  // uniform
+    const uint32_t p_first = splits.problem_of(first);
+    const size_t last = first + MSM_DIGITS_THREADS - 1 < n ? first + MSM_DIGITS_THREADS - 1 : n - 1;
+    const uint32_t n_prob = splits.problem_of(last) - p_first + 1;  // problems this workgroup's scalars belong to
+    if (IN_LDS) {
+        for (uint32_t e = threadIdx.x; e < B * n_prob; e += MSM_DIGITS_THREADS) hist[e] = 0;
+        __syncthreads();
+    }
+    int32_t d = 0;
+    uint32_t prob = p_first;
+    if (live_thread) {
+        prob = splits.problem_of(i);
+        const uint4 *sp = reinterpret_cast<const uint4 *>(scalars + i * 8);
+        uint4 lo = sp[0], hi = sp[1];
+        const uint32_t s[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+        uint32_t hw[8];
+        msm_half_limbs<C>(w, hw);
+        d = msm_digit_at(s, C, w, hw);
         digits[(size_t)w * n + i] = d;
-        // The histogram atomic also hands this entry its rank inside the bucket, so the scatter needs no atomics.
+    }
+    const uint32_t mag = d < 0 ? (uint32_t)(-d) : (uint32_t)d;
+    // the histogram count also hands this entry its rank inside the bucket, so the scatter needs no atomics
+    if (IN_LDS) {
+        const uint32_t slot = (prob - p_first) * B + (mag - 1);
+        uint32_t local = 0;
+        if (d != 0) local = atomicAdd(&hist[slot], 1u);
+        __syncthreads();
+        for (uint32_t e = threadIdx.x; e < B * n_prob; e += MSM_DIGITS_THREADS) {
+            const uint32_t cnt = hist[e];
+            if (cnt) hist[e] = atomicAdd(&counts_all[(p_first + e / B) * (uint32_t)NWIN * B + (uint32_t)w * B + e % B], cnt);
+        }
+        __syncthreads();
+        if (d != 0) ranks[(size_t)w * n + i] = hist[slot] + local;
+    } else {
         // Windows with few live buckets (the top window of a 253-bit scalar holds one or two digits; skewed scalars
         // anywhere) would serialise thousands of atomics on one address (measured: 1.7 ms of a 4.9 ms MSM at 2^18):
         // while the first live lane's bucket is shared by 8+ lanes of the wave, those lanes take ONE atomic and number
         // themselves by their position in the match mask.
+        const int lane = threadIdx.x & 63;
         bool live = d != 0;
-        const uint32_t mag = d < 0 ? (uint32_t)(-d) : (uint32_t)d;
-        const uint32_t bkt = pbase + (uint32_t)w * B + (mag - 1);
+        const uint32_t bkt = prob * (uint32_t)NWIN * B + (uint32_t)w * B + (mag - 1);
         uint32_t rank = 0;
 #pragma unroll 1
         for (int it = 0; it < 4; it++) {
@@ -647,41 +721,6 @@ __global__ void __launch_bounds__(64) msm_bit_sums_queue_kernel(const G1Xyzz *__
 struct MsmTileConsts {
     uint32_t half[24][8];  // half[w] = sum_{j < w} 2^(c j + c - 1), little-endian limbs (w >= 1)
 };
-__device__ __forceinline__ int32_t msm_digit_at(const uint32_t (&s)[8], int c, int w, const uint32_t *__restrict__ hw) {
-    // carry into window w (uniform w: every branch below is wave-uniform)
-    uint32_t carry = 0;
-    const int nbits = c * w;
-    if (w > 0) {
-        bool gt = false, decided = false;
-#pragma unroll
-        for (int j = 7; j >= 0; j--) {
-            uint32_t limb = 0;
-            if (32 * j < nbits) limb = 32 * (j + 1) <= nbits ? s[j] : (s[j] & ((1u << (nbits - 32 * j)) - 1u));
-            const uint32_t h = hw[j];
-            if (!decided && limb != h) {
-                gt = limb > h;
-                decided = true;
-            }
-        }
-        carry = gt ? 1u : 0u;
-    }
-    const int li = nbits >> 5, off = nbits & 31;
-    uint32_t lo = 0, hi = 0;
-    switch (li) {
-    case 0: lo = s[0]; hi = s[1]; break;
-    case 1: lo = s[1]; hi = s[2]; break;
-    case 2: lo = s[2]; hi = s[3]; break;
-    case 3: lo = s[3]; hi = s[4]; break;
-    case 4: lo = s[4]; hi = s[5]; break;
-    case 5: lo = s[5]; hi = s[6]; break;
-    case 6: lo = s[6]; hi = s[7]; break;
-    case 7: lo = s[7]; hi = 0; break;
-    default: break;
-    }
-    const uint32_t mask = (1u << c) - 1u, B = 1u << (c - 1);
-    const uint32_t raw = ((uint32_t)((((uint64_t)hi << 32) | lo) >> off) & mask) + carry;
-    return raw > B ? (int32_t)raw - (int32_t)(1u << c) : (int32_t)raw;
-}
 __global__ void __launch_bounds__(1024) msm_digits_tiled_kernel(const uint32_t *__restrict__ scalars, size_t n, size_t tile_size,
                                                                 int c, const MsmTileConsts *__restrict__ tc,
                                                                 int32_t *__restrict__ digits, uint32_t *__restrict__ ranks,
@@ -740,13 +779,20 @@ __global__ void __launch_bounds__(1024) msm_rank_fixup_kernel(const int32_t *__r
 }
 
 // ---------------------------------------------------------------- host driver
+template <int C, int T>
+static void launch_digits_t(const uint32_t *scalars, size_t n, int32_t *digits, uint32_t *ranks, uint32_t *counts,
+                            int scalar_bits, MsmSplits split, hipStream_t st) {
+    if (scalar_bits > 128)
+        hipLaunchKernelGGL((msm_digits_kernel<C, 254, T>), dim3(cdiv(n, T), (254 + C - 1) / C), dim3(T), 0, st, scalars, n, digits, ranks, counts, split);
+    else
+        hipLaunchKernelGGL((msm_digits_kernel<C, 129, T>), dim3(cdiv(n, T), (129 + C - 1) / C), dim3(T), 0, st, scalars, n, digits, ranks, counts, split);
+}
+// workgroups of 512: measured (tools/digits_threads.sh) 7.78e6 proofs/s streamed against 7.6e6 with 1024 (a workgroup
+// that large waits for a whole CU's worth of wave slots) and 7.3-7.7e6 with 256 (four times the global atomics of 1024)
 template <int C>
 static void launch_digits(const uint32_t *scalars, size_t n, int32_t *digits, uint32_t *ranks, uint32_t *counts,
                           int scalar_bits, MsmSplits split, hipStream_t st) {
-    if (scalar_bits > 128)
-        hipLaunchKernelGGL((msm_digits_kernel<C, 254>), dim3(cdiv(n, 256)), dim3(256), 0, st, scalars, n, digits, ranks, counts, split);
-    else
-        hipLaunchKernelGGL((msm_digits_kernel<C, 129>), dim3(cdiv(n, 256)), dim3(256), 0, st, scalars, n, digits, ranks, counts, split);
+    launch_digits_t<C, 512>(scalars, n, digits, ranks, counts, scalar_bits, split, st);
 }
 
 // Sum groups of XYZZ points on the device: in[groups][m] -> result[groups] (device pointer into workspace)
