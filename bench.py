@@ -287,13 +287,15 @@ def main():
 
 
 # ---- integer-ALU view of the dominant kernel (the verifier is latency / ALU bound: SURVEY.md 8d)
-# A pairing product is ONE workgroup of 3 waves on one compute unit (after a short first launch of 21 workgroups that
-# prepare the merged Miller factors: ~30 us, bracketed and counted separately).  Work
-# of the product kernel in 32x32-bit limb products (v_mad_u64_u32): ~450 Fq12 rounds (81 Miller + ~365 final
-# exponentiation) x 192 lanes x 179 limb products (108 product + 48 fold + 23 Barrett).  Peak for the waves the kernel
-# owns: tools/ubench at one wave per SIMD sustains 50.25 G Fq products/s chip-wide = 49.1 M products/s per wave = 14.1 G
-# limb products/s per wave.
-PAIRING_LIMB_PRODUCTS = 450 * 192 * 179
+# A pairing product is ONE workgroup on one compute unit: three waves carry the twelve coefficients of the Fq12 value, a
+# fourth its scale (pairing_wg.hpp), after a short first launch of 21 workgroups that prepare the merged Miller factors
+# (~30 us, bracketed and counted separately).  Work of the product kernel in 32x32-bit limb products (v_mad_u64_u32) on the
+# 192 coefficient lanes: 127 general Fq12 rounds (80 Miller, 47 in the final exponentiation) x 179 limb products (108
+# product + 48 fold + 23 Barrett) and the 315 cyclotomic squaring rounds of the hard part x 119 (12 to scale the operand
+# + 36 product + 48 + 23).  Peak for the waves the kernel owns: tools/ubench at one wave per SIMD sustains 50.25 G Fq
+# products/s chip-wide = 49.1 M products/s per wave = 14.1 G limb products/s per wave.
+PAIRING_LIMB_PRODUCTS = 192 * (127 * 179 + 315 * 119)
+PAIRING_WAVES = 4
 WAVE_LIMB_PRODUCT_RATE = 50.25e9 / 1024 * 288
 
 
@@ -304,8 +306,9 @@ def alu_view(kernels):
     t = k["avg_us"] * 1e-6
     ach = PAIRING_LIMB_PRODUCTS / t
     return {"kernel": "pairing", "unit": "32x32-bit limb products/s", "work_per_launch": PAIRING_LIMB_PRODUCTS,
-            "achieved": ach, "waves": 3, "peak_for_those_waves": 3 * WAVE_LIMB_PRODUCT_RATE, "frac": ach / (3 * WAVE_LIMB_PRODUCT_RATE),
-            "note": "one workgroup (3 waves, one CU) per product (its 21-workgroup line launch is bracketed separately); a launch carries "
+            "achieved": ach, "waves": PAIRING_WAVES, "peak_for_those_waves": PAIRING_WAVES * WAVE_LIMB_PRODUCT_RATE,
+            "frac": ach / (PAIRING_WAVES * WAVE_LIMB_PRODUCT_RATE),
+            "note": "one workgroup (4 waves, one CU: three carry the value, the fourth its scale) per product (its 21-workgroup line launch is bracketed separately); a launch carries "
                     "one to four products (a workgroup each: same duration, work and waves scale together, so the fraction is per "
                     "product); several launches run side by side in the streamed region, so avg_us includes their mutual slowdown"}
 
@@ -319,7 +322,7 @@ def alu_view(kernels):
 #   bit sums    per (window, bit) group one wave: ceil(matches / 64) queue additions + 6 tree levels, each a full XYZZ
 #               addition (12 products + 2 squarings) on 64 lanes; matches = half the window's chunks
 #   derive      ~165 products per proof on 32-bit limbs (11 curve checks, ~250 Fr products, the SHA-256 transcript)
-#   pairing     450 rounds x 192 lanes x 179 limb products / 288 per product, on 32-bit limbs
+#   pairing     PAIRING_LIMB_PRODUCTS (above) / 288 per product, on 32-bit limbs
 # against the rates tools/ubench.hip measures for a tight loop over the whole chip (8 waves/SIMD): 79.9 G products/s and
 # 96.7 G squarings/s on 28-bit limbs, 60 G products/s on 32-bit limbs.
 CHIP_RATE_28, CHIP_SQR_28, CHIP_RATE_32 = 79.9e9, 96.7e9, 60.0e9

@@ -171,7 +171,8 @@ __device__ __forceinline__ void msm_half_limbs(int w, uint32_t (&hw)[8]) {
 }
 
 // ---------------------------------------------------------------- K1: signed digits + histogram
-// One thread per (scalar, window): blockIdx.y is the window, a workgroup takes MSM_DIGITS_THREADS consecutive scalars.  (One thread per
+// One thread per (scalar, group of up to four windows): blockIdx.y is the group, a workgroup takes MSM_DIGITS_THREADS
+// consecutive scalars.  (One thread per
 // scalar walking its 32 windows was a chain of 32 returning global atomics: 56 us of the 1024-proof batch's latency for
 // microseconds of work, and n x windows atomics at the memory-side rate.)  A thread takes its window's carry from one
 // comparison (msm_digit_at), counts its digit in the workgroup's LDS histogram, which
@@ -179,6 +180,10 @@ __device__ __forceinline__ void msm_half_limbs(int w, uint32_t (&hw)[8]) {
 // reserves the workgroup's range of ranks.  Buckets of several problems (split points inside the workgroup's range of
 // scalars) sit side by side in LDS.  Window widths whose histogram does not fit (c > 10: never the small path's) count
 // in global memory directly, hot buckets of a wave through one atomic.
+// windows per thread: a thread reads its scalar once for G windows (one thread per window re-read 32 bytes per window
+// through L2: 1.4 % of the streamed rate) and walks them with a chain of G LDS atomics
+template <int C>
+constexpr int msm_digits_group() { return C <= 9 ? 4 : (C == 10 ? 2 : 1); }
 template <int C, int BITS, int MSM_DIGITS_THREADS>
 __global__ void __launch_bounds__(MSM_DIGITS_THREADS) msm_digits_kernel(const uint32_t *__restrict__ scalars, size_t n,
                                                                         int32_t *__restrict__ digits, uint32_t *__restrict__ ranks,
@@ -186,49 +191,69 @@ __global__ void __launch_bounds__(MSM_DIGITS_THREADS) msm_digits_kernel(const ui
     constexpr int NWIN = (BITS + C - 1) / C;
     constexpr uint32_t B = 1u << (C - 1);
     constexpr bool IN_LDS = C <= 10;
-    __shared__ uint32_t hist[IN_LDS ? B * MSM_MAX_PROBLEMS : 1];
+    constexpr int G = msm_digits_group<C>();
+    __shared__ uint32_t hist[IN_LDS ? G * B * MSM_MAX_PROBLEMS : 1];
     const size_t first = (size_t)blockIdx.x * MSM_DIGITS_THREADS, i = first + threadIdx.x;
     const bool live_thread = i < n;
-    const int w = (int)blockIdx.y;  // uniform
+    const int w0 = (int)blockIdx.y * G;  // uniform: this workgroup's windows w0 .. w0 + G - 1 (below NWIN)
     const uint32_t p_first = splits.problem_of(first);
     const size_t last = first + MSM_DIGITS_THREADS - 1 < n ? first + MSM_DIGITS_THREADS - 1 : n - 1;
     const uint32_t n_prob = splits.problem_of(last) - p_first + 1;  // problems this workgroup's scalars belong to
+    const uint32_t per_window = B * n_prob;
     if (IN_LDS) {
-        for (uint32_t e = threadIdx.x; e < B * n_prob; e += MSM_DIGITS_THREADS) hist[e] = 0;
+        for (uint32_t e = threadIdx.x; e < G * per_window; e += MSM_DIGITS_THREADS) hist[e] = 0;
         __syncthreads();
     }
-    int32_t d = 0;
+    int32_t d[G];
+    uint32_t local[G];
+#pragma unroll
+    for (int g = 0; g < G; g++) { d[g] = 0; local[g] = 0; }
     uint32_t prob = p_first;
     if (live_thread) {
         prob = splits.problem_of(i);
         const uint4 *sp = reinterpret_cast<const uint4 *>(scalars + i * 8);
         uint4 lo = sp[0], hi = sp[1];
         const uint32_t s[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
-        uint32_t hw[8];
-        msm_half_limbs<C>(w, hw);
-        d = msm_digit_at(s, C, w, hw);
-        digits[(size_t)w * n + i] = d;
+#pragma unroll
+        for (int g = 0; g < G; g++) {
+            const int w = w0 + g;
+            if (w < NWIN) {  // uniform
+                uint32_t hw[8];
+                msm_half_limbs<C>(w, hw);
+                d[g] = msm_digit_at(s, C, w, hw);
+                digits[(size_t)w * n + i] = d[g];
+            }
+        }
     }
-    const uint32_t mag = d < 0 ? (uint32_t)(-d) : (uint32_t)d;
     // the histogram count also hands this entry its rank inside the bucket, so the scatter needs no atomics
     if (IN_LDS) {
-        const uint32_t slot = (prob - p_first) * B + (mag - 1);
-        uint32_t local = 0;
-        if (d != 0) local = atomicAdd(&hist[slot], 1u);
-        __syncthreads();
-        for (uint32_t e = threadIdx.x; e < B * n_prob; e += MSM_DIGITS_THREADS) {
-            const uint32_t cnt = hist[e];
-            if (cnt) hist[e] = atomicAdd(&counts_all[(p_first + e / B) * (uint32_t)NWIN * B + (uint32_t)w * B + e % B], cnt);
+        const uint32_t pslot = (prob - p_first) * B;
+#pragma unroll
+        for (int g = 0; g < G; g++) {
+            const uint32_t mag = d[g] < 0 ? (uint32_t)(-d[g]) : (uint32_t)d[g];
+            if (d[g] != 0) local[g] = atomicAdd(&hist[g * per_window + pslot + (mag - 1)], 1u);
         }
         __syncthreads();
-        if (d != 0) ranks[(size_t)w * n + i] = hist[slot] + local;
+        for (uint32_t e = threadIdx.x; e < G * per_window; e += MSM_DIGITS_THREADS) {
+            const uint32_t cnt = hist[e];
+            const uint32_t g = e / per_window, r = e - g * per_window;
+            if (cnt) hist[e] = atomicAdd(&counts_all[(p_first + r / B) * (uint32_t)NWIN * B + (uint32_t)(w0 + (int)g) * B + r % B], cnt);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int g = 0; g < G; g++) {
+            const uint32_t mag = d[g] < 0 ? (uint32_t)(-d[g]) : (uint32_t)d[g];
+            if (d[g] != 0) ranks[(size_t)(w0 + g) * n + i] = hist[g * per_window + pslot + (mag - 1)] + local[g];
+        }
     } else {
-        // Windows with few live buckets (the top window of a 253-bit scalar holds one or two digits; skewed scalars
-        // anywhere) would serialise thousands of atomics on one address (measured: 1.7 ms of a 4.9 ms MSM at 2^18):
-        // while the first live lane's bucket is shared by 8+ lanes of the wave, those lanes take ONE atomic and number
-        // themselves by their position in the match mask.
+        // (G = 1) Windows with few live buckets (the top window of a 253-bit scalar holds one or two digits; skewed
+        // scalars anywhere) would serialise thousands of atomics on one address (measured: 1.7 ms of a 4.9 ms MSM at
+        // 2^18): while the first live lane's bucket is shared by 8+ lanes of the wave, those lanes take ONE atomic and
+        // number themselves by their position in the match mask.
         const int lane = threadIdx.x & 63;
-        bool live = d != 0;
+        const int w = w0;
+        const uint32_t mag = d[0] < 0 ? (uint32_t)(-d[0]) : (uint32_t)d[0];
+        bool live = d[0] != 0;
         const uint32_t bkt = prob * (uint32_t)NWIN * B + (uint32_t)w * B + (mag - 1);
         uint32_t rank = 0;
 #pragma unroll 1
@@ -249,7 +274,7 @@ __global__ void __launch_bounds__(MSM_DIGITS_THREADS) msm_digits_kernel(const ui
             }
         }
         if (live) rank = atomicAdd(&counts_all[bkt], 1u);
-        if (d != 0) ranks[(size_t)w * n + i] = rank;
+        if (d[0] != 0) ranks[(size_t)w * n + i] = rank;
     }
 }
 
@@ -783,9 +808,9 @@ template <int C, int T>
 static void launch_digits_t(const uint32_t *scalars, size_t n, int32_t *digits, uint32_t *ranks, uint32_t *counts,
                             int scalar_bits, MsmSplits split, hipStream_t st) {
     if (scalar_bits > 128)
-        hipLaunchKernelGGL((msm_digits_kernel<C, 254, T>), dim3(cdiv(n, T), (254 + C - 1) / C), dim3(T), 0, st, scalars, n, digits, ranks, counts, split);
+        hipLaunchKernelGGL((msm_digits_kernel<C, 254, T>), dim3(cdiv(n, T), ((254 + C - 1) / C + msm_digits_group<C>() - 1) / msm_digits_group<C>()), dim3(T), 0, st, scalars, n, digits, ranks, counts, split);
     else
-        hipLaunchKernelGGL((msm_digits_kernel<C, 129, T>), dim3(cdiv(n, T), (129 + C - 1) / C), dim3(T), 0, st, scalars, n, digits, ranks, counts, split);
+        hipLaunchKernelGGL((msm_digits_kernel<C, 129, T>), dim3(cdiv(n, T), ((129 + C - 1) / C + msm_digits_group<C>() - 1) / msm_digits_group<C>()), dim3(T), 0, st, scalars, n, digits, ranks, counts, split);
 }
 // workgroups of 512: measured (tools/digits_threads.sh) 7.78e6 proofs/s streamed against 7.6e6 with 1024 (a workgroup
 // that large waits for a whole CU's worth of wave slots) and 7.3-7.7e6 with 256 (four times the global atomics of 1024)

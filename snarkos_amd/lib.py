@@ -10,7 +10,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmi355x_snark.so")
+# MI_SNARK_LIB: another build of the same library (A/B measurements of one translation unit: tools/ab_lib.sh)
+LIB_PATH = os.environ.get("MI_SNARK_LIB") or os.path.join(_HERE, "libmi355x_snark.so")
 
 MI_OK = 0
 MI_ERR_NO_DEVICE = -2
