@@ -338,6 +338,15 @@ int32_t mi_vs_accumulate_end(uint64_t ctx, uint64_t handle, mi_vs_partial *parti
 int32_t mi_vs_accumulate_begin_multi(uint64_t ctx, int32_t count, const void *const *d_proofs, const size_t *n,
                                      const void *const *d_randomizers128, void *stream, uint64_t *handle_out);
 int32_t mi_vs_accumulate_end_multi(uint64_t ctx, uint64_t handle, mi_vs_partial *partials_out, int32_t count);
+/* The batches of a pass folded into ONE aggregate: the randomizers of all their proofs are independent, so the union of
+ * 2..4 batches is one batch-verification instance -- one MSM pair, one host fold, one pairing product for all of them.
+ * Ends with mi_vs_accumulate_end: ONE partial over all the proofs (n_proofs = their sum).  A product of one says every
+ * batch is valid; otherwise the caller checks the batches on their own (mi_vs_verify_batch_device / mi_vs_identify_device
+ * on the still-resident inputs).  MI_ERR_BAD_ARGS when the sum does not fit one pass: use _begin_multi or single passes.
+ * The native stream driver does this under load when it has no exchange between ranks (ranks would have to merge the
+ * same batches). */
+int32_t mi_vs_accumulate_begin_merged(uint64_t ctx, int32_t count, const void *const *d_proofs, const size_t *n,
+                                      const void *const *d_randomizers128, void *stream, uint64_t *handle_out);
 int32_t mi_vs_accumulate_begin_pair(uint64_t ctx, const void *d_proofs_a, size_t n_a, const void *d_randomizers128_a,
                                     const void *d_proofs_b, size_t n_b, const void *d_randomizers128_b, void *stream,
                                     uint64_t *handle_out);

@@ -494,6 +494,19 @@ class VarunaShaped:
                 "mi_vs_accumulate_begin_multi")
         return h.value
 
+    def accumulate_begin_merged(self, batches, stream=None):
+        """Two to four (proofs, randomizers) batches folded into ONE aggregate (mi_vs_accumulate_begin_merged); returns a
+        handle for accumulate_end(handle): one partial over all their proofs.  Raises MiError (MI_ERR_BAD_ARGS) when they
+        do not fit one pass."""
+        k = len(batches)
+        pr = (C.c_void_p * k)(*[L.dptr(p).value for p, _ in batches])
+        rn = (C.c_void_p * k)(*[L.dptr(r).value for _, r in batches])
+        ns = (C.c_size_t * k)(*[p.numel() * p.element_size() // self.proof_bytes for p, _ in batches])
+        h = C.c_uint64(0)
+        L.check(L.lib().mi_vs_accumulate_begin_merged(C.c_uint64(self.ctx), C.c_int32(k), pr, ns, rn, L.stream_ptr(stream), C.byref(h)),
+                "mi_vs_accumulate_begin_merged")
+        return h.value
+
     def accumulate_end_multi(self, handle, count):
         parts = np.zeros((count, L.VS_PARTIAL_BYTES), dtype=np.uint8)
         L.check(L.lib().mi_vs_accumulate_end_multi(C.c_uint64(self.ctx), C.c_uint64(handle), L.ptr(parts), C.c_int32(count)),

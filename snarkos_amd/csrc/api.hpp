@@ -87,6 +87,8 @@ int32_t vs_accumulate_begin(Context &cx, uint64_t id, const void *d_proofs, size
 int32_t vs_accumulate_end(Context &cx, uint64_t id, uint64_t handle, mi_vs_partial *out);
 int32_t vs_accumulate_begin_multi(Context &cx, uint64_t id, int count, const void *const *d_proofs, const size_t *n,
                                   const void *const *d_rand, hipStream_t st, uint64_t *handle);
+int32_t vs_accumulate_begin_merged(Context &cx, uint64_t id, int count, const void *const *d_proofs, const size_t *n,
+                                   const void *const *d_rand, hipStream_t st, uint64_t *handle);
 int32_t vs_accumulate_end_multi(Context &cx, uint64_t id, uint64_t handle, mi_vs_partial *outs, int count);
 int32_t vs_batches_per_pass(Context &cx, uint64_t id, size_t n);
 int32_t vs_finalize(Context &cx, uint64_t id, const mi_vs_partial *parts, size_t np, uint8_t *all_ok, hipStream_t st);

@@ -1007,6 +1007,15 @@ int32_t mi_vs_accumulate_begin_multi(uint64_t c, int32_t count, const void *cons
         return vs_accumulate_begin_multi(cx, c, count, d_proofs, n, d_randomizers128, (hipStream_t)stream, handle_out);
     });
 }
+int32_t mi_vs_accumulate_begin_merged(uint64_t c, int32_t count, const void *const *d_proofs, const size_t *n,
+                                      const void *const *d_randomizers128, void *stream, uint64_t *handle_out) {
+    if (count < 2 || count > MI_VS_MAX_BATCHES_PER_PASS || !d_proofs || !n || !d_randomizers128 || !handle_out) return MI_ERR_BAD_ARGS;
+    for (int k = 0; k < count; k++)
+        if (!d_proofs[k] || !n[k] || !d_randomizers128[k]) return MI_ERR_BAD_ARGS;
+    return guarded_ptr(d_proofs[0], [&](Context &cx) -> int32_t {
+        return vs_accumulate_begin_merged(cx, c, count, d_proofs, n, d_randomizers128, (hipStream_t)stream, handle_out);
+    });
+}
 int32_t mi_vs_accumulate_end_multi(uint64_t c, uint64_t handle, mi_vs_partial *partials_out, int32_t count) {
     if (!partials_out) return MI_ERR_BAD_ARGS;
     if (ensure_init() != MI_OK) return MI_ERR_NO_DEVICE;

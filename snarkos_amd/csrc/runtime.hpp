@@ -124,7 +124,7 @@ inline WorkerPool &worker_pool() {
 
 // Host-side wall-clock accounting of code sections (MI_SNARK_HOSTPROF=1; report on stderr at mi_shutdown / exit).
 struct HostProf {
-    struct Acc { double s = 0; uint64_t n = 0; };
+    struct Acc { double s = 0, mn = 1e9, mx = 0; uint64_t n = 0; };
     std::map<std::string, Acc> acc;
     std::mutex mu;
     bool on = false;
@@ -136,8 +136,8 @@ struct HostProf {
     void report() {
         if (!on) return;
         for (auto &kv : acc)
-            fprintf(stderr, "[hostprof] %-28s %8.1f us/call x %llu\n", kv.first.c_str(), 1e6 * kv.second.s / (double)kv.second.n,
-                    (unsigned long long)kv.second.n);
+            fprintf(stderr, "[hostprof] %-28s %8.1f us/call x %llu  (min %.1f, max %.1f)\n", kv.first.c_str(),
+                    1e6 * kv.second.s / (double)kv.second.n, (unsigned long long)kv.second.n, 1e6 * kv.second.mn, 1e6 * kv.second.mx);
         acc.clear();
     }
 };
@@ -155,7 +155,10 @@ struct HostSpan {
         if (!host_prof().on) return;
         std::lock_guard<std::mutex> lk(host_prof().mu);
         auto &a = host_prof().acc[name];
-        a.s += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        a.s += dt;
+        if (dt < a.mn) a.mn = dt;
+        if (dt > a.mx) a.mx = dt;
         a.n++;
     }
 };

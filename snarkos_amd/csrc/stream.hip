@@ -21,6 +21,8 @@
 
 namespace {
 
+constexpr int32_t RECHECK = 2;  // the product over several merged batches failed: this batch is verified on its own when its verdict is taken
+
 struct Stream {
     uint64_t ctx = 0;
     int products = 8, lanes = 12, group = 1;
@@ -29,10 +31,13 @@ struct Stream {
 
     std::mutex mu;
     std::condition_variable cv;
-    struct Pass { uint64_t seq, handle; int count; };    // a lane pass: batches seq .. seq + count - 1
+    struct Pass { uint64_t seq, handle; int count; bool merged; };  // a lane pass: batches seq .. seq + count - 1
     std::deque<Pass> to_fold;                           // submission order
     std::map<uint64_t, mi_vs_partial> folded;           // sequence number -> this rank's partial
-    std::deque<int32_t> results;                        // 0 / 1 verdicts, or a negative status
+    // A MERGED pass (no exchange between ranks: mi_vs_accumulate_begin_merged) has ONE partial for its `count` batches:
+    // it is stored under the first, cover[first] = count, and the others are marked 0 (covered: no product of their own).
+    std::map<uint64_t, int> cover;                      // sequence number -> batches its product decides (absent: 1)
+    std::deque<int32_t> results;                        // 0 / 1 verdicts, RECHECK, or a negative status
     struct Sub { const void *proofs; size_t n; const void *rand; };
     std::deque<Sub> pending;                            // submitted batches whose verdict has not been taken, oldest first
     std::vector<size_t> sizes;                          // every submitted batch's size, in order (counters)
@@ -44,7 +49,11 @@ struct Stream {
     // pair_at 0: one batch per pass, always.
     int pair_at = 4;
     int per_pass = 0;                                   // batches per pass for this context's shape (0: not asked yet)
-    int per_pass_max = 2;                               // MI_SNARK_STREAM_PER_PASS (measured: 2 is the best for both transcripts)
+    // MI_SNARK_STREAM_PER_PASS.  Passes that keep a partial per batch (streams with an exchange): 2 measured best for both
+    // transcripts.  Merged passes: 4 (tools/merge_sweep.sh: 400 batches 8.8e6 / 9.5e6 / 9.4-10.2e6 proofs/s with 2 / 3 / 4 per
+    // pass, 20 batches 4.2-4.3e6 / 4.4e6 / 4.6-4.7e6)
+    int per_pass_max = 2;
+    bool merge = true;                                  // MI_SNARK_STREAM_MERGE=0: the batches of a pass keep their own aggregates
     std::vector<Sub> held;
     void *held_stream = nullptr;
     bool launching = false;                             // somebody is between taking the held batch and queueing its pass
@@ -72,14 +81,17 @@ struct Stream {
                 to_fold.pop_front();
             }
             mi_vs_partial part[MI_VS_MAX_BATCHES_PER_PASS];
-            const int32_t st = item.count > 1 ? mi_vs_accumulate_end_multi(ctx, item.handle, part, item.count)  // waits for the GPU, folds
-                                              : mi_vs_accumulate_end(ctx, item.handle, &part[0]);
+            const int32_t st = item.count > 1 && !item.merged ? mi_vs_accumulate_end_multi(ctx, item.handle, part, item.count)  // waits for the GPU, folds
+                                                              : mi_vs_accumulate_end(ctx, item.handle, &part[0]);
             {
                 std::lock_guard<std::mutex> lk(mu);
                 open--;
                 if (st != MI_OK) fail(st);
                 else
-                    for (int k = 0; k < item.count; k++) folded[item.seq + k] = part[k];
+                    for (int k = 0; k < item.count; k++) {
+                        folded[item.seq + k] = part[item.merged ? 0 : k];
+                        if (item.merged) cover[item.seq + k] = k == 0 ? item.count : 0;
+                    }
                 cv.notify_all();
             }
             flush_held(false);  // a pass has ended: a held batch does not wait for company any longer than that
@@ -91,7 +103,7 @@ struct Stream {
     int32_t launch(const std::vector<Sub> &bs, void *st_in) {
         uint64_t h = 0;
         int32_t st = MI_ERR_BAD_ARGS;
-        bool together = false;
+        bool together = false, merged = false;
         const int count = (int)bs.size();
         if (count > 1) {
             const void *pr[MI_VS_MAX_BATCHES_PER_PASS], *rn[MI_VS_MAX_BATCHES_PER_PASS];
@@ -101,8 +113,17 @@ struct Stream {
                 rn[k] = bs[k].rand;
                 ns[k] = bs[k].n;
             }
-            st = mi_vs_accumulate_begin_multi(ctx, count, pr, ns, rn, st_in, &h);
-            together = st == MI_OK;
+            // Without an exchange the batches of a pass become ONE aggregate -- one MSM pair, one fold, one product --
+            // and are told apart only if that product fails.  (With an exchange every rank would have to merge the
+            // same batches, and what shares a pass depends on each rank's timing.)
+            if (!exchange && merge) {
+                st = mi_vs_accumulate_begin_merged(ctx, count, pr, ns, rn, st_in, &h);
+                merged = together = st == MI_OK;
+            }
+            if (!together) {
+                st = mi_vs_accumulate_begin_multi(ctx, count, pr, ns, rn, st_in, &h);
+                together = st == MI_OK;
+            }
         }
         if (together || count == 1) {
             if (count == 1) st = mi_vs_accumulate_begin(ctx, bs[0].proofs, bs[0].n, bs[0].rand, st_in, &h);
@@ -113,7 +134,7 @@ struct Stream {
                 fail(st);
                 return st;
             }
-            to_fold.push_back(Pass{submitted, h, count});
+            to_fold.push_back(Pass{submitted, h, count, merged});
             submitted += (uint64_t)count;
             for (const Sub &b : bs) pending.push_back(b);
             cv.notify_all();
@@ -140,7 +161,7 @@ struct Stream {
                 fail(st);
                 return st;
             }
-            to_fold.push_back(Pass{submitted++, h, 1});
+            to_fold.push_back(Pass{submitted++, h, 1, false});
             pending.push_back(bs[k]);
             cv.notify_all();
         }
@@ -173,13 +194,18 @@ struct Stream {
     // The finisher starts pairing products as partials arrive; the PUBLISHER waits for them in order and hands the
     // verdicts out.  (One thread doing both published a verdict only when it needed the product's slot back or the
     // stream was finished: a caller trickling batches in would wait for ever.)
-    std::deque<std::pair<uint64_t, int>> tickets;  // (ticket, products under it): started, oldest first (mu)
+    struct Ticket {
+        uint64_t id;
+        int products;
+        int covers[MI_VS_MAX_PRODUCTS_PER_TICKET];  // batches each product decides
+    };
+    std::deque<Ticket> tickets;    // started, oldest first (mu)
     int inflight = 0;              // started and not yet published (mu)
     bool launches_done = false;    // the finisher has ended (mu)
 
     void publisher_main() {
         for (;;) {
-            std::pair<uint64_t, int> tk;
+            Ticket tk;
             {
                 std::unique_lock<std::mutex> lk(mu);
                 cv.wait(lk, [&] { return !tickets.empty() || launches_done; });
@@ -192,14 +218,22 @@ struct Stream {
                 tickets.pop_front();
             }
             uint8_t ok[MI_VS_MAX_PRODUCTS_PER_TICKET] = {};
-            const int32_t st = mi_vs_finalize_wait_multi(ctx, tk.first, ok, tk.second);
+            const int32_t st = mi_vs_finalize_wait_multi(ctx, tk.id, ok, tk.products);
             std::lock_guard<std::mutex> lk(mu);
-            for (int k = 0; k < tk.second; k++) results.push_back(st == MI_OK ? (int32_t)ok[k] : st);
-            if (st == MI_OK) {  // counters: the batches these verdicts belong to are the oldest unpublished ones
-                mi::stats().batches_verified += (uint64_t)tk.second;
-                for (int k = 0; k < tk.second && published + (size_t)k < sizes.size(); k++) mi::stats().proofs_verified += sizes[published + (size_t)k];
-            }
-            published += (size_t)tk.second;
+            int batches = 0;
+            for (int k = 0; k < tk.products; k++)
+                for (int c = 0; c < tk.covers[k]; c++) {  // a failed product over several batches decides none of them
+                    const int32_t r = st != MI_OK ? st : (ok[k] ? 1 : (tk.covers[k] > 1 ? RECHECK : 0));
+                    results.push_back(r);
+                    // counters: the batches these verdicts belong to are the oldest unpublished ones (a batch to be
+                    // checked again is counted by that check)
+                    if (r == 0 || r == 1) {
+                        mi::stats().batches_verified++;
+                        if (published + (size_t)batches < sizes.size()) mi::stats().proofs_verified += sizes[published + (size_t)batches];
+                    }
+                    batches++;
+                }
+            published += (size_t)batches;
             inflight--;
             cv.notify_all();
         }
@@ -207,6 +241,7 @@ struct Stream {
 
     void finisher_main() {
         std::vector<mi_vs_partial> mine(8), all(8 * 64), one(64 * MI_VS_MAX_PRODUCTS_PER_TICKET);
+        int cov[8];  // per batch of the group: the batches its product decides (0: covered by a merged pass's first batch)
         uint64_t seq = 0;
         bool failed = false;
         while (!failed) {
@@ -235,9 +270,16 @@ struct Stream {
                 for (size_t k = 0; k < count; k++) {
                     mine[k] = folded[seq + k];
                     folded.erase(seq + k);
+                    auto it = cover.find(seq + k);
+                    cov[k] = it == cover.end() ? 1 : it->second;
+                    if (it != cover.end()) cover.erase(it);
                 }
             }
             seq += count;
+            // the group's products: one per batch, except that a merged pass's batches have ONE (under its first batch)
+            size_t prod_at[8], n_prod = 0;
+            for (size_t k = 0; k < count; k++)
+                if (cov[k] > 0) prod_at[n_prod++] = k;
             size_t world = 1;
             const mi_vs_partial *src = mine.data();
             if (exchange) {
@@ -252,10 +294,10 @@ struct Stream {
             }
             // the group's batches go out under as few tickets as possible: one product stream serves up to
             // MI_VS_MAX_PRODUCTS_PER_TICKET products that are ready together
-            for (size_t k0 = 0; k0 < count && !failed; k0 += MI_VS_MAX_PRODUCTS_PER_TICKET) {
-                const int m = (int)(count - k0 < (size_t)MI_VS_MAX_PRODUCTS_PER_TICKET ? count - k0 : (size_t)MI_VS_MAX_PRODUCTS_PER_TICKET);
+            for (size_t k0 = 0; k0 < n_prod && !failed; k0 += MI_VS_MAX_PRODUCTS_PER_TICKET) {
+                const int m = (int)(n_prod - k0 < (size_t)MI_VS_MAX_PRODUCTS_PER_TICKET ? n_prod - k0 : (size_t)MI_VS_MAX_PRODUCTS_PER_TICKET);
                 for (int j = 0; j < m; j++)
-                    for (size_t r = 0; r < world; r++) one[(size_t)j * world + r] = src[r * count + k0 + (size_t)j];
+                    for (size_t r = 0; r < world; r++) one[(size_t)j * world + r] = src[r * count + prod_at[k0 + (size_t)j]];
                 {
                     std::unique_lock<std::mutex> lk(mu);
                     cv.wait(lk, [&] { return inflight < products; });
@@ -276,7 +318,9 @@ struct Stream {
                     failed = true;
                     break;
                 }
-                tickets.push_back(std::make_pair(tk, m));
+                Ticket t{tk, m, {0, 0, 0, 0}};
+                for (int j = 0; j < m; j++) t.covers[j] = cov[prod_at[k0 + (size_t)j]];
+                tickets.push_back(t);
                 inflight++;
                 cv.notify_all();
             }
@@ -314,6 +358,8 @@ int32_t mi_vs_stream_open(uint64_t ctx, int32_t fold_threads, int32_t products, 
     if (fold_threads < 1) fold_threads = 1;
     if (fold_threads > 8) fold_threads = 8;
     if (const char *e = getenv("MI_SNARK_STREAM_PAIR_AT")) s->pair_at = atoi(e);  // 0: one batch per pass, always
+    if (const char *e = getenv("MI_SNARK_STREAM_MERGE")) s->merge = e[0] != '0';
+    if (!exchange && s->merge) s->per_pass_max = MI_VS_MAX_BATCHES_PER_PASS;
     if (const char *e = getenv("MI_SNARK_STREAM_PER_PASS")) {
         const int x = atoi(e);
         if (x >= 1 && x <= MI_VS_MAX_BATCHES_PER_PASS) s->per_pass_max = x;
@@ -396,6 +442,7 @@ int32_t mi_vs_stream_next_verdicts(uint64_t stream, int32_t block, uint8_t *all_
     auto s = find(stream);
     if (!s || !all_ok) return MI_ERR_BAD_ARGS;
     Stream::Sub sub{nullptr, 0, nullptr};
+    bool recheck = false;
     if (block) {
         const int32_t st = s->flush_held(true);  // a caller who waits for verdicts is not going to bring the held batch company
         if (st != MI_OK) return st;
@@ -411,7 +458,8 @@ int32_t mi_vs_stream_next_verdicts(uint64_t stream, int32_t block, uint8_t *all_
                     s->pending.pop_front();
                 }
                 if (v < 0) return v;
-                *all_ok = (uint8_t)v;
+                recheck = v == RECHECK;
+                *all_ok = v == 1 ? 1 : 0;
                 break;
             }
             if (s->finisher_done) return s->error != MI_OK ? s->error : MI_ERR_DONE;
@@ -420,6 +468,18 @@ int32_t mi_vs_stream_next_verdicts(uint64_t stream, int32_t block, uint8_t *all_
         }
     }
     if (n_out) *n_out = sub.n;
+    if (recheck) {
+        // its pass was one aggregate over several batches and that product failed: this batch's own verdict comes from
+        // its (still resident) inputs -- the whole check, then the per-proof verdicts if it is the one that fails
+        if (verdicts && capacity < sub.n) return MI_ERR_BAD_ARGS;
+        std::vector<uint8_t> tmp;
+        uint8_t *vd = verdicts;
+        if (!vd) {
+            tmp.resize(sub.n);
+            vd = tmp.data();
+        }
+        return mi_vs_verify_batch_device(s->ctx, sub.proofs, sub.n, sub.rand, vd, all_ok, nullptr);
+    }
     if (!verdicts) return MI_OK;
     if (capacity < sub.n) return MI_ERR_BAD_ARGS;
     if (*all_ok) {

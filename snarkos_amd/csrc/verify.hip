@@ -1581,6 +1581,16 @@ static bool vs_multi_ok(const VsKeys &v, const size_t *ns, int count) {
     }
     return problems <= MSM_MAX_PROBLEMS && total <= msm_small_limit();
 }
+// May these batches be folded into ONE aggregate (a pass that ends with one partial)?  The whole pass is then one batch
+// of sum n proofs on the small-MSM path.
+static bool vs_merged_ok(const VsKeys &v, const size_t *ns, int count) {
+    if (count < 2 || count > MI_VS_MAX_BATCHES_PER_PASS) return false;
+    size_t n_all = 0;
+    for (int k = 0; k < count; k++) n_all += ns[k];
+    VsWork w;
+    vs_work_sizes(v, n_all, w);
+    return vs_work_total(w) <= msm_small_limit();
+}
 // the most batches of n proofs that one pass takes
 static int vs_max_per_pass(const VsKeys &v, size_t n) {
     size_t ns[MI_VS_MAX_BATCHES_PER_PASS];
@@ -1593,8 +1603,11 @@ static int vs_max_per_pass(const VsKeys &v, size_t n) {
 
 // derive (+ merge) of the pass's batches, one launch each for all of them: the further batches' operands follow the
 // first's in the lane's operand arrays, so all their MSMs are one launch sequence.  ws[k] describes batch k.
+// merged: the batches become ONE batch of sum n proofs -- every output of the derive kernel is indexed by the proof's
+// number, so batch k writes behind the proofs before it (its VsOut is the first one's with every pointer moved on) and
+// everything after the derive kernel (merge, MSMs, fold) sees a single batch, described by ws[0].
 static void vs_run_derive(Context &cx, VsKeys &v, const void *const *d_proofs_in, const size_t *ns, const void *const *d_rand, int count,
-                          hipStream_t st, int lane, VsWork *ws) {
+                          hipStream_t st, int lane, VsWork *ws, bool merged = false) {
     const VsConsts &hc = v.shape;
     // every operand array exists once per lane: several passes are in flight on different streams
     char nm[32];
@@ -1609,13 +1622,18 @@ static void vs_run_derive(Context &cx, VsKeys &v, const void *const *d_proofs_in
         if (ns[k] > cap) cap = ns[k];
         n_all += ns[k];
     }
+    if (merged) {
+        vs_work_sizes(v, n_all, ws[0]);
+        total = vs_work_total(ws[0]);
+        cap = n_all;
+    }
     // one array for all MSMs' operands (per batch: H side, tau-H side, then the class accumulators): they run as ONE
     // launch sequence when they fit the small-MSM path
     G1Affine *pts = (G1Affine *)cx.buf(W("pts"), sizeof(G1Affine) * total);
     uint32_t *sc = (uint32_t *)cx.buf(W("sc"), 32 * total);
     size_t at = 0;
     static const char *const suffix[MI_VS_MAX_BATCHES_PER_PASS] = {"", ".b", ".c", ".d"};
-    for (int k = 0; k < count; k++) {
+    for (int k = 0; k < (merged ? 1 : count); k++) {
         VsWork &x = ws[k];
         VsOut &o = x.o;
         o.pts1 = pts + at;
@@ -1638,6 +1656,28 @@ static void vs_run_derive(Context &cx, VsKeys &v, const void *const *d_proofs_in
         snprintf(nn, sizeof nn, "circuit_of%s", suffix[k]);
         o.circuit_of = (uint32_t *)cx.buf(W(nn), 4 * cap * hc.max_circ);
         o.dec_ok = nullptr;
+    }
+    if (merged) {
+        size_t before = ns[0];  // proofs ahead of batch k
+        for (int k = 1; k < count; k++) {
+            const VsOut &b = ws[0].o;
+            VsOut &o = ws[k].o;
+            o.pts1 = b.pts1 + before * hc.per_proof;
+            o.sc1 = b.sc1 + 8 * before * hc.per_proof;
+            o.pts2 = b.pts2 + 2 * before;
+            o.sc2 = b.sc2 + 16 * before;
+            for (int c = 0; c < MI_VS_MAX_BOUNDS; c++) {
+                o.ptsb[c] = b.ptsb[c] + before * hc.class_count[c];
+                o.scb[c] = b.scb[c] + 8 * before * hc.class_count[c];
+            }
+            o.vk_scal = b.vk_scal + before * MI_VS_VK_COMMS * hc.max_circ;
+            o.g_scal = b.g_scal + before;
+            o.h_scal = b.h_scal + before;
+            o.alg_ok = b.alg_ok + before;
+            o.circuit_of = b.circuit_of + before * hc.max_circ;
+            o.dec_ok = nullptr;
+            before += ns[k];
+        }
     }
     // wire records: decoded into the lane's record buffer ahead of everything else (one launch each for all batches)
     const void *recs[MI_VS_MAX_BATCHES_PER_PASS];
@@ -1709,8 +1749,8 @@ static void vs_run_derive(Context &cx, VsKeys &v, const void *const *d_proofs_in
         hipLaunchKernelGGL(vs_derive_kernel<0>, dim3(derive_blocks), dim3(128), 0, st, d_proofs[0], n, (const uint8_t *)d_rand[0],
                            (const mi_vs_circuit_vk *)v.circuits.p, v.n_circuits, (const VsConsts *)v.consts.p, o, chal, more);
     cx.prof.end("vs_derive", st);
-    hipLaunchKernelGGL(vs_merge_kernel, dim3((unsigned)(v.n_circuits * MI_VS_VK_COMMS + 1 + hc.hiding), (unsigned)count), dim3(256), 0, st,
-                       o.vk_scal, o.g_scal, o.h_scal, o.circuit_of, n, (const mi_vs_circuit_vk *)v.circuits.p, v.n_circuits,
+    hipLaunchKernelGGL(vs_merge_kernel, dim3((unsigned)(v.n_circuits * MI_VS_VK_COMMS + 1 + hc.hiding), (unsigned)(merged ? 1 : count)), dim3(256), 0, st,
+                       o.vk_scal, o.g_scal, o.h_scal, o.circuit_of, merged ? n_all : n, (const mi_vs_circuit_vk *)v.circuits.p, v.n_circuits,
                        (const VsConsts *)v.consts.p, o.pts1, o.sc1, more);
     MI_HIP(hipGetLastError());
 }
@@ -1789,6 +1829,7 @@ static void vs_enqueue_msms_multi(Context &cx, const VsWork *ws, int count, hipS
 // more: further batches for the same pass (vs_multi_ok shapes only): each has its own operands, accumulators and partial
 struct VsBatches {
     int count = 1;
+    bool merged = false;  // fold the batches into ONE aggregate: the pass ends with one partial over all their proofs
     const void *proofs[MI_VS_MAX_BATCHES_PER_PASS] = {};
     const void *rand[MI_VS_MAX_BATCHES_PER_PASS] = {};
     size_t n[MI_VS_MAX_BATCHES_PER_PASS] = {};
@@ -1803,8 +1844,8 @@ static int32_t vs_accumulate_begin_impl(Context &cx, const VsCtx &vc, const void
     one.rand[0] = d_rand;
     one.n[0] = n;
     const VsBatches &bt = all ? *all : one;
-    const bool multi = bt.count > 1;
-    if (multi && (!msm || !vs_multi_ok(v, bt.n, bt.count))) return MI_ERR_BAD_ARGS;
+    const bool multi = bt.count > 1, merged = multi && bt.merged;
+    if (multi && (!msm || !(merged ? vs_merged_ok(v, bt.n, bt.count) : vs_multi_ok(v, bt.n, bt.count)))) return MI_ERR_BAD_ARGS;
     int par = -1;
     for (;;) {
         for (int p = 0; p < pp.lanes; p++)
@@ -1864,6 +1905,10 @@ static int32_t vs_accumulate_begin_impl(Context &cx, const VsCtx &vc, const void
             MsmJob jj[4];
             if (per_pass > 1) vs_enqueue_msms_multi(cx, ws, per_pass, sp, p, jj, 0);
             else (void)vs_enqueue_msms(cx, ws[0], sp, p, jj, 0);
+            if (per_pass > 1 && vs_merged_ok(v, rep.n, per_pass)) {  // the merged form of the same pass: its per-proof arrays are longer
+                vs_run_derive(cx, v, rep.proofs, rep.n, rep.rand, per_pass, sp, p, ws, true);
+                (void)vs_enqueue_msms(cx, ws[0], sp, p, jj, 0);
+            }
         }
         for (int p = 0; p < pp.lanes; p++)
             if (!pp.acc[p].open) MI_HIP(hipStreamSynchronize(pp.acc_st[p]));
@@ -1881,7 +1926,7 @@ static int32_t vs_accumulate_begin_impl(Context &cx, const VsCtx &vc, const void
     VsWork ws[MI_VS_MAX_BATCHES_PER_PASS];
     {
         HostSpan hs("begin.derive");
-        vs_run_derive(cx, v, bt.proofs, bt.n, bt.rand, bt.count, sa, par, ws);
+        vs_run_derive(cx, v, bt.proofs, bt.n, bt.rand, bt.count, sa, par, ws, merged);
     }
     const VsWork &w = ws[0];
     size_t n_max = 0, n_all = 0;
@@ -1897,14 +1942,15 @@ static int32_t vs_accumulate_begin_impl(Context &cx, const VsCtx &vc, const void
         {
             HostSpan hs("begin.alg_copy");
             size_t off = 0;
-            for (int k = 0; k < bt.count; k++) {  // ahead of the MSMs: their done-event covers the copies
+            if (merged) MI_HIP(hipMemcpyAsync(a.h_alg, ws[0].o.alg_ok, n_all, hipMemcpyDeviceToHost, sa));  // one array
+            for (int k = 0; k < bt.count && !merged; k++) {  // ahead of the MSMs: their done-event covers the copies
                 MI_HIP(hipMemcpyAsync(a.h_alg + off, ws[k].o.alg_ok, bt.n[k], hipMemcpyDeviceToHost, sa));
                 off += bt.n[k];
             }
         }
         HostSpan hs_msm("begin.msm_enqueue");
         static const int vs_c = getenv("MI_SNARK_VS_C") ? atoi(getenv("MI_SNARK_VS_C")) : 0;  // window width override (experiments)
-        if (multi) {
+        if (multi && !merged) {
             vs_enqueue_msms_multi(cx, ws, bt.count, sa, par, a.j, vs_c);
             a.fused = true;
         } else {
@@ -1913,13 +1959,14 @@ static int32_t vs_accumulate_begin_impl(Context &cx, const VsCtx &vc, const void
     }
     a.nb[0] = w.nb[0];
     a.nb[1] = w.nb[1];
-    a.n = n;
-    a.count = bt.count;
+    a.n = merged ? n_all : n;
+    a.count = merged ? 1 : bt.count;  // a merged pass ends like a single batch: one partial
     for (int k = 0; k < bt.count; k++) {
         a.ns[k] = bt.n[k];
         a.nbs[k][0] = ws[k].nb[0];
         a.nbs[k][1] = ws[k].nb[1];
     }
+    if (merged) a.ns[0] = n_all;
     a.st = sa;
     a.handle = hd;
     a.ctx = vc.id;
@@ -2014,6 +2061,20 @@ int32_t vs_accumulate_begin_multi(Context &cx, uint64_t id, int count, const voi
     }
     return vs_accumulate_begin_impl(cx, *v, d_proofs[0], n[0], d_rand[0], st, handle, nullptr, true, &bt);
 }
+int32_t vs_accumulate_begin_merged(Context &cx, uint64_t id, int count, const void *const *d_proofs, const size_t *n,
+                                   const void *const *d_rand, hipStream_t st, uint64_t *handle) {
+    std::shared_ptr<VsCtx> v = vs_find(id);
+    if (!v || count < 2 || count > MI_VS_MAX_BATCHES_PER_PASS) return MI_ERR_BAD_ARGS;
+    VsBatches bt;
+    bt.count = count;
+    bt.merged = true;
+    for (int k = 0; k < count; k++) {
+        bt.proofs[k] = d_proofs[k];
+        bt.rand[k] = d_rand[k];
+        bt.n[k] = n[k];
+    }
+    return vs_accumulate_begin_impl(cx, *v, d_proofs[0], n[0], d_rand[0], st, handle, nullptr, true, &bt);
+}
 int32_t vs_accumulate_end_multi(Context &cx, uint64_t id, uint64_t handle, mi_vs_partial *outs, int count) {
     if (!vs_find(id) || count < 1 || count > MI_VS_MAX_BATCHES_PER_PASS) return MI_ERR_BAD_ARGS;
     return vs_accumulate_end_impl(cx, handle, outs, false, count);
@@ -2036,6 +2097,14 @@ int32_t vs_accumulate_device(Context &cx, uint64_t id, const void *d_proofs, siz
 // sum the shards' partials on the host: the points of the pairing check (total_c, -total_w, the class accumulators) and
 // the count of algebraic failures
 static void vs_sum_partials(const mi_vs_partial *parts, size_t np, G1Affine ps[MI_MAX_PAIRS], uint64_t *fails) {
+    if (np == 1) {  // one rank: the partial's points are the pairing's (normalised already: no addition, no inversion --
+                    // the general path below spent two host inversions per product on the finisher's one thread)
+        ps[0] = host_jac_to_affine_normalised(parts[0].total_c);
+        ps[1] = neg(host_jac_to_affine_normalised(parts[0].total_w));
+        for (int c = 0; c < MI_VS_MAX_BOUNDS; c++) ps[2 + c] = host_jac_to_affine_normalised(parts[0].bound[c]);
+        *fails = parts[0].n_alg_fail;
+        return;
+    }
     G1Xyzz t[MI_MAX_PAIRS] = {G1Xyzz::inf(), G1Xyzz::inf(), G1Xyzz::inf(), G1Xyzz::inf()};
     uint64_t f = 0;
     for (size_t k = 0; k < np; k++) {
@@ -2104,14 +2173,20 @@ int32_t vs_finalize_async_multi(Context &cx, uint64_t id, const mi_vs_partial *p
     VsSlot &sl = pp.slots[slot];
     HostSpan hs("finalize_async");
     G1Affine ps[MI_VS_MAX_PRODUCTS_PER_TICKET * MI_MAX_PAIRS];
-    for (int k = 0; k < count; k++) {
-        uint64_t fails = 0;
-        vs_sum_partials(parts + (size_t)k * np, np, ps + (size_t)k * MI_MAX_PAIRS, &fails);
-        sl.fails_n[k] = fails;
+    {
+        HostSpan hs_sum("finalize_async.sum");
+        for (int k = 0; k < count; k++) {
+            uint64_t fails = 0;
+            vs_sum_partials(parts + (size_t)k * np, np, ps + (size_t)k * MI_MAX_PAIRS, &fails);
+            sl.fails_n[k] = fails;
+        }
     }
     const G2Prepared *qs[MI_MAX_PAIRS];
     const int K = vs_g2_keys(v, qs);
-    pairing_launch_multi(cx, ps, qs, K, count, sl.h_out, sl.stream, slot);  // the kernels store their results in pinned host memory
+    {
+        HostSpan hs_launch("finalize_async.launch");
+        pairing_launch_multi(cx, ps, qs, K, count, sl.h_out, sl.stream, slot);  // the kernels store their results in pinned host memory
+    }
     stats().pairing_products += (uint64_t)count;
     stats().pairing_pairs += (uint64_t)count * (uint64_t)K;
     MI_HIP(hipEventRecord(sl.done, sl.stream));
