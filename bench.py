@@ -44,7 +44,7 @@ PROOFS_PER_GPU = 1024
 # algorithmic bytes per unit of each profiled kernel (DESIGN.md "Measurement")
 ALG_BYTES = {
     "msm_accumulate": 128.0,        # per (point, scalar) pair: 96 B affine point + 32 B scalar
-    "msm_bitsums": 192.0,           # per chunk partial read (XYZZ, 4 x 48 B); units are the launch's points: see chip_alu_view
+    "msm_bitsums": 192.0,           # per chunk partial (XYZZ, 4 x 48 B); their number per pass comes from the plan: see main()
     "vs_derive": 2256.0 + 32.0,     # per proof: the proof record + its two 128-bit randomizers
     "pairing": 96.0 + 13264.0,      # per pair: one G1 point + one prepared G2 line table
     "ntt_pass": 64.0,               # per element per pass: 32 B read + 32 B written
@@ -148,6 +148,8 @@ def main():
         # streaming driver costs by itself, apart from what several ranks do to each other
         comm = L.comm_init_rank(L.comm_unique_id(), 0, 1)
     exchange_kind = ("native-" + L.comm_transport(comm)) if comm is not None else ("torch.distributed" if dist_on else "none")
+    # the stream driver merges the batches of a pass when nothing is exchanged between ranks (csrc/stream.hip)
+    merged_passes = exchange_kind == "none" and os.environ.get("MI_SNARK_STREAM_MERGE", "1")[:1] != "0"
     stamps = []
 
     def run(k, stamp=False):
@@ -215,18 +217,26 @@ def main():
             torch.distributed.destroy_process_group()
         return
 
-    dom = max((k for k in kernels if k in ALG_BYTES and k != "msm_bitsums"), key=lambda k: kernels[k]["total_ms"])
+    chip = chip_alu_view(kernels, steady, merged_passes, st1["pairing_products"] - st0["pairing_products"], args.steps)
+    if chip and "msm_bitsums" in kernels:
+        # the bit sums' unit is a chunk partial (192 B, read by the groups whose bit it carries; counted once): their number
+        # per pass comes from the library's plan, the profiler only knows the launch's points
+        kb = kernels["msm_bitsums"]
+        kb["chunk_partials_per_launch"] = chip["plan"]["chunk_partials_per_pass"]
+        kb["achieved_GBps"] = ALG_BYTES["msm_bitsums"] * kb["chunk_partials_per_launch"] / (kb["avg_us"] * 1e-6) / 1e9
+    dom = max((k for k in kernels if k in ALG_BYTES and (k != "msm_bitsums" or chip)), key=lambda k: kernels[k]["total_ms"])
     pmc_path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     traffic = None
     if os.path.exists(pmc_path):
         try:
-            traffic = json.load(open(pmc_path)).get(dom)
+            traffic = json.load(open(pmc_path)).get({"msm_bitsums": "msm_bit_sums_queue"}.get(dom, dom))
         except Exception:
             traffic = None
     roofline = {"bound": "hbm", "kernel": dom, "achieved": kernels[dom]["achieved_GBps"], "peak": HBM_PEAK_GBPS,
                 "unit": "GB/s", "frac": kernels[dom]["achieved_GBps"] / HBM_PEAK_GBPS,
                 "avg_launch_us": kernels[dom]["avg_us"],
-                "algorithmic_bytes_per_launch": ALG_BYTES[dom] * kernels[dom]["units_per_launch"], "traffic": traffic}
+                "algorithmic_bytes_per_launch": ALG_BYTES[dom] * kernels[dom].get("chunk_partials_per_launch", kernels[dom]["units_per_launch"]),
+                "traffic": traffic}
     if "msm_accumulate" in kernels:
         # SURVEY.md 8d's per-proof figure for the verifier (128 B x the proof's (point, scalar) pairs after vk merging):
         # the MSM accumulation kernel's view, beside the dominant-by-time kernel above
@@ -255,8 +265,12 @@ def main():
                    "exchange_wait_ms_per_group": (1e-6 * (st1["exchange_nanos"] - st0["exchange_nanos"]) / (st1["exchange_calls"] - st0["exchange_calls"])
                                                   if st1["exchange_calls"] > st0["exchange_calls"] else None),
                    "pipeline": "batches streamed: %d accumulation lanes, %d pairing products in flight, %d host fold threads"
-                               % (args.acc_depth, args.products, args.fold_threads)},
-        "roofline": roofline, "alu": alu_view(kernels), "alu_chip": chip_alu_view(kernels, steady), "kernels": kernels,
+                               % (args.acc_depth, args.products, args.fold_threads),
+                   # without an exchange the driver folds the batches of a lane pass (up to four under load) into ONE
+                   # aggregate: one MSM pair, one host fold, one pairing product for all of them
+                   "merged_passes": merged_passes,
+                   "pairing_products_in_timed_region": st1["pairing_products"] - st0["pairing_products"]},
+        "roofline": roofline, "alu": alu_view(kernels), "alu_chip": chip, "kernels": kernels,
     }
     roofline["traffic_source"] = "profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of tools/profile_round.sh, committed; not measured in this run)"
     if world == 1:
@@ -328,7 +342,7 @@ def alu_view(kernels):
 CHIP_RATE_28, CHIP_SQR_28, CHIP_RATE_32 = 79.9e9, 96.7e9, 60.0e9
 
 
-def chip_alu_view(kernels, steady_ms):
+def chip_alu_view(kernels, steady_ms, merged=False, products=None, steps=None):
     import ctypes as C
     if "msm_accumulate" not in kernels or "vs_derive" not in kernels:
         return None
@@ -346,18 +360,25 @@ def chip_alu_view(kernels, steady_ms):
     adds = (n_h * nwin + n_w * nwin_w) * live
     acc = adds * (8 + 2 * sq)
     buckets = 2 ** (c - 1)
-    def groups_work(n_points, windows):                          # per problem of ONE batch
+    partials = [0.0]                                             # chunk partials of the pass (what the bit sums read)
+    def groups_work(n_points, windows, times=1.0):               # per problem
         per_bucket = n_points * live / buckets
         chunks = buckets * max(1.0, per_bucket / chunk + 0.5)
+        partials[0] += times * windows * chunks
         wave_adds = -(-(chunks / 2) // 64) + 6
-        return windows * c * wave_adds * 64 * (12 + 2 * sq)
-    bits = batches * (groups_work(n_h / batches, nwin) + groups_work(n_w / batches, nwin_w))
+        return times * windows * c * wave_adds * 64 * (12 + 2 * sq)
+    if merged:  # the pass is ONE problem pair: its groups sum the chunks of all its batches
+        bits = groups_work(n_h, nwin) + groups_work(n_w, nwin_w)
+    else:
+        bits = groups_work(n_h / batches, nwin, batches) + groups_work(n_w / batches, nwin_w, batches)
     derive = 165.0 * proofs * CHIP_RATE_28 / CHIP_RATE_32
-    pairing = batches * PAIRING_LIMB_PRODUCTS / 288.0 * CHIP_RATE_28 / CHIP_RATE_32
+    products_per_pass = batches if not (products and steps) else batches * products / float(steps)
+    pairing = products_per_pass * PAIRING_LIMB_PRODUCTS / 288.0 * CHIP_RATE_28 / CHIP_RATE_32
     per_batch = (acc + bits + derive + pairing) / batches
     out = {"unit": "Fq products/s (28-bit-limb equivalents)", "work_per_batch": per_batch,
            "split_per_batch": {"msm_accumulate": acc / batches, "msm_bit_sums": bits / batches, "vs_derive": derive / batches, "pairing": pairing / batches},
-           "plan": {"points_per_pass": pts, "batches_per_pass": batches, "c": c, "windows": nwin, "chunk": chunk},
+           "plan": {"points_per_pass": pts, "batches_per_pass": batches, "c": c, "windows": nwin, "chunk": chunk,
+                    "chunk_partials_per_pass": partials[0]},
            "steady_state_ms_per_batch": steady_ms, "achieved": per_batch / (steady_ms * 1e-3), "peak": CHIP_RATE_28,
            "frac": per_batch / (steady_ms * 1e-3) / CHIP_RATE_28,
            "note": "the whole chip over the middle of the stream; counts are analytic (formulas above chip_alu_view in bench.py), the "
