@@ -379,11 +379,15 @@ typedef int32_t (*mi_vs_exchange_fn)(void *user, const mi_vs_partial *mine, size
 int32_t mi_vs_stream_open(uint64_t ctx, int32_t fold_threads, int32_t products, int32_t lanes, mi_vs_exchange_fn exchange,
                           void *user, int32_t exchange_group, uint64_t *stream_out);
 /* enqueue one batch (device pointers; blocks while every lane is taken); batches are numbered 0, 1, 2, ...
- * Under load (MI_SNARK_STREAM_PAIR_AT = 4 or more passes open) the batch may be HELD for the next submission of the
- * same size on the same hip_stream to share its lane pass (MI_SNARK_STREAM_PER_PASS = 2 batches per pass); a pass
- * that ends, mi_vs_stream_finish, a blocking mi_vs_stream_next or a submission that cannot join releases it.  The
- * inputs must stay resident until the batch's verdict has been taken (they always had to: a failed batch is taken
- * apart from them).  One submitting thread per stream; MI_ERR_AGAIN when two race on different hip_streams: retry. */
+ * Under load (MI_SNARK_STREAM_PAIR_AT = 4 or more passes open) the batch may be HELD for the next submissions of the
+ * same size on the same hip_stream to share its lane pass (MI_SNARK_STREAM_PER_PASS batches per pass: 2 with an
+ * exchange, 4 without); a pass that ends, mi_vs_stream_finish, a blocking mi_vs_stream_next or a submission that cannot
+ * join releases it.  WITHOUT an exchange the batches of a pass are folded into ONE aggregate
+ * (mi_vs_accumulate_begin_merged; MI_SNARK_STREAM_MERGE=0 keeps them apart): one pairing product decides all of them
+ * when it is one; when it is not, each of them is verified on its own (from its resident inputs) as its verdict is
+ * taken -- every verdict is exactly what mi_vs_verify_batch_device would say.  The inputs must stay resident until the
+ * batch's verdict has been taken (they always had to: a failed batch is taken apart from them).  One submitting thread
+ * per stream; MI_ERR_AGAIN when two race on different hip_streams: retry. */
 int32_t mi_vs_stream_submit(uint64_t stream, const void *d_proofs, size_t n, const void *d_randomizers128, void *hip_stream);
 /* no more batches will be submitted: lets mi_vs_stream_next drain */
 int32_t mi_vs_stream_finish(uint64_t stream);
