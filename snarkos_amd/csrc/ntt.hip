@@ -402,6 +402,10 @@ void ntt_device(Context &cx, Fr *d_data, uint32_t log_n, bool inverse, bool cose
         if (use_lds) {
             // an even number of LDS-tiled passes of 4..9 bits each
             int np = 2 * (int)((log_n + 15) / 16);  // <= 8 bits per pass
+            if (const char *e = getenv("MI_SNARK_NTT_NP")) {  // experiment: any number of passes of <= 9 bits (an odd number ends with a copy)
+                const int x = atoi(e);
+                if (x >= 1 && (int)(log_n + x - 1) / x <= 9 && (int)log_n / x >= 4) np = x;
+            }
             for (int p = 0; p < np; p++) {
                 int P = (int)(log_n - log_ns + (np - p) - 1) / (np - p);
                 bool last = p == np - 1;
