@@ -812,7 +812,7 @@ static void launch_digits_t(const uint32_t *scalars, size_t n, int32_t *digits, 
     else
         hipLaunchKernelGGL((msm_digits_kernel<C, 129, T>), dim3(cdiv(n, T), ((129 + C - 1) / C + msm_digits_group<C>() - 1) / msm_digits_group<C>()), dim3(T), 0, st, scalars, n, digits, ranks, counts, split);
 }
-// workgroups of 512: measured (tools/digits_threads.sh) 7.78e6 proofs/s streamed against 7.6e6 with 1024 (a workgroup
+// workgroups of 512: measured 7.78e6 proofs/s streamed against 7.6e6 with 1024 (a workgroup
 // that large waits for a whole CU's worth of wave slots) and 7.3-7.7e6 with 256 (four times the global atomics of 1024)
 template <int C>
 static void launch_digits(const uint32_t *scalars, size_t n, int32_t *digits, uint32_t *ranks, uint32_t *counts,
@@ -1139,7 +1139,7 @@ void msm_finish_all(Context &cx, MsmJob *job, hipStream_t st, mi_g1_jac *const *
             InFlight() : others(g_folds_in_flight.fetch_add(1)) {}
             ~InFlight() { g_folds_in_flight.fetch_sub(1); }
         } in_flight;
-        const int K = in_flight.others == 0 ? 4 : 3;  // measured (tools/foldk.sh): busy 1 / 2 / 3 within noise of each other, 3 ahead on both rates
+        const int K = in_flight.others == 0 ? 4 : 3;  // measured (a sweep of this split, 20 and 400 batches): busy 1 / 2 / 3 within noise of each other, 3 ahead on both rates
         std::vector<FoldSplit> f;
         f.reserve(MSM_MAX_PROBLEMS);
         for (int p = 0; p < np; p++) f.emplace_back(h + (size_t)p * job->groups, job->groups, job->groups > 160 ? K : (K < 2 ? K : 2));
