@@ -389,42 +389,50 @@ __device__ __forceinline__ G1Xyzz xyzz_shfl_down(const G1Xyzz &a, int delta) {
 // (exclusive scan of counts), chunk offsets (exclusive scan of ceil(count / T)) -- and clears the histogram for the
 // next MSM in this workspace.  Replaces 2 memsets + 8 launches of the general path: a 10 k-point MSM is bound by
 // launch latency, not by work.
+// sc_off (may be null): offsets of the SHORTENED chunk list, ceil(chunks / gather) entries per bucket (msm_gather_chunks_kernel)
 __global__ void __launch_bounds__(1024) msm_plan_small_kernel(uint32_t *__restrict__ counts, size_t nb, uint32_t T,
-                                                              uint32_t *__restrict__ offsets, uint32_t *__restrict__ chunk_off) {
-    __shared__ uint32_t w1[16], w2[16];
+                                                              uint32_t *__restrict__ offsets, uint32_t *__restrict__ chunk_off,
+                                                              uint32_t gather, uint32_t *__restrict__ sc_off) {
+    __shared__ uint32_t w1[16], w2[16], w3[16];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const size_t per = (nb + 1023) / 1024;
     size_t lo = (size_t)threadIdx.x * per, hi = lo + per;
     if (lo > nb) lo = nb;
     if (hi > nb) hi = nb;
-    uint32_t s1 = 0, s2 = 0;
+    uint32_t s1 = 0, s2 = 0, s3 = 0;
     for (size_t b = lo; b < hi; b++) {
-        const uint32_t c = counts[b];
+        const uint32_t c = counts[b], ch = (c + T - 1) / T;
         s1 += c;
-        s2 += (c + T - 1) / T;
+        s2 += ch;
+        s3 += (ch + gather - 1) / gather;
     }
-    const uint32_t i1 = wave_incl_scan(s1, lane), i2 = wave_incl_scan(s2, lane);
+    const uint32_t i1 = wave_incl_scan(s1, lane), i2 = wave_incl_scan(s2, lane), i3 = wave_incl_scan(s3, lane);
     if (lane == 63) {
         w1[wave] = i1;
         w2[wave] = i2;
+        w3[wave] = i3;
     }
     __syncthreads();
-    uint32_t o1 = i1 - s1, o2 = i2 - s2;
+    uint32_t o1 = i1 - s1, o2 = i2 - s2, o3 = i3 - s3;
     for (int k = 0; k < wave; k++) {
         o1 += w1[k];
         o2 += w2[k];
+        o3 += w3[k];
     }
     for (size_t b = lo; b < hi; b++) {
-        const uint32_t c = counts[b];
+        const uint32_t c = counts[b], ch = (c + T - 1) / T;
         offsets[b] = o1;
         chunk_off[b] = o2;
+        if (sc_off) sc_off[b] = o3;
         o1 += c;
-        o2 += (c + T - 1) / T;
+        o2 += ch;
+        o3 += (ch + gather - 1) / gather;
         counts[b] = 0;
     }
-    if (threadIdx.x == 1023) {  // its range is the last (possibly empty) one: o1 / o2 are the grand totals
+    if (threadIdx.x == 1023) {  // its range is the last (possibly empty) one: o1 / o2 / o3 are the grand totals
         offsets[nb] = o1;
         chunk_off[nb] = o2;
+        if (sc_off) sc_off[nb] = o3;
     }
 }
 __global__ void __launch_bounds__(256) msm_chunk_count_kernel(const uint32_t *__restrict__ counts, size_t nb, uint32_t T,
@@ -671,6 +679,39 @@ __global__ void __launch_bounds__(256) point_tree_sum_kernel(const G1Xyzz *__res
         __syncthreads();
     }
     if (t == 0) store_xyzz(&out[group * gridDim.x + blockIdx.x], have ? xyzz28_store(acc) : G1Xyzz::inf());
+}
+
+// ---------------------------------------------------------------- small-MSM reduction: shorter chunk lists first
+// A bucket of the verifier's passes is 6-7 chunks long, and the per-bit sums below add every chunk partial into the
+// c / 2 groups whose bit its bucket carries: ~3 400 partials per window of a merged four-batch pass, 27 + 6 additions in
+// sequence per group.  Here one lane adds up to MSM_GATHER consecutive chunk partials of ONE bucket (a bucket of
+// MSM_GATHER chunks or fewer becomes one entry; the few heavy buckets -- the top window's, skewed scalars' -- become
+// several, so no lane walks more than MSM_GATHER): at most MSM_GATHER additions in sequence, once, and the groups then
+// sum a list that is 6-7 times shorter: 4-5 + 6 additions in sequence for c = 10, and a third of the products.  The new
+// list has the old one's shape (offsets per bucket from the plan kernel, the bucket of every entry), so the per-bit
+// kernel does not know the difference.
+constexpr uint32_t MSM_GATHER = 8;
+__global__ void __launch_bounds__(64) msm_gather_chunks_kernel(const G1Xyzz *__restrict__ chunk_partial, const uint32_t *__restrict__ chunk_off,
+                                                              const uint32_t *__restrict__ sc_off, size_t nb,
+                                                              G1Xyzz *__restrict__ out, uint32_t *__restrict__ sc_bucket) {
+    const uint32_t s = blockIdx.x * 64 + threadIdx.x;
+    if (s >= sc_off[nb]) return;
+    uint32_t lo_b = 0, hi_b = (uint32_t)nb;  // sc_off[b] <= s < sc_off[b + 1]
+    while (hi_b - lo_b > 1) {
+        const uint32_t mid = (lo_b + hi_b) >> 1;
+        if (sc_off[mid] <= s) lo_b = mid; else hi_b = mid;
+    }
+    const uint32_t b = lo_b;
+    sc_bucket[s] = b;
+    const uint32_t lo = chunk_off[b] + (s - sc_off[b]) * MSM_GATHER, end = chunk_off[b + 1];
+    const uint32_t hi = end - lo > MSM_GATHER ? lo + MSM_GATHER : end;
+    G1Xyzz28 acc;
+    bool have = false;
+    for (uint32_t e = lo; e < hi; e++) {
+        const G1Xyzz v = load_xyzz(&chunk_partial[e]);
+        xyzz_acc28(acc, have, xyzz28_from(v), !v.is_inf());
+    }
+    store_xyzz(&out[s], have ? xyzz28_store(acc) : G1Xyzz::inf());
 }
 
 // ---------------------------------------------------------------- small-MSM reduction: per-bit subset sums
@@ -957,10 +998,15 @@ void msm_enqueue(Context &cx, const G1Affine *d_points, const uint32_t *d_scalar
     uint32_t *chunk_off = (uint32_t *)cx.buf(W("chunk_off"), sizeof(uint32_t) * (nb + 1));
     uint32_t *chunk_bucket = (uint32_t *)cx.buf(W("chunk_bucket"), sizeof(uint32_t) * max_chunks);
     G1Xyzz *chunk_partial = (G1Xyzz *)cx.buf(W("chunk_partial"), sizeof(G1Xyzz) * max_chunks);
-    uint32_t *heavy_list = nullptr, *heavy_count = nullptr, *order = nullptr;
+    uint32_t *heavy_list = nullptr, *heavy_count = nullptr, *order = nullptr, *sc_off = nullptr;
+    bool gather = false;
     if (small) {
         cx.prof.begin("msm_scan", st, n);
-        hipLaunchKernelGGL(msm_plan_small_kernel, dim3(1), dim3(1024), 0, st, counts, nb, T, offsets, chunk_off);
+        // long chunk lists (merged passes) are shortened before the per-bit sums: msm_gather_chunks_kernel
+        static const int gather_knob = getenv("MI_SNARK_MSM_GATHER") ? atoi(getenv("MI_SNARK_MSM_GATHER")) : -1;
+        gather = gather_knob >= 0 ? gather_knob != 0 : (double)n * pl.nwin / (double)T / (double)vwin >= 1000.0;
+        if (gather) sc_off = (uint32_t *)cx.buf(W("sc_off"), sizeof(uint32_t) * (nb + 1));
+        hipLaunchKernelGGL(msm_plan_small_kernel, dim3(1), dim3(1024), 0, st, counts, nb, T, offsets, chunk_off, MSM_GATHER, sc_off);
         cx.prof.end("msm_scan", st);
         mark.gen = counts_buf.gen;
         mark.nb = nb;
@@ -1016,8 +1062,18 @@ void msm_enqueue(Context &cx, const G1Affine *d_points, const uint32_t *d_scalar
         job->h = (G1Xyzz *)cx.pin_named(pn, sizeof(G1Xyzz) * all_groups);
         cx.prof.begin("msm_bitsums", st, n);
         // one wave per group, its own six tree levels, results straight into pinned host memory
-        hipLaunchKernelGGL(msm_bit_sums_queue_kernel, dim3((unsigned)all_groups), dim3(64), 0, st, chunk_partial, chunk_off,
-                           chunk_bucket, pl.B, pl.c, job->h);
+        if (gather) {
+            const size_t max_sc = nb + max_chunks / MSM_GATHER + 1;
+            G1Xyzz *sc_partial = (G1Xyzz *)cx.buf(W("sc_partial"), sizeof(G1Xyzz) * max_sc);
+            uint32_t *sc_bucket = (uint32_t *)cx.buf(W("sc_bucket"), sizeof(uint32_t) * max_sc);
+            hipLaunchKernelGGL(msm_gather_chunks_kernel, dim3((unsigned)cdiv(max_sc, 64)), dim3(64), 0, st, chunk_partial, chunk_off, sc_off, nb,
+                               sc_partial, sc_bucket);
+            hipLaunchKernelGGL(msm_bit_sums_queue_kernel, dim3((unsigned)all_groups), dim3(64), 0, st, sc_partial, sc_off, sc_bucket, pl.B, pl.c,
+                               job->h);
+        } else {
+            hipLaunchKernelGGL(msm_bit_sums_queue_kernel, dim3((unsigned)all_groups), dim3(64), 0, st, chunk_partial, chunk_off,
+                               chunk_bucket, pl.B, pl.c, job->h);
+        }
         cx.prof.end("msm_bitsums", st);
         result = nullptr;
     } else {
