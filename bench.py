@@ -334,7 +334,8 @@ def alu_view(kernels):
 #   accumulate  one mixed addition (8 products + 2 squarings) per non-zero digit: points x windows x (1 - 2^-c); the
 #               128-bit randomizer side has ceil(129 / c) live windows
 #   bit sums    per (window, bit) group one wave: ceil(matches / 64) queue additions + 6 tree levels, each a full XYZZ
-#               addition (12 products + 2 squarings) on 64 lanes; matches = half the window's chunks
+#               addition (12 products + 2 squarings) on 64 lanes; matches = half the window's chunks -- or, for the long
+#               lists of merged passes, half the entries of the list the gather stage leaves (one addition per chunk first)
 #   derive      ~165 products per proof on 32-bit limbs (11 curve checks, ~250 Fr products, the SHA-256 transcript)
 #   pairing     PAIRING_LIMB_PRODUCTS (above) / 288 per product, on 32-bit limbs
 # against the rates tools/ubench.hip measures for a tight loop over the whole chip (8 waves/SIMD): 79.9 G products/s and
@@ -360,13 +361,22 @@ def chip_alu_view(kernels, steady_ms, merged=False, products=None, steps=None):
     adds = (n_h * nwin + n_w * nwin_w) * live
     acc = adds * (8 + 2 * sq)
     buckets = 2 ** (c - 1)
-    partials = [0.0]                                             # chunk partials of the pass (what the bit sums read)
+    partials = [0.0]                                             # chunk partials of the pass (what the reduction reads)
+    # long chunk lists are shortened first (csrc/msm.hip msm_gather_chunks_kernel, the library's own rule): one addition per
+    # chunk partial, up to GATHER consecutive ones of a bucket per lane; the groups then sum the shorter list
+    GATHER = 8
+    # (msm.hip: points x windows / chunk length / all problems' windows >= 1000; a pass has two problems per aggregate)
+    gather = pts / (2.0 * chunk * (1.0 if merged else max(1.0, batches))) >= 1000.0
     def groups_work(n_points, windows, times=1.0):               # per problem
         per_bucket = n_points * live / buckets
         chunks = buckets * max(1.0, per_bucket / chunk + 0.5)
         partials[0] += times * windows * chunks
-        wave_adds = -(-(chunks / 2) // 64) + 6
-        return times * windows * c * wave_adds * 64 * (12 + 2 * sq)
+        entries, extra = chunks, 0.0
+        if gather:
+            entries = buckets * max(1.0, chunks / buckets / GATHER + 0.5)
+            extra = windows * chunks * (12 + 2 * sq)            # the gather stage's additions
+        wave_adds = -(-(entries / 2) // 64) + 6
+        return times * (windows * c * wave_adds * 64 * (12 + 2 * sq) + extra)
     if merged:  # the pass is ONE problem pair: its groups sum the chunks of all its batches
         bits = groups_work(n_h, nwin) + groups_work(n_w, nwin_w)
     else:
@@ -378,7 +388,7 @@ def chip_alu_view(kernels, steady_ms, merged=False, products=None, steps=None):
     out = {"unit": "Fq products/s (28-bit-limb equivalents)", "work_per_batch": per_batch,
            "split_per_batch": {"msm_accumulate": acc / batches, "msm_bit_sums": bits / batches, "vs_derive": derive / batches, "pairing": pairing / batches},
            "plan": {"points_per_pass": pts, "batches_per_pass": batches, "c": c, "windows": nwin, "chunk": chunk,
-                    "chunk_partials_per_pass": partials[0]},
+                    "chunk_partials_per_pass": partials[0], "gather_stage": bool(gather)},
            "steady_state_ms_per_batch": steady_ms, "achieved": per_batch / (steady_ms * 1e-3), "peak": CHIP_RATE_28,
            "frac": per_batch / (steady_ms * 1e-3) / CHIP_RATE_28,
            "note": "the whole chip over the middle of the stream; counts are analytic (formulas above chip_alu_view in bench.py), the "

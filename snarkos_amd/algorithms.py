@@ -625,16 +625,38 @@ class VarunaShaped:
                         raise keep["error"]
                     raise L.MiError(st, "mi_vs_stream_next")
 
+        # the submitting loop is on the critical path of a short stream (every batch of a burst is submitted before the
+        # first verdict exists): the caller's stream is looked up once, and a tensor submitted again (a bench, a retry)
+        # keeps its pointer
+        hip_stream = L.stream_ptr(None)
+        submit, byref_ok = lib.mi_vs_stream_submit, C.byref(ok)
+        last_p = last_r = None
         try:
             for proofs, rnd in batches:
-                n = proofs.numel() * proofs.element_size() // self.proof_bytes
+                if proofs is not last_p:
+                    last_p, dp = proofs, L.dptr(proofs)
+                    n = C.c_size_t(proofs.numel() * proofs.element_size() // self.proof_bytes)
+                if rnd is not last_r:
+                    last_r, dr = rnd, L.dptr(rnd)
                 held.append((proofs, rnd))
-                st = lib.mi_vs_stream_submit(sid, L.dptr(proofs), C.c_size_t(n), L.dptr(rnd), L.stream_ptr(None))
+                st = submit(sid, dp, n, dr, hip_stream)
                 if st != L.MI_OK:
                     if "error" in keep:
                         raise keep["error"]
                     raise L.MiError(st, "mi_vs_stream_submit")
-                yield from drain(False)
+                if verdicts:
+                    yield from drain(False)
+                else:  # the common case inline: poll without a generator frame per batch
+                    while True:
+                        st = lib.mi_vs_stream_next(sid, 0, byref_ok)
+                        if st != L.MI_OK:
+                            break
+                        held.pop(0)
+                        yield bool(ok.value)
+                    if st != L.MI_ERR_AGAIN and st != L.MI_ERR_DONE:
+                        if "error" in keep:
+                            raise keep["error"]
+                        raise L.MiError(st, "mi_vs_stream_next")
             L.check(lib.mi_vs_stream_finish(sid), "mi_vs_stream_finish")
             yield from drain(True)
         finally:

@@ -692,7 +692,7 @@ __global__ void __launch_bounds__(256) point_tree_sum_kernel(const G1Xyzz *__res
 // kernel does not know the difference.
 constexpr uint32_t MSM_GATHER = 8;
 __global__ void __launch_bounds__(64) msm_gather_chunks_kernel(const G1Xyzz *__restrict__ chunk_partial, const uint32_t *__restrict__ chunk_off,
-                                                              const uint32_t *__restrict__ sc_off, size_t nb,
+                                                              const uint32_t *__restrict__ sc_off, size_t nb, uint32_t gather,
                                                               G1Xyzz *__restrict__ out, uint32_t *__restrict__ sc_bucket) {
     const uint32_t s = blockIdx.x * 64 + threadIdx.x;
     if (s >= sc_off[nb]) return;
@@ -703,8 +703,8 @@ __global__ void __launch_bounds__(64) msm_gather_chunks_kernel(const G1Xyzz *__r
     }
     const uint32_t b = lo_b;
     sc_bucket[s] = b;
-    const uint32_t lo = chunk_off[b] + (s - sc_off[b]) * MSM_GATHER, end = chunk_off[b + 1];
-    const uint32_t hi = end - lo > MSM_GATHER ? lo + MSM_GATHER : end;
+    const uint32_t lo = chunk_off[b] + (s - sc_off[b]) * gather, end = chunk_off[b + 1];
+    const uint32_t hi = end - lo > gather ? lo + gather : end;
     G1Xyzz28 acc;
     bool have = false;
     for (uint32_t e = lo; e < hi; e++) {
@@ -1000,13 +1000,15 @@ void msm_enqueue(Context &cx, const G1Affine *d_points, const uint32_t *d_scalar
     G1Xyzz *chunk_partial = (G1Xyzz *)cx.buf(W("chunk_partial"), sizeof(G1Xyzz) * max_chunks);
     uint32_t *heavy_list = nullptr, *heavy_count = nullptr, *order = nullptr, *sc_off = nullptr;
     bool gather = false;
+    uint32_t gather_len = MSM_GATHER;
     if (small) {
         cx.prof.begin("msm_scan", st, n);
         // long chunk lists (merged passes) are shortened before the per-bit sums: msm_gather_chunks_kernel
         static const int gather_knob = getenv("MI_SNARK_MSM_GATHER") ? atoi(getenv("MI_SNARK_MSM_GATHER")) : -1;
         gather = gather_knob >= 0 ? gather_knob != 0 : (double)n * pl.nwin / (double)T / (double)vwin >= 1000.0;
+        gather_len = gather_knob > 1 ? (uint32_t)gather_knob : MSM_GATHER;
         if (gather) sc_off = (uint32_t *)cx.buf(W("sc_off"), sizeof(uint32_t) * (nb + 1));
-        hipLaunchKernelGGL(msm_plan_small_kernel, dim3(1), dim3(1024), 0, st, counts, nb, T, offsets, chunk_off, MSM_GATHER, sc_off);
+        hipLaunchKernelGGL(msm_plan_small_kernel, dim3(1), dim3(1024), 0, st, counts, nb, T, offsets, chunk_off, gather_len, sc_off);
         cx.prof.end("msm_scan", st);
         mark.gen = counts_buf.gen;
         mark.nb = nb;
@@ -1063,11 +1065,11 @@ void msm_enqueue(Context &cx, const G1Affine *d_points, const uint32_t *d_scalar
         cx.prof.begin("msm_bitsums", st, n);
         // one wave per group, its own six tree levels, results straight into pinned host memory
         if (gather) {
-            const size_t max_sc = nb + max_chunks / MSM_GATHER + 1;
+            const size_t max_sc = nb + max_chunks / gather_len + 1;
             G1Xyzz *sc_partial = (G1Xyzz *)cx.buf(W("sc_partial"), sizeof(G1Xyzz) * max_sc);
             uint32_t *sc_bucket = (uint32_t *)cx.buf(W("sc_bucket"), sizeof(uint32_t) * max_sc);
             hipLaunchKernelGGL(msm_gather_chunks_kernel, dim3((unsigned)cdiv(max_sc, 64)), dim3(64), 0, st, chunk_partial, chunk_off, sc_off, nb,
-                               sc_partial, sc_bucket);
+                               gather_len, sc_partial, sc_bucket);
             hipLaunchKernelGGL(msm_bit_sums_queue_kernel, dim3((unsigned)all_groups), dim3(64), 0, st, sc_partial, sc_off, sc_bucket, pl.B, pl.c,
                                job->h);
         } else {
