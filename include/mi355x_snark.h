@@ -330,7 +330,7 @@ int32_t mi_vs_accumulate_end(uint64_t ctx, uint64_t handle, mi_vs_partial *parti
  * and all their MSMs are problems of one launch sequence; each batch keeps its own randomizers, accumulators and
  * partial.  A lane pass is a chain of latency-bound kernels and the lanes are few (hardware queues): under load more
  * batches per pass is what raises the throughput.  A launch sequence carries 8 MSMs -- a batch brings two, plus one per
- * degree-bound class -- and all batches must fit the small-MSM path together (2^16 points); otherwise
+ * degree-bound class -- and all batches must fit the small-MSM path together (2^17 points); otherwise
  * MI_ERR_BAD_ARGS: run them as separate passes.  mi_vs_batches_per_pass tells how many batches of n proofs fit (1..4).
  * All batches' inputs must be ready on `stream`.  _end_multi writes partials_out[k] for batch k; `count` must be the
  * pass's own.  _pair = _multi with two batches. */

@@ -12,10 +12,10 @@
 //   scan / plan    bucket offsets; buckets over T entries are cut into chunks (offsets of those too)
 //   msm_scatter    lane per (w, i): sorted[offset[bucket] + rank] = (i << 1) | negate        (no atomics)
 //   msm_accumulate lane per CHUNK: gather its points (96 B each, random), mixed-add into XYZZ
-// Large path (n > 2^16): chunk map + chunks ordered by length; multi-chunk buckets summed (msm_combine_*);
+// Large path (n > 2^17): chunk map + chunks ordered by length; multi-chunk buckets summed (msm_combine_*);
 //   msm_segments (running sums per L-bucket segment + (gL) fix-up); point_tree_sum per window; the host folds the
 //   nwin window sums (<= 256 doublings) and normalises to z = 1.
-// Small path (n <= 2^16, latency bound; takes optional split points: up to four MSMs as one launch sequence, each
+// Small path (n <= 2^17, latency bound; takes optional split points: up to four MSMs as one launch sequence, each
 //   further problem as another set of windows): ONE planning workgroup instead of scans / memsets / chunk kernels, accumulate finds its
 //   bucket by bisection, msm_bit_sums_* forms per-(window, bit) subset sums straight from the chunk partials into
 //   pinned host memory, and the host folds over bit positions (halves of each problem on pool threads).
@@ -39,7 +39,9 @@ struct MsmPlan {
     uint32_t B;  // buckets per window = 2^(c-1)
 };
 
-// largest n that takes the small (latency-bound) path; MI_SNARK_MSM_SMALL_LOG overrides for experiments
+// largest n that takes the small (latency-bound) path: 2^17 since round 3 (with the gather stage ahead of the per-bit sums
+// the small path wins there: 1.51 against 1.68 ms; at 2^18 it loses, 2.77 against 1.76: tools/msm_small_limit.py);
+// MI_SNARK_MSM_SMALL_LOG overrides for experiments
 // chunk length on the small path: longer chunks = fewer partials for the bit-sum reduction (less GPU work per MSM),
 // shorter = shorter accumulation chains (latency); MI_SNARK_MSM_SMALL_T overrides for experiments
 static uint32_t msm_small_chunk() {
@@ -56,10 +58,10 @@ static uint32_t msm_small_chunk() {
 size_t msm_small_limit() {
     static size_t lim = 0;
     if (!lim) {
-        int lg = 16;
+        int lg = 17;
         if (const char *e = getenv("MI_SNARK_MSM_SMALL_LOG")) {
             const int x = atoi(e);
-            if (x >= 6 && x <= 16) lg = x;
+            if (x >= 6 && x <= 18) lg = x;
         }
         lim = (size_t)1 << lg;
     }
@@ -917,7 +919,7 @@ void msm_enqueue(Context &cx, const G1Affine *d_points, const uint32_t *d_scalar
     }
     for (int k = 0; k + 1 < problems; k++)
         if (split.at[k] == n || (k && split.at[k] < split.at[k - 1])) throw HipError{hipErrorInvalidValue, "msm split points", __LINE__};
-    if (problems > 1 && !small) throw HipError{hipErrorInvalidValue, "msm split needs n <= 2^16", __LINE__};
+    if (problems > 1 && !small) throw HipError{hipErrorInvalidValue, "msm split needs n <= 2^17", __LINE__};
     job->problems = problems;
     cx.prof.begin("msm_total", st, n);
     HostSpan hs_bufs("msm.enqueue_all");

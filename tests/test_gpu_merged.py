@@ -53,7 +53,7 @@ def test_merged_pass_partial_is_the_concatenated_batch(orc, mi, transcript):
         # one batch is not a merged pass; batches that do not fit one pass together are refused
         with pytest.raises(MiError):
             v.accumulate_begin_merged(_split(b, ()))
-        big = (torch.cat([torch.from_numpy(b.proofs).cuda()] * 30), torch.cat([torch.from_numpy(b.randomizers).cuda()] * 30))
+        big = (torch.cat([torch.from_numpy(b.proofs).cuda()] * 60), torch.cat([torch.from_numpy(b.randomizers).cuda()] * 60))  # 2 x 75 k points > 2^17
         with pytest.raises(MiError):
             v.accumulate_begin_merged([big, big])
         assert (v.accumulate(torch.from_numpy(b.proofs).cuda(), torch.from_numpy(b.randomizers).cuda()) == whole).all()

@@ -244,10 +244,10 @@ def test_block_of_8192_proofs_as_eight_shards(orc, mi):
 
 
 def test_batch_too_large_for_the_fused_msm_pair(orc, mi):
-    """5 100 proofs: 13 n + 97 operand points exceed the small-MSM limit (2^16), so the two accumulators run as two
+    """10 150 proofs: 13 n + 97 operand points exceed the small-MSM limit (2^17), so the two accumulators run as two
     separate MSMs (the H side on the large-MSM path); partial bit-exact with the oracle, verdicts with one bad proof"""
     import torch
-    n = 5100
+    n = 10150
     b = orc.VSBatch(0xB16B, n, 4, 0)
     v = _ctx(mi, b)
     try:
@@ -521,7 +521,7 @@ def test_pair_pass_partials_bit_exact(orc, mi):
         assert (parts[0] == sa).all() and (parts[1] == sb).all()
         parts = vp.accumulate_end_pair(vp.accumulate_begin_pair(pb, rb, pa, ra))
         assert (parts[0] == sb).all() and (parts[1] == sa).all()
-        big_p, big_r = torch.cat([pa] * 60), torch.cat([ra] * 60)  # 2 880 proofs each: 2 x 37.5 k points > 2^16
+        big_p, big_r = torch.cat([pa] * 120), torch.cat([ra] * 120)  # 5 760 proofs each: 2 x 75 k points > 2^17
         with pytest.raises(MiError):
             vp.accumulate_begin_pair(big_p, big_r, big_p, big_r)
         assert (vp.accumulate(pa, ra) == sa).all()
@@ -597,7 +597,7 @@ def test_multi_batch_passes_bit_exact(orc, mi):
     for transcript in ("sha256", "poseidon"):
         v = mi.VarunaShaped(a.vk, a.circuits, transcript=transcript)
         try:
-            assert v.batches_per_pass(40) == 4 and v.batches_per_pass(1024) == 4 and v.batches_per_pass(2000) == 2 and v.batches_per_pass(5000) == 1
+            assert v.batches_per_pass(40) == 4 and v.batches_per_pass(1024) == 4 and v.batches_per_pass(2000) == 4 and v.batches_per_pass(4000) == 2 and v.batches_per_pass(10100) == 1
             singles = [v.accumulate(p, r) for p, r in batches]
             for sel in ([0, 1, 2], [3, 2, 1, 0], [1, 1, 1, 1], [2, 0]):
                 got = v.accumulate_end_multi(v.accumulate_begin_multi([batches[i] for i in sel]), len(sel))
