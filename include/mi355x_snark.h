@@ -352,6 +352,7 @@ int32_t mi_vs_accumulate_begin_pair(uint64_t ctx, const void *d_proofs_a, size_t
                                     uint64_t *handle_out);
 int32_t mi_vs_accumulate_end_pair(uint64_t ctx, uint64_t handle, mi_vs_partial *partials_out);
 int32_t mi_vs_batches_per_pass(uint64_t ctx, size_t n);  /* >= 1, or a negative status */
+int32_t mi_vs_batches_per_merged_pass(uint64_t ctx, size_t n);  /* the same for mi_vs_accumulate_begin_merged (below) */
 int32_t mi_vs_finalize_async(uint64_t ctx, const mi_vs_partial *partials, size_t n_partials, uint64_t *ticket_out);
 int32_t mi_vs_finalize_wait(uint64_t ctx, uint64_t ticket, uint8_t *all_ok);
 /* Several pairing products under ONE ticket (one product stream, a workgroup per product): product k sums

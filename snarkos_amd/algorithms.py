@@ -520,6 +520,13 @@ class VarunaShaped:
             raise L.MiError(r, "mi_vs_batches_per_pass")
         return r
 
+    def batches_per_merged_pass(self, n_proofs):
+        """How many batches of n_proofs one MERGED pass takes (mi_vs_accumulate_begin_merged) for this shape (1..4)."""
+        r = L.lib().mi_vs_batches_per_merged_pass(C.c_uint64(self.ctx), C.c_size_t(n_proofs))
+        if r < 1:
+            raise L.MiError(r, "mi_vs_batches_per_merged_pass")
+        return r
+
     def finalize_multi(self, groups):
         """Several pairing products under one ticket (mi_vs_finalize_async_multi / _wait_multi): groups is a list of
         equally long lists of partials (one list per product: the shards of one batch); returns one bool per product."""

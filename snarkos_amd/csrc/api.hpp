@@ -91,6 +91,7 @@ int32_t vs_accumulate_begin_merged(Context &cx, uint64_t id, int count, const vo
                                    const void *const *d_rand, hipStream_t st, uint64_t *handle);
 int32_t vs_accumulate_end_multi(Context &cx, uint64_t id, uint64_t handle, mi_vs_partial *outs, int count);
 int32_t vs_batches_per_pass(Context &cx, uint64_t id, size_t n);
+int32_t vs_batches_per_merged_pass(Context &cx, uint64_t id, size_t n);
 int32_t vs_finalize(Context &cx, uint64_t id, const mi_vs_partial *parts, size_t np, uint8_t *all_ok, hipStream_t st);
 int32_t vs_finalize_async(Context &cx, uint64_t id, const mi_vs_partial *parts, size_t np, uint64_t *ticket);
 int32_t vs_finalize_wait(Context &cx, uint64_t id, uint64_t ticket, uint8_t *all_ok);

@@ -1036,6 +1036,10 @@ int32_t mi_vs_batches_per_pass(uint64_t c, size_t n) {
     if (!n) return MI_ERR_BAD_ARGS;
     return guarded([&](Context &cx) -> int32_t { return vs_batches_per_pass(cx, c, n); });
 }
+int32_t mi_vs_batches_per_merged_pass(uint64_t c, size_t n) {
+    if (!n) return MI_ERR_BAD_ARGS;
+    return guarded([&](Context &cx) -> int32_t { return vs_batches_per_merged_pass(cx, c, n); });
+}
 int32_t mi_vs_finalize_async(uint64_t c, const mi_vs_partial *partials, size_t n_partials, uint64_t *ticket_out) {
     if (!partials || !n_partials || !ticket_out) return MI_ERR_BAD_ARGS;
     return guarded([&](Context &cx) -> int32_t { return vs_finalize_async(cx, c, partials, n_partials, ticket_out); });

@@ -390,7 +390,7 @@ int32_t mi_vs_stream_submit(uint64_t stream, const void *d_proofs, size_t n, con
         ask = s->per_pass == 0;
     }
     if (ask) {  // how many batches of this size one pass takes (asked once: the shape is the context's)
-        const int32_t pp = mi_vs_batches_per_pass(s->ctx, n);
+        const int32_t pp = !s->exchange && s->merge ? mi_vs_batches_per_merged_pass(s->ctx, n) : mi_vs_batches_per_pass(s->ctx, n);
         std::lock_guard<std::mutex> lk(s->mu);
         s->per_pass = pp < 1 ? 1 : (pp > s->per_pass_max ? s->per_pass_max : pp);
     }

@@ -1864,6 +1864,16 @@ static int32_t vs_accumulate_begin_impl(Context &cx, const VsCtx &vc, const void
         vs_work_sizes(v, n, wq);
         need_points = vs_work_total(wq) * (size_t)per_pass_prime;
         need_bytes = (size_t)v.shape.proof_words * 4 * n * (size_t)per_pass_prime;
+        {  // what priming covers: the largest pass of either form for batches of n proofs
+            size_t ns4[MI_VS_MAX_BATCHES_PER_PASS];
+            for (int k = 0; k < MI_VS_MAX_BATCHES_PER_PASS; k++) ns4[k] = n;
+            for (int c = 2; c <= MI_VS_MAX_BATCHES_PER_PASS; c++)
+                if (vs_merged_ok(v, ns4, c)) {
+                    vs_work_sizes(v, n * (size_t)c, wq);
+                    if (vs_work_total(wq) > need_points) need_points = vs_work_total(wq);
+                    if ((size_t)v.shape.proof_words * 4 * n * (size_t)c > need_bytes) need_bytes = (size_t)v.shape.proof_words * 4 * n * (size_t)c;
+                }
+        }
         if (multi) {
             size_t tot = 0, nb = 0;
             for (int k = 0; k < bt.count; k++) {
@@ -1905,8 +1915,17 @@ static int32_t vs_accumulate_begin_impl(Context &cx, const VsCtx &vc, const void
             MsmJob jj[4];
             if (per_pass > 1) vs_enqueue_msms_multi(cx, ws, per_pass, sp, p, jj, 0);
             else (void)vs_enqueue_msms(cx, ws[0], sp, p, jj, 0);
-            if (per_pass > 1 && vs_merged_ok(v, rep.n, per_pass)) {  // the merged form of the same pass: its per-proof arrays are longer
-                vs_run_derive(cx, v, rep.proofs, rep.n, rep.rand, per_pass, sp, p, ws, true);
+            // the merged form, with as many batches as IT takes (its problems do not multiply with the batches): its
+            // per-proof arrays are longer
+            int merged_count = 0;
+            for (int k = 0; k < MI_VS_MAX_BATCHES_PER_PASS; k++) {
+                rep.proofs[k] = d_proofs;
+                rep.rand[k] = d_rand;
+                rep.n[k] = n;
+                if (k >= 1 && vs_merged_ok(v, rep.n, k + 1)) merged_count = k + 1;
+            }
+            if (merged_count) {
+                vs_run_derive(cx, v, rep.proofs, rep.n, rep.rand, merged_count, sp, p, ws, true);
                 (void)vs_enqueue_msms(cx, ws[0], sp, p, jj, 0);
             }
         }
@@ -2083,6 +2102,18 @@ int32_t vs_batches_per_pass(Context &cx, uint64_t id, size_t n) {
     std::shared_ptr<VsCtx> v = vs_find(id);
     if (!v || !n) return MI_ERR_BAD_ARGS;
     return vs_max_per_pass(vs_keys(cx, *v), n);
+}
+// the most batches of n proofs that one MERGED pass takes (its MSM problems do not multiply with the batches: shapes
+// with degree-bound classes merge more batches than they can carry side by side)
+int32_t vs_batches_per_merged_pass(Context &cx, uint64_t id, size_t n) {
+    std::shared_ptr<VsCtx> v = vs_find(id);
+    if (!v || !n) return MI_ERR_BAD_ARGS;
+    size_t ns[MI_VS_MAX_BATCHES_PER_PASS];
+    for (int k = 0; k < MI_VS_MAX_BATCHES_PER_PASS; k++) ns[k] = n;
+    int best = 1;
+    for (int c = 2; c <= MI_VS_MAX_BATCHES_PER_PASS; c++)
+        if (vs_merged_ok(vs_keys(cx, *v), ns, c)) best = c;
+    return best;
 }
 int32_t vs_accumulate_device(Context &cx, uint64_t id, const void *d_proofs, size_t n, const void *d_rand,
                              mi_vs_partial *out, hipStream_t st) {

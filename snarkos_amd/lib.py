@@ -51,7 +51,7 @@ EXPORTS = [
     "mi_pairing_product_is_one", "mi_pairing", "mi_kzg_batch_check", "mi_kzg_batch_check_hiding",
     "mi_poseidon_fq_hash_many", "mi_poseidon_fq_hash_many_device", "mi_schnorr_verify_batch", "mi_schnorr_verify_batch_device",
     "mi_vs_ctx_create", "mi_vs_ctx_create_ex", "mi_vs_ctx_create_v2", "mi_vs_ctx_destroy", "mi_vs_verify_batch", "mi_vs_verify_batch_device", "mi_vs_identify_device",
-    "mi_vs_accumulate_device", "mi_vs_accumulate_begin", "mi_vs_accumulate_end", "mi_vs_accumulate_begin_pair", "mi_vs_accumulate_end_pair", "mi_vs_accumulate_begin_multi", "mi_vs_accumulate_end_multi", "mi_vs_accumulate_begin_merged", "mi_vs_batches_per_pass", "mi_g1_decompress", "mi_g1_decompress_device", "mi_g1_compress", "mi_vs_finalize", "mi_vs_finalize_async", "mi_vs_finalize_wait", "mi_vs_finalize_async_multi", "mi_vs_finalize_wait_multi", "mi_vs_wait_product_slot",
+    "mi_vs_accumulate_device", "mi_vs_accumulate_begin", "mi_vs_accumulate_end", "mi_vs_accumulate_begin_pair", "mi_vs_accumulate_end_pair", "mi_vs_accumulate_begin_multi", "mi_vs_accumulate_end_multi", "mi_vs_accumulate_begin_merged", "mi_vs_batches_per_pass", "mi_vs_batches_per_merged_pass", "mi_g1_decompress", "mi_g1_decompress_device", "mi_g1_compress", "mi_vs_finalize", "mi_vs_finalize_async", "mi_vs_finalize_wait", "mi_vs_finalize_async_multi", "mi_vs_finalize_wait_multi", "mi_vs_wait_product_slot",
     "mi_vs_verify_block", "mi_vs_verify_block_device",
     "mi_vs_stream_open", "mi_vs_stream_submit", "mi_vs_stream_finish", "mi_vs_stream_next", "mi_vs_stream_next_verdicts", "mi_vs_stream_close",
     "mi_comm_unique_id", "mi_comm_init_rank", "mi_comm_init_local", "mi_comm_world", "mi_comm_transport", "mi_comm_destroy", "mi_comm_all_gather",

@@ -71,7 +71,9 @@ def test_merged_pass_v2_shape_and_wire_records(orc, mi):
     try:
         pb, rb = b.record_bytes, len(b.randomizers) // b.n
         whole = v.accumulate(torch.from_numpy(b.proofs).cuda(), torch.from_numpy(b.randomizers).cuda())
-        for cuts in ((20,), (7, 30)):
+        # four MSM problems per batch: two batches side by side fill a pass (eight problems), four merged ones do not
+        assert v.batches_per_pass(44) == 2 and v.batches_per_merged_pass(44) == 4 and v.batches_per_merged_pass(3000) == 2
+        for cuts in ((20,), (7, 30), (5, 20, 40)):
             parts = _split(b, cuts, rand_bytes=rb, proof_bytes=pb)
             assert (v.accumulate_end(v.accumulate_begin_merged(parts)) == whole).all(), cuts
     finally:
