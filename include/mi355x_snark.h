@@ -331,15 +331,15 @@ int32_t mi_vs_accumulate_end(uint64_t ctx, uint64_t handle, mi_vs_partial *parti
  * partial.  A lane pass is a chain of latency-bound kernels and the lanes are few (hardware queues): under load more
  * batches per pass is what raises the throughput.  A launch sequence carries 8 MSMs -- a batch brings two, plus one per
  * degree-bound class -- and all batches must fit the small-MSM path together (2^17 points); otherwise
- * MI_ERR_BAD_ARGS: run them as separate passes.  mi_vs_batches_per_pass tells how many batches of n proofs fit (1..4).
+ * MI_ERR_BAD_ARGS: run them as separate passes.  mi_vs_batches_per_pass tells how many batches of n proofs fit (1..4: eight MSM problems).
  * All batches' inputs must be ready on `stream`.  _end_multi writes partials_out[k] for batch k; `count` must be the
  * pass's own.  _pair = _multi with two batches. */
-#define MI_VS_MAX_BATCHES_PER_PASS 4
+#define MI_VS_MAX_BATCHES_PER_PASS 8
 int32_t mi_vs_accumulate_begin_multi(uint64_t ctx, int32_t count, const void *const *d_proofs, const size_t *n,
                                      const void *const *d_randomizers128, void *stream, uint64_t *handle_out);
 int32_t mi_vs_accumulate_end_multi(uint64_t ctx, uint64_t handle, mi_vs_partial *partials_out, int32_t count);
 /* The batches of a pass folded into ONE aggregate: the randomizers of all their proofs are independent, so the union of
- * 2..4 batches is one batch-verification instance -- one MSM pair, one host fold, one pairing product for all of them.
+ * 2..8 batches is one batch-verification instance -- one MSM pair, one host fold, one pairing product for all of them.
  * Ends with mi_vs_accumulate_end: ONE partial over all the proofs (n_proofs = their sum).  A product of one says every
  * batch is valid; otherwise the caller checks the batches on their own (mi_vs_verify_batch_device / mi_vs_identify_device
  * on the still-resident inputs).  MI_ERR_BAD_ARGS when the sum does not fit one pass: use _begin_multi or single passes.

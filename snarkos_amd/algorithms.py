@@ -495,7 +495,7 @@ class VarunaShaped:
         return h.value
 
     def accumulate_begin_merged(self, batches, stream=None):
-        """Two to four (proofs, randomizers) batches folded into ONE aggregate (mi_vs_accumulate_begin_merged); returns a
+        """Two to eight (proofs, randomizers) batches folded into ONE aggregate (mi_vs_accumulate_begin_merged); returns a
         handle for accumulate_end(handle): one partial over all their proofs.  Raises MiError (MI_ERR_BAD_ARGS) when they
         do not fit one pass."""
         k = len(batches)
@@ -521,7 +521,7 @@ class VarunaShaped:
         return r
 
     def batches_per_merged_pass(self, n_proofs):
-        """How many batches of n_proofs one MERGED pass takes (mi_vs_accumulate_begin_merged) for this shape (1..4)."""
+        """How many batches of n_proofs one MERGED pass takes (mi_vs_accumulate_begin_merged) for this shape (1..8)."""
         r = L.lib().mi_vs_batches_per_merged_pass(C.c_uint64(self.ctx), C.c_size_t(n_proofs))
         if r < 1:
             raise L.MiError(r, "mi_vs_batches_per_merged_pass")

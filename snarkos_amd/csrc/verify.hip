@@ -1632,7 +1632,7 @@ static void vs_run_derive(Context &cx, VsKeys &v, const void *const *d_proofs_in
     G1Affine *pts = (G1Affine *)cx.buf(W("pts"), sizeof(G1Affine) * total);
     uint32_t *sc = (uint32_t *)cx.buf(W("sc"), 32 * total);
     size_t at = 0;
-    static const char *const suffix[MI_VS_MAX_BATCHES_PER_PASS] = {"", ".b", ".c", ".d"};
+    static const char *const suffix[MI_VS_MAX_BATCHES_PER_PASS] = {"", ".b", ".c", ".d", ".e", ".f", ".g", ".h"};
     for (int k = 0; k < (merged ? 1 : count); k++) {
         VsWork &x = ws[k];
         VsOut &o = x.o;
@@ -1875,11 +1875,16 @@ static int32_t vs_accumulate_begin_impl(Context &cx, const VsCtx &vc, const void
                 }
         }
         if (multi) {
-            size_t tot = 0, nb = 0;
+            size_t tot = 0, nb = 0, n_sum = 0;
             for (int k = 0; k < bt.count; k++) {
                 vs_work_sizes(v, bt.n[k], wq);
                 tot += vs_work_total(wq);
                 nb += (size_t)v.shape.proof_words * 4 * bt.n[k];
+                n_sum += bt.n[k];
+            }
+            if (merged) {  // one batch of the sum: the merged slots (vk, G) once
+                vs_work_sizes(v, n_sum, wq);
+                tot = vs_work_total(wq);
             }
             if (tot > need_points) need_points = tot;
             if (nb > need_bytes) need_bytes = nb;

@@ -30,7 +30,7 @@ def test_merged_pass_partial_is_the_concatenated_batch(orc, mi, transcript):
     try:
         whole = v.accumulate(torch.from_numpy(b.proofs).cuda(), torch.from_numpy(b.randomizers).cuda())
         assert (whole == orc.vs_partial_from_oracle(b)).all()
-        for cuts in ((40,), (1,), (96,), (33, 64), (10, 11, 90)):
+        for cuts in ((40,), (1,), (96,), (33, 64), (10, 11, 90), (5, 17, 30, 31, 60, 77, 90)):
             parts = _split(b, cuts)
             merged = v.accumulate_end(v.accumulate_begin_merged(parts))
             assert (merged == whole).all(), cuts
@@ -72,7 +72,7 @@ def test_merged_pass_v2_shape_and_wire_records(orc, mi):
         pb, rb = b.record_bytes, len(b.randomizers) // b.n
         whole = v.accumulate(torch.from_numpy(b.proofs).cuda(), torch.from_numpy(b.randomizers).cuda())
         # four MSM problems per batch: two batches side by side fill a pass (eight problems), four merged ones do not
-        assert v.batches_per_pass(44) == 2 and v.batches_per_merged_pass(44) == 4 and v.batches_per_merged_pass(3000) == 2
+        assert v.batches_per_pass(44) == 2 and v.batches_per_merged_pass(44) == 8 and v.batches_per_merged_pass(3000) == 2
         for cuts in ((20,), (7, 30), (5, 20, 40)):
             parts = _split(b, cuts, rand_bytes=rb, proof_bytes=pb)
             assert (v.accumulate_end(v.accumulate_begin_merged(parts)) == whole).all(), cuts
