@@ -9,6 +9,7 @@
 // Host only: the device pass of a .hip file sees the types and declarations (it parses the host functions that use
 // them), the bodies -- x86 inline assembly among them -- exist in the host pass alone.
 #pragma once
+#include <stdlib.h>
 #include "curve.hpp"
 
 namespace mi {
@@ -106,8 +107,8 @@ __attribute__((target("bmi2,adx"))) inline H6 mul_adx(const H6 &a, const H6 &b) 
     return r;
 }
 #undef MI_HF_MULADD6
-inline bool have_adx() {
-    static const bool ok = __builtin_cpu_supports("bmi2") && __builtin_cpu_supports("adx");
+inline bool have_adx() {  // MI_SNARK_HOSTFOLD_NO_ADX=1: the portable product (tests run both)
+    static const bool ok = __builtin_cpu_supports("bmi2") && __builtin_cpu_supports("adx") && !getenv("MI_SNARK_HOSTFOLD_NO_ADX");
     return ok;
 }
 #endif

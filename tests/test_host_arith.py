@@ -121,6 +121,17 @@ def test_g1_group_law(hc, orc):
     assert (out == orc.g1_mul(a[6], orc.limbs_to_int(k))).all()
 
 
+def test_host_fold_arithmetic_without_adx(orc):
+    """the same checks through the portable product (MI_SNARK_HOSTFOLD_NO_ADX=1 is read once per process: a child)"""
+    import subprocess, sys
+    code = ("import os, sys; sys.path[:0] = [%r, %r]; import conftest, test_host_arith as t, orc_py; "
+            "hc = t.hc.__wrapped__(); assert hc.hc_hf_has_adx() == 0; t.test_host_fold_arithmetic(hc, orc_py); print('ok')"
+            % (HERE, os.path.join(os.path.dirname(HERE), "oracle")))
+    env = dict(os.environ, MI_SNARK_HOSTFOLD_NO_ADX="1")
+    out = subprocess.run([sys.executable, "-c", code], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+    assert out.returncode == 0 and out.stdout.strip().endswith("ok"), out.stderr[-2000:]
+
+
 def test_host_fold_arithmetic(hc, orc):
     """csrc/hostfold.hpp (the host fold of a small MSM's per-bit sums): its Fq product / sum / difference on 64-bit
     limbs against the oracle, and the fold itself -- Horner over per-bit sums, split into a low part and a shifted high
