@@ -180,19 +180,19 @@ __device__ __forceinline__ void msm_half_limbs(int w, uint32_t (&hw)[8]) {
 // comparison (msm_digit_at), counts its digit in the workgroup's LDS histogram, which
 // also numbers it among the workgroup's entries of that bucket; one global atomic per (workgroup, live bucket) then
 // reserves the workgroup's range of ranks.  Buckets of several problems (split points inside the workgroup's range of
-// scalars) sit side by side in LDS.  Window widths whose histogram does not fit (c > 10: never the small path's) count
+// scalars) sit side by side in LDS.  Window widths whose histogram does not fit (c > 11: never the verifier's passes) count
 // in global memory directly, hot buckets of a wave through one atomic.
 // windows per thread: a thread reads its scalar once for G windows (one thread per window re-read 32 bytes per window
 // through L2: 1.4 % of the streamed rate) and walks them with a chain of G LDS atomics
 template <int C>
-constexpr int msm_digits_group() { return C <= 9 ? 4 : (C == 10 ? 2 : 1); }
+constexpr int msm_digits_group() { return C <= 9 ? 4 : (C == 10 ? 2 : 1); }  // G x 2^(C-1) x MSM_MAX_PROBLEMS counters: 32 KB at most
 template <int C, int BITS, int MSM_DIGITS_THREADS>
 __global__ void __launch_bounds__(MSM_DIGITS_THREADS) msm_digits_kernel(const uint32_t *__restrict__ scalars, size_t n,
                                                                         int32_t *__restrict__ digits, uint32_t *__restrict__ ranks,
                                                                         uint32_t *__restrict__ counts_all, MsmSplits splits) {
     constexpr int NWIN = (BITS + C - 1) / C;
     constexpr uint32_t B = 1u << (C - 1);
-    constexpr bool IN_LDS = C <= 10;
+    constexpr bool IN_LDS = C <= 11;
     constexpr int G = msm_digits_group<C>();
     __shared__ uint32_t hist[IN_LDS ? G * B * MSM_MAX_PROBLEMS : 1];
     const size_t first = (size_t)blockIdx.x * MSM_DIGITS_THREADS, i = first + threadIdx.x;
@@ -435,6 +435,76 @@ __global__ void __launch_bounds__(1024) msm_plan_small_kernel(uint32_t *__restri
         offsets[nb] = o1;
         chunk_off[nb] = o2;
         if (sc_off) sc_off[nb] = o3;
+    }
+}
+// The same plan over MANY buckets (merged passes: c = 11, 49 k buckets -- the one workgroup above took 150 us of every
+// such pass's chain): a workgroup per 1024 buckets, coalesced.  First launch: the workgroups' totals; second: every
+// workgroup adds up the totals before its own (at most a few dozen), scans its buckets and writes the offsets.
+__global__ void __launch_bounds__(1024) msm_plan_sums_kernel(const uint32_t *__restrict__ counts, size_t nb, uint32_t T, uint32_t gather,
+                                                             uint32_t *__restrict__ block_sums) {
+    __shared__ uint32_t w[3][16];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const size_t b = (size_t)blockIdx.x * 1024 + threadIdx.x;
+    const uint32_t c = b < nb ? counts[b] : 0u, ch = (c + T - 1) / T, sc = (ch + gather - 1) / gather;
+    const uint32_t i1 = wave_incl_scan(c, lane), i2 = wave_incl_scan(ch, lane), i3 = wave_incl_scan(sc, lane);
+    if (lane == 63) {
+        w[0][wave] = i1;
+        w[1][wave] = i2;
+        w[2][wave] = i3;
+    }
+    __syncthreads();
+    if (threadIdx.x < 3) {
+        uint32_t t = 0;
+        for (int k = 0; k < 16; k++) t += w[threadIdx.x][k];
+        block_sums[3 * blockIdx.x + threadIdx.x] = t;
+    }
+}
+__global__ void __launch_bounds__(1024) msm_plan_offsets_kernel(uint32_t *__restrict__ counts, size_t nb, uint32_t T, uint32_t gather,
+                                                                const uint32_t *__restrict__ block_sums, uint32_t *__restrict__ offsets,
+                                                                uint32_t *__restrict__ chunk_off, uint32_t *__restrict__ sc_off) {
+    __shared__ uint32_t w[3][16], base[3];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (wave == 0) {  // the totals of the workgroups before this one
+        uint32_t t0 = 0, t1 = 0, t2 = 0;
+        for (uint32_t j = (uint32_t)lane; j < blockIdx.x; j += 64) {
+            t0 += block_sums[3 * j];
+            t1 += block_sums[3 * j + 1];
+            t2 += block_sums[3 * j + 2];
+        }
+        t0 = wave_incl_scan(t0, lane);
+        t1 = wave_incl_scan(t1, lane);
+        t2 = wave_incl_scan(t2, lane);
+        if (lane == 63) {
+            base[0] = t0;
+            base[1] = t1;
+            base[2] = t2;
+        }
+    }
+    const size_t b = (size_t)blockIdx.x * 1024 + threadIdx.x;
+    const uint32_t c = b < nb ? counts[b] : 0u, ch = (c + T - 1) / T, sc = (ch + gather - 1) / gather;
+    const uint32_t i1 = wave_incl_scan(c, lane), i2 = wave_incl_scan(ch, lane), i3 = wave_incl_scan(sc, lane);
+    if (lane == 63) {
+        w[0][wave] = i1;
+        w[1][wave] = i2;
+        w[2][wave] = i3;
+    }
+    __syncthreads();
+    uint32_t o1 = base[0] + i1 - c, o2 = base[1] + i2 - ch, o3 = base[2] + i3 - sc;
+    for (int k = 0; k < wave; k++) {
+        o1 += w[0][k];
+        o2 += w[1][k];
+        o3 += w[2][k];
+    }
+    if (b < nb) {
+        offsets[b] = o1;
+        chunk_off[b] = o2;
+        if (sc_off) sc_off[b] = o3;
+        counts[b] = 0;
+    }
+    if (b == nb - 1) {  // the grand totals
+        offsets[nb] = o1 + c;
+        chunk_off[nb] = o2 + ch;
+        if (sc_off) sc_off[nb] = o3 + sc;
     }
 }
 __global__ void __launch_bounds__(256) msm_chunk_count_kernel(const uint32_t *__restrict__ counts, size_t nb, uint32_t T,
@@ -1010,7 +1080,14 @@ void msm_enqueue(Context &cx, const G1Affine *d_points, const uint32_t *d_scalar
         gather = gather_knob >= 0 ? gather_knob != 0 : (double)n * pl.nwin / (double)T / (double)vwin >= 1000.0;
         gather_len = gather_knob > 1 ? (uint32_t)gather_knob : MSM_GATHER;
         if (gather) sc_off = (uint32_t *)cx.buf(W("sc_off"), sizeof(uint32_t) * (nb + 1));
-        hipLaunchKernelGGL(msm_plan_small_kernel, dim3(1), dim3(1024), 0, st, counts, nb, T, offsets, chunk_off, gather_len, sc_off);
+        if (nb > 16384) {  // many buckets: a workgroup per 1024 of them, two launches
+            const unsigned nblk = (unsigned)cdiv(nb, 1024);
+            uint32_t *plan_sums = (uint32_t *)cx.buf(W("plan_sums"), sizeof(uint32_t) * 3 * nblk);
+            hipLaunchKernelGGL(msm_plan_sums_kernel, dim3(nblk), dim3(1024), 0, st, counts, nb, T, gather_len, plan_sums);
+            hipLaunchKernelGGL(msm_plan_offsets_kernel, dim3(nblk), dim3(1024), 0, st, counts, nb, T, gather_len, plan_sums, offsets, chunk_off, sc_off);
+        } else {
+            hipLaunchKernelGGL(msm_plan_small_kernel, dim3(1), dim3(1024), 0, st, counts, nb, T, offsets, chunk_off, gather_len, sc_off);
+        }
         cx.prof.end("msm_scan", st);
         mark.gen = counts_buf.gen;
         mark.nb = nb;
