@@ -763,27 +763,40 @@ __global__ void __launch_bounds__(256) point_tree_sum_kernel(const G1Xyzz *__res
 // list has the old one's shape (offsets per bucket from the plan kernel, the bucket of every entry), so the per-bit
 // kernel does not know the difference.
 constexpr uint32_t MSM_GATHER = 8;
+// Two lanes per entry: each adds half of the entry's partials (at most gather / 2 in sequence), the even lane then adds
+// its neighbour's sum -- five additions in sequence instead of eight.
 __global__ void __launch_bounds__(64) msm_gather_chunks_kernel(const G1Xyzz *__restrict__ chunk_partial, const uint32_t *__restrict__ chunk_off,
                                                               const uint32_t *__restrict__ sc_off, size_t nb, uint32_t gather,
                                                               G1Xyzz *__restrict__ out, uint32_t *__restrict__ sc_bucket) {
-    const uint32_t s = blockIdx.x * 64 + threadIdx.x;
-    if (s >= sc_off[nb]) return;
-    uint32_t lo_b = 0, hi_b = (uint32_t)nb;  // sc_off[b] <= s < sc_off[b + 1]
-    while (hi_b - lo_b > 1) {
-        const uint32_t mid = (lo_b + hi_b) >> 1;
-        if (sc_off[mid] <= s) lo_b = mid; else hi_b = mid;
+    const uint32_t s = blockIdx.x * 32 + (threadIdx.x >> 1), half = threadIdx.x & 1;
+    const bool live = s < sc_off[nb];  // (no early return: the neighbours exchange their sums below)
+    uint32_t lo = 0, hi = 0;
+    if (live) {
+        uint32_t lo_b = 0, hi_b = (uint32_t)nb;  // sc_off[b] <= s < sc_off[b + 1]
+        while (hi_b - lo_b > 1) {
+            const uint32_t mid = (lo_b + hi_b) >> 1;
+            if (sc_off[mid] <= s) lo_b = mid; else hi_b = mid;
+        }
+        const uint32_t b = lo_b;
+        if (!half) sc_bucket[s] = b;
+        const uint32_t first = chunk_off[b] + (s - sc_off[b]) * gather, end = chunk_off[b + 1];
+        const uint32_t last = end - first > gather ? first + gather : end;
+        const uint32_t mid = first + (gather + 1) / 2 < last ? first + (gather + 1) / 2 : last;
+        lo = half ? mid : first;
+        hi = half ? last : mid;
     }
-    const uint32_t b = lo_b;
-    sc_bucket[s] = b;
-    const uint32_t lo = chunk_off[b] + (s - sc_off[b]) * gather, end = chunk_off[b + 1];
-    const uint32_t hi = end - lo > gather ? lo + gather : end;
     G1Xyzz28 acc;
     bool have = false;
     for (uint32_t e = lo; e < hi; e++) {
         const G1Xyzz v = load_xyzz(&chunk_partial[e]);
         xyzz_acc28(acc, have, xyzz28_from(v), !v.is_inf());
     }
-    store_xyzz(&out[s], have ? xyzz28_store(acc) : G1Xyzz::inf());
+    const G1Xyzz28 other = xyzz28_shfl_down(acc, 1);
+    const bool have_other = __shfl_down((int)have, 1, 64) != 0;
+    if (!half) {
+        xyzz_acc28(acc, have, other, have_other);
+        if (live) store_xyzz(&out[s], have ? xyzz28_store(acc) : G1Xyzz::inf());
+    }
 }
 
 // ---------------------------------------------------------------- small-MSM reduction: per-bit subset sums
@@ -1147,7 +1160,7 @@ void msm_enqueue(Context &cx, const G1Affine *d_points, const uint32_t *d_scalar
             const size_t max_sc = nb + max_chunks / gather_len + 1;
             G1Xyzz *sc_partial = (G1Xyzz *)cx.buf(W("sc_partial"), sizeof(G1Xyzz) * max_sc);
             uint32_t *sc_bucket = (uint32_t *)cx.buf(W("sc_bucket"), sizeof(uint32_t) * max_sc);
-            hipLaunchKernelGGL(msm_gather_chunks_kernel, dim3((unsigned)cdiv(max_sc, 64)), dim3(64), 0, st, chunk_partial, chunk_off, sc_off, nb,
+            hipLaunchKernelGGL(msm_gather_chunks_kernel, dim3((unsigned)cdiv(max_sc, 32)), dim3(64), 0, st, chunk_partial, chunk_off, sc_off, nb,
                                gather_len, sc_partial, sc_bucket);
             hipLaunchKernelGGL(msm_bit_sums_queue_kernel, dim3((unsigned)all_groups), dim3(64), 0, st, sc_partial, sc_off, sc_bucket, pl.B, pl.c,
                                job->h);
