@@ -122,3 +122,34 @@ def test_stream_merges_under_load_and_resolves_a_failing_aggregate(orc, mi, monk
             assert list(v.verify_stream(iter(seq))) == [not x for x in pattern]
     finally:
         v.close()
+
+
+def test_merged_pass_at_full_size(orc, mi):
+    """BASELINE configs[3] at the pass the stream driver forms under load: eight 1024-proof batches (the committed fixture
+    with eight different sets of randomizers) folded into one aggregate of 8192 proofs -- the partial is the oracle's for
+    the concatenated batch, the product is one, and with one invalid proof in the sixth batch the aggregate fails while
+    every batch on its own gives the right verdict"""
+    import os
+    import torch
+    d = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "vs_batch_1024.npz"))
+    v = mi.VarunaShaped(d["vk"], d["circuits"])
+    try:
+        assert v.batches_per_merged_pass(1024) == 8
+        proofs = d["proofs"]
+        rnds = [np.ascontiguousarray(np.roll(d["randomizers"].reshape(-1, 32), k, axis=0)).reshape(-1) for k in range(8)]
+        parts = [(torch.from_numpy(proofs).cuda(), torch.from_numpy(r).cuda()) for r in rnds]
+        merged = v.accumulate_end(v.accumulate_begin_merged(parts))
+        whole = orc.VSArrays(d["vk"], d["circuits"], np.tile(proofs, 8), np.concatenate(rnds))
+        want = np.frombuffer(np.ascontiguousarray(orc.vs_partial_from_oracle(whole, threads=8)).tobytes(), dtype=np.uint8)
+        assert (merged == want).all()
+        assert v.finalize([merged])
+        bad = proofs.copy()
+        bad[777 * 2256 + 16 + 512 + 864 + 32 * 4] ^= 2
+        parts[5] = (torch.from_numpy(bad).cuda(), parts[5][1])
+        merged = v.accumulate_end(v.accumulate_begin_merged(parts))
+        assert not v.finalize([merged])
+        res = list(v.verify_stream(iter(parts), verdicts=True))
+        assert [ok for ok, _ in res] == [k != 5 for k in range(8)]
+        assert res[5][1] is not None and res[5][1][777] == 0 and int(res[5][1].sum()) == 1023
+    finally:
+        v.close()
