@@ -11,6 +11,7 @@
 #include <string.h>
 #include <condition_variable>
 #include <deque>
+#include <functional>
 #include <map>
 #include <memory>
 #include <mutex>
@@ -20,6 +21,45 @@
 #include "runtime.hpp"  // the process-wide counters only: the driver itself runs on the public entry points
 
 namespace {
+
+// The driver's threads come from a cache: a stream opens and closes around every block (or every verify_stream call), and
+// five thread creations and joins were 0.12 ms of a 4 ms burst.  Idle threads wait for the next stream's job; the cache
+// grows when none is idle (several streams at once).  The cache lives as long as the process (its idle threads touch
+// nothing of the devices: mi_shutdown closes the streams, which ends their jobs); it is never destroyed, so there is
+// no join at exit that a stream nobody closed could hang (std::thread members used to end that case with
+// std::terminate).
+class ThreadCache {
+  public:
+    void run(std::function<void()> job) {
+        std::lock_guard<std::mutex> lk(mu_);
+        q_.push_back(std::move(job));
+        if (idle_ < (int)q_.size()) std::thread([this] { main(); }).detach();  // nobody free for it: one more thread
+        cv_.notify_one();
+    }
+
+  private:
+    void main() {
+        std::unique_lock<std::mutex> lk(mu_);
+        for (;;) {
+            idle_++;
+            cv_.wait(lk, [this] { return !q_.empty(); });
+            idle_--;
+            std::function<void()> job = std::move(q_.front());
+            q_.pop_front();
+            lk.unlock();
+            job();
+            lk.lock();
+        }
+    }
+    std::mutex mu_;
+    std::condition_variable cv_;
+    std::deque<std::function<void()>> q_;
+    int idle_ = 0;
+};
+ThreadCache &thread_cache() {
+    static ThreadCache *c = new ThreadCache;  // never destroyed (above)
+    return *c;
+}
 
 constexpr int32_t RECHECK = 2;  // the product over several merged batches failed: this batch is verified on its own when its verdict is taken
 
@@ -62,8 +102,7 @@ struct Stream {
     bool finisher_done = false;
     int32_t error = MI_OK;                              // first failure inside the pipeline
 
-    std::vector<std::thread> folders;
-    std::thread finisher, publisher;
+    int running = 0;  // driver threads (folders, finisher, publisher) that have not returned yet (mu)
 
     void fail(int32_t st) {  // mu held
         if (error == MI_OK) error = st;
@@ -366,10 +405,19 @@ int32_t mi_vs_stream_open(uint64_t ctx, int32_t fold_threads, int32_t products, 
     }
     // (Streams with an exchange pair as well: the collectives go by batch sequence number, in order, whatever pass a
     // batch rode on; a held batch never waits for a collective, only for a pass to end.)
-    Stream *raw = s.get();
-    for (int i = 0; i < fold_threads; i++) s->folders.emplace_back([raw] { raw->folder_main(); });
-    s->finisher = std::thread([raw] { raw->finisher_main(); });
-    s->publisher = std::thread([raw] { raw->publisher_main(); });
+    // (the jobs hold the stream alive: mi_vs_stream_close waits for them)
+    auto job = [s](void (Stream::*main)()) {
+        return [s, main] {
+            ((*s).*main)();
+            std::lock_guard<std::mutex> lk(s->mu);
+            s->running--;
+            s->cv.notify_all();
+        };
+    };
+    s->running = fold_threads + 2;
+    for (int i = 0; i < fold_threads; i++) thread_cache().run(job(&Stream::folder_main));
+    thread_cache().run(job(&Stream::finisher_main));
+    thread_cache().run(job(&Stream::publisher_main));
     std::lock_guard<std::mutex> lk(g_mu);
     const uint64_t id = g_next++;
     g_streams[id] = s;
@@ -510,9 +558,10 @@ int32_t mi_vs_stream_close(uint64_t stream) {
         s->cv.notify_all();
     }
     (void)s->flush_held(true);
-    for (auto &t : s->folders) t.join();
-    s->finisher.join();
-    s->publisher.join();
+    {
+        std::unique_lock<std::mutex> lk(s->mu);
+        s->cv.wait(lk, [&] { return s->running == 0; });
+    }
     return MI_OK;
 }
 
